@@ -1,0 +1,149 @@
+"""Regenerates the committed golden fixtures (run in the BUILD container only:
+`python tests/golden/make_golden.py`).  Everything comes from the oracle except
+deformer.npz, whose expected outputs come from the reference's own
+extras/deformer.py:7-18 executed from /root/reference (the module cannot be
+imported under python3 -- it has py2 print statements from line 92 -- so only its
+first 28 lines are exec'd; no reference source is stored in this repo)."""
+import ast
+import hashlib
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+from oracle import theanet_oracle as O  # noqa: E402
+
+
+def load_prms(name, img_sz, seed=555555, batch=None):
+    with open(os.path.join(ROOT, "params", name)) as fh:
+        prms = ast.literal_eval(fh.read())
+    prms["layers"][0][1]["img_sz"] = img_sz
+    prms["training_params"]["SEED"] = seed
+    if batch:
+        prms["training_params"]["BATCH_SZ"] = batch
+    return prms
+
+
+def make_kat():
+    prms = load_prms("mnist.prms", 28)
+    net = O.OracleNet(prms["layers"], prms["training_params"])
+    out = {}
+    for i, l in enumerate(net.L):
+        for j, p in enumerate(l.params):
+            out["init_sha_%d_%d" % (i, j)] = hashlib.sha256(
+                np.ascontiguousarray(p).tobytes()).hexdigest()
+    np.savez(os.path.join(HERE, "kat.npz"), **out)
+
+
+def sub_index(size, n=4096):
+    """Fixed pseudo-random subsample used for tensors too large to commit whole."""
+    return np.random.RandomState(size % (2 ** 31)).choice(size, n, replace=False)
+
+
+def put(out, name, arr, f64_small=False):
+    arr = np.asarray(arr)
+    if arr.size > 20000:
+        out[name + "@sub"] = arr.reshape(-1)[sub_index(arr.size)]
+        out[name + "@sum"] = np.asarray(arr.sum(dtype=np.float64))
+        out[name + "@abs"] = np.asarray(np.abs(arr).sum(dtype=np.float64))
+    else:
+        out[name] = arr
+
+
+def draws_to_dict(prefix, d):
+    return {prefix + k: np.asarray(getattr(d, k)) for k in d.__slots__
+            if getattr(d, k) is not None}
+
+
+def make_gold_net(fname, elastic_on, steps=3, B=8):
+    """GOLD-A / GOLD-B: mnist.prms, B=8, every random draw recorded so the HIP
+    path can replay them; float32 net with a float64 twin."""
+    out = {}
+    rng = np.random.default_rng(0)
+    x = rng.random((steps * B, 1, 28, 28), dtype=np.float32)
+    y = np.random.default_rng(1).integers(0, 10, steps * B).astype(np.int32)
+    out["x"], out["y"] = x, y
+    for tag, dt in (("f32", np.float32), ("f64", np.float64)):
+        prms = load_prms("mnist.prms", 28, batch=B)
+        if not elastic_on:
+            prms["layers"][0] = ("ElasticLayer", {"img_sz": 28, "invert_image": True})
+        net = O.OracleNet(prms["layers"], prms["training_params"], dtype=dt)
+        if tag == "f32":
+            for i, l in enumerate(net.L):
+                for j, p in enumerate(l.params):
+                    put(out, "init_%d_%d" % (i, j), p.copy())
+        for s in range(steps):
+            xb, yb = x[s * B:(s + 1) * B], y[s * B:(s + 1) * B]
+            draws = {}
+            if elastic_on:
+                draws[0] = net.L[0].stage.draw(xb.shape)
+            draws[5] = net.L[5].mask_rv.draw((B, 500))
+            if tag == "f32":
+                if elastic_on:
+                    out.update(draws_to_dict("s%d_el_" % s, draws[0]))
+                out["s%d_mask5" % s] = draws[5].astype(np.uint8)
+            cost, logprob, grads, cache = net.grads(xb, yb, draws)
+            out["%s_s%d_cost" % (tag, s)] = np.asarray(cost)
+            out["%s_s%d_logprob" % (tag, s)] = logprob
+            if s == 0:
+                for i, c in enumerate(cache):
+                    if tag == "f32" or i >= 5:
+                        out["%s_s0_act%d" % (tag, i)] = c["out"]
+                if elastic_on:
+                    out["%s_s0_target" % tag] = cache[0]["target"]
+            for i, g in enumerate(grads):
+                if g is not None:
+                    for j, gg in enumerate(g):
+                        put(out, "%s_s%d_grad_%d_%d" % (tag, s, i, j), gg)
+            # apply the update exactly as train_step does
+            for l, g in zip(net.L, grads):
+                if not l.params or not l.reg["rate"]:
+                    continue
+                if l.vel is None:
+                    l.vel = [np.zeros_like(p) for p in l.params]
+                for j in range(len(l.params)):
+                    l.params[j], l.vel[j] = O.sgd_update(l.params[j], l.vel[j], g[j],
+                                                         net.cur_learn_rate, l.reg)
+            if s == steps - 1:
+                for i, l in enumerate(net.L):
+                    for j, p in enumerate(l.params):
+                        put(out, "%s_w_%d_%d" % (tag, i, j), p.copy())
+        sym, pm, lp, preds = net.test(x[:B], y[:B])
+        out["%s_test_logprob" % tag] = lp
+        out["%s_test_preds" % tag] = preds
+        out["%s_test_stats" % tag] = np.array([sym, pm])
+    np.savez_compressed(os.path.join(HERE, fname), **out)
+
+
+def make_deformer():
+    """GOLD-C: expected outputs from the REFERENCE's transform()."""
+    ref = "/root/reference/extras/deformer.py"
+    with open(ref) as fh:
+        head = "".join(fh.readlines()[:28])
+    ns = {}
+    exec(compile(head, ref, "exec"), ns)     # numpy + scipy only
+    rng = np.random.RandomState(11)
+    imgs = rng.rand(4, 28, 28)
+    imgs[1] = (imgs[1] > .7) * 1.0
+    out = {"imgs": imgs}
+    cases = [(3.0, 2.0, 0.0), (8.0, 4.0, 0.0), (5.0, 3.0, 1.0), (1.5, 1.0, 0.25)]
+    for k, (img, (scale, sigma, cval)) in enumerate(zip(imgs, cases)):
+        np.random.seed(100 + k)
+        noise = np.random.uniform(-1, 1, (2,) + img.shape)   # same draw transform() makes
+        np.random.seed(100 + k)
+        ret, trans = ns["transform"](img.copy(), scale, sigma, cval=cval, ret_trans=True)
+        out["noise%d" % k], out["out%d" % k], out["trans%d" % k] = noise, ret, trans
+        out["prm%d" % k] = np.array([scale, sigma, cval])
+    np.savez_compressed(os.path.join(HERE, "deformer.npz"), **out)
+
+
+if __name__ == "__main__":
+    make_kat()
+    make_gold_net("gold_a.npz", elastic_on=False)
+    make_gold_net("gold_b.npz", elastic_on=True)
+    make_deformer()
+    for f in sorted(os.listdir(HERE)):
+        print(f, os.path.getsize(os.path.join(HERE, f)))
