@@ -1,0 +1,215 @@
+/*
+ * theanet_hip.h -- C-ABI of libtheanet_hip.so: the MI355X (gfx950) compute backend
+ * that replaces Theano underneath theanet's convolutional training hot path.
+ *
+ * The reference (rakeshvar/theanet) has no FFI: its boundary to the compute
+ * backend is "build a Theano graph, call theano.function".  Every entry point
+ * below therefore cites the *reference call site into Theano* it replaces
+ * (paths relative to the reference root).  The Python host package
+ * (theanet_amd/) binds these with ctypes; see INTEGRATION.md for the stub.
+ *
+ * Conventions
+ *  - plain C symbols, plain pointers and sizes; no C++/torch types.
+ *  - every function returns int: 0 = ok, <0 = error (TN_E_*); the message is
+ *    available from tn_last_error(ctx) (ctx may be NULL for creation errors).
+ *  - one ctx <-> one device <-> one HIP stream.  All ops ENQUEUE on that stream
+ *    and return immediately; tn_sync / tn_d2h wait.  A ctx is not thread-safe;
+ *    distinct ctxs are independent.
+ *  - all tensors float32, NCHW, row-major, device pointers from tn_alloc.
+ *    Labels int32.  Masks uint8 (0/1).
+ *  - "d_*" scalar-pointer arguments are DEVICE pointers (may be NULL -> the
+ *    by-value sibling is used) so a captured HIP graph can be replayed with
+ *    per-step values changed on the device.
+ */
+#ifndef THEANET_HIP_H
+#define THEANET_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TN_OK 0
+#define TN_E_HIP (-1)     /* a HIP runtime call failed            */
+#define TN_E_ARG (-2)     /* invalid argument / unsupported shape */
+#define TN_E_COMM (-3)    /* RCCL failure                         */
+#define TN_E_NOMEM (-4)
+
+/* activation kinds -- theanet/layer/layer.py:27-39 (activation_list) */
+enum tn_act {
+    TN_ACT_LINEAR = 0,
+    TN_ACT_LEAKY = 1,       /* relu / relu00..relu99: max(0,z)+min(0,z)*slope   */
+    TN_ACT_TANH = 2,
+    TN_ACT_SIGMOID = 3,
+    TN_ACT_SOFTPLUS = 4,
+    TN_ACT_SCALED_TANH = 5  /* 1.7*tanh(2z/3)                                   */
+};
+
+typedef struct tn_ctx tn_ctx;
+
+/* ---- lifecycle (replaces: theano device init; neuralnet.py:236 theano.function) ---- */
+int tn_version(void);
+int tn_device_count(int* count);
+int tn_ctx_create(int device, tn_ctx** ctx);
+int tn_ctx_destroy(tn_ctx* ctx);
+const char* tn_last_error(tn_ctx* ctx);
+int tn_sync(tn_ctx* ctx);
+/* name_len bytes are written to name; cus = compute units; hbm_bytes = total memory */
+int tn_device_info(tn_ctx* ctx, char* name, int name_len, int* cus, size_t* hbm_bytes);
+
+/* ---- memory (replaces: theano.shared / get_value; train.py:18-19, weights.py:18-22,78-79) ---- */
+int tn_alloc(tn_ctx* ctx, size_t bytes, void** dptr);
+int tn_free(tn_ctx* ctx, void* dptr);
+int tn_h2d(tn_ctx* ctx, void* dst, const void* src, size_t bytes);   /* returns after the copy */
+int tn_d2h(tn_ctx* ctx, void* dst, const void* src, size_t bytes);   /* returns after the copy */
+int tn_d2d(tn_ctx* ctx, void* dst, const void* src, size_t bytes);   /* enqueued                */
+int tn_memset(tn_ctx* ctx, void* dst, int byte_value, size_t bytes); /* enqueued                */
+int tn_set_u32(tn_ctx* ctx, uint32_t* d_dst, uint32_t value);        /* enqueued scalar store   */
+int tn_set_i64(tn_ctx* ctx, int64_t* d_dst, int64_t value);
+int tn_set_f32(tn_ctx* ctx, float* d_dst, float value);
+int tn_add_u32(tn_ctx* ctx, uint32_t* d_dst, uint32_t inc);          /* *d_dst += inc (step counter) */
+
+/* ---- HIP graph capture of an op sequence issued through this ABI ---- */
+int tn_graph_begin(tn_ctx* ctx);                   /* start stream capture            */
+int tn_graph_end(tn_ctx* ctx, void** graph_exec);  /* stop, instantiate               */
+int tn_graph_launch(tn_ctx* ctx, void* graph_exec);
+int tn_graph_destroy(tn_ctx* ctx, void* graph_exec);
+
+/* ---- timing with HIP events on the ctx stream (bench.py roofline leg) ---- */
+int tn_event_create(tn_ctx* ctx, void** ev);
+int tn_event_record(tn_ctx* ctx, void* ev);
+int tn_event_elapsed_ms(tn_ctx* ctx, void* ev_start, void* ev_stop, float* ms); /* syncs on stop */
+int tn_event_destroy(tn_ctx* ctx, void* ev);
+
+/* ---- conv (replaces nnconv.conv2d + tt.grad through it; convpool.py:54-72, layer.py:83) ----
+ * True convolution (kernel flipped), W layout (K,C,f,f):
+ *   z[n,k,i,j] = b[k] + sum_{c,u,v} xpad[n,c,i*s+u,j*s+v] * W[k,c,f-1-u,f-1-v]
+ * pad_lo zeros are virtually prepended to rows/cols (0 for 'valid', f-1-(f-1)/2 for
+ * 'same'); Ho/Wo are the output sizes the caller computed (convpool.py:57-70).
+ * fwd fuses bias + activation:  a = act(z).                                         */
+int tn_conv2d_fwd(tn_ctx* ctx, const float* x, const float* W, const float* b, float* a,
+                  int N, int C, int H, int Wd, int K, int f, int stride, int pad_lo,
+                  int Ho, int Wo, int act, float act_param);
+/* dW (K,C,f,f) and db (K) from dz = dcost/dz (activation gradient already applied by
+ * the kernel that produced dz).  OVERWRITES dW/db.                                   */
+int tn_conv2d_wgrad(tn_ctx* ctx, const float* x, const float* dz, float* dW, float* db,
+                    int N, int C, int H, int Wd, int K, int f, int stride, int pad_lo,
+                    int Ho, int Wo);
+/* dx (N,C,H,W) = full correlation of dz with W.  If prev_a != NULL the gradient of the
+ * producing layer's activation is fused:  dx *= act'(prev_a)  (prev_a = that layer's
+ * OUTPUT, same shape as dx) -- i.e. the result is already dcost/dz of the layer below. */
+int tn_conv2d_dgrad(tn_ctx* ctx, const float* dz, const float* W, float* dx,
+                    int N, int C, int H, int Wd, int K, int f, int stride, int pad_lo,
+                    int Ho, int Wo, const float* prev_a, int prev_act, float prev_act_param);
+
+/* ---- pool / mean (replaces pool.pool_2d + MaxPoolGrad, tt.mean; convpool.py:106-107,131) ----
+ * max over p x p, stride p, no padding; Ho = ceil(H/p) unless ignore_border (floor).   */
+int tn_pool_fwd(tn_ctx* ctx, const float* x, float* y, int NC, int H, int Wd, int p,
+                int Ho, int Wo);
+/* dx = (x == y[window]) ? dy[window] : 0  (every tie gets the full gradient), then the
+ * producing layer's activation gradient is fused exactly as in tn_conv2d_dgrad
+ * (x IS that layer's output).  prev_act = TN_ACT_LINEAR disables it.                    */
+int tn_pool_bwd(tn_ctx* ctx, const float* x, const float* y, const float* dy, float* dx,
+                int NC, int H, int Wd, int p, int Ho, int Wo, int prev_act, float prev_act_param);
+int tn_mean_fwd(tn_ctx* ctx, const float* x, float* y, int NC, int HW);
+int tn_mean_bwd(tn_ctx* ctx, const float* dy, float* dx, int NC, int HW,
+                const float* prev_a, int prev_act, float prev_act_param);
+
+/* ---- fully connected (replaces tt.dot + bias + act + drop_output; hidden.py:30-32) ----
+ * a = act(x(B,n_in) . W(n_in,n_out) + b) ; if mask != NULL: a *= mask (uint8 B x n_out,
+ * non-inverted dropout, dropout.py:12-13).  fp32 MFMA (v_mfma_f32_32x32x2_f32).         */
+int tn_fc_fwd(tn_ctx* ctx, const float* x, const float* W, const float* b, float* a,
+              int B, int n_in, int n_out, int act, float act_param, const uint8_t* mask);
+/* dW = x^T . dz, db = sum_rows dz (OVERWRITE).  ws: workspace of tn_fc_wgrad_ws_bytes.   */
+size_t tn_fc_wgrad_ws_bytes(int B, int n_in, int n_out);
+int tn_fc_wgrad(tn_ctx* ctx, const float* x, const float* dz, float* dW, float* db,
+                int B, int n_in, int n_out, void* ws);
+/* dx = dz . W^T, with the layer-below's activation gradient and dropout mask fused:
+ * dx *= act'(prev_a) * prev_mask   (either may be NULL).                                */
+int tn_fc_dgrad(tn_ctx* ctx, const float* dz, const float* W, float* dx,
+                int B, int n_in, int n_out,
+                const float* prev_a, int prev_act, float prev_act_param, const uint8_t* prev_mask);
+
+/* ---- dropout (replaces RandomStreams.binomial; dropout.py:9-31) ----
+ * mask[i] = uniform(seed, *d_step + step, elem0 + i) >= pdrop  (Philox4x32-10), i < n.
+ * elem0 = global index of element 0 so masks do not depend on how a batch is sharded.  */
+int tn_dropout_mask(tn_ctx* ctx, uint8_t* mask, size_t n, float pdrop, uint64_t seed,
+                    uint32_t step, const uint32_t* d_step, uint64_t elem0);
+/* stand-alone DropOutLayer: y = x * mask (fwd);  dx = dy * mask * act'(prev_a) (bwd).   */
+int tn_scale_mask(tn_ctx* ctx, const float* x, const uint8_t* mask, float scale, float* y,
+                  size_t n, const float* prev_a, int prev_act, float prev_act_param);
+
+/* ---- softmax + NLL (replaces tt.nnet.softmax, log, argmax, -mean; outlayers.py:50-51,69-95) ----
+ * logprob = log_softmax(z); rowloss[n] = -logprob[n,y[n]]; pred[n] = argmax (first max);
+ * rowp[n] = exp(logprob[n,y[n]]); dz = (softmax - onehot) * inv_batch (NULL to skip).
+ * y is read at y[y_row0 + (d_row0 ? *d_row0 : 0) + n].                                  */
+int tn_softmax_nll(tn_ctx* ctx, const float* z, const int32_t* y, int64_t y_row0,
+                   const int64_t* d_row0, float* logprob, float* rowloss, int32_t* pred,
+                   float* rowp, float* dz, int B, int n_out, float inv_batch);
+/* out[0] = scale * sum(v[0..n))  (+ out[0] if accumulate) -- cost and error-rate scalars */
+int tn_reduce_sum(tn_ctx* ctx, const float* v, size_t n, float scale, float* out, int accumulate);
+/* out[0] (+)= L1*sum|p| + L2*sum p^2  (layer.py:109-117)                                 */
+int tn_wtcost(tn_ctx* ctx, const float* p, size_t n, float L1, float L2, float* out, int accumulate);
+/* out[0] = mean(pred != y) ; out[1] = mean(rowp)   (outlayers.py:69-80)                  */
+int tn_error_stats(tn_ctx* ctx, const int32_t* pred, const int32_t* y, int64_t y_row0,
+                   const float* rowp, int B, float* out2);
+
+/* ---- momentum SGD + maxnorm (replaces Layer.get_updates; layer.py:70-107) ----
+ * g' = g*gscale + L1*sign(p) + 2*L2*p ; v_new = m*v + (1-m)*g' ; p_new = p - rate*lr*v_OLD
+ * (simultaneous Theano update: the OLD velocity moves p).  lr is read from *d_lr.
+ * Then maxnorm (0 = off): ndim 1 -> clip ; ndim 2 (rows x cols) -> per-column L2 ;
+ * ndim 4 (d0 x rest) -> per-d0 L2, scale (1e-7+clip(n,0,M))/(1e-7+n).                    */
+int tn_sgd_update(tn_ctx* ctx, float* p, float* v, const float* g, size_t n,
+                  float momentum, float rate, const float* d_lr, float L1, float L2, float gscale);
+int tn_maxnorm(tn_ctx* ctx, float* p, int ndim, int d0, int rest, float maxnorm);
+
+/* ---- elastic input stage (replaces ElasticLayer's graph; inlayers.py:63-144) ----
+ * draws layout (float32, device): [0:2] translation u(-1,1) ; [2:4] origin u(.25,.75) ;
+ * [4:6] zoom u(-1,1) ; [6] theta u(-1,1) ; [7] pad ; [8 : 8+2hw] N(0,1) noise planes.
+ * tn_elastic_draws fills it from Philox (seed, step); parity runs upload it instead.    */
+size_t tn_elastic_draws_count(int h, int w);
+int tn_elastic_draws(tn_ctx* ctx, float* draws, int h, int w, uint64_t seed,
+                     uint32_t step, const uint32_t* d_step);
+/* Field -> sample map (one per call, shared by the whole batch; coordinates in float64
+ * like the Theano CPU path).  map_idx[h*w] int32 = top*w+left (nearest: the rounded
+ * pixel), map_fy/map_fx[h*w] = bilinear fractions (unused for nearest).  target (2hw
+ * float64, may be NULL) receives the un-clipped coordinates (debugout, inlayers.py:146). */
+int tn_elastic_field(tn_ctx* ctx, const float* draws, int h, int w,
+                     double translation, double zoom, double magnitude, int sigma, double angle,
+                     int nearest, int32_t* map_idx, float* map_fy, float* map_fx, double* target);
+/* out[n,c,:] = resample(invert ? 1-x : x) then flip noise: with flipmask (uint8, N*C*h*w)
+ * if given, else Philox(seed, step, global element index) < pflip, else none (pflip=0).
+ * x rows are read at x_row0 + (d_row0 ? *d_row0 : 0) + n ; row_global0 is the global
+ * index of the first row (for sharding-independent noise).  map_idx == NULL -> identity. */
+int tn_elastic_apply(tn_ctx* ctx, const float* x, int64_t x_row0, const int64_t* d_row0,
+                     float* out, int N, int C, int h, int w, int invert, int nearest,
+                     const int32_t* map_idx, const float* map_fy, const float* map_fx,
+                     float pflip, const uint8_t* flipmask, uint64_t seed, uint32_t step,
+                     const uint32_t* d_step, int64_t row_global0);
+/* extras/deformer.py:7-18 -- per-IMAGE deformation, in place semantics of Deformer:
+ * trans = indices + scale*noise ; each plane gaussian_filter(sigma, truncate 2, nearest) ;
+ * bilinear map_coordinates(mode constant, cval).  noise (N,2,h,w) float32 U(-1,1) given,
+ * or NULL -> Philox(seed, image index).  imgs float32 (N,h,w) -> out.                    */
+int tn_deformer_transform(tn_ctx* ctx, const float* imgs, float* out, int N, int h, int w,
+                          double scale, double sigma, double cval, const float* noise,
+                          uint64_t seed, int64_t img_global0);
+
+/* ---- minibatch gather (replaces x_data[indx]; neuralnet.py:228-234) ---- */
+int tn_gather_rows(tn_ctx* ctx, const void* src, const int32_t* d_index, void* dst,
+                   int nrows, size_t row_bytes);
+
+/* ---- data-parallel gradient exchange over RCCL/xGMI (new) ---- */
+#define TN_UNIQUE_ID_BYTES 128
+int tn_comm_unique_id(tn_ctx* ctx, void* id128);                 /* rank 0 */
+int tn_comm_init(tn_ctx* ctx, const void* id128, int rank, int world);
+int tn_comm_destroy(tn_ctx* ctx);
+int tn_allreduce_sum(tn_ctx* ctx, float* buf, size_t n);         /* in place, on the ctx stream */
+int tn_allreduce_max(tn_ctx* ctx, float* buf, size_t n);
+int tn_axpby(tn_ctx* ctx, float* y, const float* x, size_t n, float a, float b); /* y = a*x + b*y */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* THEANET_HIP_H */

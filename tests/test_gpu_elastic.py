@@ -1,0 +1,135 @@
+"""Elastic / deformer stage parity against the oracle with INJECTED random draws, plus
+statistical checks of the on-device generator."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import theanet_oracle as O
+from tests.gpu_util import assert_close, call, ctx, dev, empty
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _pack(d, h, w):
+    v = np.zeros(8 + 2 * h * w, np.float32)
+    if d.transln is not None:
+        v[0:2] = d.transln.reshape(2)
+    if d.origin_u is not None:
+        v[2:4] = d.origin_u.reshape(2)
+    if d.zoom_u is not None:
+        v[4:6] = d.zoom_u.reshape(2)
+    if d.theta_u is not None:
+        v[6] = d.theta_u
+    if d.noise is not None:
+        v[8:] = d.noise.reshape(-1)
+    return v
+
+
+@pytest.mark.parametrize("prm,nearest,hw,C", [
+    (dict(translation=2, zoom=1.1, magnitude=60, sigma=15, pflip=.03, angle=5), True, 28, 1),
+    (dict(translation=2, zoom=1.1, magnitude=30, sigma=4, pflip=0, angle=5), False, 32, 3),
+    (dict(translation=3, zoom=1, magnitude=0, sigma=1, pflip=.1, angle=0), False, 17, 2),
+    (dict(translation=0, zoom=1.3, magnitude=0, sigma=1, pflip=0, angle=0), True, 20, 1),
+    (dict(translation=0, zoom=1, magnitude=12, sigma=3, pflip=0, angle=30), False, 24, 1),
+])
+def test_elastic_field_and_apply_match_oracle(prm, nearest, hw, C):
+    st = O.ElasticStage(hw, num_maps=C, nearest=nearest, invert_image=True,
+                        rand_gen=np.random.RandomState(5), **prm)
+    rng = np.random.RandomState(0)
+    x = rng.rand(10, C, hw, hw).astype(np.float32)
+    d = st.draw((6, C, hw, hw))
+    want, target = st.forward(x[2:8], d)
+    draws = dev(_pack(d, hw, hw))
+    idx, fy, fx = empty((hw * hw,), np.int32), empty((hw * hw,)), empty((hw * hw,))
+    tgt = empty((2, hw, hw), np.float64)
+    call("tn_elastic_field", draws.ptr, hw, hw, float(prm["translation"]), float(prm["zoom"]),
+         float(prm["magnitude"]), prm["sigma"], float(prm["angle"]), int(nearest), idx.ptr, fy.ptr,
+         fx.ptr, tgt.ptr)
+    got_t = tgt.get_value()
+    # the smoothed-noise plane is a float32 sum of up to 961 terms in a different order
+    np.testing.assert_allclose(got_t, target, rtol=0, atol=2e-4)
+    out = empty((6, C, hw, hw))
+    fm = dev(d.flipmask.astype(np.uint8)) if prm["pflip"] else None
+    row0 = dev(np.array([1], np.int64))
+    call("tn_elastic_apply", dev(x).ptr, 1, row0.ptr, out.ptr, 6, C, hw, hw, 1, int(nearest),
+         idx.ptr, fy.ptr, fx.ptr, 0.0, fm.ptr if fm is not None else None, 0, 0, None, 0)
+    got = out.get_value()
+    if nearest:
+        # identical except where the coordinate sits within 2e-4 of a rounding boundary
+        cy = np.clip(target[0], 0, hw - 1.001)
+        cx = np.clip(target[1], 0, hw - 1.001)
+        safe = (np.abs(cy - np.floor(cy) - .5) > 5e-4) & (np.abs(cx - np.floor(cx) - .5) > 5e-4)
+        assert safe.mean() > .99
+        np.testing.assert_array_equal(got[:, :, safe], want[:, :, safe])
+    else:
+        assert_close(got, want, atol=2e-3, rtol=0, what="bilinear")
+        assert np.abs(got - want).mean() < 2e-5
+
+
+def test_elastic_identity_and_invert():
+    x = np.random.RandomState(0).rand(4, 2, 9, 9).astype(np.float32)
+    out = empty((3, 2, 9, 9))
+    call("tn_elastic_apply", dev(x).ptr, 1, None, out.ptr, 3, 2, 9, 9, 1, 1, None, None, None, 0.0,
+         None, 0, 0, None, 0)
+    np.testing.assert_array_equal(out.get_value(), np.float32(1) - x[1:4])
+    call("tn_elastic_apply", dev(x).ptr, 0, None, out.ptr, 3, 2, 9, 9, 0, 0, None, None, None, 0.0,
+         None, 0, 0, None, 0)
+    np.testing.assert_array_equal(out.get_value(), x[:3])
+
+
+def test_device_rng_statistics_and_flip_noise():
+    h = w = 28
+    n = ctx().lib.tn_elastic_draws_count(h, w)
+    assert n == 8 + 2 * h * w
+    d = empty((n,))
+    vals = []
+    for step in range(40):
+        call("tn_elastic_draws", d.ptr, h, w, 4242, step, None)
+        vals.append(d.get_value())
+    v = np.stack(vals)
+    assert np.all(np.abs(v[:, 0:2]) <= 1) and np.all(np.abs(v[:, 4:7]) <= 1)
+    assert np.all((v[:, 2:4] >= .25) & (v[:, 2:4] <= .75))
+    noise = v[:, 8:].ravel()
+    assert abs(noise.mean()) < .02 and abs(noise.std() - 1) < .02
+    assert abs((np.abs(noise) < 1).mean() - .6827) < .01
+    assert not np.array_equal(v[0], v[1])
+    call("tn_elastic_draws", d.ptr, h, w, 4242, 0, None)
+    np.testing.assert_array_equal(d.get_value(), v[0])          # counter RNG: reproducible
+    # flip noise: P(flip) = pflip, independent of sharding (row_global0)
+    x = np.zeros((64, 1, 28, 28), np.float32)
+    out = empty(x.shape)
+    call("tn_elastic_apply", dev(x).ptr, 0, None, out.ptr, 64, 1, 28, 28, 0, 1, None, None, None,
+         .03, None, 77, 5, None, 0)
+    full = out.get_value()
+    assert abs(full.mean() - .03) < .003
+    out2 = empty((16, 1, 28, 28))
+    call("tn_elastic_apply", dev(x).ptr, 32, None, out2.ptr, 16, 1, 28, 28, 0, 1, None, None, None,
+         .03, None, 77, 5, None, 32)
+    np.testing.assert_array_equal(out2.get_value(), full[32:48])
+
+
+def test_deformer_matches_reference_fixture():
+    g = np.load(os.path.join(G, "deformer.npz"))
+    for k in range(4):
+        scale, sigma, cval = g["prm%d" % k]
+        img = g["imgs"][k].astype(np.float32)
+        out = empty((1, 28, 28))
+        call("tn_deformer_transform", dev(img[None]).ptr, out.ptr, 1, 28, 28, float(scale),
+             float(sigma), float(cval), dev(g["noise%d" % k].astype(np.float32)[None]).ptr, 0, 0)
+        # fixture = the reference's own transform(); inputs were rounded to float32 here
+        assert_close(out.get_value()[0], g["out%d" % k], atol=2e-4, rtol=0, what="deformer %d" % k)
+
+
+def test_deformer_device_rng_batch():
+    rng = np.random.RandomState(0)
+    imgs = rng.rand(32, 28, 28).astype(np.float32)
+    out = empty(imgs.shape)
+    call("tn_deformer_transform", dev(imgs).ptr, out.ptr, 32, 28, 28, 3.0, 2.0, 0.0, None, 11, 0)
+    a = out.get_value()
+    assert a.shape == imgs.shape and np.isfinite(a).all()
+    assert .2 < np.corrcoef(a.ravel(), imgs.ravel())[0, 1] < .999   # deformed, not destroyed
+    out2 = empty((8, 28, 28))
+    call("tn_deformer_transform", dev(imgs[8:16]).ptr, out2.ptr, 8, 28, 28, 3.0, 2.0, 0.0, None, 11, 8)
+    np.testing.assert_array_equal(out2.get_value(), a[8:16])          # keyed by global image index

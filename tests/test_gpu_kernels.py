@@ -1,0 +1,273 @@
+"""Per-kernel parity: every HIP op (through the C-ABI) against the numpy oracle on the
+same seeded inputs.  Tolerance for fp32 kernels: rtol 1e-4 / atol 1e-5 (north_star:
+1e-4 rel on logits); index / mask / argmax outputs are bit-exact."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import theanet_oracle as O
+from tests.gpu_util import act_code, assert_close, call, ctx, dev, empty
+
+pytestmark = pytest.mark.gpu
+
+CONV_CASES = [
+    # N, C, H, K, f, stride, mode, act
+    (3, 1, 28, 4, 3, 1, "valid", "relu10"),
+    (2, 4, 13, 20, 3, 1, "valid", "relu05"),
+    (2, 3, 12, 8, 3, 1, "same", "tanh"),
+    (2, 2, 11, 6, 5, 1, "valid", "relu"),
+    (2, 3, 10, 5, 3, 2, "valid", "sigmoid"),
+    (1, 5, 9, 33, 3, 1, "same", "relu10"),
+    (2, 2, 8, 3, 4, 1, "same", "linear"),
+    (2, 3, 9, 4, 2, 1, "valid", "scaled_tanh"),
+    (2, 2, 7, 3, 1, 1, "valid", "softplus"),
+    (2, 9, 8, 16, 3, 1, "same", "relu10"),
+]
+
+
+def _conv_setup(case, seed=0):
+    N, C, H, K, f, s, mode, act = case
+    rng = np.random.RandomState(seed)
+    x = rng.randn(N, C, H, H).astype(np.float32)
+    W = (rng.randn(K, C, f, f) / np.sqrt(C * f * f)).astype(np.float32)
+    b = rng.randn(K).astype(np.float32)
+    pad_lo, _, out = O.conv_geometry(H, f, s, mode)
+    return x, W, b, pad_lo, out
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_fwd(case):
+    N, C, H, K, f, s, mode, act = case
+    x, W, b, pad_lo, out = _conv_setup(case)
+    want = O.activation(act)[0](O.conv2d_fwd(x, W, b, s, mode))
+    a = empty((N, K, out, out))
+    kind, prm = act_code(act)
+    call("tn_conv2d_fwd", dev(x).ptr, dev(W).ptr, dev(b).ptr, a.ptr, N, C, H, H, K, f, s, pad_lo,
+         out, out, kind, prm)
+    assert_close(a.get_value(), want, what="conv fwd %s" % (case,))
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_wgrad_dgrad(case):
+    N, C, H, K, f, s, mode, act = case
+    x, W, b, pad_lo, out = _conv_setup(case, 1)
+    rng = np.random.RandomState(2)
+    dz = rng.randn(N, K, out, out).astype(np.float32)
+    dx_w, dW_w, db_w = O.conv2d_bwd(x.astype(np.float64), W.astype(np.float64),
+                                    dz.astype(np.float64), s, mode)
+    dW, db, dx = empty(W.shape), empty((K,)), empty(x.shape)
+    dxd, dzd, Wd = dev(x), dev(dz), dev(W)
+    call("tn_conv2d_wgrad", dxd.ptr, dzd.ptr, dW.ptr, db.ptr, N, C, H, H, K, f, s, pad_lo, out, out)
+    assert_close(dW.get_value(), dW_w, atol=1e-4, what="conv dW %s" % (case,))
+    assert_close(db.get_value(), db_w, atol=1e-4, what="conv db %s" % (case,))
+    call("tn_conv2d_dgrad", dzd.ptr, Wd.ptr, dx.ptr, N, C, H, H, K, f, s, pad_lo, out, out,
+         None, 0, 0.0)
+    assert_close(dx.get_value(), dx_w, atol=1e-4, what="conv dx %s" % (case,))
+    # fused activation gradient of the layer below
+    prev_a = rng.randn(*x.shape).astype(np.float32)
+    prev_a[0, 0, 0, :3] = 0          # exact zeros exercise the tie rule
+    kind, prm = act_code("relu10")
+    call("tn_conv2d_dgrad", dzd.ptr, Wd.ptr, dx.ptr, N, C, H, H, K, f, s, pad_lo, out, out,
+         dev(prev_a).ptr, kind, prm)
+    g = np.where(prev_a > 0, 1.0, np.where(prev_a < 0, .1, 1.1))
+    assert_close(dx.get_value(), dx_w * g, atol=1e-4, what="conv dx*act' %s" % (case,))
+
+
+def test_conv_big_batch_wgrad_is_deterministic():
+    case = (64, 4, 13, 20, 3, 1, "valid", "relu05")
+    N, C, H, K, f, s, mode, act = case
+    x, W, b, pad_lo, out = _conv_setup(case, 3)
+    dz = np.random.RandomState(4).randn(N, K, out, out).astype(np.float32)
+    dW, db = empty(W.shape), empty((K,))
+    xd, dzd = dev(x), dev(dz)
+    res = []
+    for _ in range(2):
+        call("tn_conv2d_wgrad", xd.ptr, dzd.ptr, dW.ptr, db.ptr, N, C, H, H, K, f, s, pad_lo, out, out)
+        res.append((dW.get_value(), db.get_value()))
+    np.testing.assert_array_equal(res[0][0], res[1][0])
+    _, dW_w, db_w = O.conv2d_bwd(x.astype(np.float64), W.astype(np.float64), dz.astype(np.float64), s,
+                                 mode, need_dx=False)
+    assert_close(res[0][0], dW_w, atol=2e-4, what="dW")
+    assert_close(res[0][1], db_w, atol=2e-4, what="db")
+
+
+@pytest.mark.parametrize("H,p,ib", [(26, 2, False), (11, 2, False), (11, 2, True), (7, 3, False),
+                                    (5, 5, False), (9, 4, True)])
+def test_pool_fwd_bwd(H, p, ib):
+    rng = np.random.RandomState(H * 10 + p)
+    x = rng.randn(3, 5, H, H).astype(np.float32)
+    x[0, 0, :2, :2] = 7.0            # a tied window: every tie gets the gradient
+    x[1, 1, 0, 0] = 0.0
+    Ho = O.pool_out_sz(H, p, ib)
+    y = empty((3, 5, Ho, Ho))
+    xd = dev(x)
+    call("tn_pool_fwd", xd.ptr, y.ptr, 15, H, H, p, Ho, Ho)
+    want = O.pool_fwd(x, p, ib)
+    np.testing.assert_array_equal(y.get_value(), want)
+    dy = rng.randn(3, 5, Ho, Ho).astype(np.float32)
+    dx = empty(x.shape)
+    call("tn_pool_bwd", xd.ptr, y.ptr, dev(dy).ptr, dx.ptr, 15, H, H, p, Ho, Ho, 0, 0.0)
+    np.testing.assert_array_equal(dx.get_value(), O.pool_bwd(x, dy, p, ib))
+    kind, prm = act_code("relu05")
+    call("tn_pool_bwd", xd.ptr, y.ptr, dev(dy).ptr, dx.ptr, 15, H, H, p, Ho, Ho, kind, prm)
+    g = np.where(x > 0, 1.0, np.where(x < 0, .05, 1.05)).astype(np.float32)
+    assert_close(dx.get_value(), O.pool_bwd(x, dy, p, ib) * g, what="pool bwd * act'")
+
+
+def test_mean_fwd_bwd():
+    rng = np.random.RandomState(0)
+    x = rng.randn(4, 6, 5, 5).astype(np.float32)
+    y = empty((4, 6))
+    call("tn_mean_fwd", dev(x).ptr, y.ptr, 24, 25)
+    assert_close(y.get_value(), O.mean_fwd(x))
+    dy = rng.randn(4, 6).astype(np.float32)
+    dx = empty(x.shape)
+    call("tn_mean_bwd", dev(dy).ptr, dx.ptr, 24, 25, None, 0, 0.0)
+    assert_close(dx.get_value(), O.mean_bwd(x, dy))
+
+
+FC_CASES = [(64, 720, 500, "relu01"), (33, 500, 10, "linear"), (5, 7, 3, "tanh"),
+            (128, 100, 64, "sigmoid"), (70, 33, 130, "relu10"), (256, 64, 457, "relu")]
+
+
+@pytest.mark.parametrize("B,n_in,n_out,act", FC_CASES)
+def test_fc_fwd(B, n_in, n_out, act):
+    rng = np.random.RandomState(B)
+    x = rng.randn(B, n_in).astype(np.float32)
+    W = (rng.randn(n_in, n_out) / np.sqrt(n_in)).astype(np.float32)
+    b = rng.randn(n_out).astype(np.float32)
+    mask = (rng.rand(B, n_out) > .5).astype(np.uint8)
+    kind, prm = act_code(act)
+    z = x.astype(np.float64) @ W.astype(np.float64) + b
+    want = O.activation(act)[0](z)
+    a = empty((B, n_out))
+    xd, Wd, bd = dev(x), dev(W), dev(b)
+    call("tn_fc_fwd", xd.ptr, Wd.ptr, bd.ptr, a.ptr, B, n_in, n_out, kind, prm, None)
+    assert_close(a.get_value(), want, what="fc fwd")
+    call("tn_fc_fwd", xd.ptr, Wd.ptr, bd.ptr, a.ptr, B, n_in, n_out, kind, prm, dev(mask).ptr)
+    assert_close(a.get_value(), want * mask, what="fc fwd masked")
+
+
+@pytest.mark.parametrize("B,n_in,n_out,act", FC_CASES)
+def test_fc_bwd(B, n_in, n_out, act):
+    rng = np.random.RandomState(B + 1)
+    x = rng.randn(B, n_in).astype(np.float32)
+    W = (rng.randn(n_in, n_out) / np.sqrt(n_in)).astype(np.float32)
+    dz = rng.randn(B, n_out).astype(np.float32)
+    lib = ctx().lib
+    ws = empty((lib.tn_fc_wgrad_ws_bytes(B, n_in, n_out) // 4 + 1,))
+    dW, db, dx = empty((n_in, n_out)), empty((n_out,)), empty((B, n_in))
+    xd, Wd, dzd = dev(x), dev(W), dev(dz)
+    call("tn_fc_wgrad", xd.ptr, dzd.ptr, dW.ptr, db.ptr, B, n_in, n_out, ws.ptr)
+    assert_close(dW.get_value(), x.astype(np.float64).T @ dz.astype(np.float64), atol=1e-4, what="fc dW")
+    assert_close(db.get_value(), dz.astype(np.float64).sum(0), atol=1e-4, what="fc db")
+    call("tn_fc_dgrad", dzd.ptr, Wd.ptr, dx.ptr, B, n_in, n_out, None, 0, 0.0, None)
+    want = dz.astype(np.float64) @ W.astype(np.float64).T
+    assert_close(dx.get_value(), want, atol=1e-4, what="fc dx")
+    prev_a = rng.randn(B, n_in).astype(np.float32)
+    pm = (rng.rand(B, n_in) > .5).astype(np.uint8)
+    kind, prm = act_code("relu01")
+    call("tn_fc_dgrad", dzd.ptr, Wd.ptr, dx.ptr, B, n_in, n_out, dev(prev_a * pm).ptr, kind, prm,
+         dev(pm).ptr)
+    g = np.where(prev_a > 0, 1.0, .01) * pm
+    assert_close(dx.get_value(), want * g, atol=1e-4, what="fc dx * act' * mask")
+
+
+def test_fc_wgrad_large_batch_split_k():
+    B, n_in, n_out = 4096, 720, 500
+    rng = np.random.RandomState(9)
+    x = rng.rand(B, n_in).astype(np.float32)
+    dz = (rng.randn(B, n_out) / B).astype(np.float32)
+    ws = empty((ctx().lib.tn_fc_wgrad_ws_bytes(B, n_in, n_out) // 4 + 1,))
+    dW, db = empty((n_in, n_out)), empty((n_out,))
+    call("tn_fc_wgrad", dev(x).ptr, dev(dz).ptr, dW.ptr, db.ptr, B, n_in, n_out, ws.ptr)
+    assert_close(dW.get_value(), x.astype(np.float64).T @ dz.astype(np.float64), atol=1e-5, what="dW")
+    assert_close(db.get_value(), dz.astype(np.float64).sum(0), atol=1e-5, what="db")
+
+
+@pytest.mark.parametrize("B,n", [(8, 10), (37, 457), (4096, 10), (5, 1)])
+def test_softmax_nll(B, n):
+    rng = np.random.RandomState(n)
+    z = (3 * rng.randn(B, n)).astype(np.float32)
+    z[0, :] = 1.5                                  # all tied: argmax must be the first index
+    y = rng.randint(0, n, B + 3).astype(np.int32)
+    lp, rl, pred, rp, dz = empty((B, n)), empty((B,)), empty((B,), np.int32), empty((B,)), empty((B, n))
+    call("tn_softmax_nll", dev(z).ptr, dev(y).ptr, 3, None, lp.ptr, rl.ptr, pred.ptr, rp.ptr, dz.ptr,
+         B, n, 1.0 / B)
+    yy = y[3:]
+    want = O.log_softmax(z.astype(np.float64))
+    assert_close(lp.get_value(), want, what="logprob")
+    np.testing.assert_array_equal(pred.get_value(), z.argmax(1))
+    assert_close(rl.get_value(), -want[np.arange(B), yy], what="rowloss")
+    assert_close(rp.get_value(), np.exp(want[np.arange(B), yy]), what="rowp")
+    assert_close(dz.get_value(), O.nll_dlogits(want, yy), atol=1e-7, what="dlogits")
+    cost = empty((1,))
+    call("tn_reduce_sum", rl.ptr, B, 1.0 / B, cost.ptr, 0)
+    assert_close(cost.get_value()[0], O.nll(want, yy), what="cost")
+    st = empty((2,))
+    call("tn_error_stats", pred.ptr, dev(y).ptr, 3, rp.ptr, B, st.ptr)
+    assert_close(st.get_value(), [np.mean(z.argmax(1) != yy), np.exp(want[np.arange(B), yy]).mean()])
+
+
+def test_sgd_update_and_maxnorm():
+    rng = np.random.RandomState(0)
+    for shape in [(500,), (720, 500), (20, 4, 3, 3)]:
+        p = rng.randn(*shape).astype(np.float32)
+        v = rng.randn(*shape).astype(np.float32)
+        g = rng.randn(*shape).astype(np.float32)
+        for reg in [dict(O.DEFAULT_REG), dict(O.DEFAULT_REG, L1=.01, L2=.02, momentum=.9, rate=.5),
+                    dict(O.DEFAULT_REG, maxnorm=1.5)]:
+            pd, vd, lr = dev(p), dev(v), dev(np.array([.1], np.float32))
+            call("tn_sgd_update", pd.ptr, vd.ptr, dev(g).ptr, p.size, reg["momentum"], reg["rate"],
+                 lr.ptr, reg["L1"], reg["L2"], 1.0)
+            if reg["maxnorm"]:
+                call("tn_maxnorm", pd.ptr, p.ndim, shape[0],
+                     int(np.prod(shape[1:])) if p.ndim > 1 else 1, reg["maxnorm"])
+            gg = g + O.wtcost_grad(p, reg)
+            p_w, v_w = O.sgd_update(p, v, gg, .1, reg)
+            assert_close(pd.get_value(), p_w, atol=1e-6, what="p %s %s" % (shape, reg))
+            assert_close(vd.get_value(), v_w, atol=1e-6, what="v %s %s" % (shape, reg))
+    cost = dev(np.array([2.0], np.float32))
+    p = rng.randn(1000).astype(np.float32)
+    call("tn_wtcost", dev(p).ptr, 1000, .01, .02, cost.ptr, 1)
+    assert_close(cost.get_value()[0], 2 + .01 * np.abs(p).sum() + .02 * (p * p).sum())
+
+
+def test_dropout_mask_statistics_and_sharding_invariance():
+    n = 4096 * 500
+    m = empty((n,), np.uint8)
+    call("tn_dropout_mask", m.ptr, n, .5, 1234, 7, None, 0)
+    full = m.get_value()
+    assert abs(full.mean() - .5) < 2e-3
+    # a shard that starts at element 1001 must reproduce the same bits
+    call("tn_dropout_mask", m.ptr, 5000, .5, 1234, 7, None, 1001)
+    np.testing.assert_array_equal(m.get_value()[:5000], full[1001:6001])
+    # different step / seed -> different mask; device-side step is added to the value one
+    step = dev(np.array([3], np.uint32))
+    call("tn_dropout_mask", m.ptr, n, .5, 1234, 4, step.ptr, 0)
+    np.testing.assert_array_equal(m.get_value(), full)
+    call("tn_dropout_mask", m.ptr, n, .5, 1234, 8, None, 0)
+    assert (m.get_value() != full).mean() > .4
+    call("tn_dropout_mask", m.ptr, n, .3, 99, 0, None, 0)
+    assert abs(m.get_value().mean() - .7) < 2e-3
+    # rows/columns are not correlated
+    mm = m.get_value().reshape(4096, 500).astype(np.float64)
+    assert abs(np.corrcoef(mm[:, 0], mm[:, 1])[0, 1]) < .06
+
+
+def test_scale_mask_gather_axpby():
+    rng = np.random.RandomState(1)
+    x = rng.randn(1000).astype(np.float32)
+    m = (rng.rand(1000) > .5).astype(np.uint8)
+    y = empty((1000,))
+    call("tn_scale_mask", dev(x).ptr, dev(m).ptr, .5, y.ptr, 1000, None, 0, 0.0)
+    assert_close(y.get_value(), x * .5 * m)
+    src = rng.randn(50, 12).astype(np.float32)
+    idx = rng.randint(0, 50, 20).astype(np.int32)
+    dst = empty((20, 12))
+    call("tn_gather_rows", dev(src).ptr, dev(idx).ptr, dst.ptr, 20, 48)
+    np.testing.assert_array_equal(dst.get_value(), src[idx])
+    yd = dev(x)
+    call("tn_axpby", yd.ptr, dev(x[::-1].copy()).ptr, 1000, 2.0, -1.0)
+    assert_close(yd.get_value(), 2 * x[::-1] - x)

@@ -1,0 +1,237 @@
+"""End-to-end parity of the NeuralNet drop-in against the oracle / golden fixtures:
+forward activations, logits (1e-4 rel, argmax bit-exact), every gradient, the 3-step
+weight trajectory (catches the v_old subtlety), the test functions and checkpoints."""
+import os
+import pickle
+
+import numpy as np
+import pytest
+
+from oracle import theanet_oracle as O
+from tests.gpu_util import assert_close, load_prms
+from tests.golden.make_golden import sub_index
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _cmp(got, gold, name, rtol=1e-4, atol=1e-5):
+    """Compare against a fixture entry that may be stored whole or subsampled."""
+    if name in gold:
+        assert_close(got, gold[name], rtol, atol, what=name)
+    else:
+        flat = np.asarray(got).reshape(-1)
+        assert_close(flat[sub_index(flat.size)], gold[name + "@sub"], rtol, atol, what=name + "@sub")
+        np.testing.assert_allclose(flat.sum(dtype=np.float64), gold[name + "@sum"],
+                                   rtol=1e-4, atol=1e-3 * max(1.0, float(gold[name + "@abs"]) ** .5))
+
+
+def _elastic_draws(gold, s):
+    keys = ("transln", "noise", "origin_u", "zoom_u", "theta_u", "flipmask")
+    return {k: gold["s%d_el_%s" % (s, k)] for k in keys if "s%d_el_%s" % (s, k) in gold}
+
+
+@pytest.mark.parametrize("fname,elastic_on", [("gold_a.npz", False), ("gold_b.npz", True)])
+def test_gold_mnist_three_steps(fname, elastic_on):
+    from theanet_amd import NeuralNet
+    gold = np.load(os.path.join(G, fname))
+    B, steps = 8, 3
+    prms = load_prms("mnist.prms", 28, batch=B)
+    if not elastic_on:
+        prms["layers"][0] = ("ElasticLayer", {"img_sz": 28, "invert_image": True})
+    net = NeuralNet(prms["layers"], prms["training_params"])
+    # initial weights are bit-identical (same numpy seed chain)
+    for i, lyr in enumerate(net.tr_layers):
+        for j, w in enumerate(lyr.get_wts()):
+            name = "init_%d_%d" % (i, j)
+            if name in gold:
+                np.testing.assert_array_equal(w, gold[name])
+            else:
+                np.testing.assert_array_equal(w.reshape(-1)[sub_index(w.size)], gold[name + "@sub"])
+    fn = net.get_trin_model(gold["x"], gold["y"])
+    for s in range(steps):
+        if elastic_on:
+            net.tr_layers[0].inject(**_elastic_draws(gold, s))
+        net.tr_layers[5].drop.inject(gold["s%d_mask5" % s])
+        cost, feats, logprob = fn(s)
+        assert_close(cost, gold["f32_s%d_cost" % s], what="cost step %d" % s)
+        assert_close(logprob, gold["f64_s%d_logprob" % s], what="logprob step %d" % s)
+        np.testing.assert_array_equal(logprob.argmax(1), gold["f64_s%d_logprob" % s].argmax(1))
+        if s == 0:
+            for i, lyr in enumerate(net.tr_layers[:-1]):
+                got = lyr.output.get_value()
+                want = gold["f32_s0_act%d" % i]
+                if elastic_on and i == 0:
+                    assert (got != want).mean() < 2e-3      # rounding-boundary pixels only
+                    continue
+                if elastic_on:
+                    assert_close(got.reshape(want.shape), want, 1e-3, 2e-2, what="act%d" % i)
+                else:
+                    assert_close(got.reshape(want.shape), want, what="act%d" % i)
+        for i, lyr in enumerate(net.tr_layers):
+            for j, g in enumerate(lyr.grads or ()):
+                _cmp(g.get_value(), gold, "f64_s%d_grad_%d_%d" % (s, i, j), 1e-3, 2e-6)
+    for i, lyr in enumerate(net.tr_layers):
+        for j, w in enumerate(lyr.get_wts()):
+            _cmp(w, gold, "f64_w_%d_%d" % (i, j), 1e-4, 1e-6)
+    # test function (TestVersion layers share the weights)
+    tfn = net.get_test_model(gold["x"], gold["y"], preds_feats=True)
+    sym, pm, feats, preds = tfn(0)
+    assert_close([sym, pm], gold["f64_test_stats"], what="test stats")
+    assert_close(feats, gold["f64_test_logprob"], what="test logprob")
+    np.testing.assert_array_equal(preds, gold["f64_test_preds"])
+    assert preds.dtype == np.int64
+
+
+def _random_net_case(layers, B, img, C, n_cls, seed=3, steps=2):
+    from theanet_amd import NeuralNet
+    tr = {"SEED": seed, "BATCH_SZ": B, "INIT_LEARNING_RATE": .05, "EPOCHS_TO_HALF_RATE": 1}
+    rng = np.random.RandomState(seed)
+    x = rng.rand(steps * B, C, img, img).astype(np.float32)
+    y = rng.randint(0, n_cls, steps * B).astype(np.int32)
+    import copy
+    net = NeuralNet(copy.deepcopy(layers), dict(tr))
+    ora = O.OracleNet(copy.deepcopy(layers), dict(tr), dtype=np.float64)
+    fn = net.get_trin_model(x, y)
+    for s in range(steps):
+        draws = {}
+        for i, l in enumerate(ora.L):
+            if getattr(l, "mask_rv", None) is not None:
+                m = l.mask_rv.draw((B, l.n_out))
+                draws[i] = m
+                net.tr_layers[i].drop.inject(m)
+        cost_w, lp_w, _ = ora.train_step(x[s * B:(s + 1) * B], y[s * B:(s + 1) * B], draws)
+        cost, _, lp = fn(s)
+        assert_close(lp, lp_w, 1e-4, 1e-5, what="logprob step %d" % s)
+        assert_close(cost, cost_w, 1e-4, 1e-5, what="cost step %d" % s)
+        np.testing.assert_array_equal(lp.argmax(1), lp_w.argmax(1))
+    for i, (lyr, ol) in enumerate(zip(net.tr_layers, ora.L)):
+        for j, w in enumerate(lyr.get_wts()):
+            assert_close(w, ol.params[j], 1e-4, 1e-6, what="w %d %d" % (i, j))
+    return net, ora, x, y
+
+
+def test_cifar_like_net_matches_oracle():
+    layers = [
+        ("InputLayer", {"img_sz": 16, "num_maps": 3}),
+        ("ConvLayer", {"num_maps": 8, "filter_sz": 3, "stride": 1, "mode": "same", "actvn": "relu10",
+                       "reg": {"L2": .001, "maxnorm": 2}}),
+        ("PoolLayer", {"pool_sz": 2}),
+        ("ConvLayer", {"num_maps": 16, "filter_sz": 3, "stride": 1, "mode": "same", "actvn": "relu10"}),
+        ("DropOutLayer", {"pdrop": .25}),
+        ("PoolLayer", {"pool_sz": 2}),
+        ("ConvLayer", {"num_maps": 12, "filter_sz": 3, "stride": 1, "actvn": "tanh"}),
+        ("MeanLayer", {}),
+        ("HiddenLayer", {"n_out": 40, "pdrop": .5, "reg": {"L1": .0005, "maxnorm": 3}}),
+        ("SoftmaxLayer", {"n_out": 10, "reg": {"maxnorm": 2}}),
+    ]
+    _random_net_case(layers, 32, 16, 3, 10)
+
+
+def test_mlp_3flat_like_net_matches_oracle():
+    layers = [
+        ("InputLayer", {"img_sz": 12, "num_maps": 1}),
+        ("HiddenLayer", {"n_out": 100, "pdrop": .5, "actvn": "relu10", "reg": {"L2": .001}}),
+        ("HiddenLayer", {"n_out": 30, "actvn": "scaled_tanh", "reg": {"rate": 0}}),
+        ("SoftmaxLayer", {"n_out": 57}),
+    ]
+    _random_net_case(layers, 48, 12, 1, 57)
+
+
+def test_full_batch_size_properties_mnist_4096():
+    """BASELINE config 2 size: properties that do not need the oracle at 4096."""
+    from theanet_amd import NeuralNet
+    prms = load_prms("mnist.prms", 28, batch=4096)
+    net = NeuralNet(prms["layers"], prms["training_params"])
+    rng = np.random.default_rng(0)
+    x = rng.random((8192, 1, 28, 28), dtype=np.float32)
+    y = np.random.default_rng(1).integers(0, 10, 8192).astype(np.int32)
+    fn = net.get_trin_model(x, y)
+    w0 = net.tr_layers[5].get_wts()[0]
+    cost0, _, lp = fn(0)
+    # step 0 applies the (zero) previous velocity: weights must not move (layer.py:86)
+    np.testing.assert_array_equal(net.tr_layers[5].get_wts()[0], w0)
+    assert np.isfinite(cost0) and abs(cost0 - np.log(10)) < 1.5
+    np.testing.assert_allclose(np.exp(lp).sum(1), 1, rtol=1e-4)     # rows are distributions
+    costs = [fn(i % 2)[0] for i in range(1, 30)]
+    assert np.isfinite(costs).all() and costs[-1] < cost0            # it learns the two batches
+    assert not np.array_equal(net.tr_layers[5].get_wts()[0], w0)
+    mask = net.tr_layers[5].drop.mask.get_value()
+    assert abs(mask.mean() - .5) < .01
+    # oracle cross-check of the first 64 rows of a forward pass with the current weights
+    ora = O.OracleNet(prms["layers"], prms["training_params"], allwts=net.get_init_params()["allwts"])
+    tfn = net.get_test_model(x, y, preds_feats=True)
+    sym, pm, feats, preds = tfn(1)
+    _, _, lp_w, preds_w = ora.test(x[4096:4096 + 64], y[4096:4096 + 64])
+    assert_close(feats[:64], lp_w, what="test logprob rows 0..63")
+    np.testing.assert_array_equal(preds[:64], preds_w)
+
+
+def test_checkpoint_roundtrip_and_data_test_model(tmp_path):
+    from theanet_amd import NeuralNet
+    prms = load_prms("mnist.prms", 28, batch=16)
+    net = NeuralNet(prms["layers"], prms["training_params"])
+    rng = np.random.RandomState(0)
+    x = rng.rand(32, 1, 28, 28).astype(np.float32)
+    y = rng.randint(0, 10, 32).astype(np.int32)
+    fn = net.get_trin_model(x, y)
+    for i in range(4):
+        fn(i % 2)
+    net.inc_epoch_set_rate()
+    ckpt = net.get_init_params()
+    assert set(ckpt) == {"layers", "training_params", "allwts"}
+    assert [len(w) for w in ckpt["allwts"]] == [0, 2, 0, 2, 0, 2, 2]
+    assert all(w.dtype == np.float32 for ww in ckpt["allwts"] for w in ww)
+    f = tmp_path / "net.pkl"
+    with open(f, "wb") as fh:
+        pickle.dump(ckpt, fh, -1)
+    with open(f, "rb") as fh:
+        back = pickle.load(fh)
+    net2 = NeuralNet(back["layers"], back["training_params"], back["allwts"])
+    assert net2.get_epoch() == 1
+    a = net.get_data_test_model()(x[:16])
+    b = net2.get_data_test_model(get_output_of_layers=(1,))(x[:16])
+    np.testing.assert_array_equal(a[0], b[0])
+    np.testing.assert_array_equal(a[1], b[1])
+    assert b[2].shape == (16, 4, 26, 26)
+    ora = O.OracleNet(back["layers"], dict(back["training_params"]), allwts=back["allwts"])
+    _, _, lp_w, preds_w = ora.test(x[:16], y[:16])
+    assert_close(a[0], lp_w, what="data test model logprob")
+    np.testing.assert_array_equal(a[1], preds_w)
+    net.reset_accumulated_gradients()
+    assert all((v.get_value() == 0).all() for l in net.tr_layers for v in (l.accumulated_updates or ()))
+    print(net)   # __str__ works
+    print(net.get_wts_info(detailed=True))
+
+
+def test_take_index_list_mode():
+    from theanet_amd import NeuralNet
+    prms = load_prms("mnist.prms", 28, batch=8)
+    prms["layers"][0] = ("InputLayer", {"img_sz": 28})
+    prms["layers"][5][1]["pdrop"] = 0
+    rng = np.random.RandomState(0)
+    x = rng.rand(40, 1, 28, 28).astype(np.float32)
+    y = rng.randint(0, 10, 40).astype(np.int32)
+    idx = rng.choice(40, 8, replace=False).astype(np.int32)
+    import copy
+    n1 = NeuralNet(copy.deepcopy(prms["layers"]), dict(prms["training_params"]))
+    n2 = NeuralNet(copy.deepcopy(prms["layers"]), dict(prms["training_params"]))
+    c1 = n1.get_trin_model(x, y, take_index_list=True)(idx)
+    c2 = n2.get_trin_model(x[idx], y[idx])(0)
+    np.testing.assert_array_equal(c1[2], c2[2])
+    assert c1[0] == c2[0]
+
+
+def test_errors_mirror_the_reference():
+    from theanet_amd import NeuralNet
+    tr = {"SEED": 1, "BATCH_SZ": 4, "INIT_LEARNING_RATE": .1, "EPOCHS_TO_HALF_RATE": 1}
+    with pytest.raises(AssertionError):
+        NeuralNet([("ConvLayer", {"num_maps": 2, "filter_sz": 3, "stride": 1})], dict(tr))
+    with pytest.raises(NotImplementedError):
+        NeuralNet([("InputLayer", {"img_sz": 8}),
+                   ("ConvLayer", {"num_maps": 2, "filter_sz": 3, "stride": 1, "actvn": "nope"}),
+                   ("SoftmaxLayer", {"n_out": 3})], dict(tr))
+    with pytest.raises(NotImplementedError):
+        NeuralNet([("InputLayer", {"img_sz": 8}), ("HingeLayer", {"n_out": 3})], dict(tr))
+    with pytest.raises(AttributeError):
+        NeuralNet([("InputLayer", {"img_sz": 8}), ("BogusLayer", {})], dict(tr))

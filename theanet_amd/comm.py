@@ -1,0 +1,197 @@
+"""Data-parallel plumbing: rank discovery, shard ranges, RCCL bootstrap.
+
+The reference is single-process; this is new.  One process per
+GPU, launched by ``python -m torch.distributed.run`` (RANK / LOCAL_RANK /
+WORLD_SIZE / MASTER_ADDR / MASTER_PORT in the environment).  The data path has
+exactly one exchange per step: a flat fp32 sum-all-reduce of the gradient buffer
+(RCCL over xGMI, issued by libtheanet_hip.so on the compute stream).
+
+The 128-byte RCCL unique id is exchanged with a tiny TCP rendezvous written on
+plain sockets (rank 0 listens on MASTER_PORT + 101) so the hot path never
+imports torch (torch ships its own HIP runtime).  CPU tests exercise the shard
+math and the rendezvous with world_size 2, and the host-buffer reduction through
+``torch.distributed``'s gloo backend (``HostGroup``).
+"""
+import os
+import socket
+import struct
+import time
+
+import numpy as np
+
+RDZV_PORT_OFFSET = 101
+
+
+class World:
+    def __init__(self, rank=0, size=1, local_rank=0, master_addr="127.0.0.1", master_port=29500):
+        self.rank, self.size, self.local_rank = rank, size, local_rank
+        self.master_addr, self.master_port = master_addr, master_port
+
+    @classmethod
+    def from_env(cls, env=None):
+        env = os.environ if env is None else env
+        return cls(int(env.get("RANK", 0)), int(env.get("WORLD_SIZE", 1)),
+                   int(env.get("LOCAL_RANK", 0)), env.get("MASTER_ADDR", "127.0.0.1"),
+                   int(env.get("MASTER_PORT", 29500)))
+
+
+def shard_rows(global_batch, world_size, rank):
+    """Rows [lo, hi) of a minibatch owned by ``rank`` (equal shards; the loss is a
+    batch MEAN -- outlayers.py:50-51 -- so equal shards make g = mean_r g_r)."""
+    if global_batch % world_size:
+        raise ValueError("BATCH_SZ %d is not divisible by the number of GPUs %d"
+                         % (global_batch, world_size))
+    per = global_batch // world_size
+    return rank * per, (rank + 1) * per
+
+
+def minibatch_row0(index, global_batch, world_size, rank):
+    """First dataset row of minibatch ``index`` for ``rank`` (neuralnet.py:222-224)."""
+    lo, _ = shard_rows(global_batch, world_size, rank)
+    return index * global_batch + lo
+
+
+# --------------------------------------------------------------------------- #
+# socket rendezvous: broadcast of a small blob from rank 0, and a barrier
+# --------------------------------------------------------------------------- #
+
+def _recv_exact(conn, n):
+    buf = b""
+    while len(buf) < n:
+        chunk = conn.recv(n - len(buf))
+        if not chunk:
+            raise ConnectionError("rendezvous peer closed the connection")
+        buf += chunk
+    return buf
+
+
+class Rendezvous:
+    """Star topology over TCP: rank 0 accepts world-1 connections and keeps them."""
+
+    def __init__(self, world, timeout=300.0):
+        self.world = world
+        self.conns = []          # rank 0: sockets to every other rank
+        self.sock = None         # other ranks: socket to rank 0
+        if world.size == 1:
+            return
+        port = world.master_port + RDZV_PORT_OFFSET
+        if world.rank == 0:
+            srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+            srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            srv.bind(("", port))
+            srv.listen(world.size)
+            srv.settimeout(timeout)
+            peers = {}
+            while len(peers) < world.size - 1:
+                c, _ = srv.accept()
+                c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                r = struct.unpack("<i", _recv_exact(c, 4))[0]
+                peers[r] = c
+            srv.close()
+            self.conns = [peers[r] for r in sorted(peers)]
+        else:
+            deadline = time.time() + timeout
+            while True:
+                try:
+                    s = socket.create_connection((world.master_addr, port), timeout=5.0)
+                    break
+                except OSError:
+                    if time.time() > deadline:
+                        raise
+                    time.sleep(0.05)
+            s.settimeout(timeout)
+            s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+            s.sendall(struct.pack("<i", world.rank))
+            self.sock = s
+
+    def broadcast(self, blob, nbytes):
+        """Rank 0's ``blob`` (bytes) is returned on every rank."""
+        if self.world.size == 1:
+            return blob
+        if self.world.rank == 0:
+            assert len(blob) == nbytes
+            for c in self.conns:
+                c.sendall(blob)
+            return blob
+        return _recv_exact(self.sock, nbytes)
+
+    def gather_max(self, value):
+        """max over ranks of a python float, returned on every rank (timing)."""
+        if self.world.size == 1:
+            return value
+        if self.world.rank == 0:
+            vals = [value] + [struct.unpack("<d", _recv_exact(c, 8))[0] for c in self.conns]
+            m = max(vals)
+            for c in self.conns:
+                c.sendall(struct.pack("<d", m))
+            return m
+        self.sock.sendall(struct.pack("<d", value))
+        return struct.unpack("<d", _recv_exact(self.sock, 8))[0]
+
+    def barrier(self):
+        self.gather_max(0.0)
+
+    def close(self):
+        for c in self.conns:
+            c.close()
+        if self.sock:
+            self.sock.close()
+        self.conns, self.sock = [], None
+
+
+class DeviceGroup:
+    """RCCL communicator bound to a theanet_amd Context (GPU path)."""
+
+    def __init__(self, ctx, world, rdzv=None):
+        import ctypes
+        self.ctx, self.world = ctx, world
+        self.rdzv = rdzv if rdzv is not None else Rendezvous(world)
+        idbuf = ctypes.create_string_buffer(128)
+        if world.rank == 0:
+            ctx.call("tn_comm_unique_id", idbuf)
+        blob = self.rdzv.broadcast(idbuf.raw, 128)
+        idbuf = ctypes.create_string_buffer(blob, 128)
+        ctx.call("tn_comm_init", idbuf, world.rank, world.size)
+
+    def allreduce_sum(self, darr, count=None):
+        self.ctx.call("tn_allreduce_sum", darr.ptr, darr.size if count is None else count)
+
+    def allreduce_max(self, darr, count=None):
+        self.ctx.call("tn_allreduce_max", darr.ptr, darr.size if count is None else count)
+
+    def barrier(self):
+        self.ctx.sync()
+        self.rdzv.barrier()
+
+
+class HostGroup:
+    """Same reduction contract on HOST numpy buffers through torch.distributed
+    (gloo).  Used by the CPU test-suite to cover the N>1 logic without GPUs."""
+
+    def __init__(self, world):
+        import torch.distributed as dist
+        self.world = world
+        self.dist = dist
+        if not dist.is_initialized():
+            dist.init_process_group(
+                "gloo", init_method="tcp://%s:%d" % (world.master_addr, world.master_port),
+                rank=world.rank, world_size=world.size)
+
+    def allreduce_sum(self, arr):
+        import torch
+        t = torch.from_numpy(arr)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return arr
+
+    def barrier(self):
+        self.dist.barrier()
+
+
+_world = None
+
+
+def get_world():
+    global _world
+    if _world is None:
+        _world = World.from_env()
+    return _world

@@ -1,0 +1,123 @@
+// Shared internals of libtheanet_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "../../include/theanet_hip.h"
+
+struct tn_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int num_cus = 256;
+    char err[512] = {0};
+    // RCCL (loaded lazily, comm.hip)
+    void* rccl_lib = nullptr;
+    void* comm = nullptr;
+    int rank = 0, world = 1;
+    // small persistent scratch (reductions)
+    float* scratch = nullptr;
+    size_t scratch_bytes = 0;
+};
+
+extern char g_tn_err[512];
+
+inline int tn_fail(tn_ctx* ctx, int code, const char* fmt, ...) {
+    char* dst = ctx ? ctx->err : g_tn_err;
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(dst, 512, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define TN_HIP(call)                                                                      \
+    do {                                                                                  \
+        hipError_t e_ = (call);                                                           \
+        if (e_ != hipSuccess)                                                             \
+            return tn_fail(ctx, TN_E_HIP, "%s:%d %s -> %s", __FILE__, __LINE__, #call,    \
+                           hipGetErrorString(e_));                                        \
+    } while (0)
+
+#define TN_LAUNCH_CHECK()                                                                 \
+    do {                                                                                  \
+        hipError_t e_ = hipGetLastError();                                                \
+        if (e_ != hipSuccess)                                                             \
+            return tn_fail(ctx, TN_E_HIP, "%s:%d launch -> %s", __FILE__, __LINE__,       \
+                           hipGetErrorString(e_));                                        \
+    } while (0)
+
+#define TN_REQUIRE(cond, ...)                                                             \
+    do {                                                                                  \
+        if (!(cond)) return tn_fail(ctx, TN_E_ARG, __VA_ARGS__);                          \
+    } while (0)
+
+static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// ---------------------------------------------------------------------------
+// activations (theanet/layer/layer.py:27-39).  The backward pass only keeps the
+// layer OUTPUT a, so act'(z) is expressed through a:
+//   leaky(s): a>0 -> 1 ; a<0 -> s ; a==0 -> 1+s  (Theano's Maximum/Minimum tie rule;
+//             for s==0 an exact a==0 is read as z<0 -> 0: documented in DESIGN.md)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float tn_act_fwd(float z, int act, float prm) {
+    switch (act) {
+        case TN_ACT_LEAKY: return fmaxf(0.f, z) + fminf(0.f, z) * prm;
+        case TN_ACT_TANH: return tanhf(z);
+        case TN_ACT_SIGMOID: return 1.f / (1.f + expf(-z));
+        case TN_ACT_SOFTPLUS: return z > 20.f ? z : log1pf(expf(z));
+        case TN_ACT_SCALED_TANH: return 1.7f * tanhf(2.f * z / 3.f);
+        default: return z;
+    }
+}
+
+__device__ __forceinline__ float tn_act_grad_from_out(float a, int act, float prm) {
+    switch (act) {
+        case TN_ACT_LEAKY:
+            if (a > 0.f) return 1.f;
+            if (a < 0.f) return prm;
+            return prm > 0.f ? 1.f + prm : 0.f;
+        case TN_ACT_TANH: return 1.f - a * a;
+        case TN_ACT_SIGMOID: return a * (1.f - a);
+        case TN_ACT_SOFTPLUS: return 1.f - expf(-a);
+        case TN_ACT_SCALED_TANH: {
+            float t = a * (1.f / 1.7f);
+            return (1.7f * 2.f / 3.f) * (1.f - t * t);
+        }
+        default: return 1.f;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Philox4x32-10 counter RNG: key = seed, counter = (lo(idx), hi(idx), step, stream)
+// ---------------------------------------------------------------------------
+struct u32x4 {
+    uint32_t x, y, z, w;
+};
+
+__host__ __device__ __forceinline__ u32x4 philox4x32(uint32_t c0, uint32_t c1, uint32_t c2,
+                                                     uint32_t c3, uint32_t k0, uint32_t k1) {
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint64_t p0 = (uint64_t)M0 * c0, p1 = (uint64_t)M1 * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        c1 = (uint32_t)p1;
+        c3 = (uint32_t)p0;
+        c0 = n0;
+        c2 = n2;
+        k0 += W0;
+        k1 += W1;
+    }
+    return {c0, c1, c2, c3};
+}
+
+// uniform in [0,1) with 24 bits
+__host__ __device__ __forceinline__ float tn_u01(uint32_t r) { return (r >> 8) * (1.0f / 16777216.0f); }
+
+enum { TN_STREAM_DROPOUT = 1, TN_STREAM_FLIP = 2, TN_STREAM_ELASTIC = 3, TN_STREAM_DEFORMER = 4 };

@@ -1,0 +1,291 @@
+// Elastic-distortion / noising input stage on the device.
+//   tn_elastic_draws / _field / _apply : theanet/layer/inlayers.py:63-144 (one field per batch)
+//   tn_deformer_transform              : extras/deformer.py:7-18 (one field per image)
+// Coordinates are computed in float64 exactly as the Theano CPU path does (int64 indices +
+// float32 random inputs upcast to float64); the field is tiny (2 x h x w) so fp64 is free.
+// The gather kernel is the HBM-bound part: x read once, out written once.
+#include "common.h"
+
+#define EL_HDR 8   // draws: [0:2] transln, [2:4] origin, [4:6] zoom, [6] theta, [7] pad, [8:] noise
+
+__global__ __launch_bounds__(256) void elastic_draws_kernel(float* __restrict__ draws, int total,
+                                                           uint32_t k0, uint32_t k1, uint32_t step,
+                                                           const uint32_t* d_step) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const uint32_t st = step + (d_step ? *d_step : 0u);
+    const u32x4 r = philox4x32((uint32_t)i, 0u, st, TN_STREAM_ELASTIC, k0, k1);
+    float v;
+    if (i < EL_HDR) {
+        const float u = tn_u01(r.x);
+        if (i == 2 || i == 3) v = .25f + .5f * u;   // origin  U(.25,.75)
+        else v = -1.f + 2.f * u;                    // U(-1,1)
+    } else {                                         // N(0,1), Box-Muller
+        const float u1 = ((r.x >> 8) + 1) * (1.0f / 16777216.0f);
+        const float u2 = tn_u01(r.y);
+        v = sqrtf(-2.f * logf(u1)) * cosf(6.28318530717958647692f * u2);
+    }
+    draws[i] = v;
+}
+
+// one thread per output pixel, both planes.
+__global__ __launch_bounds__(256) void elastic_field_kernel(
+    const float* __restrict__ draws, int h, int w, double translation, double zoom, double magnitude,
+    int sigma, double angle, int nearest, int32_t* __restrict__ map_idx, float* __restrict__ map_fy,
+    float* __restrict__ map_fx, double* __restrict__ target) {
+    extern __shared__ float filt[];   // (2s+1)^2, float32 like the reference's filter
+    const int ks = 2 * sigma + 1;
+    if (magnitude != 0.0) {
+        const double var = (double)sigma * sigma;
+        const float norm = (float)(2.0 * 3.14159265358979323846 * var);
+        for (int t = threadIdx.x; t < ks * ks; t += 256) {
+            const int i = t % ks - sigma, j = t / ks - sigma;
+            filt[t] = (float)exp(-.5 * (i * i + j * j) / var) / norm;
+        }
+        __syncthreads();
+    }
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= h * w) return;
+    const int y = p / w, x = p - y * w;
+    double ty = y, tx = x;
+    if (translation != 0.0) {
+        ty += (double)((float)translation * draws[0]);
+        tx += (double)((float)translation * draws[1]);
+    }
+    if (magnitude != 0.0) {
+        const float* n0 = draws + EL_HDR;
+        const float* n1 = n0 + h * w;
+        const float mag = (float)magnitude;
+        float s0 = 0.f, s1 = 0.f;
+        for (int u = 0; u < ks; ++u) {
+            const int yy = y + u - sigma;
+            if (yy < 0 || yy >= h) continue;
+            for (int v = 0; v < ks; ++v) {
+                const int xx = x + v - sigma;
+                if (xx < 0 || xx >= w) continue;
+                const float fw = filt[u * ks + v];   // symmetric: convolution == correlation
+                s0 = fmaf(fw, mag * n0[yy * w + xx], s0);
+                s1 = fmaf(fw, mag * n1[yy * w + xx], s1);
+            }
+        }
+        ty += (double)s0;
+        tx += (double)s1;
+    }
+    if (zoom != 1.0 || angle != 0.0) {
+        const double oy = (double)draws[2] * h, ox = (double)draws[3] * w;
+        ty -= oy;
+        tx -= ox;
+        if (zoom != 1.0) {
+            const double lz = log(zoom);
+            ty *= exp(lz * (double)draws[4]);
+            tx *= exp(lz * (double)draws[5]);
+        }
+        if (angle != 0.0) {
+            const double theta = (angle * 3.14159265358979323846 / 180.0) * (double)draws[6];
+            const double c = cos(theta), s = sin(theta);
+            // tensordot(R, target, axes=(0,0)) with R=[[c,-s],[s,c]] -> R^T applied
+            const double ry = c * ty + s * tx;
+            const double rx = -s * ty + c * tx;
+            ty = ry;
+            tx = rx;
+        }
+        ty += oy;
+        tx += ox;
+    }
+    if (target) {
+        target[p] = ty;
+        target[h * w + p] = tx;
+    }
+    const double cy = fmin(fmax(ty, 0.0), (double)h - 1 - .001);
+    const double cx = fmin(fmax(tx, 0.0), (double)w - 1 - .001);
+    if (nearest) {
+        map_idx[p] = (int)rint(cy) * w + (int)rint(cx);
+    } else {
+        const int top = (int)cy, left = (int)cx;
+        map_idx[p] = top * w + left;
+        map_fy[p] = (float)(cy - top);
+        map_fx[p] = (float)(cx - left);
+    }
+}
+
+__global__ __launch_bounds__(256) void elastic_apply_kernel(
+    const float* __restrict__ x, int64_t x_row0, const int64_t* __restrict__ d_row0,
+    float* __restrict__ out, long long total, int C, int hw, int w, int invert, int nearest,
+    const int32_t* __restrict__ map_idx, const float* __restrict__ map_fy,
+    const float* __restrict__ map_fx, float pflip, const uint8_t* __restrict__ flipmask, uint32_t k0,
+    uint32_t k1, uint32_t step, const uint32_t* d_step, int64_t row_global0) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= total) return;
+    const long long img = t / hw;              // n*C + c
+    const int p = (int)(t - img * hw);
+    const int64_t row_off = x_row0 + (d_row0 ? *d_row0 : 0);
+    const float* xi = x + ((size_t)row_off * C + img) * hw;
+    float v;
+    if (!map_idx) {
+        v = xi[p];
+        if (invert) v = 1.f - v;
+    } else if (nearest) {
+        v = xi[map_idx[p]];
+        if (invert) v = 1.f - v;
+    } else {
+        const int i00 = map_idx[p];
+        const float fy = map_fy[p], fx = map_fx[p];
+        float a = xi[i00], b = xi[i00 + 1], c = xi[i00 + w], d = xi[i00 + w + 1];
+        if (invert) {
+            a = 1.f - a;
+            b = 1.f - b;
+            c = 1.f - c;
+            d = 1.f - d;
+        }
+        // same association as inlayers.py:134-137
+        v = a * (1.f - fy) * (1.f - fx) + b * (1.f - fy) * fx + c * fy * (1.f - fx) + d * fy * fx;
+    }
+    if (flipmask) {
+        if (flipmask[t]) v = 1.f - v;
+    } else if (pflip > 0.f) {
+        const uint32_t st = step + (d_step ? *d_step : 0u);
+        const uint64_t e = (uint64_t)row_global0 * C * hw + (uint64_t)t;
+        const uint64_t cq = e >> 2;
+        const u32x4 r = philox4x32((uint32_t)cq, (uint32_t)(cq >> 32), st, TN_STREAM_FLIP, k0, k1);
+        const uint32_t wd = ((e & 3) == 0) ? r.x : ((e & 3) == 1) ? r.y : ((e & 3) == 2) ? r.z : r.w;
+        if (tn_u01(wd) < pflip) v = 1.f - v;
+    }
+    out[t] = v;
+}
+
+// ---- extras/deformer.py:7-18, one block per image, float64 like scipy -------------------
+__global__ __launch_bounds__(256) void deformer_kernel(const float* __restrict__ imgs,
+                                                      float* __restrict__ out, int h, int w,
+                                                      double scale, double sigma, double cval,
+                                                      const float* __restrict__ noise, uint32_t k0,
+                                                      uint32_t k1, int64_t img_global0) {
+    extern __shared__ double sm[];
+    const int hw = h * w;
+    double* tr = sm;              // [2][hw]
+    double* tmp = sm + 2 * hw;    // [2][hw]
+    double* kern = sm + 4 * hw;   // [2r+1]
+    const int r = (int)(2.0 * sigma + 0.5);
+    const int img = blockIdx.x;
+    for (int t = threadIdx.x; t <= 2 * r; t += 256) {
+        const double d = t - r;
+        kern[t] = exp(-0.5 / (sigma * sigma) * d * d);
+    }
+    __syncthreads();
+    double ksum = 0.0;
+    for (int t = 0; t <= 2 * r; ++t) ksum += kern[t];
+    __syncthreads();
+    for (int t = threadIdx.x; t <= 2 * r; t += 256) kern[t] /= ksum;
+    for (int t = threadIdx.x; t < 2 * hw; t += 256) {
+        const int a = t / hw, p = t - a * hw;
+        double u;
+        if (noise) {
+            u = (double)noise[(size_t)img * 2 * hw + t];
+        } else {
+            const uint64_t e = (uint64_t)(img_global0 + img) * 2 * hw + t;
+            const u32x4 q = philox4x32((uint32_t)e, (uint32_t)(e >> 32), 0u, TN_STREAM_DEFORMER, k0, k1);
+            u = -1.0 + 2.0 * (double)tn_u01(q.x);
+        }
+        tr[t] = (double)(a == 0 ? p / w : p % w) + scale * u;
+    }
+    __syncthreads();
+    // axis 0 (rows), edge replicated
+    for (int t = threadIdx.x; t < 2 * hw; t += 256) {
+        const int a = t / hw, p = t - a * hw, y = p / w, x = p - y * w;
+        double s = 0.0;
+        for (int k = -r; k <= r; ++k) {
+            const int yy = min(max(y + k, 0), h - 1);
+            s += kern[k + r] * tr[a * hw + yy * w + x];
+        }
+        tmp[t] = s;
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < 2 * hw; t += 256) {
+        const int a = t / hw, p = t - a * hw, y = p / w, x = p - y * w;
+        double s = 0.0;
+        for (int k = -r; k <= r; ++k) {
+            const int xx = min(max(x + k, 0), w - 1);
+            s += kern[k + r] * tmp[a * hw + y * w + xx];
+        }
+        tr[t] = s;
+    }
+    __syncthreads();
+    const float* im = imgs + (size_t)img * hw;
+    for (int p = threadIdx.x; p < hw; p += 256) {
+        const double cy = tr[p], cx = tr[hw + p];
+        double v;
+        if (cy < 0.0 || cy > h - 1 || cx < 0.0 || cx > w - 1) {
+            v = cval;
+        } else {
+            const int y0 = (int)floor(cy), x0 = (int)floor(cx);
+            const double fy = cy - y0, fx = cx - x0;
+            auto tap = [&](int yy, int xx) -> double {
+                return (yy >= 0 && yy < h && xx >= 0 && xx < w) ? (double)im[yy * w + xx] : cval;
+            };
+            v = tap(y0, x0) * (1 - fy) * (1 - fx) + tap(y0, x0 + 1) * (1 - fy) * fx +
+                tap(y0 + 1, x0) * fy * (1 - fx) + tap(y0 + 1, x0 + 1) * fy * fx;
+        }
+        out[(size_t)img * hw + p] = (float)v;
+    }
+}
+
+extern "C" {
+
+size_t tn_elastic_draws_count(int h, int w) { return (size_t)EL_HDR + 2 * (size_t)h * w; }
+
+int tn_elastic_draws(tn_ctx* ctx, float* draws, int h, int w, uint64_t seed, uint32_t step,
+                     const uint32_t* d_step) {
+    const int total = (int)tn_elastic_draws_count(h, w);
+    elastic_draws_kernel<<<cdiv(total, 256), 256, 0, ctx->stream>>>(
+        draws, total, (uint32_t)seed, (uint32_t)(seed >> 32), step, d_step);
+    TN_LAUNCH_CHECK();
+    return TN_OK;
+}
+
+int tn_elastic_field(tn_ctx* ctx, const float* draws, int h, int w, double translation, double zoom,
+                     double magnitude, int sigma, double angle, int nearest, int32_t* map_idx,
+                     float* map_fy, float* map_fx, double* target) {
+    TN_REQUIRE(h > 0 && w > 0 && zoom > 0 && sigma >= 0 && map_idx != nullptr,
+               "tn_elastic_field: bad arguments");
+    TN_REQUIRE(nearest || (map_fy && map_fx), "tn_elastic_field: bilinear needs map_fy/map_fx");
+    const int ks = 2 * sigma + 1;
+    const size_t lds = (size_t)ks * ks * sizeof(float);
+    TN_REQUIRE(lds <= 64 * 1024, "tn_elastic_field: sigma %d too large", sigma);
+    elastic_field_kernel<<<cdiv(h * w, 256), 256, lds, ctx->stream>>>(
+        draws, h, w, translation, zoom, magnitude, sigma, angle, nearest, map_idx, map_fy, map_fx,
+        target);
+    TN_LAUNCH_CHECK();
+    return TN_OK;
+}
+
+int tn_elastic_apply(tn_ctx* ctx, const float* x, int64_t x_row0, const int64_t* d_row0, float* out,
+                     int N, int C, int h, int w, int invert, int nearest, const int32_t* map_idx,
+                     const float* map_fy, const float* map_fx, float pflip, const uint8_t* flipmask,
+                     uint64_t seed, uint32_t step, const uint32_t* d_step, int64_t row_global0) {
+    TN_REQUIRE(N > 0 && C > 0 && h > 0 && w > 0, "tn_elastic_apply: bad shape");
+    const long long total = (long long)N * C * h * w;
+    elastic_apply_kernel<<<cdiv(total, 256), 256, 0, ctx->stream>>>(
+        x, x_row0, d_row0, out, total, C, h * w, w, invert, nearest, map_idx, map_fy, map_fx, pflip,
+        flipmask, (uint32_t)seed, (uint32_t)(seed >> 32), step, d_step, row_global0);
+    TN_LAUNCH_CHECK();
+    return TN_OK;
+}
+
+int tn_deformer_transform(tn_ctx* ctx, const float* imgs, float* out, int N, int h, int w,
+                          double scale, double sigma, double cval, const float* noise, uint64_t seed,
+                          int64_t img_global0) {
+    TN_REQUIRE(N > 0 && h > 0 && w > 0 && sigma > 0, "tn_deformer_transform: bad arguments");
+    const int r = (int)(2.0 * sigma + 0.5);
+    const size_t lds = ((size_t)4 * h * w + 2 * r + 1) * sizeof(double);
+    TN_REQUIRE(lds <= 160 * 1024, "tn_deformer_transform: image %dx%d (sigma %g) exceeds LDS", h, w,
+               sigma);
+    if (lds > 64 * 1024) {
+        TN_HIP(hipFuncSetAttribute((const void*)deformer_kernel,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
+    deformer_kernel<<<N, 256, lds, ctx->stream>>>(imgs, out, h, w, scale, sigma, cval, noise,
+                                                  (uint32_t)seed, (uint32_t)(seed >> 32), img_global0);
+    TN_LAUNCH_CHECK();
+    return TN_OK;
+}
+
+}  // extern "C"

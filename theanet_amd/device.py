@@ -1,0 +1,152 @@
+"""Device context and device-resident arrays.
+
+Counterpart of the reference's ``theano.shared`` variables (train.py:18-19,
+theanet/layer/weights.py:18-22,73-79): datasets, weights, velocities and every
+activation live in HBM for the life of the net; only the minibatch index crosses
+the host/device boundary per step.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+from . import _lib
+
+_context = None
+
+
+class Context:
+    """One tn_ctx: one GPU, one HIP stream.  One process drives one GPU
+    (LOCAL_RANK picks it when launched by torch.distributed.run)."""
+
+    def __init__(self, device=None):
+        self.lib = _lib.get_lib()
+        if device is None:
+            device = int(os.environ.get("LOCAL_RANK", "0"))
+        h = ctypes.c_void_p()
+        rc = self.lib.tn_ctx_create(device, ctypes.byref(h))
+        if rc != 0:
+            msg = self.lib.tn_last_error(None)
+            raise _lib.BackendError(
+                "theanet_amd needs an AMD GPU (MI355X/gfx950); tn_ctx_create(%d) failed: %s. "
+                "There is no CPU fallback." % (device, msg.decode() if msg else "?"))
+        self.h = h
+        self.device = device
+
+    def call(self, name, *args):
+        rc = getattr(self.lib, name)(self.h, *args)
+        if rc != 0:
+            _lib.check(self.h, rc, name)
+
+    def sync(self):
+        self.call("tn_sync")
+
+    def info(self):
+        name = ctypes.create_string_buffer(128)
+        cus = ctypes.c_int()
+        mem = ctypes.c_size_t()
+        self.call("tn_device_info", name, 128, ctypes.byref(cus), ctypes.byref(mem))
+        return name.value.decode(), cus.value, mem.value
+
+    # -- allocation ----------------------------------------------------------
+    def empty(self, shape, dtype=np.float32):
+        return DeviceArray(self, shape, dtype)
+
+    def zeros(self, shape, dtype=np.float32):
+        a = DeviceArray(self, shape, dtype)
+        a.fill_bytes(0)
+        return a
+
+    def array(self, data, dtype=None):
+        data = np.ascontiguousarray(data, dtype=dtype)
+        a = DeviceArray(self, data.shape, data.dtype)
+        a.set_value(data)
+        return a
+
+
+def get_context():
+    """Process-wide context (created on first use; raises without a GPU)."""
+    global _context
+    if _context is None:
+        _context = Context()
+    return _context
+
+
+class DeviceArray:
+    """Typed view of HBM.  ``get_value``/``set_value`` mirror the reference's
+    shared-variable accessors (weights.py:18-22)."""
+
+    def __init__(self, ctx, shape, dtype=np.float32, ptr=None, base=None):
+        self.ctx = ctx
+        self.shape = tuple(int(s) for s in (shape if hasattr(shape, "__len__") else (shape,)))
+        self.dtype = np.dtype(dtype)
+        self.size = int(np.prod(self.shape)) if self.shape else 1
+        self.nbytes = self.size * self.dtype.itemsize
+        self.base = base            # keeps the owning allocation alive for views
+        if ptr is None:
+            p = ctypes.c_void_p()
+            ctx.call("tn_alloc", self.nbytes, ctypes.byref(p))
+            self.ptr = p.value
+            self._owns = True
+        else:
+            self.ptr = int(ptr)
+            self._owns = False
+
+    @property
+    def ndim(self):
+        return len(self.shape)
+
+    def __len__(self):
+        return self.shape[0]
+
+    def view(self, offset_elems, shape, dtype=None):
+        dtype = self.dtype if dtype is None else np.dtype(dtype)
+        return DeviceArray(self.ctx, shape, dtype,
+                           ptr=self.ptr + offset_elems * self.dtype.itemsize,
+                           base=self.base or self)
+
+    def reshape(self, *shape):
+        if len(shape) == 1 and hasattr(shape[0], "__len__"):
+            shape = tuple(shape[0])
+        if -1 in shape:
+            known = -int(np.prod(shape))
+            shape = tuple(self.size // known if s == -1 else s for s in shape)
+        assert int(np.prod(shape)) == self.size
+        return DeviceArray(self.ctx, shape, self.dtype, ptr=self.ptr, base=self.base or self)
+
+    def flatten(self, ndim=1):
+        """``tensor.flatten(2)`` of the reference (neuralnet.py:168-169)."""
+        if ndim == 2:
+            return self.reshape(self.shape[0], -1)
+        return self.reshape(self.size)
+
+    def get_value(self, borrow=True):
+        out = np.empty(self.shape, self.dtype)
+        self.ctx.call("tn_d2h", out.ctypes.data, self.ptr, self.nbytes)
+        return out
+
+    def set_value(self, data):
+        data = np.ascontiguousarray(data, dtype=self.dtype)
+        assert data.size == self.size, (data.shape, self.shape)
+        self.ctx.call("tn_h2d", self.ptr, data.ctypes.data, self.nbytes)
+
+    def fill_bytes(self, byte):
+        self.ctx.call("tn_memset", self.ptr, byte, self.nbytes)
+
+    def __del__(self):
+        if getattr(self, "_owns", False) and self.ptr:
+            try:
+                self.ctx.lib.tn_free(self.ctx.h, self.ptr)
+            except Exception:   # interpreter teardown
+                pass
+            self.ptr = 0
+
+    def __repr__(self):
+        return "DeviceArray(shape=%s, dtype=%s, ptr=0x%x)" % (self.shape, self.dtype, self.ptr)
+
+
+def share(data, dtype=np.float32, borrow=True):
+    """train.py:18-19 ``share()``: put a host array in HBM once."""
+    if isinstance(data, DeviceArray):
+        return data
+    return get_context().array(np.asarray(data), dtype=dtype)

@@ -1,0 +1,185 @@
+"""Conv / Pool / Mean layers -- host mirror of theanet/layer/convpool.py.
+Same constructor arguments, shape rules and ``representation`` strings; the
+compute is enqueued on the HIP backend (include/theanet_hip.h)."""
+import math
+
+from .. import _lib
+from .layer import Layer, activation_by_name
+from .weights import init_wb
+
+
+class ConvLayer(Layer):
+    def __init__(self, inpt, wts, rand_gen,
+                 batch_sz, num_prev_maps, in_sz,
+                 num_maps, filter_sz, stride,
+                 mode='valid',
+                 actvn='relu50',
+                 reg=()):
+        assert (wts is not None or rand_gen is not None)
+        assert mode in ("valid", "full", "same")
+        if mode == "full":
+            raise NotImplementedError(
+                "ConvLayer mode 'full': the reference computes out_sz = in+f+1 "
+                "(convpool.py:63-64), which no backend can honour")
+
+        filter_shape = (num_maps, num_prev_maps, filter_sz, filter_sz)
+        fan_in = num_prev_maps * filter_sz * filter_sz
+        fan_out = num_maps * filter_sz * filter_sz
+        self.W, self.b = init_wb(wts, rand_gen, filter_shape, (filter_shape[0], ),
+                                 fan_in, fan_out, actvn, 'Conv')
+
+        if mode == 'same':
+            assert stride == 1, "For Same mode stride should be 1"
+            shift = (filter_sz - 1) // 2
+            self.pad_lo, pad_hi = filter_sz - 1 - shift, shift
+            self.out_sz = in_sz
+        else:
+            self.pad_lo, pad_hi = 0, 0
+            self.out_sz = in_sz - filter_sz + 1
+        self.out_sz //= stride
+        theano_out = (in_sz + self.pad_lo + pad_hi - filter_sz) // stride + 1
+        assert self.out_sz == theano_out, (
+            "stride {} must divide the stride-1 output size {}".format(
+                stride, in_sz + self.pad_lo + pad_hi - filter_sz + 1))
+
+        self.act = activation_by_name(actvn)
+        assert self.act.kind is not None, "softmax is not a conv activation"
+        self.ctx = self.W.ctx
+        self.inpt = inpt
+        self.batch_sz, self.num_prev_maps, self.in_sz = batch_sz, num_prev_maps, in_sz
+        self.filter_sz, self.stride = filter_sz, stride
+        self.output = self.ctx.empty((batch_sz, num_maps, self.out_sz, self.out_sz))
+        self.gin = None
+
+        self.params = [self.W, self.b]
+        self.num_maps = num_maps
+        self.mode = mode
+        self.n_out = num_maps * self.out_sz ** 2
+        self.reg = {"L1": 0, "L2": 0,
+                    "momentum": .95,
+                    "rate": 1,
+                    "maxnorm": 0, }
+        self.reg.update(reg)
+
+        self.args = (batch_sz, num_prev_maps, in_sz, num_maps, filter_sz,
+                     stride, mode, actvn, reg)
+        self.representation = (
+            "Conv Maps:{:2d} Filter:{} Stride:{} Mode:{} Output:{:2d} "
+            "Act:{}\n\t  L1:{L1} L2:{L2} Momentum:{momentum} Rate:{rate} Max Norm:{maxnorm}"
+            "".format(num_maps, filter_sz, stride, mode, self.out_sz,
+                      actvn, **self.reg))
+
+    def TestVersion(self, inpt):
+        return ConvLayer(inpt, (self.W, self.b), None, *self.args)
+
+    def act_info(self):
+        return self.output, self.act.kind, self.act.prm, None
+
+    def _geom(self):
+        return (self.batch_sz, self.num_prev_maps, self.in_sz, self.in_sz, self.num_maps,
+                self.filter_sz, self.stride, self.pad_lo, self.out_sz, self.out_sz)
+
+    def forward(self, train=True):
+        self.ctx.call("tn_conv2d_fwd", self.inpt.ptr, self.W.ptr, self.b.ptr, self.output.ptr,
+                      *self._geom(), self.act.kind, self.act.prm)
+
+    def backward(self, gout, need_gin, below):
+        """gout = d cost / d z of this layer (activation gradient already fused in)."""
+        if self.has_updates():
+            self.ctx.call("tn_conv2d_wgrad", self.inpt.ptr, gout.ptr, self.grads[0].ptr,
+                          self.grads[1].ptr, *self._geom())
+        if not need_gin:
+            return None
+        if self.gin is None:
+            self.gin = self.ctx.empty(self.inpt.shape)
+        b_out, b_act, b_prm, b_mask = below.act_info()
+        assert b_mask is None
+        self.ctx.call("tn_conv2d_dgrad", gout.ptr, self.W.ptr, self.gin.ptr, *self._geom(),
+                      b_out.ptr if b_out is not None and b_act != _lib.TN_ACT_LINEAR else None,
+                      b_act, b_prm)
+        return self.gin
+
+
+class PoolLayer(Layer):
+    def __init__(self, inpt, num_maps, in_sz, pool_sz, ignore_border=False):
+        """Max-pool, stride = window.  ignore_border=False keeps the partial last
+        window: (5,5) with pool 2 -> (3,3); True -> (2,2) (convpool.py:98-112)."""
+        if ignore_border:
+            self.out_sz = in_sz // pool_sz
+        else:
+            self.out_sz = math.ceil(in_sz / pool_sz)
+
+        self.ctx = inpt.ctx
+        self.params = []
+        self.inpt = inpt
+        self.num_maps = num_maps
+        self.in_sz, self.pool_sz = in_sz, pool_sz
+        self.ignore_border = ignore_border
+        self.args = (num_maps, in_sz, pool_sz, ignore_border)
+        self.n_out = num_maps * self.out_sz ** 2
+        self.batch_sz = inpt.shape[0]
+        self.output = self.ctx.empty((self.batch_sz, num_maps, self.out_sz, self.out_sz))
+        self.gin = None
+        self.representation = (
+            "Pool Maps:{:2d} Pool_sz:{} Border:{} Output:{:2d}"
+            "".format(num_maps, pool_sz,
+                      "Ignore" if ignore_border else "Keep",
+                      self.out_sz))
+
+    def TestVersion(self, inpt):
+        return PoolLayer(inpt, *self.args)
+
+    def forward(self, train=True):
+        self.ctx.call("tn_pool_fwd", self.inpt.ptr, self.output.ptr,
+                      self.batch_sz * self.num_maps, self.in_sz, self.in_sz, self.pool_sz,
+                      self.out_sz, self.out_sz)
+
+    def backward(self, gout, need_gin, below):
+        if not need_gin:
+            return None
+        if self.gin is None:
+            self.gin = self.ctx.empty(self.inpt.shape)
+        b_out, b_act, b_prm, b_mask = below.act_info()
+        assert b_mask is None
+        # below.output IS self.inpt, so the activation gradient rides along for free
+        self.ctx.call("tn_pool_bwd", self.inpt.ptr, self.output.ptr, gout.ptr, self.gin.ptr,
+                      self.batch_sz * self.num_maps, self.in_sz, self.in_sz, self.pool_sz,
+                      self.out_sz, self.out_sz, b_act, b_prm)
+        return self.gin
+
+
+class MeanLayer(Layer):
+    def __init__(self, inpt, num_maps, in_sz):
+        self.ctx = inpt.ctx
+        self.params = []
+        self.inpt = inpt
+        self.num_maps = num_maps
+        self.in_sz = in_sz
+        self.out_sz = 1
+        self.n_out = num_maps
+        self.batch_sz = inpt.shape[0]
+        self.output = self.ctx.empty((self.batch_sz, num_maps))
+        self.gin = None
+        self.representation = (
+            "Mean Maps:{:2d} Output:{:2d}"
+            "".format(num_maps, self.out_sz))
+
+    def TestVersion(self, inpt):
+        return MeanLayer(inpt, self.num_maps, self.in_sz)
+
+    def forward(self, train=True):
+        self.ctx.call("tn_mean_fwd", self.inpt.ptr, self.output.ptr,
+                      self.batch_sz * self.num_maps, self.in_sz * self.in_sz)
+
+    def backward(self, gout, need_gin, below):
+        if not need_gin:
+            return None
+        if self.gin is None:
+            self.gin = self.ctx.empty(self.inpt.shape)
+        b_out, b_act, b_prm, b_mask = below.act_info()
+        assert b_mask is None
+        self.ctx.call("tn_mean_bwd", gout.ptr, self.gin.ptr, self.batch_sz * self.num_maps,
+                      self.in_sz * self.in_sz,
+                      b_out.ptr if b_out is not None and b_act != _lib.TN_ACT_LINEAR else None,
+                      b_act, b_prm)
+        return self.gin

@@ -1,0 +1,190 @@
+"""Input layers -- host mirror of theanet/layer/inlayers.py.
+
+``InputLayer`` passes the minibatch through; ``ElasticLayer`` is the in-graph
+augmentation stage: invert -> one random coordinate field per CALL (translation,
+gaussian-smoothed elastic displacement, zoom, rotation; shared by every image and
+channel of the batch) -> clip -> nearest/bilinear resample -> pixel-flip noise
+(:63-144).  The field is built on the device in float64 from a small vector of
+random draws which either comes from the on-device Philox generator or is
+injected by a parity test (``inject``).  The test version is identity + invert
+(:157-163).
+"""
+import numpy as np
+
+from .layer import Layer
+
+
+class InputSlot:
+    """Stand-in for the reference's symbolic ``x`` (neuralnet.py:79): a window of
+    ``batch`` rows into a device-resident dataset, moved by the step functions."""
+
+    def __init__(self, batch):
+        self.batch = batch
+        self.data = None        # DeviceArray (N, C, H, W)
+        self.row0 = 0           # first row of the current minibatch (this rank's shard)
+        self.row_global0 = 0    # same, as a global sample index (for sharding-proof RNG)
+        self.d_row0 = None      # optional device-side offset (graph replay)
+
+    def bind(self, data):
+        self.data = data
+
+
+class InputLayer(Layer):
+    def __init__(self, inpt, img_sz, num_maps=1, rand_gen=None):
+        self.params = []
+        self.inpt = inpt
+        self.out_sz = img_sz
+        self.num_maps = num_maps
+        self.n_out = self.num_maps * self.out_sz ** 2
+        self.representation = \
+            'Input Maps:{} Sizes Input:{:2d} Output:{:2d}'.format(num_maps,
+                                                                  img_sz,
+                                                                  img_sz)
+        from ..device import get_context
+        self.ctx = get_context()
+        self.batch_sz = inpt.batch
+        self.output = self.ctx.empty((self.batch_sz, num_maps, img_sz, img_sz))
+
+    def TestVersion(self, inpt):
+        return InputLayer(inpt, self.out_sz, self.num_maps)
+
+    def forward(self, train=True):
+        s = self.inpt
+        self.ctx.call("tn_elastic_apply", s.data.ptr, int(s.row0),
+                      s.d_row0.ptr if s.d_row0 is not None else None, self.output.ptr,
+                      self.batch_sz, self.num_maps, self.out_sz, self.out_sz, 0, 1,
+                      None, None, None, 0.0, None, 0, 0, None, int(s.row_global0))
+
+
+class ElasticLayer(Layer):
+    def __init__(self, inpt, img_sz,
+                 num_maps=1,
+                 translation=0,
+                 zoom=1,
+                 magnitude=0,
+                 sigma=1,
+                 pflip=0,
+                 angle=0,
+                 rand_gen=None,
+                 invert_image=False,
+                 nearest=False):
+        self.inpt = inpt
+        self.img_sz = img_sz
+        self.translation = translation
+        self.zoom = zoom
+        self.magnitude = magnitude
+        self.sigma = sigma
+        self.pflip = pflip
+        self.angle = angle
+        self.invert = invert_image
+        self.nearest = nearest
+
+        self.out_sz = img_sz
+        self.num_maps = num_maps
+        self.n_out = self.num_maps * self.out_sz ** 2
+        self.params = []
+        self.representation = ('Elastic Maps:{:d} Size:{:2d} Translation:{:} '
+                               'Zoom:{} Mag:{:d} Sig:{:d} Noise:{} '
+                               'Angle:{} Invert:{} '
+                               'Interpolation:{}'.format(
+            self.num_maps, img_sz,
+            translation, zoom, magnitude, sigma,
+            pflip, angle, invert_image,
+            'Nearest' if nearest else 'Linear'))
+
+        from ..device import get_context
+        self.ctx = ctx = get_context()
+        self.batch_sz = inpt.batch if isinstance(inpt, InputSlot) else inpt.shape[0]
+        self.output = ctx.empty((self.batch_sz, num_maps, img_sz, img_sz))
+
+        assert zoom > 0
+        self.active = bool(magnitude or translation or pflip or angle) or zoom != 1
+        self.has_field = bool(magnitude or translation or angle) or zoom != 1
+        self.d_step = None
+        self._inj_draws = False
+        self._inj_flip = None
+        if not self.active:
+            return
+
+        # the stream seed consumes the seed chain exactly like inlayers.py:72-73
+        self.seed = int(rand_gen.randint(1e6)) if rand_gen is not None \
+            else int(np.random.randint(0, 1e6))
+        h = w = img_sz
+        n_draws = ctx.lib.tn_elastic_draws_count(h, w)
+        self.draws = ctx.zeros((n_draws,))
+        self.map_idx = ctx.empty((h * w,), np.int32)
+        self.map_fy = ctx.empty((h * w,))
+        self.map_fx = ctx.empty((h * w,))
+        self.target = ctx.empty((2, h, w), np.float64)     # debugout[1] + indices (:146)
+
+    def TestVersion(self, te_inpt):
+        return ElasticLayer(te_inpt, self.img_sz,
+                            num_maps=self.num_maps,
+                            translation=0, zoom=1,
+                            magnitude=0, sigma=1,
+                            pflip=0, angle=0,
+                            invert_image=self.invert,
+                            nearest=self.nearest)
+
+    # -- parity hooks -----------------------------------------------------------------
+    def inject(self, transln=None, noise=None, origin_u=None, zoom_u=None, theta_u=None,
+               flipmask=None):
+        """Replace the device RNG by explicit draws (layout: include/theanet_hip.h).
+        Call with no arguments to return to the generator."""
+        if all(v is None for v in (transln, noise, origin_u, zoom_u, theta_u, flipmask)):
+            self._inj_draws, self._inj_flip = False, None
+            return
+        h = w = self.img_sz
+        d = np.zeros(self.draws.size, np.float32)
+        if transln is not None:
+            d[0:2] = np.asarray(transln, np.float32).reshape(2)
+        if origin_u is not None:
+            d[2:4] = np.asarray(origin_u, np.float32).reshape(2)
+        if zoom_u is not None:
+            d[4:6] = np.asarray(zoom_u, np.float32).reshape(2)
+        if theta_u is not None:
+            d[6] = np.float32(theta_u)
+        if noise is not None:
+            d[8:] = np.asarray(noise, np.float32).reshape(2 * h * w)
+        self.draws.set_value(d)
+        self._inj_draws = True
+        if flipmask is not None:
+            self._inj_flip = self.ctx.array(
+                np.asarray(flipmask).reshape(self.output.shape).astype(np.uint8))
+
+    def forward(self, train=True):
+        s = self.inpt
+        if isinstance(s, InputSlot):
+            x_ptr, row0, d_row0, rg0 = s.data.ptr, int(s.row0), s.d_row0, int(s.row_global0)
+        else:       # mid-net elastic layer (neuralnet.py:132-142): plain device tensor
+            x_ptr, row0, d_row0, rg0 = s.ptr, 0, None, 0
+        h = w = self.img_sz
+        d_row0_ptr = d_row0.ptr if d_row0 is not None else None
+        if not self.active:
+            self.ctx.call("tn_elastic_apply", x_ptr, row0, d_row0_ptr, self.output.ptr,
+                          self.batch_sz, self.num_maps, h, w, int(self.invert), 1,
+                          None, None, None, 0.0, None, 0, 0, None, rg0)
+            return
+        d_step_ptr = self.d_step.ptr if self.d_step is not None else None
+        if self.has_field:
+            if not self._inj_draws:
+                self.ctx.call("tn_elastic_draws", self.draws.ptr, h, w, self.seed, 0, d_step_ptr)
+            self.ctx.call("tn_elastic_field", self.draws.ptr, h, w, float(self.translation),
+                          float(self.zoom), float(self.magnitude), int(self.sigma),
+                          float(self.angle), int(self.nearest), self.map_idx.ptr,
+                          self.map_fy.ptr, self.map_fx.ptr, self.target.ptr)
+        self.ctx.call("tn_elastic_apply", x_ptr, row0, d_row0_ptr, self.output.ptr,
+                      self.batch_sz, self.num_maps, h, w, int(self.invert), int(self.nearest),
+                      self.map_idx.ptr if self.has_field else None,
+                      self.map_fy.ptr, self.map_fx.ptr,
+                      float(self.pflip) if self._inj_flip is None else 0.0,
+                      self._inj_flip.ptr if self._inj_flip is not None else None,
+                      self.seed, 0, d_step_ptr, rg0)
+
+    @property
+    def debugout(self):
+        """[output, displacement field] like inlayers.py:145-147 (host copies)."""
+        if not self.active or not self.has_field:
+            return [self.output.get_value(), np.zeros(2)]
+        h = w = self.img_sz
+        return [self.output.get_value(), self.target.get_value() - np.indices((h, w))]

@@ -1,0 +1,428 @@
+"""NeuralNet -- the drop-in for theanet/neuralnet.py on MI355X.
+
+Same constructor, same ``.prms`` layer-spec surface and the same methods as the
+reference class (neuralnet.py:59-332), but instead of building twin Theano graphs
+and compiling them, construction plans device buffers (weights, activations,
+gradients all resident in HBM) and the step functions enqueue hand-written HIP
+kernels through the C-ABI of libtheanet_hip.so.  Per training step only the
+minibatch index crosses the host/device boundary.
+
+Data-parallel: one process per GPU (RANK/WORLD_SIZE from torch.distributed.run);
+rank r works on rows [i*B + r*B/R, i*B + (r+1)*B/R) of minibatch i and the flat
+gradient buffer (+ the scalar cost) is sum-all-reduced once per step over RCCL.
+"""
+from functools import reduce
+from operator import mul
+
+import numpy as np
+
+from . import comm, layer
+from .device import DeviceArray, get_context, share
+from .layer import (ConvLayer, DropOutLayer, ElasticLayer, HiddenLayer, InputLayer, InputSlot,
+                    MeanLayer, PoolLayer, SoftmaxLayer)
+
+# ########################### Helper Functions #################################
+
+
+def get_layers_info(layers):
+    out = []
+    for name, args in layers:
+        out.append('\n{} : '.format(name))
+        out.extend('\n\t{} : \t{}'.format(key, args[key]) for key in args)
+    return ''.join(out)
+
+
+def get_wts_info(wts, detailed=False):
+    out, n_wts = [], 0
+    for l, ww in enumerate(wts):
+        out.append("\nLayer {}:".format(l))
+        for w in ww:
+            n_ww = reduce(mul, w.shape)
+            n_wts += n_ww
+            out.append('\n\t {} {} ❲{}❳'.format(w.shape, w.dtype, n_ww))
+            if detailed:
+                out.append(" ❲{:.2e}, {:.2e}, {:.2e}❳".format(w.min(), w.mean(), w.max()))
+    out.append('\n\nTotal Number of Weights : {:,}'.format(n_wts))
+    return ''.join(out)
+
+
+def get_training_params_info(training_params):
+    return "Training Parameters:" + ''.join(
+        '\n\t{} : \t{}'.format(key, training_params[key]) for key in sorted(training_params))
+
+
+_GRAD_ALIGN = 64      # floats: every tensor in the flat gradient buffer starts 256-byte aligned
+
+
+# ###############################################################################
+#                            Compiled step functions
+# ###############################################################################
+
+
+class _TrainFn:
+    """What ``get_trin_model`` returns: ``fn(i) -> [cost, features, logprob]``
+    (neuralnet.py:236-241).  ``enqueue(i)`` issues the step without reading anything
+    back (the GPU runs ahead of the host); ``fetch()`` copies the last step's outputs."""
+
+    def __init__(self, net, x_data, y_data, take_index_list):
+        self.net, self.x_data, self.y_data = net, x_data, y_data
+        self.take_index_list = take_index_list
+        ctx = net.ctx
+        if take_index_list:
+            row = int(np.prod(x_data.shape[1:]))
+            self.x_stage = ctx.empty((net.local_bsz,) + tuple(x_data.shape[1:]))
+            self.y_stage = ctx.empty((net.local_bsz,), np.int32)
+            self.idx_dev = ctx.empty((net.local_bsz,), np.int32)
+            self.row_bytes = row * 4
+
+    def enqueue(self, i):
+        net, ctx = self.net, self.net.ctx
+        B, lo = net.batch_sz, net.shard_lo
+        slot = net.x
+        if self.take_index_list:
+            idx = np.ascontiguousarray(np.asarray(i, np.int32)[lo:lo + net.local_bsz])
+            self.idx_dev.set_value(idx)
+            ctx.call("tn_gather_rows", self.x_data.ptr, self.idx_dev.ptr, self.x_stage.ptr,
+                     net.local_bsz, self.row_bytes)
+            ctx.call("tn_gather_rows", self.y_data.ptr, self.idx_dev.ptr, self.y_stage.ptr,
+                     net.local_bsz, 4)
+            slot.bind(self.x_stage)
+            slot.row0, y, y_row0 = 0, self.y_stage, 0
+        else:
+            slot.bind(self.x_data)
+            slot.row0 = int(i) * B + lo
+            y, y_row0 = self.y_data, slot.row0
+        slot.row_global0 = lo
+        net._train_step(y, y_row0)
+
+    def fetch(self):
+        net = self.net
+        out = net.tr_layers[-1]
+        cost = net.d_cost.get_value()[0]
+        logprob = out.logprob.get_value()
+        return [cost, logprob, logprob]      # features IS logprob for Softmax (outlayers.py:92-93)
+
+    def __call__(self, i):
+        self.enqueue(i)
+        return self.fetch()
+
+
+class _TestFn:
+    """``get_test_model``'s function: ``fn(i) -> [sym_err, P(MLE)](, features, y_preds)``."""
+
+    def __init__(self, net, x_data, y_data, preds_feats):
+        self.net, self.x_data, self.y_data, self.preds_feats = net, x_data, y_data, preds_feats
+
+    def __call__(self, i):
+        net, ctx = self.net, self.net.ctx
+        slot = net.test_x
+        slot.bind(self.x_data)
+        slot.row0 = int(i) * net.batch_sz + net.shard_lo
+        slot.row_global0 = net.shard_lo
+        out = net.te_layers[-1]
+        for lyr in net.te_layers[:-1]:
+            lyr.forward(False)
+        out.forward(False, y=self.y_data, y_row0=slot.row0)
+        ctx.call("tn_error_stats", out.y_preds.ptr, self.y_data.ptr, slot.row0, out.rowp.ptr,
+                 net.local_bsz, out.d_stats.ptr)
+        if net.world.size > 1:
+            net._group().allreduce_sum(out.d_stats)
+        stats = out.d_stats.get_value() / net.world.size
+        res = [stats[0], stats[1]]
+        if self.preds_feats:
+            res += [out.features.get_value(), out.y_preds.get_value().astype(np.int64)]
+        return res
+
+
+# ###############################################################################
+#                            The Neural Network
+# ###############################################################################
+
+
+class NeuralNet():
+    def __init__(self, layers, training_params, allwts=None,
+                 test_x=None):
+        # Either a random seed or the weights of a previously trained net (neuralnet.py:63-68)
+        if allwts is None:
+            self.rand_gen = np.random.RandomState(training_params['SEED'])
+        else:
+            self.rand_gen = None
+
+        self.ctx = get_context()             # raises without libtheanet_hip.so / a GPU
+        self.world = comm.get_world()
+        self._dev_group = None
+
+        self.tr_prms = training_params
+        self.layers = layers
+        self.allwts = allwts
+        self.tr_layers = []
+        self.te_layers = []
+        self.batch_sz = training_params['BATCH_SZ']
+        self.shard_lo, hi = comm.shard_rows(self.batch_sz, self.world.size, self.world.rank)
+        self.local_bsz = hi - self.shard_lo
+        self.num_layers = 0
+
+        # "symbolic variables": windows into device-resident datasets
+        self.x = InputSlot(self.local_bsz)
+        self.y = None
+        if test_x is None:
+            self.test_x = InputSlot(self.local_bsz)
+        else:
+            self.test_x = InputSlot(self.local_bsz)
+            self.test_x.bind(share(test_x))
+
+        # device-side step state
+        self.d_step = self.ctx.zeros((1,), np.uint32)       # RNG step counter
+        self.cur_learn_rate = self.ctx.zeros((1,), np.float32)
+
+        # Input Layer
+        input_layer_type = getattr(layer, layers[0][0])
+        assert input_layer_type in (InputLayer, ElasticLayer), \
+            "First layer needs to be Input or Elastic or Color Layer"
+
+        self.tr_layers.append(input_layer_type(self.x, rand_gen=self.rand_gen,
+                                               **layers[0][1]))
+        self.te_layers.append(self.tr_layers[0].TestVersion(self.test_x))
+        self.num_layers += 1
+
+        # Rest of the layers
+        while self.num_layers < len(layers):
+            self.append_next_layer()
+
+        assert isinstance(self.tr_layers[-1], SoftmaxLayer), \
+            "the accelerated path ends in a SoftmaxLayer (other heads: SURVEY.md 8f)"
+
+        # random streams read the device step counter; masks/noise are keyed by the
+        # position inside the GLOBAL minibatch so that sharding does not change them
+        for lyr in self.tr_layers:
+            if isinstance(lyr, ElasticLayer):
+                lyr.d_step = self.d_step
+            drop = getattr(lyr, "drop", None)
+            if drop is not None:
+                drop.d_step = self.d_step
+                drop.elem0 = self.shard_lo * int(np.prod(drop.shape[1:]))
+        out = self.tr_layers[-1]
+        out.inv_batch = 1.0 / self.batch_sz          # global batch: grads sum to the mean
+        self.te_layers[-1].inv_batch = 1.0 / self.batch_sz
+
+        self._grads_ready = False
+
+        # Set Epoch and learning rate
+        if 'CUR_EPOCH' not in training_params:
+            training_params['CUR_EPOCH'] = 0
+        self.set_rate()
+
+    def append_next_layer(self):
+        layer_type, layer_args = self.layers[self.num_layers]
+        prev_tr_layer = self.tr_layers[self.num_layers - 1]
+        prev_te_layer = self.te_layers[self.num_layers - 1]
+        wts = self.allwts[self.num_layers] if self.allwts else None
+
+        tr_inpt = prev_tr_layer.output
+        te_inpt = prev_te_layer.output
+        curr_layer_type = getattr(layer, layer_type)
+
+        if curr_layer_type in (ElasticLayer, ConvLayer, PoolLayer, MeanLayer):
+            if type(prev_tr_layer) is DropOutLayer:
+                use_tr_layer = self.tr_layers[self.num_layers - 2]
+            else:
+                use_tr_layer = prev_tr_layer
+            num_prev_maps = use_tr_layer.num_maps
+            prev_out_sz = use_tr_layer.out_sz
+            if tr_inpt.ndim != 4:
+                tr_inpt = tr_inpt.reshape(self.local_bsz, num_prev_maps, prev_out_sz, prev_out_sz)
+                te_inpt = te_inpt.reshape(self.local_bsz, num_prev_maps, prev_out_sz, prev_out_sz)
+
+        if curr_layer_type is ElasticLayer:
+            layer_args = dict(layer_args)
+            layer_args.pop("num_maps", None)
+            layer_args.pop("img_sz", None)
+            curr_layer = ElasticLayer(tr_inpt,
+                                      num_maps=num_prev_maps,
+                                      img_sz=prev_out_sz,
+                                      rand_gen=self.rand_gen,
+                                      **layer_args)
+
+        elif curr_layer_type is ConvLayer:
+            curr_layer = ConvLayer(tr_inpt,
+                                   wts,
+                                   self.rand_gen,
+                                   self.local_bsz,
+                                   num_prev_maps,
+                                   prev_out_sz,
+                                   **layer_args)
+
+        elif curr_layer_type in (PoolLayer, MeanLayer):
+            curr_layer = curr_layer_type(tr_inpt,
+                                         num_maps=num_prev_maps,
+                                         in_sz=prev_out_sz,
+                                         **layer_args)
+
+        elif curr_layer_type is DropOutLayer:
+            curr_layer = DropOutLayer(tr_inpt,
+                                      self.rand_gen,
+                                      prev_tr_layer.n_out,
+                                      **layer_args)
+
+        elif curr_layer_type in (HiddenLayer, SoftmaxLayer):
+            te_inpt = te_inpt.flatten(2)
+            curr_layer = curr_layer_type(tr_inpt.flatten(2),
+                                         wts,
+                                         self.rand_gen,
+                                         prev_tr_layer.n_out,
+                                         **layer_args)
+        else:
+            raise NotImplementedError("Unknown Layer Type" + layer_type)
+
+        self.tr_layers.append(curr_layer)
+        self.te_layers.append(curr_layer.TestVersion(te_inpt))
+        self.num_layers += 1
+
+    # ------------------------------------------------------------------------------
+    def _group(self):
+        if self._dev_group is None:
+            self._dev_group = comm.DeviceGroup(self.ctx, self.world)
+        return self._dev_group
+
+    def _prepare_training(self):
+        """Flat gradient buffer (all dW/db as views, + the scalar cost at the end so that
+        ONE all-reduce moves everything) and the velocity buffers (layer.py:77-79)."""
+        if self._grads_ready:
+            return
+        total = 0
+        slots = []
+        for lyr in self.tr_layers:
+            for p in lyr.params:
+                slots.append((lyr, p, total))
+                total += -(-p.size // _GRAD_ALIGN) * _GRAD_ALIGN
+        self.flat_grads = self.ctx.zeros((total + _GRAD_ALIGN,))
+        self.d_cost = self.flat_grads.view(total, (1,))
+        self.n_flat = total + 1
+        for lyr in self.tr_layers:
+            if lyr.params:
+                lyr.grads = []
+                lyr.accumulated_updates = []
+        for lyr, p, off in slots:
+            lyr.grads.append(self.flat_grads.view(off, p.shape))
+            lyr.accumulated_updates.append(self.ctx.zeros(p.shape))
+        self.tr_layers[-1].d_cost = self.d_cost
+        # which layers must propagate a gradient to their input
+        self._need_gin = []
+        seen = False
+        for lyr in self.tr_layers:
+            self._need_gin.append(seen)
+            seen = seen or lyr.has_updates()
+        if self.world.size > 1:
+            self._group()
+        self._grads_ready = True
+
+    def _train_step(self, y, y_row0):
+        """forward + backward + all-reduce + update for the minibatch the input slot
+        currently points at.  Everything is enqueued; nothing is read back."""
+        ctx = self.ctx
+        out = self.tr_layers[-1]
+        for lyr in self.tr_layers[:-1]:
+            lyr.forward(True)
+        out.forward(True, y=y, y_row0=y_row0)
+        # cost = -mean logprob[n, y_n]  (this rank's share of the global mean)
+        ctx.call("tn_reduce_sum", out.rowloss.ptr, self.local_bsz, 1.0 / self.batch_sz,
+                 self.d_cost.ptr, 0)
+        g = out.dlogits
+        for idx in range(len(self.tr_layers) - 1, -1, -1):
+            lyr = self.tr_layers[idx]
+            below = self.tr_layers[idx - 1] if idx > 0 else None
+            g = lyr.backward(g, self._need_gin[idx], below)
+            if g is None:
+                break
+        if self.world.size > 1:
+            self._group().allreduce_sum(self.flat_grads, self.n_flat)
+        for lyr in self.tr_layers:
+            lyr.get_wtcost(self.d_cost)
+        for lyr in self.tr_layers:
+            lyr.get_updates(self.cur_learn_rate)
+        ctx.call("tn_add_u32", self.d_step.ptr, 1)
+
+    # ------------------------------------------------------------------------------
+    def get_trin_model(self, x_data, y_data, aux_data=None,
+                       take_index_list=False):
+        print('Compiling training function...')
+        self.tr_layers[-1].cost(None)            # validates the loss name (outlayers.py:12-36)
+        assert aux_data is None, "auxiliary inputs are outside the accelerated path"
+        self._prepare_training()
+        return _TrainFn(self, share(x_data), share(y_data, np.int32), take_index_list)
+
+    def reset_accumulated_gradients(self):
+        self._prepare_training()
+        for lyr in self.tr_layers:
+            for au in (lyr.accumulated_updates or ()):
+                au.fill_bytes(0)
+
+    def get_test_model(self, x_data, y_data, aux_data=None, preds_feats=False):
+        print('Compiling testing function... ')
+        assert aux_data is None, "auxiliary inputs are outside the accelerated path"
+        return _TestFn(self, share(x_data), share(y_data, np.int32), preds_feats)
+
+    def takes_aux(self):
+        return False
+
+    def get_data_test_model(self, get_output_of_layers=()):
+        print('Compiling full test function...')
+        if self.tr_prms['BATCH_SZ'] != 1:
+            print("\n****WARNING****: BATCH SIZE IS NOT 1. "
+                  "WILL BE EXPECTING A BATCH OF INPUT IMAGES AT A TIME.\n")
+        first = self.te_layers[0]
+        stage = self.ctx.empty((self.local_bsz, first.num_maps, first.out_sz, first.out_sz))
+
+        def fn(x):
+            x = np.ascontiguousarray(x, np.float32).reshape(stage.shape)
+            stage.set_value(x)
+            slot = self.test_x
+            slot.bind(stage)
+            slot.row0 = slot.row_global0 = 0
+            for lyr in self.te_layers[:-1]:
+                lyr.forward(False)
+            out = self.te_layers[-1]
+            out.forward(False)
+            res = [out.features.get_value(), out.y_preds.get_value().astype(np.int64)]
+            for index in get_output_of_layers:
+                res.append(self.te_layers[index].output.get_value())
+            return res
+
+        return fn
+
+    def get_init_params(self):
+        return {"layers": self.layers,
+                "training_params": self.tr_prms,
+                "allwts": [l.get_wts() for l in self.tr_layers]}
+
+    def set_rate(self):
+        self.cur_learn_rate.set_value(np.float32(
+            self.tr_prms['INIT_LEARNING_RATE'] /
+            (1 + self.tr_prms['CUR_EPOCH'] /
+             self.tr_prms['EPOCHS_TO_HALF_RATE'])))
+
+    def inc_epoch_set_rate(self):
+        self.tr_prms['CUR_EPOCH'] += 1
+        self.set_rate()
+
+    def get_epoch(self):
+        return self.tr_prms['CUR_EPOCH']
+
+    def __str__(self):
+        prmstr = '; '.join([', '.join([getattr(prm, "name", "param") for prm in lyr.params])
+                            for lyr in self.tr_layers])
+        return \
+            '\nTrain Layers\n\t' + \
+            '\n\t'.join([str(l) for l in self.tr_layers]) + \
+            '\nTest Layers\n\t' + \
+            '\n\t'.join([str(l) for l in self.te_layers]) + \
+            '\nParams ' + prmstr
+
+    def get_layers_info(self):
+        return get_layers_info(self.layers)
+
+    def get_wts_info(self, detailed=False):
+        return get_wts_info((l.get_wts() for l in self.tr_layers), detailed)
+
+    def get_training_params_info(self):
+        return get_training_params_info(self.tr_prms)
