@@ -1,0 +1,165 @@
+#!/usr/bin/env python
+"""Headline benchmark: training images/sec (fwd + bwd + update) of the MNIST CNN
+(params/mnist.prms, 28x28x1 synthetic, batch 4096 per GPU) on 1..8 MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One process per GPU; RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* come from the launcher (torch itself
+is not imported: the hot path is libtheanet_hip.so + RCCL).  Rank 0 prints ONE JSON line.
+Weak scaling: every GPU trains on 4096 images per step (global batch 4096*N), one flat
+gradient all-reduce per step.
+"""
+import argparse
+import ast
+import copy
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def load_prms(name):
+    with open(os.path.join(ROOT, "params", name)) as fh:
+        return ast.literal_eval(fh.read())
+
+
+def synthetic(rows, c, hw):
+    x = np.random.default_rng(0).random((rows, c, hw, hw), dtype=np.float32)
+    y = np.random.default_rng(1).integers(0, 10, rows).astype(np.int32)
+    return x, y
+
+
+def cpu_baseline(prms, hw, c, budget_s=12.0, batch=256):
+    """The numpy oracle (a CPU port of the reference path -- Theano itself cannot be
+    installed) timed on a bounded sample of the same workload, on this box's host cores."""
+    from oracle import theanet_oracle as O
+    p = copy.deepcopy(prms)
+    p["training_params"]["BATCH_SZ"] = batch
+    net = O.OracleNet(p["layers"], p["training_params"])
+    x, y = synthetic(batch * 2, c, hw)
+    net.train_step(x[:batch], y[:batch])            # warm-up
+    t0, n = time.perf_counter(), 0
+    while time.perf_counter() - t0 < budget_s and n < 200:
+        net.train_step(x[(n % 2) * batch:(n % 2 + 1) * batch], y[(n % 2) * batch:(n % 2 + 1) * batch])
+        n += 1
+    dt = time.perf_counter() - t0
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([i.get("num_threads", 1) for i in threadpool_info()] or [1])
+    except Exception:
+        threads = os.cpu_count()
+    return {"value": batch * n / dt, "unit": "images/sec", "cores": int(threads), "kind": "port",
+            "sample": "numpy oracle (oracle/theanet_oracle.py), %s fwd+bwd+update, %d steps of "
+                      "batch %d in %.1f s; host has %d cores" % (prms.get("_name", "net"), n, batch,
+                                                                dt, os.cpu_count())}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--prms", default="mnist.prms")
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: 4096 for mnist)")
+    ap.add_argument("--img", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--time-op", default="", help="C-ABI function to bracket with HIP events, "
+                    "e.g. tn_fc_wgrad:1 (nth call inside a step)")
+    args = ap.parse_args()
+
+    from theanet_amd import NeuralNet, comm, roofline
+    from theanet_amd.device import get_context
+
+    world = comm.get_world()
+    assert world.size == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    prms = load_prms(args.prms)
+    prms["_name"] = args.prms
+    defaults = {"mnist.prms": (4096, 28, 1), "cifar_like.prms": (2048, 32, 3),
+                "wide6.prms": (128, 64, 3), "3flat.prms": (4096, 28, 1)}
+    dB, dimg, C = defaults.get(args.prms, (4096, 28, 1))
+    per_gpu = args.batch or dB
+    img = args.img or dimg
+    C = prms["layers"][0][1].get("num_maps", C)
+    prms["layers"][0][1]["img_sz"] = img
+    tr = prms["training_params"]
+    tr["SEED"] = 555555
+    tr["BATCH_SZ"] = per_gpu * world.size
+
+    ctx = get_context()
+    net = NeuralNet(copy.deepcopy(prms["layers"]), dict(tr))
+    n_batches = max(2, 65536 // tr["BATCH_SZ"]) if per_gpu * img * img * C < (1 << 24) else 2
+    x, y = synthetic(n_batches * tr["BATCH_SZ"], C, img)
+    fn = net.get_trin_model(x, y)
+    del x
+    group = net._group() if world.size > 1 else None
+
+    def barrier():
+        ctx.sync()
+        if group is not None:
+            group.barrier()
+
+    for i in range(args.warmup):
+        fn.enqueue(i % n_batches)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        fn.enqueue(i % n_batches)
+    barrier()
+    dt = time.perf_counter() - t0
+    if group is not None:
+        dt = group.rdzv.gather_max(dt)
+    cost = fn.fetch()[0]
+    assert np.isfinite(cost), "training diverged"
+
+    # ---- per-kernel roofline leg: HIP events around the dominant kernel, same workload ----
+    conv2 = net.tr_layers[3] if args.prms == "mnist.prms" else None
+    op, nth = (args.time_op.split(":") + ["1"])[:2] if args.time_op else ("tn_fc_wgrad", "1")
+    ctx.time_calls(op, int(nth))
+    for i in range(min(args.steps, 50)):
+        ctx.new_step()
+        fn.enqueue(i % n_batches)
+    ctx.sync()
+    times = ctx.collect_times_ms()
+    roof = None
+    if times:
+        avg_ms = float(np.mean(times))
+        fc1 = net.tr_layers[5] if args.prms == "mnist.prms" else None
+        if op.startswith("tn_fc") and fc1 is not None:
+            fl, by = roofline.kernel_cost(op[3:], B=per_gpu, n_in=fc1.n_in, n_out=fc1.n_out)
+            ach = fl / (avg_ms * 1e-3) / 1e12
+            roof = {"kernel": op, "bound": "mfma", "achieved": ach, "peak": roofline.MFMA_F32_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": ach / roofline.MFMA_F32_PEAK_TFLOPS, "traffic": None,
+                    "avg_launch_ms": avg_ms, "flops_per_launch": fl, "bytes_per_launch": by}
+        else:
+            roof = {"kernel": op, "avg_launch_ms": avg_ms}
+
+    if world.rank != 0:
+        return
+    value = tr["BATCH_SZ"] * args.steps / dt
+    step_flops = roofline.net_step_flops(net) * world.size
+    line = {
+        "metric": "training images/sec (fwd+bwd+update) MNIST-CNN bs4096, 1/2/4/8 MI355X",
+        "value": value, "unit": "images/sec", "n_gpus": world.size, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "params/%s %dx%dx%d synthetic, %d images/GPU/step, elastic stage on"
+                               % (args.prms, img, img, C, per_gpu),
+                   "global_batch": tr["BATCH_SZ"], "parallelism": "dp%d" % world.size,
+                   "step_gflop_algorithmic": step_flops / 1e9,
+                   "step_tflops_algorithmic": step_flops / (dt / args.steps) / 1e12},
+        "roofline": roof,
+        "final_cost": float(cost),
+    }
+    if world.size == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(prms, img, C)
+    print(json.dumps(line))
+
+
+if __name__ == "__main__":
+    main()

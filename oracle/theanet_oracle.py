@@ -351,8 +351,10 @@ def elastic_field(h, w, prm, draws, coord_dtype=np.float64):
         # the gaussian is symmetric so convolution == correlation.
         pad = np.pad(elast, ((0, 0), (sigma, sigma), (sigma, sigma)))
         win = sliding_window_view(pad, filt.shape, axis=(1, 2))         # 2,h,w,k,k
+        # float32 inputs, float64 accumulation, result rounded to float32: within one
+        # float32 ulp of ANY summation order of Theano's float32 conv2d, and reproducible
         sm = np.einsum("chwuv,uv->chw", win.astype(np.float32), filt[::-1, ::-1],
-                       dtype=np.float32)
+                       dtype=np.float64).astype(np.float32)
         target = target + sm.astype(ct)                                 # :97
     if prm["zoom"] - 1 or prm["angle"]:
         origin = (draws.origin_u.astype(ct) *

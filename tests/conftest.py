@@ -10,3 +10,10 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+
+
+@pytest.fixture(autouse=True)
+def _release_device_temporaries():
+    yield
+    from tests import gpu_util
+    gpu_util._KEEP.clear()

@@ -12,8 +12,13 @@ def ctx():
     return get_context()
 
 
+_KEEP = []      # device arrays made by dev() stay alive until the test ends (conftest clears)
+
+
 def dev(a, dtype=None):
-    return ctx().array(np.ascontiguousarray(a), dtype=dtype)
+    d = ctx().array(np.ascontiguousarray(a), dtype=dtype)
+    _KEEP.append(d)
+    return d
 
 
 def empty(shape, dtype=np.float32):

@@ -56,7 +56,9 @@ __global__ __launch_bounds__(256) void elastic_field_kernel(
         const float* n0 = draws + EL_HDR;
         const float* n1 = n0 + h * w;
         const float mag = (float)magnitude;
-        float s0 = 0.f, s1 = 0.f;
+        // float32 products, float64 accumulation, rounded to float32 at the end: independent
+        // of the summation order, so it reproduces the oracle bit for bit
+        double s0 = 0.0, s1 = 0.0;
         for (int u = 0; u < ks; ++u) {
             const int yy = y + u - sigma;
             if (yy < 0 || yy >= h) continue;
@@ -64,12 +66,12 @@ __global__ __launch_bounds__(256) void elastic_field_kernel(
                 const int xx = x + v - sigma;
                 if (xx < 0 || xx >= w) continue;
                 const float fw = filt[u * ks + v];   // symmetric: convolution == correlation
-                s0 = fmaf(fw, mag * n0[yy * w + xx], s0);
-                s1 = fmaf(fw, mag * n1[yy * w + xx], s1);
+                s0 += (double)fw * (double)(mag * n0[yy * w + xx]);
+                s1 += (double)fw * (double)(mag * n1[yy * w + xx]);
             }
         }
-        ty += (double)s0;
-        tx += (double)s1;
+        ty += (double)(float)s0;
+        tx += (double)(float)s1;
     }
     if (zoom != 1.0 || angle != 0.0) {
         const double oy = (double)draws[2] * h, ox = (double)draws[3] * w;

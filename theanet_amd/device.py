@@ -32,11 +32,53 @@ class Context:
                 "There is no CPU fallback." % (device, msg.decode() if msg else "?"))
         self.h = h
         self.device = device
+        self.ev_hook = None       # (name, nth) -> HIP-event bracket around that C-ABI call
+        self._ev_seen = 0
+        self.ev_pairs = []
 
     def call(self, name, *args):
+        hook = self.ev_hook
+        if hook is not None and hook[0] == name:
+            self._ev_seen += 1
+            if self._ev_seen == hook[1]:
+                return self._timed_call(name, args)
         rc = getattr(self.lib, name)(self.h, *args)
         if rc != 0:
             _lib.check(self.h, rc, name)
+
+    # -- per-kernel timing with HIP events on the compute stream (bench.py roofline leg) --
+    def _timed_call(self, name, args):
+        a, b = ctypes.c_void_p(), ctypes.c_void_p()
+        for e in (a, b):
+            rc = self.lib.tn_event_create(self.h, ctypes.byref(e))
+            _lib.check(self.h, rc, "tn_event_create")
+        self.lib.tn_event_record(self.h, a)
+        rc = getattr(self.lib, name)(self.h, *args)
+        self.lib.tn_event_record(self.h, b)
+        self.ev_pairs.append((a, b))
+        if rc != 0:
+            _lib.check(self.h, rc, name)
+
+    def time_calls(self, name, nth=1):
+        """Bracket the nth call of C-ABI function ``name`` after each ``new_step()``."""
+        self.ev_hook = (name, nth)
+        self._ev_seen = 0
+        self.ev_pairs = []
+
+    def new_step(self):
+        self._ev_seen = 0
+
+    def collect_times_ms(self):
+        out = []
+        for a, b in self.ev_pairs:
+            ms = ctypes.c_float()
+            self.call("tn_event_elapsed_ms", a, b, ctypes.byref(ms))
+            out.append(ms.value)
+            self.lib.tn_event_destroy(self.h, a)
+            self.lib.tn_event_destroy(self.h, b)
+        self.ev_pairs = []
+        self.ev_hook = None
+        return out
 
     def sync(self):
         self.call("tn_sync")
