@@ -104,6 +104,21 @@ int tn_conv2d_dgrad(tn_ctx* ctx, const float* dz, const float* W, float* dx,
                     int N, int C, int H, int Wd, int K, int f, int stride, int pad_lo,
                     int Ho, int Wo, const float* prev_a, int prev_act, float prev_act_param);
 
+/* ---- fused conv + bias + act + max-pool for small feature maps (same reference call sites as
+ * tn_conv2d_* followed by tn_pool_*: convpool.py:54-72 then :106-107).  The conv activation
+ * never reaches HBM: fwd writes only the pooled map y (N,K,Hp,Wp); bwd takes g = dcost/dy,
+ * recomputes the window, routes g to every maximal element (MaxPoolGrad tie rule) times
+ * act'(a), and produces dW/db (OVERWRITE) and -- only if dz != NULL -- dz (N,K,Ho,Wo) for a
+ * following tn_conv2d_dgrad.  Supported: stride 1, p == 2, f == 3 with C <= 4, f == 5 with
+ * C <= 2 (tn_convpool_supported); anything else uses the unfused ops.                      */
+int tn_convpool_supported(int C, int f, int stride, int p);
+int tn_convpool_fwd(tn_ctx* ctx, const float* x, const float* W, const float* b, float* y,
+                    int N, int C, int H, int Wd, int K, int f, int pad_lo, int Ho, int Wo,
+                    int p, int Hp, int Wp, int act, float act_param);
+int tn_convpool_bwd(tn_ctx* ctx, const float* x, const float* W, const float* b, const float* g,
+                    float* dz, float* dW, float* db, int N, int C, int H, int Wd, int K, int f,
+                    int pad_lo, int Ho, int Wo, int p, int Hp, int Wp, int act, float act_param);
+
 /* ---- pool / mean (replaces pool.pool_2d + MaxPoolGrad, tt.mean; convpool.py:106-107,131) ----
  * max over p x p, stride p, no padding; Ho = ceil(H/p) unless ignore_border (floor).   */
 int tn_pool_fwd(tn_ctx* ctx, const float* x, float* y, int NC, int H, int Wd, int p,
@@ -164,6 +179,17 @@ int tn_error_stats(tn_ctx* ctx, const int32_t* pred, const int32_t* y, int64_t y
 int tn_sgd_update(tn_ctx* ctx, float* p, float* v, const float* g, size_t n,
                   float momentum, float rate, const float* d_lr, float L1, float L2, float gscale);
 int tn_maxnorm(tn_ctx* ctx, float* p, int ndim, int d0, int rest, float maxnorm);
+/* The same update for EVERY parameter tensor of the net in one launch.  d_segs = device
+ * array of nseg descriptors; max_n = largest n among them (sizes the grid).               */
+typedef struct tn_sgd_seg {
+    float* p;
+    float* v;
+    const float* g;
+    uint64_t n;
+    float momentum, rate, L1, L2;
+} tn_sgd_seg;
+int tn_sgd_update_multi(tn_ctx* ctx, const tn_sgd_seg* d_segs, int nseg, size_t max_n,
+                        const float* d_lr, float gscale);
 
 /* ---- elastic input stage (replaces ElasticLayer's graph; inlayers.py:63-144) ----
  * draws layout (float32, device): [0:2] translation u(-1,1) ; [2:4] origin u(.25,.75) ;

@@ -74,6 +74,69 @@ def test_conv_wgrad_dgrad(case):
     assert_close(dx.get_value(), dx_w * g, atol=1e-4, what="conv dx*act' %s" % (case,))
 
 
+CONVPOOL_CASES = [
+    # N, C, H, K, f, mode, act, ignore_border
+    (5, 1, 28, 4, 3, "valid", "relu10", False),
+    (3, 4, 13, 20, 3, "valid", "relu05", False),     # 11 -> 6: partial last window
+    (3, 4, 13, 20, 3, "valid", "relu05", True),      # 11 -> 5: last row/col in no window
+    (2, 3, 16, 9, 3, "same", "relu10", False),
+    (2, 2, 12, 5, 5, "valid", "tanh", False),
+    (2, 1, 10, 3, 5, "same", "relu", False),
+    (70, 2, 9, 6, 3, "same", "sigmoid", False),
+]
+
+
+@pytest.mark.parametrize("case", CONVPOOL_CASES)
+def test_convpool_fused_fwd_bwd(case):
+    N, C, H, K, f, mode, act, ib = case
+    assert ctx().lib.tn_convpool_supported(C, f, 1, 2)
+    rng = np.random.RandomState(N + K)
+    x = rng.randn(N, C, H, H).astype(np.float32)
+    W = (rng.randn(K, C, f, f) / np.sqrt(C * f * f)).astype(np.float32)
+    b = rng.randn(K).astype(np.float32)
+    pad_lo, _, Ho = O.conv_geometry(H, f, 1, mode)
+    Hp = O.pool_out_sz(Ho, 2, ib)
+    fa, dfa = O.activation(act)
+    x64, W64, b64 = x.astype(np.float64), W.astype(np.float64), b.astype(np.float64)
+    z = O.conv2d_fwd(x64, W64, b64, 1, mode)
+    a = fa(z)
+    want_y = O.pool_fwd(a, 2, ib)
+    kind, prm = act_code(act)
+    xd, Wd, bd = dev(x), dev(W), dev(b)
+    y = empty((N, K, Hp, Hp))
+    geom = (N, C, H, H, K, f, pad_lo, Ho, Ho, 2, Hp, Hp, kind, prm)
+    call("tn_convpool_fwd", xd.ptr, Wd.ptr, bd.ptr, y.ptr, *geom)
+    assert_close(y.get_value(), want_y, what="convpool fwd %s" % (case,))
+    g = rng.randn(N, K, Hp, Hp).astype(np.float32)
+    da = O.pool_bwd(a, g.astype(np.float64), 2, ib)
+    dz_w = da * dfa(z)
+    dx_w, dW_w, db_w = O.conv2d_bwd(x64, W64, dz_w, 1, mode)
+    dz, dW, db = empty((N, K, Ho, Ho)), empty(W.shape), empty((K,))
+    dz.fill_bytes(0xff)
+    call("tn_convpool_bwd", xd.ptr, Wd.ptr, bd.ptr, dev(g).ptr, dz.ptr, dW.ptr, db.ptr, *geom)
+    assert_close(dz.get_value(), dz_w, atol=1e-5, what="convpool dz %s" % (case,))
+    assert_close(dW.get_value(), dW_w, atol=2e-4, what="convpool dW %s" % (case,))
+    assert_close(db.get_value(), db_w, atol=2e-4, what="convpool db %s" % (case,))
+    dW.fill_bytes(0)
+    call("tn_convpool_bwd", xd.ptr, Wd.ptr, bd.ptr, dev(g).ptr, None, dW.ptr, db.ptr, *geom)
+    assert_close(dW.get_value(), dW_w, atol=2e-4, what="convpool dW (no dz) %s" % (case,))
+
+
+def test_convpool_tie_rule():
+    # constant image, zero weights -> every conv output equals the bias: all four tie
+    x = np.ones((1, 1, 6, 6), np.float32)
+    W = np.zeros((2, 1, 3, 3), np.float32)
+    b = np.array([.5, -1.], np.float32)
+    g = np.arange(8, dtype=np.float32).reshape(1, 2, 2, 2) + 1
+    kind, prm = act_code("relu10")
+    dz, dW, db = empty((1, 2, 4, 4)), empty(W.shape), empty((2,))
+    call("tn_convpool_bwd", dev(x).ptr, dev(W).ptr, dev(b).ptr, dev(g).ptr, dz.ptr, dW.ptr, db.ptr,
+         1, 1, 6, 6, 2, 3, 0, 4, 4, 2, 2, 2, kind, prm)
+    want = np.kron(g[0], np.ones((2, 2), np.float32)) * np.array([1., .1])[:, None, None]
+    assert_close(dz.get_value()[0], want, what="tie dz")
+    assert_close(db.get_value(), want.sum((1, 2)), what="tie db")
+
+
 def test_conv_big_batch_wgrad_is_deterministic():
     case = (64, 4, 13, 20, 3, 1, "valid", "relu05")
     N, C, H, K, f, s, mode, act = case

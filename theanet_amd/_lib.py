@@ -64,6 +64,10 @@ SIGNATURES = {
     "tn_error_stats": (c_int, [CTX, P, P, c_int64, P, c_int, P]),
     "tn_sgd_update": (c_int, [CTX, P, P, P, c_size_t, c_float, c_float, P, c_float, c_float, c_float]),
     "tn_maxnorm": (c_int, [CTX, P, c_int, c_int, c_int, c_float]),
+    "tn_sgd_update_multi": (c_int, [CTX, P, c_int, c_size_t, P, c_float]),
+    "tn_convpool_supported": (c_int, [c_int, c_int, c_int, c_int]),
+    "tn_convpool_fwd": (c_int, [CTX, P, P, P, P] + [c_int] * 12 + [c_int, c_float]),
+    "tn_convpool_bwd": (c_int, [CTX, P, P, P, P, P, P, P] + [c_int] * 12 + [c_int, c_float]),
     "tn_elastic_draws_count": (c_size_t, [c_int, c_int]),
     "tn_elastic_draws": (c_int, [CTX, P, c_int, c_int, c_uint64, c_uint32, P]),
     "tn_elastic_field": (c_int, [CTX, P, c_int, c_int, c_double, c_double, c_double, c_int, c_double,

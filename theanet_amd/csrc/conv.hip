@@ -200,24 +200,31 @@ __global__ __launch_bounds__(256) void conv_bgrad_generic(const float* __restric
     if (threadIdx.x == 0) db[k] = red[0] + red[1] + red[2] + red[3];
 }
 
-// reduce partials over blocks; flip (u,v) -> (f-1-u, f-1-v)
-__global__ void conv_wgrad_finish(const float* __restrict__ partial, const float* __restrict__ dbpartial,
-                                  float* __restrict__ dW, float* __restrict__ db, int nblk, int K,
-                                  int C, int f) {
+// reduce partials over blocks (one wave per output element, fixed order -> deterministic);
+// flip (u,v) -> (f-1-u, f-1-v)
+__global__ __launch_bounds__(256) void conv_wgrad_finish(const float* __restrict__ partial,
+                                                        const float* __restrict__ dbpartial,
+                                                        float* __restrict__ dW, float* __restrict__ db,
+                                                        int nblk, int K, int C, int f) {
     const int ff = f * f;
     const int KCFF = K * C * ff;
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
     if (t < KCFF) {
         float s = 0.f;
-        for (int bk = 0; bk < nblk; ++bk) s += partial[(size_t)bk * KCFF + t];
-        const int uv = t % ff, kc = t / ff;
-        const int u = uv / f, v = uv % f;
-        dW[(size_t)kc * ff + (f - 1 - u) * f + (f - 1 - v)] = s;
+        for (int bk = lane; bk < nblk; bk += 64) s += partial[(size_t)bk * KCFF + t];
+        s = wave_sum_f(s);
+        if (lane == 0) {
+            const int uv = t % ff, kc = t / ff;
+            const int u = uv / f, v = uv % f;
+            dW[(size_t)kc * ff + (f - 1 - u) * f + (f - 1 - v)] = s;
+        }
     } else if (t < KCFF + K) {
         const int k = t - KCFF;
         float s = 0.f;
-        for (int bk = 0; bk < nblk; ++bk) s += dbpartial[(size_t)bk * K + k];
-        db[k] = s;
+        for (int bk = lane; bk < nblk; bk += 64) s += dbpartial[(size_t)bk * K + k];
+        s = wave_sum_f(s);
+        if (lane == 0) db[k] = s;
     }
 }
 
@@ -245,25 +252,53 @@ __global__ __launch_bounds__(256) void conv_dgrad_direct(
 #pragma unroll
     for (int cc = 0; cc < CT; ++cc) acc[cc] = 0.f;
 
-    for (int k = 0; k < K; ++k) {
-        const float* dzk = dz + ((size_t)n * K + k) * HoWo;
-        const float* wk = W + ((size_t)k * C + c0) * ff;
-        for (int u = 0; u < f; ++u) {
-            const int ty = y + pad - u;
-            if (ty < 0) continue;
-            const int i = ty / stride;
-            if (i * stride != ty || i >= Ho) continue;
-            for (int v = 0; v < f; ++v) {
-                const int tx = xq + pad - v;
-                if (tx < 0) continue;
-                const int j = tx / stride;
-                if (j * stride != tx || j >= Wo) continue;
-                const float g = dzk[i * Wo + j];
-                const int widx = (f - 1 - u) * f + (f - 1 - v);
+    if (F > 0 && stride == 1) {
+        // stride-1 fast path: branch-free, fully unrolled taps (independent loads in flight)
+        for (int k = 0; k < K; ++k) {
+            const float* dzk = dz + ((size_t)n * K + k) * HoWo;
+            const float* wk = W + ((size_t)k * C + c0) * ff;
 #pragma unroll
-                for (int cc = 0; cc < CT; ++cc) {
-                    const float wv = (c0 + cc < C) ? wk[(size_t)cc * ff + widx] : 0.f;
-                    acc[cc] = fmaf(g, wv, acc[cc]);
+            for (int u = 0; u < f; ++u) {
+                const int i = y + pad - u;
+                const bool iok = (unsigned)i < (unsigned)Ho;
+                const int ic = min(max(i, 0), Ho - 1);
+#pragma unroll
+                for (int v = 0; v < f; ++v) {
+                    const int j = xq + pad - v;
+                    const bool ok = iok && ((unsigned)j < (unsigned)Wo);
+                    const int jc = min(max(j, 0), Wo - 1);
+                    const float t = dzk[ic * Wo + jc];
+                    const float g = ok ? t : 0.f;
+                    const int widx = (f - 1 - u) * f + (f - 1 - v);
+#pragma unroll
+                    for (int cc = 0; cc < CT; ++cc) {
+                        const float wv = (c0 + cc < C) ? wk[(size_t)cc * ff + widx] : 0.f;
+                        acc[cc] = fmaf(g, wv, acc[cc]);
+                    }
+                }
+            }
+        }
+    } else {
+        for (int k = 0; k < K; ++k) {
+            const float* dzk = dz + ((size_t)n * K + k) * HoWo;
+            const float* wk = W + ((size_t)k * C + c0) * ff;
+            for (int u = 0; u < f; ++u) {
+                const int ty = y + pad - u;
+                if (ty < 0) continue;
+                const int i = ty / stride;
+                if (i * stride != ty || i >= Ho) continue;
+                for (int v = 0; v < f; ++v) {
+                    const int tx = xq + pad - v;
+                    if (tx < 0) continue;
+                    const int j = tx / stride;
+                    if (j * stride != tx || j >= Wo) continue;
+                    const float g = dzk[i * Wo + j];
+                    const int widx = (f - 1 - u) * f + (f - 1 - v);
+#pragma unroll
+                    for (int cc = 0; cc < CT; ++cc) {
+                        const float wv = (c0 + cc < C) ? wk[(size_t)cc * ff + widx] : 0.f;
+                        acc[cc] = fmaf(g, wv, acc[cc]);
+                    }
                 }
             }
         }
@@ -280,7 +315,7 @@ __global__ __launch_bounds__(256) void conv_dgrad_direct(
 }
 
 // ------------------------------------------------------------------------------------
-static int ensure_scratch(tn_ctx* ctx, size_t bytes) {
+int tn_ensure_scratch(tn_ctx* ctx, size_t bytes) {
     if (bytes <= ctx->scratch_bytes) return TN_OK;
     TN_HIP(hipStreamSynchronize(ctx->stream));
     if (ctx->scratch) TN_HIP(hipFree(ctx->scratch));
@@ -290,6 +325,14 @@ static int ensure_scratch(tn_ctx* ctx, size_t bytes) {
     hipError_t e = hipMalloc((void**)&ctx->scratch, nb);
     if (e != hipSuccess) return tn_fail(ctx, TN_E_NOMEM, "scratch hipMalloc(%zu) failed", nb);
     ctx->scratch_bytes = nb;
+    return TN_OK;
+}
+
+int tn_conv_wgrad_finish(tn_ctx* ctx, const float* partial, const float* dbpartial, float* dW,
+                         float* db, int nblk, int K, int C, int f) {
+    const int outs = K * C * f * f + K;
+    conv_wgrad_finish<<<cdiv(outs, 4), 256, 0, ctx->stream>>>(partial, dbpartial, dW, db, nblk, K, C, f);
+    TN_LAUNCH_CHECK();
     return TN_OK;
 }
 
@@ -328,7 +371,7 @@ int tn_conv2d_wgrad(tn_ctx* ctx, const float* x, const float* dz, float* dW, flo
         if (nblk < 1) nblk = 1;
         const size_t KCFF = (size_t)K * C * f * f;
         const size_t need = ((size_t)nblk * (KCFF + K)) * sizeof(float);
-        int rc = ensure_scratch(ctx, need);
+        int rc = tn_ensure_scratch(ctx, need);
         if (rc) return rc;
         float* partial = ctx->scratch;
         float* dbpartial = ctx->scratch + (size_t)nblk * KCFF;
@@ -348,9 +391,8 @@ int tn_conv2d_wgrad(tn_ctx* ctx, const float* x, const float* dz, float* dW, flo
         }
 #undef LAUNCH_WG
         TN_LAUNCH_CHECK();
-        conv_wgrad_finish<<<cdiv(KCFF + K, 256), 256, 0, ctx->stream>>>(partial, dbpartial, dW, db,
-                                                                        nblk, K, C, f);
-        TN_LAUNCH_CHECK();
+        rc = tn_conv_wgrad_finish(ctx, partial, dbpartial, dW, db, nblk, K, C, f);
+        if (rc) return rc;
     } else {
         conv_wgrad_generic<<<K * C * f * f, 256, 0, ctx->stream>>>(x, dz, dW, N, C, H, Wd, K, f,
                                                                   stride, pad_lo, Ho, Wo);

@@ -1,0 +1,295 @@
+// Fused conv + bias + activation + max-pool kernels for small feature maps (the MNIST /
+// CIFAR-first-layer regime: C*f*f far below the MFMA break-even, whole receptive fields fit
+// in registers).  MI355X-first design: the conv activation tensor -- the largest tensor of the
+// net -- never exists in HBM.
+//
+//   forward : thread = one POOLED output pixel of one image.  It loads its (p+f-1)^2 x C input
+//             patch into registers once, then for every output map k computes the p x p conv
+//             outputs of its pooling window with wave-uniform (scalar-loaded) weights, applies
+//             the activation and writes only the max.       HBM: read x once, write y once.
+//   backward: same mapping; recomputes the window's conv outputs (cheap: C*f*f FMAs each),
+//             finds the max itself (every tie receives the gradient, like Theano's MaxPoolGrad),
+//             forms dz = g * act'(a) in registers and accumulates dW / db in registers over many
+//             pixels; dz is written out only when a dgrad pass needs it.
+//             HBM: read x and g once (+ write dz when needed) instead of the unfused
+//             pool-bwd + wgrad traffic of ~5x that.
+//
+// Semantics: theanet/layer/convpool.py:54-72 (true convolution, flipped W), :106-112 (pool).
+#include "common.h"
+
+template <int F, int P, int C>
+struct Patch {
+    static constexpr int S = P + F - 1;
+    float v[C][S][S];
+    __device__ __forceinline__ void load(const float* __restrict__ xn, int H, int Wd, int y0, int x0) {
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+#pragma unroll
+            for (int r = 0; r < S; ++r) {
+                const int yy = y0 + r;
+                const bool yok = (yy >= 0) && (yy < H);
+                const int yc = min(max(yy, 0), H - 1);
+#pragma unroll
+                for (int q = 0; q < S; ++q) {
+                    const int xx = x0 + q;
+                    const bool ok = yok && (xx >= 0) && (xx < Wd);
+                    const int xc = min(max(xx, 0), Wd - 1);
+                    const float t = xn[((size_t)c * H + yc) * Wd + xc];   // always in bounds
+                    v[c][r][q] = ok ? t : 0.f;
+                }
+            }
+    }
+};
+
+// conv outputs of the P x P window for map k (fixed FMA order: c, u, v -- shared by fwd and bwd)
+template <int F, int P, int C>
+__device__ __forceinline__ void window_conv(const Patch<F, P, C>& pt, const float* __restrict__ Wk,
+                                            float bias, float (&z)[P][P]) {
+#pragma unroll
+    for (int di = 0; di < P; ++di)
+#pragma unroll
+        for (int dj = 0; dj < P; ++dj) z[di][dj] = bias;
+#pragma unroll
+    for (int c = 0; c < C; ++c)
+#pragma unroll
+        for (int u = 0; u < F; ++u)
+#pragma unroll
+            for (int v = 0; v < F; ++v) {
+                const float w = Wk[(c * F + (F - 1 - u)) * F + (F - 1 - v)];   // wave-uniform
+#pragma unroll
+                for (int di = 0; di < P; ++di)
+#pragma unroll
+                    for (int dj = 0; dj < P; ++dj)
+                        z[di][dj] = fmaf(pt.v[c][di + u][dj + v], w, z[di][dj]);
+            }
+}
+
+template <int F, int P, int C>
+__global__ __launch_bounds__(256) void convpool_fwd_kernel(
+    const float* __restrict__ x, const float* __restrict__ W, const float* __restrict__ b,
+    float* __restrict__ y, int N, int H, int Wd, int K, int pad, int Ho, int Wo, int Hp, int Wp,
+    int act, float prm) {
+    const int HpWp = Hp * Wp;
+    const long long total = (long long)N * HpWp;
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= total) return;
+    const int n = (int)(t / HpWp);
+    const int q = (int)(t - (long long)n * HpWp);
+    const int pi = q / Wp, pj = q - pi * Wp;
+    Patch<F, P, C> pt;
+    pt.load(x + (size_t)n * C * H * Wd, H, Wd, pi * P - pad, pj * P - pad);
+    bool valid[P][P];
+#pragma unroll
+    for (int di = 0; di < P; ++di)
+#pragma unroll
+        for (int dj = 0; dj < P; ++dj) valid[di][dj] = (pi * P + di < Ho) && (pj * P + dj < Wo);
+    float* yn = y + (size_t)n * K * HpWp + q;
+    for (int k = 0; k < K; ++k) {
+        float z[P][P];
+        window_conv<F, P, C>(pt, W + (size_t)k * C * F * F, b[k], z);
+        float m = -INFINITY;
+#pragma unroll
+        for (int di = 0; di < P; ++di)
+#pragma unroll
+            for (int dj = 0; dj < P; ++dj) {
+                const float a = tn_act_fwd(z[di][dj], act, prm);
+                if (valid[di][dj]) m = fmaxf(m, a);
+            }
+        yn[(size_t)k * HpWp] = m;
+    }
+}
+
+__device__ __forceinline__ float wave_sum_cp(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+template <int F, int P, int C, int KT>
+__global__ __launch_bounds__(256) void convpool_bwd_kernel(
+    const float* __restrict__ x, const float* __restrict__ W, const float* __restrict__ b,
+    const float* __restrict__ g, float* __restrict__ dz_out, float* __restrict__ partial,
+    float* __restrict__ dbpartial, int N, int H, int Wd, int K, int pad, int Ho, int Wo, int Hp,
+    int Wp, int act, float prm) {
+    constexpr int FF = F * F;
+    __shared__ float red[4][KT * C * FF + KT];
+    const int HpWp = Hp * Wp, HoWo = Ho * Wo;
+    const long long total = (long long)N * HpWp;
+    const int k0 = blockIdx.y * KT;
+
+    float acc[KT][C][FF];
+    float accb[KT];
+#pragma unroll
+    for (int kk = 0; kk < KT; ++kk) {
+        accb[kk] = 0.f;
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+#pragma unroll
+            for (int s = 0; s < FF; ++s) acc[kk][c][s] = 0.f;
+    }
+
+    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total;
+         t += (long long)gridDim.x * 256) {
+        const int n = (int)(t / HpWp);
+        const int q = (int)(t - (long long)n * HpWp);
+        const int pi = q / Wp, pj = q - pi * Wp;
+        Patch<F, P, C> pt;
+        pt.load(x + (size_t)n * C * H * Wd, H, Wd, pi * P - pad, pj * P - pad);
+        bool valid[P][P];
+#pragma unroll
+        for (int di = 0; di < P; ++di)
+#pragma unroll
+            for (int dj = 0; dj < P; ++dj) valid[di][dj] = (pi * P + di < Ho) && (pj * P + dj < Wo);
+#pragma unroll
+        for (int kk = 0; kk < KT; ++kk) {
+            const int k = k0 + kk;
+            if (k < K) {   // wave-uniform
+                float z[P][P];
+                window_conv<F, P, C>(pt, W + (size_t)k * C * FF, b[k], z);
+                float m = -INFINITY;
+#pragma unroll
+                for (int di = 0; di < P; ++di)
+#pragma unroll
+                    for (int dj = 0; dj < P; ++dj) {
+                        z[di][dj] = tn_act_fwd(z[di][dj], act, prm);
+                        if (valid[di][dj]) m = fmaxf(m, z[di][dj]);
+                    }
+                const float gk = g[((size_t)n * K + k) * HpWp + q];
+#pragma unroll
+                for (int di = 0; di < P; ++di)
+#pragma unroll
+                    for (int dj = 0; dj < P; ++dj) {
+                        float d = 0.f;
+                        if (valid[di][dj] && z[di][dj] == m)
+                            d = gk * tn_act_grad_from_out(z[di][dj], act, prm);
+                        if (dz_out && valid[di][dj])
+                            dz_out[((size_t)n * K + k) * HoWo + (pi * P + di) * Wo + pj * P + dj] = d;
+                        accb[kk] += d;
+#pragma unroll
+                        for (int c = 0; c < C; ++c)
+#pragma unroll
+                            for (int u = 0; u < F; ++u)
+#pragma unroll
+                                for (int v = 0; v < F; ++v)
+                                    acc[kk][c][u * F + v] =
+                                        fmaf(d, pt.v[c][di + u][dj + v], acc[kk][c][u * F + v]);
+                    }
+            }
+        }
+    }
+
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int kk = 0; kk < KT; ++kk) {
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+#pragma unroll
+            for (int s = 0; s < FF; ++s) {
+                const float r = wave_sum_cp(acc[kk][c][s]);
+                if (lane == 0) red[wave][(kk * C + c) * FF + s] = r;
+            }
+        const float rb = wave_sum_cp(accb[kk]);
+        if (lane == 0) red[wave][KT * C * FF + kk] = rb;
+    }
+    __syncthreads();
+    const int KCFF = K * C * FF;
+    for (int s = threadIdx.x; s < KT * C * FF + KT; s += 256) {
+        const float r = red[0][s] + red[1][s] + red[2][s] + red[3][s];
+        if (s < KT * C * FF) {
+            const int kk = s / (C * FF), rem = s - kk * C * FF;
+            if (k0 + kk < K) partial[(size_t)blockIdx.x * KCFF + (size_t)(k0 + kk) * C * FF + rem] = r;
+        } else {
+            const int kk = s - KT * C * FF;
+            if (k0 + kk < K) dbpartial[(size_t)blockIdx.x * K + k0 + kk] = r;
+        }
+    }
+}
+
+// shared with conv.hip
+int tn_conv_wgrad_finish(tn_ctx* ctx, const float* partial, const float* dbpartial, float* dW,
+                         float* db, int nblk, int K, int C, int f);
+int tn_ensure_scratch(tn_ctx* ctx, size_t bytes);
+
+template <int F, int P, int C>
+static int launch_fwd(tn_ctx* ctx, const float* x, const float* W, const float* b, float* y, int N,
+                      int H, int Wd, int K, int pad, int Ho, int Wo, int Hp, int Wp, int act,
+                      float prm) {
+    const long long total = (long long)N * Hp * Wp;
+    convpool_fwd_kernel<F, P, C><<<cdiv(total, 256), 256, 0, ctx->stream>>>(
+        x, W, b, y, N, H, Wd, K, pad, Ho, Wo, Hp, Wp, act, prm);
+    TN_LAUNCH_CHECK();
+    return TN_OK;
+}
+
+template <int F, int P, int C, int KT>
+static int launch_bwd(tn_ctx* ctx, const float* x, const float* W, const float* b, const float* g,
+                      float* dz, float* dW, float* db, int N, int H, int Wd, int K, int pad, int Ho,
+                      int Wo, int Hp, int Wp, int act, float prm) {
+    const long long total = (long long)N * Hp * Wp;
+    int nblk = cdiv(total, 256 * 6);
+    if (nblk > 512) nblk = 512;
+    if (nblk < 1) nblk = 1;
+    const size_t KCFF = (size_t)K * C * F * F;
+    int rc = tn_ensure_scratch(ctx, (size_t)nblk * (KCFF + K) * sizeof(float));
+    if (rc) return rc;
+    float* partial = ctx->scratch;
+    float* dbpartial = ctx->scratch + (size_t)nblk * KCFF;
+    convpool_bwd_kernel<F, P, C, KT><<<dim3(nblk, cdiv(K, KT)), 256, 0, ctx->stream>>>(
+        x, W, b, g, dz, partial, dbpartial, N, H, Wd, K, pad, Ho, Wo, Hp, Wp, act, prm);
+    TN_LAUNCH_CHECK();
+    return tn_conv_wgrad_finish(ctx, partial, dbpartial, dW, db, nblk, K, C, F);
+}
+
+extern "C" {
+
+int tn_convpool_supported(int C, int f, int stride, int p) {
+    if (stride != 1 || p != 2) return 0;
+    if (f == 3) return C >= 1 && C <= 4;
+    if (f == 5) return C >= 1 && C <= 2;
+    return 0;
+}
+
+int tn_convpool_fwd(tn_ctx* ctx, const float* x, const float* W, const float* b, float* y, int N,
+                    int C, int H, int Wd, int K, int f, int pad_lo, int Ho, int Wo, int p, int Hp,
+                    int Wp, int act, float act_param) {
+    TN_REQUIRE(tn_convpool_supported(C, f, 1, p), "tn_convpool_fwd: unsupported C=%d f=%d p=%d", C, f, p);
+#define CP_FWD(F_, C_)                                                                            \
+    return launch_fwd<F_, 2, C_>(ctx, x, W, b, y, N, H, Wd, K, pad_lo, Ho, Wo, Hp, Wp, act, act_param)
+    if (f == 3) {
+        switch (C) {
+            case 1: CP_FWD(3, 1);
+            case 2: CP_FWD(3, 2);
+            case 3: CP_FWD(3, 3);
+            default: CP_FWD(3, 4);
+        }
+    } else {
+        if (C == 1) CP_FWD(5, 1);
+        CP_FWD(5, 2);
+    }
+#undef CP_FWD
+}
+
+int tn_convpool_bwd(tn_ctx* ctx, const float* x, const float* W, const float* b, const float* g,
+                    float* dz, float* dW, float* db, int N, int C, int H, int Wd, int K, int f,
+                    int pad_lo, int Ho, int Wo, int p, int Hp, int Wp, int act, float act_param) {
+    TN_REQUIRE(tn_convpool_supported(C, f, 1, p), "tn_convpool_bwd: unsupported C=%d f=%d p=%d", C, f, p);
+    if (dz && (Hp * p < Ho || Wp * p < Wo))   // rows/cols outside every window (ignore_border)
+        TN_HIP(hipMemsetAsync(dz, 0, (size_t)N * K * Ho * Wo * sizeof(float), ctx->stream));
+#define CP_BWD(F_, C_, KT_)                                                                       \
+    return launch_bwd<F_, 2, C_, KT_>(ctx, x, W, b, g, dz, dW, db, N, H, Wd, K, pad_lo, Ho, Wo, Hp, \
+                                      Wp, act, act_param)
+    if (f == 3) {
+        switch (C) {
+            case 1: CP_BWD(3, 1, 4);
+            case 2: CP_BWD(3, 2, 4);
+            case 3: CP_BWD(3, 3, 4);
+            default: CP_BWD(3, 4, 4);
+        }
+    } else {
+        if (C == 1) CP_BWD(5, 1, 4);
+        CP_BWD(5, 2, 2);
+    }
+#undef CP_BWD
+}
+
+}  // extern "C"

@@ -28,7 +28,9 @@ __global__ __launch_bounds__(256) void elastic_draws_kernel(float* __restrict__ 
     draws[i] = v;
 }
 
-// one thread per output pixel, both planes.
+// one 64-lane WAVE per output pixel (4 pixels per block): the lanes split the (2s+1)^2 taps of
+// the gaussian, so the 31x31 smoothing of mnist.prms is ~15 taps per lane instead of a
+// 961-tap serial loop; lane 0 then applies translation / zoom / rotation / clipping.
 __global__ __launch_bounds__(256) void elastic_field_kernel(
     const float* __restrict__ draws, int h, int w, double translation, double zoom, double magnitude,
     int sigma, double angle, int nearest, int32_t* __restrict__ map_idx, float* __restrict__ map_fy,
@@ -44,7 +46,8 @@ __global__ __launch_bounds__(256) void elastic_field_kernel(
         }
         __syncthreads();
     }
-    const int p = blockIdx.x * 256 + threadIdx.x;
+    const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
     if (p >= h * w) return;
     const int y = p / w, x = p - y * w;
     double ty = y, tx = x;
@@ -59,20 +62,23 @@ __global__ __launch_bounds__(256) void elastic_field_kernel(
         // float32 products, float64 accumulation, rounded to float32 at the end: independent
         // of the summation order, so it reproduces the oracle bit for bit
         double s0 = 0.0, s1 = 0.0;
-        for (int u = 0; u < ks; ++u) {
-            const int yy = y + u - sigma;
-            if (yy < 0 || yy >= h) continue;
-            for (int v = 0; v < ks; ++v) {
-                const int xx = x + v - sigma;
-                if (xx < 0 || xx >= w) continue;
-                const float fw = filt[u * ks + v];   // symmetric: convolution == correlation
-                s0 += (double)fw * (double)(mag * n0[yy * w + xx]);
-                s1 += (double)fw * (double)(mag * n1[yy * w + xx]);
-            }
+        for (int t = lane; t < ks * ks; t += 64) {
+            const int u = t / ks, v = t - u * ks;
+            const int yy = y + u - sigma, xx = x + v - sigma;
+            if (yy < 0 || yy >= h || xx < 0 || xx >= w) continue;
+            const float fw = filt[t];   // symmetric: convolution == correlation
+            s0 += (double)fw * (double)(mag * n0[yy * w + xx]);
+            s1 += (double)fw * (double)(mag * n1[yy * w + xx]);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            s0 += __shfl_xor(s0, o, 64);
+            s1 += __shfl_xor(s1, o, 64);
         }
         ty += (double)(float)s0;
         tx += (double)(float)s1;
     }
+    if (lane != 0) return;
     if (zoom != 1.0 || angle != 0.0) {
         const double oy = (double)draws[2] * h, ox = (double)draws[3] * w;
         ty -= oy;
@@ -252,7 +258,7 @@ int tn_elastic_field(tn_ctx* ctx, const float* draws, int h, int w, double trans
     const int ks = 2 * sigma + 1;
     const size_t lds = (size_t)ks * ks * sizeof(float);
     TN_REQUIRE(lds <= 64 * 1024, "tn_elastic_field: sigma %d too large", sigma);
-    elastic_field_kernel<<<cdiv(h * w, 256), 256, lds, ctx->stream>>>(
+    elastic_field_kernel<<<cdiv(h * w, 4), 256, lds, ctx->stream>>>(
         draws, h, w, translation, zoom, magnitude, sigma, angle, nearest, map_idx, map_fy, map_fx,
         target);
     TN_LAUNCH_CHECK();

@@ -21,6 +21,27 @@ __global__ __launch_bounds__(256) void sgd_update_kernel(float* __restrict__ p, 
     }
 }
 
+// all parameter tensors of the net in ONE launch: blockIdx.y selects the segment descriptor
+__global__ __launch_bounds__(256) void sgd_update_multi_kernel(const tn_sgd_seg* __restrict__ segs,
+                                                              const float* __restrict__ d_lr,
+                                                              float gscale) {
+    const tn_sgd_seg sg = segs[blockIdx.y];
+    const float step = sg.rate * d_lr[0];
+    float* __restrict__ p = sg.p;
+    float* __restrict__ v = sg.v;
+    const float* __restrict__ g = sg.g;
+    const size_t n = sg.n;
+    const float m = sg.momentum, L1 = sg.L1, L2 = sg.L2;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float pv = p[i], vv = v[i];
+        float gg = g[i] * gscale;
+        if (L1 != 0.f) gg += L1 * ((pv > 0.f) - (pv < 0.f));
+        if (L2 != 0.f) gg += 2.f * L2 * pv;
+        v[i] = m * vv + (1.f - m) * gg;
+        p[i] = pv - step * vv;
+    }
+}
+
 __global__ __launch_bounds__(256) void clip_kernel(float* __restrict__ p, size_t n, float mx) {
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n) p[i] = fminf(fmaxf(p[i], -mx), mx);
@@ -77,6 +98,18 @@ int tn_sgd_update(tn_ctx* ctx, float* p, float* v, const float* g, size_t n, flo
     if (blocks > 2048) blocks = 2048;
     sgd_update_kernel<<<blocks, 256, 0, ctx->stream>>>(p, v, g, n, momentum, rate, d_lr, L1, L2,
                                                       gscale);
+    TN_LAUNCH_CHECK();
+    return TN_OK;
+}
+
+int tn_sgd_update_multi(tn_ctx* ctx, const tn_sgd_seg* d_segs, int nseg, size_t max_n,
+                        const float* d_lr, float gscale) {
+    if (nseg <= 0) return TN_OK;
+    TN_REQUIRE(d_segs != nullptr && d_lr != nullptr, "tn_sgd_update_multi: NULL argument");
+    int bx = cdiv(max_n, 1024);
+    if (bx > 256) bx = 256;
+    if (bx < 1) bx = 1;
+    sgd_update_multi_kernel<<<dim3(bx, nseg), 256, 0, ctx->stream>>>(d_segs, d_lr, gscale);
     TN_LAUNCH_CHECK();
     return TN_OK;
 }

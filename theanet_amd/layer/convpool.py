@@ -50,6 +50,8 @@ class ConvLayer(Layer):
         self.filter_sz, self.stride = filter_sz, stride
         self.output = self.ctx.empty((batch_sz, num_maps, self.out_sz, self.out_sz))
         self.gin = None
+        self.fused_pool = None     # set by NeuralNet: conv+act+pool run as ONE kernel
+        self.dz = None
 
         self.params = [self.W, self.b]
         self.num_maps = num_maps
@@ -79,13 +81,42 @@ class ConvLayer(Layer):
         return (self.batch_sz, self.num_prev_maps, self.in_sz, self.in_sz, self.num_maps,
                 self.filter_sz, self.stride, self.pad_lo, self.out_sz, self.out_sz)
 
+    def can_fuse_with(self, pool):
+        """conv -> act -> 2x2 max-pool on small channel counts runs as one fused kernel pair
+        (tn_convpool_fwd / tn_convpool_bwd): the conv activation never reaches HBM."""
+        return bool(self.stride == 1 and self.ctx.lib.tn_convpool_supported(
+            self.num_prev_maps, self.filter_sz, self.stride, pool.pool_sz))
+
+    def _fused_geom(self):
+        pool = self.fused_pool
+        return (self.batch_sz, self.num_prev_maps, self.in_sz, self.in_sz, self.num_maps,
+                self.filter_sz, self.pad_lo, self.out_sz, self.out_sz, pool.pool_sz,
+                pool.out_sz, pool.out_sz, self.act.kind, self.act.prm)
+
     def forward(self, train=True):
+        if self.fused_pool is not None:
+            return                       # the pool layer launches the fused kernel
         self.ctx.call("tn_conv2d_fwd", self.inpt.ptr, self.W.ptr, self.b.ptr, self.output.ptr,
                       *self._geom(), self.act.kind, self.act.prm)
 
+    def _backward_fused(self, gpool, need_gin, below):
+        """gpool = d cost / d (pooled output).  One kernel recomputes the windows, routes the
+        gradient through max-pool and activation and reduces dW/db; dz is only materialised
+        when the layer below needs a gradient."""
+        if need_gin and self.dz is None:
+            self.dz = self.ctx.empty(self.output.shape)
+        self.ctx.call("tn_convpool_bwd", self.inpt.ptr, self.W.ptr, self.b.ptr, gpool.ptr,
+                      self.dz.ptr if need_gin else None, self.grads[0].ptr, self.grads[1].ptr,
+                      *self._fused_geom())
+        return self.dz if need_gin else None
+
     def backward(self, gout, need_gin, below):
         """gout = d cost / d z of this layer (activation gradient already fused in)."""
-        if self.has_updates():
+        if self.fused_pool is not None:
+            gout = self._backward_fused(gout, need_gin, below)
+            if not need_gin:
+                return None
+        elif self.has_updates():
             self.ctx.call("tn_conv2d_wgrad", self.inpt.ptr, gout.ptr, self.grads[0].ptr,
                           self.grads[1].ptr, *self._geom())
         if not need_gin:
@@ -120,6 +151,7 @@ class PoolLayer(Layer):
         self.batch_sz = inpt.shape[0]
         self.output = self.ctx.empty((self.batch_sz, num_maps, self.out_sz, self.out_sz))
         self.gin = None
+        self.fused_conv = None
         self.representation = (
             "Pool Maps:{:2d} Pool_sz:{} Border:{} Output:{:2d}"
             "".format(num_maps, pool_sz,
@@ -130,6 +162,11 @@ class PoolLayer(Layer):
         return PoolLayer(inpt, *self.args)
 
     def forward(self, train=True):
+        conv = self.fused_conv
+        if conv is not None:
+            self.ctx.call("tn_convpool_fwd", conv.inpt.ptr, conv.W.ptr, conv.b.ptr,
+                          self.output.ptr, *conv._fused_geom())
+            return
         self.ctx.call("tn_pool_fwd", self.inpt.ptr, self.output.ptr,
                       self.batch_sz * self.num_maps, self.in_sz, self.in_sz, self.pool_sz,
                       self.out_sz, self.out_sz)
@@ -137,6 +174,8 @@ class PoolLayer(Layer):
     def backward(self, gout, need_gin, below):
         if not need_gin:
             return None
+        if self.fused_conv is not None:
+            return gout               # the conv layer's fused backward consumes d cost / d y
         if self.gin is None:
             self.gin = self.ctx.empty(self.inpt.shape)
         b_out, b_act, b_prm, b_mask = below.act_info()

@@ -81,14 +81,22 @@ class Layer:
             ctx.call("tn_sgd_update", p.ptr, v.ptr, g.ptr, p.size, float(reg['momentum']),
                      float(reg['rate']), d_lr.ptr, float(reg['L1']), float(reg['L2']),
                      float(gscale))
-            if reg['maxnorm']:
-                if p.ndim == 1:
-                    ctx.call("tn_maxnorm", p.ptr, 1, p.shape[0], 1, float(reg['maxnorm']))
-                elif p.ndim == 2:
-                    ctx.call("tn_maxnorm", p.ptr, 2, p.shape[0], p.shape[1], float(reg['maxnorm']))
-                elif p.ndim == 4:
-                    ctx.call("tn_maxnorm", p.ptr, 4, p.shape[0], int(np.prod(p.shape[1:])),
-                             float(reg['maxnorm']))
+        self.apply_maxnorm()
+
+    def apply_maxnorm(self):
+        """layer.py:88-103: clip (1-D) / per-column (2-D) / per-kernel (4-D) norm projection
+        of the freshly updated parameters."""
+        if not self.has_updates() or not self.reg['maxnorm']:
+            return
+        ctx = self.params[0].ctx
+        mx = float(self.reg['maxnorm'])
+        for p in self.params:
+            if p.ndim == 1:
+                ctx.call("tn_maxnorm", p.ptr, 1, p.shape[0], 1, mx)
+            elif p.ndim == 2:
+                ctx.call("tn_maxnorm", p.ptr, 2, p.shape[0], p.shape[1], mx)
+            elif p.ndim == 4:
+                ctx.call("tn_maxnorm", p.ptr, 4, p.shape[0], int(np.prod(p.shape[1:])), mx)
 
     # -- layer.py:109-117 ---------------------------------------------------------------
     def get_wtcost(self, d_cost):

@@ -140,6 +140,8 @@ class _TestFn:
 
 
 class NeuralNet():
+    fuse_conv_pool = True     # class-level switch (tests run both the fused and unfused paths)
+
     def __init__(self, layers, training_params, allwts=None,
                  test_x=None):
         # Either a random seed or the weights of a previously trained net (neuralnet.py:63-68)
@@ -188,6 +190,10 @@ class NeuralNet():
         # Rest of the layers
         while self.num_layers < len(layers):
             self.append_next_layer()
+
+        if self.fuse_conv_pool:
+            self._fuse(self.tr_layers)
+            self._fuse(self.te_layers)
 
         assert isinstance(self.tr_layers[-1], SoftmaxLayer), \
             "the accelerated path ends in a SoftmaxLayer (other heads: SURVEY.md 8f)"
@@ -278,6 +284,15 @@ class NeuralNet():
         self.te_layers.append(curr_layer.TestVersion(te_inpt))
         self.num_layers += 1
 
+    @staticmethod
+    def _fuse(lyrs):
+        """Pair every ConvLayer that is directly followed by a 2x2 PoolLayer (and is small
+        enough for the register-resident kernel) into one fused conv+act+pool launch."""
+        for conv, pool in zip(lyrs[:-1], lyrs[1:]):
+            if isinstance(conv, ConvLayer) and isinstance(pool, PoolLayer) \
+                    and conv.can_fuse_with(pool):
+                conv.fused_pool, pool.fused_conv = pool, conv
+
     # ------------------------------------------------------------------------------
     def _group(self):
         if self._dev_group is None:
@@ -306,6 +321,20 @@ class NeuralNet():
             lyr.grads.append(self.flat_grads.view(off, p.shape))
             lyr.accumulated_updates.append(self.ctx.zeros(p.shape))
         self.tr_layers[-1].d_cost = self.d_cost
+        # one multi-tensor momentum-SGD launch for every parameter tensor (layer.py:70-107)
+        seg_dt = np.dtype([('p', 'u8'), ('v', 'u8'), ('g', 'u8'), ('n', 'u8'),
+                           ('momentum', 'f4'), ('rate', 'f4'), ('L1', 'f4'), ('L2', 'f4')])
+        segs = []
+        for lyr in self.tr_layers:
+            if lyr.has_updates():
+                for p, v, g in zip(lyr.params, lyr.accumulated_updates, lyr.grads):
+                    segs.append((p.ptr, v.ptr, g.ptr, p.size, lyr.reg['momentum'], lyr.reg['rate'],
+                                 lyr.reg['L1'], lyr.reg['L2']))
+        self._n_segs = len(segs)
+        self._max_seg = max([sg[3] for sg in segs] or [0])
+        if segs:
+            host = np.array(segs, dtype=seg_dt)
+            self._d_segs = self.ctx.array(host.view(np.uint8))
         # which layers must propagate a gradient to their input
         self._need_gin = []
         seen = False
@@ -338,8 +367,11 @@ class NeuralNet():
             self._group().allreduce_sum(self.flat_grads, self.n_flat)
         for lyr in self.tr_layers:
             lyr.get_wtcost(self.d_cost)
+        if self._n_segs:
+            ctx.call("tn_sgd_update_multi", self._d_segs.ptr, self._n_segs, self._max_seg,
+                     self.cur_learn_rate.ptr, 1.0)
         for lyr in self.tr_layers:
-            lyr.get_updates(self.cur_learn_rate)
+            lyr.apply_maxnorm()
         ctx.call("tn_add_u32", self.d_step.ptr, 1)
 
     # ------------------------------------------------------------------------------
@@ -372,6 +404,11 @@ class NeuralNet():
                   "WILL BE EXPECTING A BATCH OF INPUT IMAGES AT A TIME.\n")
         first = self.te_layers[0]
         stage = self.ctx.empty((self.local_bsz, first.num_maps, first.out_sz, first.out_sz))
+
+        for index in get_output_of_layers:          # a requested conv map must be materialised
+            lyr = self.te_layers[index]
+            if isinstance(lyr, ConvLayer) and lyr.fused_pool is not None:
+                lyr.fused_pool.fused_conv, lyr.fused_pool = None, None
 
         def fn(x):
             x = np.ascontiguousarray(x, np.float32).reshape(stage.shape)
