@@ -58,6 +58,24 @@ def draws_to_dict(prefix, d):
             if getattr(d, k) is not None}
 
 
+def perturbed_init(prms):
+    """Seed-chain initial weights with the conv kernels de-symmetrised.  The reference's
+    conv init is +-1/sqrt(fan_in) (weights.py:52-54); with nearest-neighbour zoom the
+    elastic stage duplicates pixels, so different pooling-window members become
+    MATHEMATICALLY equal sums whose floating-point tie depends on summation order.
+    GOLD-B pins gradient routing, so it must not depend on such ties."""
+    import copy
+    net = O.OracleNet(copy.deepcopy(prms["layers"]), dict(prms["training_params"]))
+    rng = np.random.RandomState(123)
+    allwts = []
+    for l in net.L:
+        ws = [p.copy() for p in l.params]
+        if l.kind == "Conv":
+            ws[0] = (ws[0] * (1 + .1 * rng.standard_normal(ws[0].shape))).astype(np.float32)
+        allwts.append(ws)
+    return allwts
+
+
 def make_gold_net(fname, elastic_on, steps=3, B=8):
     """GOLD-A / GOLD-B: mnist.prms, B=8, every random draw recorded so the HIP
     path can replay them; float32 net with a float64 twin."""
@@ -70,7 +88,14 @@ def make_gold_net(fname, elastic_on, steps=3, B=8):
         prms = load_prms("mnist.prms", 28, batch=B)
         if not elastic_on:
             prms["layers"][0] = ("ElasticLayer", {"img_sz": 28, "invert_image": True})
-        net = O.OracleNet(prms["layers"], prms["training_params"], dtype=dt)
+        allwts = perturbed_init(prms) if elastic_on else None
+        net = O.OracleNet(prms["layers"], prms["training_params"], allwts, dtype=dt)
+        if elastic_on:      # with weights given the reference seeds its streams from OS entropy
+            st = net.L[0].stage
+            st.__init__(rand_gen=np.random.RandomState(99), **{k: v for k, v in
+                        prms["layers"][0][1].items()})
+            from oracle.randomstreams import RandomStreams
+            net.L[5].mask_rv = RandomStreams(98).binomial(None, n=1, p=.5)
         if tag == "f32":
             for i, l in enumerate(net.L):
                 for j, p in enumerate(l.params):
