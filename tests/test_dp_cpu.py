@@ -1,0 +1,72 @@
+"""Data-parallel host logic on CPU: shard math, flat layout, and a real world_size-2 run
+(two processes, socket rendezvous + gloo all-reduce) whose reduced gradient must equal the
+single-process full-batch gradient."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from theanet_amd import comm
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_shard_rows_and_row0():
+    assert comm.shard_rows(4096, 1, 0) == (0, 4096)
+    assert [comm.shard_rows(4096, 8, r) for r in (0, 7)] == [(0, 512), (3584, 4096)]
+    with pytest.raises(ValueError):
+        comm.shard_rows(20, 8, 0)
+    assert comm.minibatch_row0(3, 4096, 8, 2) == 3 * 4096 + 1024
+    # shards tile the minibatch exactly
+    rows = sorted(r for k in range(4) for r in range(*comm.shard_rows(64, 4, k)))
+    assert rows == list(range(64))
+
+
+def test_flat_layout_alignment():
+    offs, cost_off, n = comm.flat_layout([36, 4, 720, 20, 360000, 500, 5000, 10])
+    assert offs[0] == 0 and all(o % 64 == 0 for o in offs)
+    assert offs[1] == 64 and offs[2] == 128 and offs[3] == 128 + 768
+    assert n == cost_off + 1 and cost_off % 64 == 0
+    sizes = [36, 4, 720, 20, 360000, 500, 5000, 10]
+    for (o, s), o2 in zip(zip(offs, sizes), offs[1:] + [cost_off]):
+        assert o + s <= o2
+
+
+def test_world_from_env():
+    w = comm.World.from_env({"RANK": "3", "WORLD_SIZE": "8", "LOCAL_RANK": "3",
+                             "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "1234"})
+    assert (w.rank, w.size, w.local_rank, w.master_port) == (3, 8, 3, 1234)
+    assert comm.World.from_env({}).size == 1
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_world_size_2_gradient_allreduce_equals_full_batch(tmp_path):
+    port = _free_port()
+    out = str(tmp_path / "dp.npz")
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="2")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dp_worker.py"), out],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=240)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        assert p.returncode == 0, o.decode()[-2000:]
+    r = np.load(out)
+    assert r["err"] < 1e-12
+    np.testing.assert_allclose(r["cost"], r["cost_full"], rtol=1e-12)

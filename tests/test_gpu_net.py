@@ -247,3 +247,44 @@ def test_errors_mirror_the_reference():
         NeuralNet([("InputLayer", {"img_sz": 8}), ("HingeLayer", {"n_out": 3})], dict(tr))
     with pytest.raises(AttributeError):
         NeuralNet([("InputLayer", {"img_sz": 8}), ("BogusLayer", {})], dict(tr))
+
+
+def test_rccl_single_rank_allreduce_and_dp_plumbing():
+    """RCCL is dlopen'ed and a 1-rank communicator reduces in place (the 8-GPU run is the
+    driver's; the N>1 host logic is covered on CPU by tests/test_dp_cpu.py)."""
+    from theanet_amd import comm
+    from tests.gpu_util import ctx, dev
+    group = comm.DeviceGroup(ctx(), comm.World(0, 1))
+    a = np.arange(1000, dtype=np.float32)
+    d = dev(a)
+    group.allreduce_sum(d)
+    group.allreduce_max(d, 10)
+    group.barrier()
+    np.testing.assert_array_equal(d.get_value(), a)
+    ctx().call("tn_comm_destroy")
+
+
+def test_train_py_end_to_end(tmp_path):
+    """The harness runs, prints the reference's table, learns, and writes a loadable pickle."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    prm = tmp_path / "tiny.prms"
+    prms = load_prms("mnist.prms")
+    prms["training_params"].update(SEED=11, BATCH_SZ=64, NUM_EPOCHS=3, TEST_SAMP_SZ=256,
+                                   INIT_LEARNING_RATE=.1)
+    prm.write_text(repr(prms))
+    env = dict(os.environ, THEANET_SYNTH_TRAIN="1024", THEANET_SYNTH_TEST="256", PYTHONPATH=root)
+    r = subprocess.run([sys.executable, os.path.join(root, "train.py"), "synthetic", str(prm)],
+                       cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "Epoch   Cost  Tr_Error Tr_P(MLE)    Te_Error Te_P(MLE)" in r.stdout
+    rows = [l for l in r.stdout.splitlines() if l.strip().startswith(("0 ", "1 ", "2 ", "3 "))]
+    assert len(rows) == 4, r.stdout
+    errs = [float(l.split()[2].rstrip("%")) for l in rows]
+    assert errs[-1] < errs[0] or errs[-1] < 5.0, rows
+    pk = [f for f in os.listdir(tmp_path) if f.endswith(".pkl")]
+    assert len(pk) == 1
+    with open(tmp_path / pk[0], "rb") as fh:
+        ck = pickle.load(fh)
+    assert ck["training_params"]["CUR_EPOCH"] >= 2 and len(ck["allwts"]) == 7

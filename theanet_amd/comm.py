@@ -51,6 +51,18 @@ def minibatch_row0(index, global_batch, world_size, rank):
     return index * global_batch + lo
 
 
+def flat_layout(sizes, align=64):
+    """Offsets of tensors of ``sizes`` elements inside ONE flat fp32 buffer (each start
+    aligned to ``align`` elements = 256 B) followed by one extra scalar slot (the cost), so a
+    single all-reduce moves every gradient and the loss.  Returns (offsets, cost_offset,
+    n_reduce) where n_reduce = number of elements the all-reduce must cover."""
+    offsets, total = [], 0
+    for n in sizes:
+        offsets.append(total)
+        total += -(-int(n) // align) * align
+    return offsets, total, total + 1
+
+
 # --------------------------------------------------------------------------- #
 # socket rendezvous: broadcast of a small blob from rank 0, and a barrier
 # --------------------------------------------------------------------------- #

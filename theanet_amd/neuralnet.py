@@ -304,15 +304,11 @@ class NeuralNet():
         ONE all-reduce moves everything) and the velocity buffers (layer.py:77-79)."""
         if self._grads_ready:
             return
-        total = 0
-        slots = []
-        for lyr in self.tr_layers:
-            for p in lyr.params:
-                slots.append((lyr, p, total))
-                total += -(-p.size // _GRAD_ALIGN) * _GRAD_ALIGN
+        plist = [(lyr, p) for lyr in self.tr_layers for p in lyr.params]
+        offs, total, self.n_flat = comm.flat_layout([p.size for _, p in plist], _GRAD_ALIGN)
+        slots = [(lyr, p, off) for (lyr, p), off in zip(plist, offs)]
         self.flat_grads = self.ctx.zeros((total + _GRAD_ALIGN,))
         self.d_cost = self.flat_grads.view(total, (1,))
-        self.n_flat = total + 1
         for lyr in self.tr_layers:
             if lyr.params:
                 lyr.grads = []
