@@ -15,7 +15,20 @@
 //             pool-bwd + wgrad traffic of ~5x that.
 //
 // Semantics: theanet/layer/convpool.py:54-72 (true convolution, flipped W), :106-112 (pool).
+#include <cstdlib>
+
 #include "common.h"
+
+template <int ACT>
+__device__ __forceinline__ float act_fwd_t(float z, int act, float prm) {
+    if (ACT == TN_ACT_LEAKY) return fmaxf(0.f, z) + fminf(0.f, z) * prm;
+    return tn_act_fwd(z, act, prm);
+}
+template <int ACT>
+__device__ __forceinline__ float act_grad_t(float a, int act, float prm) {
+    if (ACT == TN_ACT_LEAKY) return a > 0.f ? 1.f : (a < 0.f ? prm : (prm > 0.f ? 1.f + prm : 0.f));
+    return tn_act_grad_from_out(a, act, prm);
+}
 
 template <int F, int P, int C>
 struct Patch {
@@ -64,7 +77,7 @@ __device__ __forceinline__ void window_conv(const Patch<F, P, C>& pt, const floa
             }
 }
 
-template <int F, int P, int C>
+template <int F, int P, int C, int ACT>
 __global__ __launch_bounds__(256) void convpool_fwd_kernel(
     const float* __restrict__ x, const float* __restrict__ W, const float* __restrict__ b,
     float* __restrict__ y, int N, int H, int Wd, int K, int pad, int Ho, int Wo, int Hp, int Wp,
@@ -92,29 +105,52 @@ __global__ __launch_bounds__(256) void convpool_fwd_kernel(
         for (int di = 0; di < P; ++di)
 #pragma unroll
             for (int dj = 0; dj < P; ++dj) {
-                const float a = tn_act_fwd(z[di][dj], act, prm);
+                const float a = act_fwd_t<ACT>(z[di][dj], act, prm);
                 if (valid[di][dj]) m = fmaxf(m, a);
             }
         yn[(size_t)k * HpWp] = m;
     }
 }
 
-__device__ __forceinline__ float wave_sum_cp(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+// ---- cross-lane helpers (DPP: no LDS round trip) -------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+#define DPP_QUAD_XOR1 0xB1      // quad_perm [1,0,3,2]
+#define DPP_QUAD_XOR2 0x4E      // quad_perm [2,3,0,1]
+#define DPP_ROW_HALF_MIRROR 0x141
+#define DPP_ROW_MIRROR 0x140
+
+// sum over the 64 lanes; the total is returned in every lane of... lane 0 (uniform scalar adds)
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+    v += dpp_f<DPP_QUAD_XOR1>(v);
+    v += dpp_f<DPP_QUAD_XOR2>(v);
+    v += dpp_f<DPP_ROW_HALF_MIRROR>(v);
+    v += dpp_f<DPP_ROW_MIRROR>(v);          // every lane of a 16-lane row now holds the row sum
+    const int iv = __float_as_int(v);
+    return __int_as_float(__builtin_amdgcn_readlane(iv, 0)) +
+           __int_as_float(__builtin_amdgcn_readlane(iv, 16)) +
+           __int_as_float(__builtin_amdgcn_readlane(iv, 32)) +
+           __int_as_float(__builtin_amdgcn_readlane(iv, 48));
 }
 
-template <int F, int P, int C, int KT>
+// Backward of the fused block, p = 2.  Thread = one CONV output position; the four positions of
+// a pooling window sit in four adjacent lanes (a DPP quad), so the window max is two DPP ops
+// and every lane does exactly its own C*f*f wgrad FMAs (no multiply-by-zero work).
+// Slot s of an image: window = s >> 2, (di, dj) = ((s >> 1) & 1, s & 1).
+template <int F, int C, int KT, int ACT>
 __global__ __launch_bounds__(256) void convpool_bwd_kernel(
     const float* __restrict__ x, const float* __restrict__ W, const float* __restrict__ b,
     const float* __restrict__ g, float* __restrict__ dz_out, float* __restrict__ partial,
     float* __restrict__ dbpartial, int N, int H, int Wd, int K, int pad, int Ho, int Wo, int Hp,
     int Wp, int act, float prm) {
     constexpr int FF = F * F;
-    __shared__ float red[4][KT * C * FF + KT];
+    constexpr int NACC = KT * C * FF + KT;
+    __shared__ float red[4][NACC];
     const int HpWp = Hp * Wp, HoWo = Ho * Wo;
-    const long long total = (long long)N * HpWp;
+    const int slots = HpWp * 4;
+    const long long total = (long long)N * slots;
     const int k0 = blockIdx.y * KT;
 
     float acc[KT][C][FF];
@@ -127,53 +163,64 @@ __global__ __launch_bounds__(256) void convpool_bwd_kernel(
 #pragma unroll
             for (int s = 0; s < FF; ++s) acc[kk][c][s] = 0.f;
     }
-
-    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total;
-         t += (long long)gridDim.x * 256) {
-        const int n = (int)(t / HpWp);
-        const int q = (int)(t - (long long)n * HpWp);
+    // grid-stride over slots; the trip count is uniform per block so the DPP quads stay whole
+    const long long stride = (long long)gridDim.x * 256;
+    for (long long base = (long long)blockIdx.x * 256; base < total; base += stride) {
+        const long long t = base + threadIdx.x;
+        const bool live = t < total;
+        const long long tt = live ? t : total - 1;
+        const int n = (int)(tt / slots);
+        const int s = (int)(tt - (long long)n * slots);
+        const int q = s >> 2;
         const int pi = q / Wp, pj = q - pi * Wp;
-        Patch<F, P, C> pt;
-        pt.load(x + (size_t)n * C * H * Wd, H, Wd, pi * P - pad, pj * P - pad);
-        bool valid[P][P];
+        const int i = pi * 2 + ((s >> 1) & 1), j = pj * 2 + (s & 1);
+        const bool valid = live && (i < Ho) && (j < Wo);
+        // 3x3xC (FxFxC) input window of this conv output, zero outside the image
+        float pt[C][FF];
+        const float* xn = x + (size_t)n * C * H * Wd;
 #pragma unroll
-        for (int di = 0; di < P; ++di)
+        for (int u = 0; u < F; ++u) {
+            const int yy = i - pad + u;
+            const bool yok = (yy >= 0) && (yy < H);
+            const int yc = min(max(yy, 0), H - 1);
 #pragma unroll
-            for (int dj = 0; dj < P; ++dj) valid[di][dj] = (pi * P + di < Ho) && (pj * P + dj < Wo);
+            for (int v = 0; v < F; ++v) {
+                const int xx = j - pad + v;
+                const bool ok = yok && (xx >= 0) && (xx < Wd);
+                const int xc = min(max(xx, 0), Wd - 1);
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    const float tv = xn[((size_t)c * H + yc) * Wd + xc];
+                    pt[c][u * F + v] = ok ? tv : 0.f;
+                }
+            }
+        }
 #pragma unroll
         for (int kk = 0; kk < KT; ++kk) {
             const int k = k0 + kk;
             if (k < K) {   // wave-uniform
-                float z[P][P];
-                window_conv<F, P, C>(pt, W + (size_t)k * C * FF, b[k], z);
-                float m = -INFINITY;
+                const float* Wk = W + (size_t)k * C * FF;      // wave-uniform -> scalar loads
+                float z = b[k];
 #pragma unroll
-                for (int di = 0; di < P; ++di)
+                for (int c = 0; c < C; ++c)
 #pragma unroll
-                    for (int dj = 0; dj < P; ++dj) {
-                        z[di][dj] = tn_act_fwd(z[di][dj], act, prm);
-                        if (valid[di][dj]) m = fmaxf(m, z[di][dj]);
-                    }
+                    for (int u = 0; u < F; ++u)
+#pragma unroll
+                        for (int v = 0; v < F; ++v)
+                            z = fmaf(pt[c][u * F + v], Wk[(c * F + (F - 1 - u)) * F + (F - 1 - v)], z);
+                const float a = act_fwd_t<ACT>(z, act, prm);
+                float m = valid ? a : -INFINITY;
+                m = fmaxf(m, dpp_f<DPP_QUAD_XOR1>(m));
+                m = fmaxf(m, dpp_f<DPP_QUAD_XOR2>(m));
                 const float gk = g[((size_t)n * K + k) * HpWp + q];
+                float d = 0.f;
+                if (valid && a == m) d = gk * act_grad_t<ACT>(a, act, prm);
+                if (dz_out && valid) dz_out[((size_t)n * K + k) * HoWo + i * Wo + j] = d;
+                accb[kk] += d;
 #pragma unroll
-                for (int di = 0; di < P; ++di)
+                for (int c = 0; c < C; ++c)
 #pragma unroll
-                    for (int dj = 0; dj < P; ++dj) {
-                        float d = 0.f;
-                        if (valid[di][dj] && z[di][dj] == m)
-                            d = gk * tn_act_grad_from_out(z[di][dj], act, prm);
-                        if (dz_out && valid[di][dj])
-                            dz_out[((size_t)n * K + k) * HoWo + (pi * P + di) * Wo + pj * P + dj] = d;
-                        accb[kk] += d;
-#pragma unroll
-                        for (int c = 0; c < C; ++c)
-#pragma unroll
-                            for (int u = 0; u < F; ++u)
-#pragma unroll
-                                for (int v = 0; v < F; ++v)
-                                    acc[kk][c][u * F + v] =
-                                        fmaf(d, pt.v[c][di + u][dj + v], acc[kk][c][u * F + v]);
-                    }
+                    for (int uv = 0; uv < FF; ++uv) acc[kk][c][uv] = fmaf(d, pt[c][uv], acc[kk][c][uv]);
             }
         }
     }
@@ -185,15 +232,15 @@ __global__ __launch_bounds__(256) void convpool_bwd_kernel(
         for (int c = 0; c < C; ++c)
 #pragma unroll
             for (int s = 0; s < FF; ++s) {
-                const float r = wave_sum_cp(acc[kk][c][s]);
+                const float r = wave_sum_dpp(acc[kk][c][s]);
                 if (lane == 0) red[wave][(kk * C + c) * FF + s] = r;
             }
-        const float rb = wave_sum_cp(accb[kk]);
+        const float rb = wave_sum_dpp(accb[kk]);
         if (lane == 0) red[wave][KT * C * FF + kk] = rb;
     }
     __syncthreads();
     const int KCFF = K * C * FF;
-    for (int s = threadIdx.x; s < KT * C * FF + KT; s += 256) {
+    for (int s = threadIdx.x; s < NACC; s += 256) {
         const float r = red[0][s] + red[1][s] + red[2][s] + red[3][s];
         if (s < KT * C * FF) {
             const int kk = s / (C * FF), rem = s - kk * C * FF;
@@ -215,18 +262,31 @@ static int launch_fwd(tn_ctx* ctx, const float* x, const float* W, const float* 
                       int H, int Wd, int K, int pad, int Ho, int Wo, int Hp, int Wp, int act,
                       float prm) {
     const long long total = (long long)N * Hp * Wp;
-    convpool_fwd_kernel<F, P, C><<<cdiv(total, 256), 256, 0, ctx->stream>>>(
-        x, W, b, y, N, H, Wd, K, pad, Ho, Wo, Hp, Wp, act, prm);
+    if (act == TN_ACT_LEAKY)
+        convpool_fwd_kernel<F, P, C, TN_ACT_LEAKY><<<cdiv(total, 256), 256, 0, ctx->stream>>>(
+            x, W, b, y, N, H, Wd, K, pad, Ho, Wo, Hp, Wp, act, prm);
+    else
+        convpool_fwd_kernel<F, P, C, -1><<<cdiv(total, 256), 256, 0, ctx->stream>>>(
+            x, W, b, y, N, H, Wd, K, pad, Ho, Wo, Hp, Wp, act, prm);
     TN_LAUNCH_CHECK();
     return TN_OK;
 }
 
-template <int F, int P, int C, int KT>
+static int tn_tune_kt() {
+    static int kt = -1;
+    if (kt < 0) {
+        const char* e = getenv("TN_CONVPOOL_KT");
+        kt = e ? atoi(e) : 4;
+    }
+    return kt;
+}
+
+template <int F, int C, int KT>
 static int launch_bwd(tn_ctx* ctx, const float* x, const float* W, const float* b, const float* g,
                       float* dz, float* dW, float* db, int N, int H, int Wd, int K, int pad, int Ho,
                       int Wo, int Hp, int Wp, int act, float prm) {
-    const long long total = (long long)N * Hp * Wp;
-    int nblk = cdiv(total, 256 * 6);
+    const long long total = (long long)N * Hp * Wp * 4;
+    int nblk = cdiv(total, 256 * 12);
     if (nblk > 512) nblk = 512;
     if (nblk < 1) nblk = 1;
     const size_t KCFF = (size_t)K * C * F * F;
@@ -234,8 +294,13 @@ static int launch_bwd(tn_ctx* ctx, const float* x, const float* W, const float* 
     if (rc) return rc;
     float* partial = ctx->scratch;
     float* dbpartial = ctx->scratch + (size_t)nblk * KCFF;
-    convpool_bwd_kernel<F, P, C, KT><<<dim3(nblk, cdiv(K, KT)), 256, 0, ctx->stream>>>(
-        x, W, b, g, dz, partial, dbpartial, N, H, Wd, K, pad, Ho, Wo, Hp, Wp, act, prm);
+    const dim3 grid(nblk, cdiv(K, KT));
+    if (act == TN_ACT_LEAKY)
+        convpool_bwd_kernel<F, C, KT, TN_ACT_LEAKY><<<grid, 256, 0, ctx->stream>>>(
+            x, W, b, g, dz, partial, dbpartial, N, H, Wd, K, pad, Ho, Wo, Hp, Wp, act, prm);
+    else
+        convpool_bwd_kernel<F, C, KT, -1><<<grid, 256, 0, ctx->stream>>>(
+            x, W, b, g, dz, partial, dbpartial, N, H, Wd, K, pad, Ho, Wo, Hp, Wp, act, prm);
     TN_LAUNCH_CHECK();
     return tn_conv_wgrad_finish(ctx, partial, dbpartial, dW, db, nblk, K, C, F);
 }
@@ -276,14 +341,16 @@ int tn_convpool_bwd(tn_ctx* ctx, const float* x, const float* W, const float* b,
     if (dz && (Hp * p < Ho || Wp * p < Wo))   // rows/cols outside every window (ignore_border)
         TN_HIP(hipMemsetAsync(dz, 0, (size_t)N * K * Ho * Wo * sizeof(float), ctx->stream));
 #define CP_BWD(F_, C_, KT_)                                                                       \
-    return launch_bwd<F_, 2, C_, KT_>(ctx, x, W, b, g, dz, dW, db, N, H, Wd, K, pad_lo, Ho, Wo, Hp, \
-                                      Wp, act, act_param)
+    return launch_bwd<F_, C_, KT_>(ctx, x, W, b, g, dz, dW, db, N, H, Wd, K, pad_lo, Ho, Wo, Hp, Wp, \
+                                   act, act_param)
     if (f == 3) {
         switch (C) {
             case 1: CP_BWD(3, 1, 4);
             case 2: CP_BWD(3, 2, 4);
             case 3: CP_BWD(3, 3, 4);
-            default: CP_BWD(3, 4, 4);
+            default:
+                if (tn_tune_kt() == 2) CP_BWD(3, 4, 2);
+                CP_BWD(3, 4, 4);
         }
     } else {
         if (C == 1) CP_BWD(5, 1, 4);
