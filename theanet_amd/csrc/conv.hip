@@ -314,75 +314,70 @@ __global__ __launch_bounds__(256) void conv_dgrad_direct(
     }
 }
 
-// LDS-staged dgrad (stride 1): a block stages dz of G whole images in LDS (coalesced float4
-// loads, dz read from HBM exactly once), then thread = one input pixel gathers its f*f*K taps
-// from LDS (2 cycles per wave read, no L1 traffic) and FMAs them with scalar-loaded weights.
-template <int F, int CT>
+// LDS-staged dgrad (stride 1).  A block stages dz of G whole images in LDS with a ZERO HALO of
+// f-1 pixels around every map, plus the weights as one float4 (4 input channels) per (k, tap).
+// Then thread = one input pixel: every tap is an unconditional LDS read (no bounds selects, so
+// the reads pipeline), the weights are wave-broadcast b128 reads, 4 FMAs per tap.
+//   dx[n,c,y,x] = sum_{k,u',v'} dzh[n,k,y+pad+u',x+pad+v'] * W[k,c,u',v']      (dzh = haloed dz)
+template <int F>
 __global__ __launch_bounds__(256) void conv_dgrad_lds(
     const float* __restrict__ dz, const float* __restrict__ W, float* __restrict__ dx, int N, int C,
     int H, int Wd, int K, int pad, int Ho, int Wo, int G, const float* __restrict__ prev_a,
     int prev_act, float prev_prm) {
-    extern __shared__ __attribute__((aligned(16))) float sdz[];
+    extern __shared__ __attribute__((aligned(16))) float sm[];
     constexpr int FF = F * F;
-    const int HoWo = Ho * Wo, HW = H * Wd;
+    const int Hh = Ho + 2 * (F - 1), Wh = Wo + 2 * (F - 1);
+    const int plane = Hh * Wh, HoWo = Ho * Wo, HW = H * Wd;
+    float4* sW = reinterpret_cast<float4*>(sm);                  // [K][FF]
+    float* sdz = sm + (size_t)K * FF * 4;                        // [G][K][Hh][Wh]
     const int n0 = blockIdx.x * G;
     const int gcnt = min(G, N - n0);
-    const int c0 = blockIdx.y * CT;
-    {
-        const size_t per = (size_t)K * HoWo;
-        const float* src = dz + (size_t)n0 * per;
-        const int tot = (int)(gcnt * per);
-        if (((reinterpret_cast<uintptr_t>(src) & 15) == 0) && (tot % 4 == 0)) {
-            const float4* s4 = reinterpret_cast<const float4*>(src);
-            float4* d4 = reinterpret_cast<float4*>(sdz);
-            for (int t = threadIdx.x; t < tot / 4; t += 256) d4[t] = s4[t];
-        } else {
-            for (int t = threadIdx.x; t < tot; t += 256) sdz[t] = src[t];
-        }
+    const int c0 = blockIdx.y * 4;
+    for (int t = threadIdx.x; t < K * FF; t += 256) {
+        const int k = t / FF, uv = t - k * FF;
+        float4 w;
+        w.x = (c0 + 0 < C) ? W[((size_t)k * C + c0 + 0) * FF + uv] : 0.f;
+        w.y = (c0 + 1 < C) ? W[((size_t)k * C + c0 + 1) * FF + uv] : 0.f;
+        w.z = (c0 + 2 < C) ? W[((size_t)k * C + c0 + 2) * FF + uv] : 0.f;
+        w.w = (c0 + 3 < C) ? W[((size_t)k * C + c0 + 3) * FF + uv] : 0.f;
+        sW[t] = w;
+    }
+    const float* src = dz + (size_t)n0 * K * HoWo;
+    for (int t = threadIdx.x; t < gcnt * K * plane; t += 256) {
+        const int gk = t / plane, r = t - gk * plane;
+        const int ii = r / Wh - (F - 1), jj = r % Wh - (F - 1);
+        const bool in = ((unsigned)ii < (unsigned)Ho) && ((unsigned)jj < (unsigned)Wo);
+        const float v = src[(size_t)gk * HoWo + min(max(ii, 0), Ho - 1) * Wo + min(max(jj, 0), Wo - 1)];
+        sdz[t] = in ? v : 0.f;
     }
     __syncthreads();
     for (int t = threadIdx.x; t < gcnt * HW; t += 256) {
         const int gi = t / HW;
         const int p = t - gi * HW;
         const int y = p / Wd, xq = p - y * Wd;
-        int off[FF];
-        bool ok[FF];
-#pragma unroll
-        for (int u = 0; u < F; ++u) {
-            const int i = y + pad - u;
-            const bool iok = (unsigned)i < (unsigned)Ho;
-            const int ic = min(max(i, 0), Ho - 1);
-#pragma unroll
-            for (int v = 0; v < F; ++v) {
-                const int j = xq + pad - v;
-                ok[u * F + v] = iok && ((unsigned)j < (unsigned)Wo);
-                off[u * F + v] = ic * Wo + min(max(j, 0), Wo - 1);
-            }
-        }
-        float acc[CT];
-#pragma unroll
-        for (int cc = 0; cc < CT; ++cc) acc[cc] = 0.f;
-        const float* sg = sdz + (size_t)gi * K * HoWo;
+        const float* base = sdz + (size_t)gi * K * plane + (y + pad) * Wh + xq + pad;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int k = 0; k < K; ++k) {
-            const float* wk = W + ((size_t)k * C + c0) * FF;   // wave-uniform
-            const float* sk = sg + k * HoWo;
+            const float* bk = base + k * plane;
+            const float4* wk = sW + k * FF;
 #pragma unroll
-            for (int uv = 0; uv < FF; ++uv) {
-                const float tv = sk[off[uv]];
-                const float gv = ok[uv] ? tv : 0.f;
-                const int widx = (F - 1 - uv / F) * F + (F - 1 - uv % F);
+            for (int u = 0; u < F; ++u)
 #pragma unroll
-                for (int cc = 0; cc < CT; ++cc) {
-                    const float wv = (c0 + cc < C) ? wk[cc * FF + widx] : 0.f;
-                    acc[cc] = fmaf(gv, wv, acc[cc]);
+                for (int v = 0; v < F; ++v) {
+                    const float gv = bk[u * Wh + v];
+                    const float4 w = wk[u * F + v];
+                    acc.x = fmaf(gv, w.x, acc.x);
+                    acc.y = fmaf(gv, w.y, acc.y);
+                    acc.z = fmaf(gv, w.z, acc.z);
+                    acc.w = fmaf(gv, w.w, acc.w);
                 }
-            }
         }
+        const float r4[4] = {acc.x, acc.y, acc.z, acc.w};
 #pragma unroll
-        for (int cc = 0; cc < CT; ++cc) {
+        for (int cc = 0; cc < 4; ++cc) {
             if (c0 + cc < C) {
                 const size_t o = ((size_t)(n0 + gi) * C + c0 + cc) * HW + p;
-                float r = acc[cc];
+                float r = r4[cc];
                 if (prev_a) r *= tn_act_grad_from_out(prev_a[o], prev_act, prev_prm);
                 dx[o] = r;
             }
@@ -484,18 +479,14 @@ int tn_conv2d_dgrad(tn_ctx* ctx, const float* dz, const float* W, float* dx, int
                     int prev_act, float prev_act_param) {
     TN_REQUIRE(N > 0 && C > 0 && K > 0 && f > 0 && stride > 0, "tn_conv2d_dgrad: bad shape");
     if (f == 3 && stride == 1) {
-        const size_t per = (size_t)K * Ho * Wo * sizeof(float);
-        if (per <= 48 * 1024) {
-            int G = (int)((48 * 1024) / per);
-            if (G > 8) G = 8;
-            if (G < 1) G = 1;
-            const size_t lds = (size_t)G * per;
-            if (C <= 4)
-                conv_dgrad_lds<3, 4><<<dim3(cdiv(N, G), 1), 256, lds, ctx->stream>>>(
-                    dz, W, dx, N, C, H, Wd, K, pad_lo, Ho, Wo, G, prev_a, prev_act, prev_act_param);
-            else
-                conv_dgrad_lds<3, 8><<<dim3(cdiv(N, G), cdiv(C, 8)), 256, lds, ctx->stream>>>(
-                    dz, W, dx, N, C, H, Wd, K, pad_lo, Ho, Wo, G, prev_a, prev_act, prev_act_param);
+        const size_t per = (size_t)K * (Ho + 4) * (Wo + 4) * sizeof(float);
+        const size_t wbytes = (size_t)K * 9 * 16;
+        if (per + wbytes <= 60 * 1024) {
+            int G = (int)((60 * 1024 - wbytes) / per);
+            if (G > 4) G = 4;
+            const size_t lds = wbytes + (size_t)G * per;
+            conv_dgrad_lds<3><<<dim3(cdiv(N, G), cdiv(C, 4)), 256, lds, ctx->stream>>>(
+                dz, W, dx, N, C, H, Wd, K, pad_lo, Ho, Wo, G, prev_a, prev_act, prev_act_param);
             TN_LAUNCH_CHECK();
             return TN_OK;
         }

@@ -30,34 +30,48 @@ __device__ __forceinline__ float act_grad_t(float a, int act, float prm) {
     return tn_act_grad_from_out(a, act, prm);
 }
 
-template <int F, int P, int C>
-struct Patch {
-    static constexpr int S = P + F - 1;
+// Input window of S x S x C values held in registers.  Row / column offsets are clamped ONCE
+// (S + S integer ops), then all loads are issued back to back from base + roff + coff (hipcc
+// serialises "load; wait; select" chains, so the zero-padding selects -- needed only for
+// mode 'same' -- come in a separate pass after every load is in flight).  Without padding,
+// clamped reads only ever feed conv outputs that are excluded by the valid flags.
+template <int S, int C, bool PADDED>
+struct Window {
     float v[C][S][S];
     __device__ __forceinline__ void load(const float* __restrict__ xn, int H, int Wd, int y0, int x0) {
+        int roff[S], coff[S];
+        bool rok[S], cok[S];
+#pragma unroll
+        for (int r = 0; r < S; ++r) {
+            const int yy = y0 + r, xx = x0 + r;
+            rok[r] = (yy >= 0) && (yy < H);
+            cok[r] = (xx >= 0) && (xx < Wd);
+            roff[r] = min(max(yy, 0), H - 1) * Wd;
+            coff[r] = min(max(xx, 0), Wd - 1);
+        }
+        const int HW = H * Wd;
 #pragma unroll
         for (int c = 0; c < C; ++c)
 #pragma unroll
-            for (int r = 0; r < S; ++r) {
-                const int yy = y0 + r;
-                const bool yok = (yy >= 0) && (yy < H);
-                const int yc = min(max(yy, 0), H - 1);
+            for (int r = 0; r < S; ++r)
 #pragma unroll
-                for (int q = 0; q < S; ++q) {
-                    const int xx = x0 + q;
-                    const bool ok = yok && (xx >= 0) && (xx < Wd);
-                    const int xc = min(max(xx, 0), Wd - 1);
-                    const float t = xn[((size_t)c * H + yc) * Wd + xc];   // always in bounds
-                    v[c][r][q] = ok ? t : 0.f;
-                }
-            }
+                for (int q = 0; q < S; ++q) v[c][r][q] = xn[c * HW + roff[r] + coff[q]];
+        if (PADDED) {
+#pragma unroll
+            for (int c = 0; c < C; ++c)
+#pragma unroll
+                for (int r = 0; r < S; ++r)
+#pragma unroll
+                    for (int q = 0; q < S; ++q) v[c][r][q] = (rok[r] && cok[q]) ? v[c][r][q] : 0.f;
+        }
     }
 };
 
 // conv outputs of the P x P window for map k (fixed FMA order: c, u, v -- shared by fwd and bwd)
-template <int F, int P, int C>
-__device__ __forceinline__ void window_conv(const Patch<F, P, C>& pt, const float* __restrict__ Wk,
-                                            float bias, float (&z)[P][P]) {
+template <int F, int P, int C, bool PADDED>
+__device__ __forceinline__ void window_conv(const Window<P + F - 1, C, PADDED>& pt,
+                                            const float* __restrict__ Wk, float bias,
+                                            float (&z)[P][P]) {
 #pragma unroll
     for (int di = 0; di < P; ++di)
 #pragma unroll
@@ -77,19 +91,19 @@ __device__ __forceinline__ void window_conv(const Patch<F, P, C>& pt, const floa
             }
 }
 
-template <int F, int P, int C, int ACT>
+template <int F, int P, int C, int ACT, bool PADDED>
 __global__ __launch_bounds__(256) void convpool_fwd_kernel(
     const float* __restrict__ x, const float* __restrict__ W, const float* __restrict__ b,
     float* __restrict__ y, int N, int H, int Wd, int K, int pad, int Ho, int Wo, int Hp, int Wp,
     int act, float prm) {
     const int HpWp = Hp * Wp;
-    const long long total = (long long)N * HpWp;
-    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const unsigned total = (unsigned)N * HpWp;
+    const unsigned t = blockIdx.x * 256u + threadIdx.x;
     if (t >= total) return;
-    const int n = (int)(t / HpWp);
-    const int q = (int)(t - (long long)n * HpWp);
+    const int n = (int)(t / (unsigned)HpWp);
+    const int q = (int)(t - (unsigned)n * HpWp);
     const int pi = q / Wp, pj = q - pi * Wp;
-    Patch<F, P, C> pt;
+    Window<P + F - 1, C, PADDED> pt;
     pt.load(x + (size_t)n * C * H * Wd, H, Wd, pi * P - pad, pj * P - pad);
     bool valid[P][P];
 #pragma unroll
@@ -99,14 +113,14 @@ __global__ __launch_bounds__(256) void convpool_fwd_kernel(
     float* yn = y + (size_t)n * K * HpWp + q;
     for (int k = 0; k < K; ++k) {
         float z[P][P];
-        window_conv<F, P, C>(pt, W + (size_t)k * C * F * F, b[k], z);
+        window_conv<F, P, C, PADDED>(pt, W + (size_t)k * C * F * F, b[k], z);
         float m = -INFINITY;
 #pragma unroll
         for (int di = 0; di < P; ++di)
 #pragma unroll
             for (int dj = 0; dj < P; ++dj) {
                 const float a = act_fwd_t<ACT>(z[di][dj], act, prm);
-                if (valid[di][dj]) m = fmaxf(m, a);
+                m = valid[di][dj] ? fmaxf(m, a) : m;
             }
         yn[(size_t)k * HpWp] = m;
     }
@@ -139,7 +153,7 @@ __device__ __forceinline__ float wave_sum_dpp(float v) {
 // a pooling window sit in four adjacent lanes (a DPP quad), so the window max is two DPP ops
 // and every lane does exactly its own C*f*f wgrad FMAs (no multiply-by-zero work).
 // Slot s of an image: window = s >> 2, (di, dj) = ((s >> 1) & 1, s & 1).
-template <int F, int C, int KT, int ACT>
+template <int F, int C, int KT, int ACT, bool PADDED>
 __global__ __launch_bounds__(256) void convpool_bwd_kernel(
     const float* __restrict__ x, const float* __restrict__ W, const float* __restrict__ b,
     const float* __restrict__ g, float* __restrict__ dz_out, float* __restrict__ partial,
@@ -149,8 +163,8 @@ __global__ __launch_bounds__(256) void convpool_bwd_kernel(
     constexpr int NACC = KT * C * FF + KT;
     __shared__ float red[4][NACC];
     const int HpWp = Hp * Wp, HoWo = Ho * Wo;
-    const int slots = HpWp * 4;
-    const long long total = (long long)N * slots;
+    const unsigned slots = HpWp * 4;
+    const unsigned total = (unsigned)N * slots;
     const int k0 = blockIdx.y * KT;
 
     float acc[KT][C][FF];
@@ -163,38 +177,26 @@ __global__ __launch_bounds__(256) void convpool_bwd_kernel(
 #pragma unroll
             for (int s = 0; s < FF; ++s) acc[kk][c][s] = 0.f;
     }
+
     // grid-stride over slots; the trip count is uniform per block so the DPP quads stay whole
-    const long long stride = (long long)gridDim.x * 256;
-    for (long long base = (long long)blockIdx.x * 256; base < total; base += stride) {
-        const long long t = base + threadIdx.x;
+    const unsigned stride = gridDim.x * 256u;
+    for (unsigned base = blockIdx.x * 256u; base < total; base += stride) {
+        const unsigned t = base + threadIdx.x;
         const bool live = t < total;
-        const long long tt = live ? t : total - 1;
+        const unsigned tt = live ? t : total - 1;
         const int n = (int)(tt / slots);
-        const int s = (int)(tt - (long long)n * slots);
+        const int s = (int)(tt - (unsigned)n * slots);
         const int q = s >> 2;
         const int pi = q / Wp, pj = q - pi * Wp;
         const int i = pi * 2 + ((s >> 1) & 1), j = pj * 2 + (s & 1);
         const bool valid = live && (i < Ho) && (j < Wo);
-        // 3x3xC (FxFxC) input window of this conv output, zero outside the image
-        float pt[C][FF];
-        const float* xn = x + (size_t)n * C * H * Wd;
+        // F x F x C input window of this conv output (all loads in flight together)
+        Window<F, C, PADDED> pt;
+        pt.load(x + (size_t)n * C * H * Wd, H, Wd, min(i, Ho - 1) - pad, min(j, Wo - 1) - pad);
+        float gk[KT];
 #pragma unroll
-        for (int u = 0; u < F; ++u) {
-            const int yy = i - pad + u;
-            const bool yok = (yy >= 0) && (yy < H);
-            const int yc = min(max(yy, 0), H - 1);
-#pragma unroll
-            for (int v = 0; v < F; ++v) {
-                const int xx = j - pad + v;
-                const bool ok = yok && (xx >= 0) && (xx < Wd);
-                const int xc = min(max(xx, 0), Wd - 1);
-#pragma unroll
-                for (int c = 0; c < C; ++c) {
-                    const float tv = xn[((size_t)c * H + yc) * Wd + xc];
-                    pt[c][u * F + v] = ok ? tv : 0.f;
-                }
-            }
-        }
+        for (int kk = 0; kk < KT; ++kk)
+            gk[kk] = g[((size_t)n * K + min(k0 + kk, K - 1)) * HpWp + q];
 #pragma unroll
         for (int kk = 0; kk < KT; ++kk) {
             const int k = k0 + kk;
@@ -207,20 +209,21 @@ __global__ __launch_bounds__(256) void convpool_bwd_kernel(
                     for (int u = 0; u < F; ++u)
 #pragma unroll
                         for (int v = 0; v < F; ++v)
-                            z = fmaf(pt[c][u * F + v], Wk[(c * F + (F - 1 - u)) * F + (F - 1 - v)], z);
+                            z = fmaf(pt.v[c][u][v], Wk[(c * F + (F - 1 - u)) * F + (F - 1 - v)], z);
                 const float a = act_fwd_t<ACT>(z, act, prm);
                 float m = valid ? a : -INFINITY;
                 m = fmaxf(m, dpp_f<DPP_QUAD_XOR1>(m));
                 m = fmaxf(m, dpp_f<DPP_QUAD_XOR2>(m));
-                const float gk = g[((size_t)n * K + k) * HpWp + q];
-                float d = 0.f;
-                if (valid && a == m) d = gk * act_grad_t<ACT>(a, act, prm);
+                const float d = (valid && a == m) ? gk[kk] * act_grad_t<ACT>(a, act, prm) : 0.f;
                 if (dz_out && valid) dz_out[((size_t)n * K + k) * HoWo + i * Wo + j] = d;
                 accb[kk] += d;
 #pragma unroll
                 for (int c = 0; c < C; ++c)
 #pragma unroll
-                    for (int uv = 0; uv < FF; ++uv) acc[kk][c][uv] = fmaf(d, pt[c][uv], acc[kk][c][uv]);
+                    for (int u = 0; u < F; ++u)
+#pragma unroll
+                        for (int v = 0; v < F; ++v)
+                            acc[kk][c][u * F + v] = fmaf(d, pt.v[c][u][v], acc[kk][c][u * F + v]);
             }
         }
     }
@@ -262,12 +265,16 @@ static int launch_fwd(tn_ctx* ctx, const float* x, const float* W, const float* 
                       int H, int Wd, int K, int pad, int Ho, int Wo, int Hp, int Wp, int act,
                       float prm) {
     const long long total = (long long)N * Hp * Wp;
-    if (act == TN_ACT_LEAKY)
-        convpool_fwd_kernel<F, P, C, TN_ACT_LEAKY><<<cdiv(total, 256), 256, 0, ctx->stream>>>(
-            x, W, b, y, N, H, Wd, K, pad, Ho, Wo, Hp, Wp, act, prm);
-    else
-        convpool_fwd_kernel<F, P, C, -1><<<cdiv(total, 256), 256, 0, ctx->stream>>>(
-            x, W, b, y, N, H, Wd, K, pad, Ho, Wo, Hp, Wp, act, prm);
+    TN_REQUIRE(total < (1ll << 31), "tn_convpool_fwd: too many outputs for 32-bit indexing");
+#define CP_L(ACT_, PAD_)                                                                          \
+    convpool_fwd_kernel<F, P, C, ACT_, PAD_><<<cdiv(total, 256), 256, 0, ctx->stream>>>(           \
+        x, W, b, y, N, H, Wd, K, pad, Ho, Wo, Hp, Wp, act, prm)
+    if (act == TN_ACT_LEAKY) {
+        if (pad) CP_L(TN_ACT_LEAKY, true); else CP_L(TN_ACT_LEAKY, false);
+    } else {
+        if (pad) CP_L(-1, true); else CP_L(-1, false);
+    }
+#undef CP_L
     TN_LAUNCH_CHECK();
     return TN_OK;
 }
@@ -281,26 +288,39 @@ static int tn_tune_kt() {
     return kt;
 }
 
+static int tn_tune_ppt() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("TN_CONVPOOL_PPT");
+        v = e ? atoi(e) : 8;
+    }
+    return v;
+}
+
 template <int F, int C, int KT>
 static int launch_bwd(tn_ctx* ctx, const float* x, const float* W, const float* b, const float* g,
                       float* dz, float* dW, float* db, int N, int H, int Wd, int K, int pad, int Ho,
                       int Wo, int Hp, int Wp, int act, float prm) {
     const long long total = (long long)N * Hp * Wp * 4;
-    int nblk = cdiv(total, 256 * 12);
-    if (nblk > 512) nblk = 512;
+    int nblk = cdiv(total, 256 * tn_tune_ppt());
+    if (nblk > 2048) nblk = 2048;
     if (nblk < 1) nblk = 1;
     const size_t KCFF = (size_t)K * C * F * F;
     int rc = tn_ensure_scratch(ctx, (size_t)nblk * (KCFF + K) * sizeof(float));
     if (rc) return rc;
     float* partial = ctx->scratch;
     float* dbpartial = ctx->scratch + (size_t)nblk * KCFF;
+    TN_REQUIRE(total < (1ll << 31), "tn_convpool_bwd: too many outputs for 32-bit indexing");
     const dim3 grid(nblk, cdiv(K, KT));
-    if (act == TN_ACT_LEAKY)
-        convpool_bwd_kernel<F, C, KT, TN_ACT_LEAKY><<<grid, 256, 0, ctx->stream>>>(
-            x, W, b, g, dz, partial, dbpartial, N, H, Wd, K, pad, Ho, Wo, Hp, Wp, act, prm);
-    else
-        convpool_bwd_kernel<F, C, KT, -1><<<grid, 256, 0, ctx->stream>>>(
-            x, W, b, g, dz, partial, dbpartial, N, H, Wd, K, pad, Ho, Wo, Hp, Wp, act, prm);
+#define CP_L(ACT_, PAD_)                                                                          \
+    convpool_bwd_kernel<F, C, KT, ACT_, PAD_><<<grid, 256, 0, ctx->stream>>>(                       \
+        x, W, b, g, dz, partial, dbpartial, N, H, Wd, K, pad, Ho, Wo, Hp, Wp, act, prm)
+    if (act == TN_ACT_LEAKY) {
+        if (pad) CP_L(TN_ACT_LEAKY, true); else CP_L(TN_ACT_LEAKY, false);
+    } else {
+        if (pad) CP_L(-1, true); else CP_L(-1, false);
+    }
+#undef CP_L
     TN_LAUNCH_CHECK();
     return tn_conv_wgrad_finish(ctx, partial, dbpartial, dW, db, nblk, K, C, F);
 }

@@ -2,24 +2,34 @@
 //
 //   C[M,N] = op(A)[M,K] . op(B)[K,N]     v_mfma_f32_32x32x2_f32 (exact fp32, fmaf chain)
 //
-// Block tile (64*WM) x (64*WN), BK=16, 4 waves in a 2x2 arrangement, each wave owning
-// WM x WN accumulators of 32x32 (so one A/B fragment read feeds WN/WM MFMAs).  Double-buffered
-// LDS with a register-staged prefetch (global loads of tile t+1 are in flight while tile t is
-// multiplied), one barrier per K-tile.  Operands may be row- or column-contiguous (NN / NT / TN)
-// so that forward, dgrad (dz.W^T) and wgrad (x^T.dz) all run on the same kernel; wgrad uses
-// split-K over the batch dimension (M x N is small, K = batch is long) with a deterministic
-// slab reduce, and picks up the bias gradient (column sums of dz) from the tiles it stages.
-// Epilogues fuse bias + activation + dropout mask (forward) and activation-gradient + mask
-// (dgrad), so no elementwise pass touches HBM again.
+// * Block tile (64*WM) x (64*WN), BK = 16, 4 waves (2x2), each wave WM x WN accumulators of 32x32.
+// * LDS tiles are [row][k] with k contiguous (row stride 20 floats = 5 x 16 B, coprime with the
+//   16 slots of a bank row): a lane's eight k-values of a K-tile are TWO ds_read_b128
+//   (lanes 0-31 take k = 0..7, lanes 32-63 k = 8..15 -- any k<->slot assignment is legal as long
+//   as A and B agree), so a whole K-tile costs 2*(WM+WN) LDS reads for 8*WM*WN MFMAs.
+// * Register-staged prefetch: global loads of tile t+1 are issued before the MFMAs of tile t
+//   and written to the other LDS buffer after them; one barrier per K-tile.  Interior tiles use
+//   unguarded float4 loads; only edge tiles take the bounds-checked path (uniform branch).
+// * XCD-aware block decode: MI355X dispatches block b to XCD b % 8 and every XCD has a private
+//   4 MB L2.  Blocks that share an A row-panel (forward / dgrad) or a split-K slice (wgrad) are
+//   given ids congruent mod 8, so each XCD streams 1/8 of the big operand from HBM once and
+//   serves the re-reads from its own L2.
+// * Operands may be row- or column-contiguous (NN / NT / TN): forward, dgrad (dz.W^T) and wgrad
+//   (x^T.dz) share the kernel; wgrad splits K (= batch) into 8 slabs reduced in a fixed order
+//   (deterministic) and picks up the bias gradient (column sums of dz) from the tiles it stages.
+// * Epilogues fuse bias + activation + dropout mask (forward) and activation-gradient + mask
+//   (dgrad), so no elementwise pass touches HBM again.
 //
 // Skinny layers (n_out <= 16, the 10-way softmax layer) would waste >2/3 of a 32-wide MFMA
 // tile and leave most CUs idle; they run on dedicated VALU kernels at the end of this file.
+#include <cstdlib>
+
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define BK 16
-#define LDS_PAD 4   // rows stay 16-byte aligned for b128 stores; fragment reads conflict-free
+#define LDK 20      // LDS row stride in floats (5 x 16 B: coprime with the 16 slots of a bank row)
 
 enum { EPI_PLAIN = 0, EPI_FWD = 1, EPI_DGRAD = 2 };
 
@@ -29,19 +39,21 @@ struct GemmArgs {
     float* C;          // or split-K workspace
     int M, N, K;
     int lda, ldb, ldc;
-    int kchunk;        // K range per blockIdx.z (multiple of BK)
+    int kchunk;        // K range per split (multiple of BK)
+    int S;             // number of K splits
+    int MT, NT;        // tiles along M and N
     int epi;
     const float* bias;       // EPI_FWD
     const float* prev_a;     // EPI_DGRAD: output of the layer below (same shape as C)
     const uint8_t* mask;     // EPI_FWD / EPI_DGRAD (may be NULL)
     int act;
     float act_prm;
-    float* colsum;     // BSUM: [gridDim.z][N] partial column sums of B
+    float* colsum;     // BSUM: [S][N] partial column sums of B
     int a_vec, b_vec;  // 16-byte vector loads allowed (ld % 4 == 0 and base aligned)
 };
 
-// ---- tile loaders: global -> 4 registers -------------------------------------------------
-// KC: source is k-contiguous: element (r, k) at src[r*ld + k]; thread -> row r = t>>2, k = 4*(t&3)..+3
+// ---- guarded tile loaders (edge tiles only) ------------------------------------------------
+// KC: element (r, k) at src[r*ld + k]
 __device__ __forceinline__ float4 load_kc(const float* __restrict__ src, int ld, int r, int rlim, int k,
                                           int klim, int vec) {
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -58,7 +70,7 @@ __device__ __forceinline__ float4 load_kc(const float* __restrict__ src, int ld,
     }
     return v;
 }
-// RC: source is row(mn)-contiguous: element (r, k) at src[k*ld + r]; thread -> k = t>>4, r = 4*(t&15)..+3
+// RC: element (r, k) at src[k*ld + r]
 __device__ __forceinline__ float4 load_rc(const float* __restrict__ src, int ld, int r, int rlim, int k,
                                           int klim, int vec) {
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -76,26 +88,115 @@ __device__ __forceinline__ float4 load_rc(const float* __restrict__ src, int ld,
     return v;
 }
 
+// ---- shared epilogue ---------------------------------------------------------------------
+template <int WM, int WN>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[WM][WN], int m0, int n0,
+                                              int z, int wm, int wn, int lane) {
+    const int hi = lane >> 5;
+    float* Cz = g.C + (size_t)z * ((g.S > 1) ? (size_t)g.M * g.ldc : 0);
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+        const int col = n0 + wn * 32 * WN + 32 * j + (lane & 31);
+        const bool cok = col < g.N;
+        const int colc = min(col, g.N - 1);
+        const float bias = (g.epi == EPI_FWD && g.bias) ? g.bias[colc] : 0.f;
+#pragma unroll
+        for (int i = 0; i < WM; ++i) {
+            const int rbase = m0 + wm * 32 * WM + 32 * i + 4 * hi;
+            float pa[16], pm[16];
+            if (g.epi == EPI_DGRAD && g.prev_a) {   // all side loads first (in flight together)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = min(rbase + (r & 3) + 8 * (r >> 2), g.M - 1);
+                    pa[r] = g.prev_a[(size_t)row * g.ldc + colc];
+                }
+            }
+            if (g.mask) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = min(rbase + (r & 3) + 8 * (r >> 2), g.M - 1);
+                    pm[r] = (float)g.mask[(size_t)row * g.ldc + colc];
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = rbase + (r & 3) + 8 * (r >> 2);
+                float v = acc[i][j][r];
+                if (g.epi == EPI_FWD) {
+                    v = tn_act_fwd(v + bias, g.act, g.act_prm);
+                    if (g.mask) v *= pm[r];
+                } else if (g.epi == EPI_DGRAD) {
+                    if (g.prev_a) v *= tn_act_grad_from_out(pa[r], g.act, g.act_prm);
+                    if (g.mask) v *= pm[r];
+                }
+                if (cok && row < g.M) Cz[(size_t)row * g.ldc + col] = v;
+            }
+        }
+    }
+}
+
+// XCD-aware decode of the 1-D block id; returns false for padding blocks
+__device__ __forceinline__ bool gemm_decode(const GemmArgs& g, int& mt, int& nt, int& z) {
+    const int bid = blockIdx.x, xcd = bid & 7, idx = bid >> 3;
+    if (g.S == 1) {
+        mt = (idx / g.NT) * 8 + xcd;      // all N-tiles of an A row-panel on one XCD
+        nt = idx % g.NT;
+        z = 0;
+        return mt < g.MT;
+    }
+    const int per = g.MT * g.NT;
+    z = (idx / per) * 8 + xcd;            // one K-slab per XCD
+    const int rem = idx % per;
+    mt = rem / g.NT;
+    nt = rem % g.NT;
+    return z < g.S;
+}
+
+// ---- FAST kernel ---------------------------------------------------------------------------
+// Preconditions (checked by the host): both operands 16-byte aligned with ld % 4 == 0, and the
+// extent of every row-contiguous operand is a multiple of 4.  Then EVERY tile -- edge tiles
+// included -- can use unguarded float4 loads with the row index clamped to the last valid
+// row/group: the duplicates only feed output elements that are never stored.  The hot loop is
+// branch-free, so hipcc emits counted vmcnt waits and the two-tile look-ahead really overlaps:
+//   registers R0/R1 hold tiles t+1 / t+2, LDS buffers 0/1 hold tiles t / t+1.
+// A K-tail (K % 16 != 0, e.g. dgrad with n_out = 500) is one guarded tile after the loop.
 template <bool AKC, bool BKC, bool BSUM, int WM, int WN>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
+__global__ __launch_bounds__(256) void gemm_f32_fast(GemmArgs g) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
-    constexpr int LDA = BM + LDS_PAD, LDB = BN + LDS_PAD;
-    __shared__ __attribute__((aligned(16))) float As[2][BK][LDA];
-    __shared__ __attribute__((aligned(16))) float Bs[2][BK][LDB];
+    __shared__ __attribute__((aligned(16))) float As[2][BM][LDK];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BN][LDK];
+    int mt, nt, z;
+    if (!gemm_decode(g, mt, nt, z)) return;
 
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    const int kbeg = blockIdx.z * g.kchunk;
+    const int m0 = mt * BM, n0 = nt * BN;
+    const int kbeg = z * g.kchunk;
     const int kend = min(g.K, kbeg + g.kchunk);
-    const int ntiles = (kend - kbeg + BK - 1) / BK;
+    const int nk = (kend - kbeg) / BK;               // full tiles
+    const bool tail = (kend - kbeg) % BK != 0;
 
-    // per-thread staging coordinates inside a 64-row slice
-    const int a_r = AKC ? (t >> 2) : 4 * (t & 15);
-    const int a_k = AKC ? 4 * (t & 3) : (t >> 4);
-    const int b_r = BKC ? (t >> 2) : 4 * (t & 15);
-    const int b_k = BKC ? 4 * (t & 3) : (t >> 4);
+    const int a_r = AKC ? (t >> 2) : 4 * (t >> 4);
+    const int a_k = AKC ? 4 * (t & 3) : (t & 15);
+    const int b_r = BKC ? (t >> 2) : 4 * (t >> 4);
+    const int b_k = BKC ? 4 * (t & 3) : (t & 15);
+
+    // clamped source pointers of tile 0; advance by `tile * step`
+    const float* pA[WM];
+    const float* pB[WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+        const int r = min(m0 + 64 * i + a_r, AKC ? g.M - 1 : g.M - 4);
+        pA[i] = AKC ? g.A + (size_t)r * g.lda + kbeg + a_k : g.A + (size_t)(kbeg + a_k) * g.lda + r;
+    }
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+        const int r = min(n0 + 64 * j + b_r, BKC ? g.N - 1 : g.N - 4);
+        pB[j] = BKC ? g.B + (size_t)r * g.ldb + kbeg + b_k : g.B + (size_t)(kbeg + b_k) * g.ldb + r;
+    }
+    const size_t stepA = AKC ? BK : (size_t)BK * g.lda;
+    const size_t stepB = BKC ? BK : (size_t)BK * g.ldb;
 
     f32x16 acc[WM][WN];
 #pragma unroll
@@ -108,118 +209,208 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
 #pragma unroll
     for (int j = 0; j < WN; ++j) csum[j] = make_float4(0.f, 0.f, 0.f, 0.f);
 
-    float4 ra[WM], rb[WN];
-    auto gload = [&](int tile) {
-        const int k0 = kbeg + tile * BK;
+    float4 a0[WM], b0[WN], a1[WM], b1[WN];          // staging sets R0 / R1
+    const int last = max(nk - 1, 0);
+#define GLOAD(RA, RB, TILE)                                                                     \
+    {                                                                                           \
+        const int tl_ = min((TILE), last);                                                      \
+        _Pragma("unroll") for (int i = 0; i < WM; ++i)                                          \
+            RA[i] = *reinterpret_cast<const float4*>(pA[i] + tl_ * stepA);                      \
+        _Pragma("unroll") for (int j = 0; j < WN; ++j)                                          \
+            RB[j] = *reinterpret_cast<const float4*>(pB[j] + tl_ * stepB);                      \
+    }
+#define LSTORE(RA, RB, BUF)                                                                     \
+    {                                                                                           \
+        _Pragma("unroll") for (int i = 0; i < WM; ++i) {                                        \
+            if (AKC) {                                                                          \
+                *reinterpret_cast<float4*>(&As[BUF][64 * i + a_r][a_k]) = RA[i];                \
+            } else {                                                                            \
+                As[BUF][64 * i + a_r + 0][a_k] = RA[i].x;                                       \
+                As[BUF][64 * i + a_r + 1][a_k] = RA[i].y;                                       \
+                As[BUF][64 * i + a_r + 2][a_k] = RA[i].z;                                       \
+                As[BUF][64 * i + a_r + 3][a_k] = RA[i].w;                                       \
+            }                                                                                   \
+        }                                                                                       \
+        _Pragma("unroll") for (int j = 0; j < WN; ++j) {                                        \
+            if (BKC) {                                                                          \
+                *reinterpret_cast<float4*>(&Bs[BUF][64 * j + b_r][b_k]) = RB[j];                \
+            } else {                                                                            \
+                Bs[BUF][64 * j + b_r + 0][b_k] = RB[j].x;                                       \
+                Bs[BUF][64 * j + b_r + 1][b_k] = RB[j].y;                                       \
+                Bs[BUF][64 * j + b_r + 2][b_k] = RB[j].z;                                       \
+                Bs[BUF][64 * j + b_r + 3][b_k] = RB[j].w;                                       \
+            }                                                                                   \
+        }                                                                                       \
+    }
+#define CSUM(RB)                                                                                \
+    if (BSUM && !BKC) {                                                                         \
+        _Pragma("unroll") for (int j = 0; j < WN; ++j) {                                        \
+            csum[j].x += RB[j].x; csum[j].y += RB[j].y; csum[j].z += RB[j].z; csum[j].w += RB[j].w; \
+        }                                                                                       \
+    }
+    const int ar = wm * 32 * WM + (lane & 31), br = wn * 32 * WN + (lane & 31), hi = lane >> 5;
+#define COMPUTE(BUF)                                                                            \
+    {                                                                                           \
+        float av[WM][8], bv[WN][8];                                                             \
+        _Pragma("unroll") for (int i = 0; i < WM; ++i) {                                        \
+            const float4* p_ = reinterpret_cast<const float4*>(&As[BUF][ar + 32 * i][8 * hi]);  \
+            const float4 lo = p_[0], up = p_[1];                                                \
+            av[i][0] = lo.x; av[i][1] = lo.y; av[i][2] = lo.z; av[i][3] = lo.w;                 \
+            av[i][4] = up.x; av[i][5] = up.y; av[i][6] = up.z; av[i][7] = up.w;                 \
+        }                                                                                       \
+        _Pragma("unroll") for (int j = 0; j < WN; ++j) {                                        \
+            const float4* p_ = reinterpret_cast<const float4*>(&Bs[BUF][br + 32 * j][8 * hi]);  \
+            const float4 lo = p_[0], up = p_[1];                                                \
+            bv[j][0] = lo.x; bv[j][1] = lo.y; bv[j][2] = lo.z; bv[j][3] = lo.w;                 \
+            bv[j][4] = up.x; bv[j][5] = up.y; bv[j][6] = up.z; bv[j][7] = up.w;                 \
+        }                                                                                       \
+        _Pragma("unroll") for (int s_ = 0; s_ < 8; ++s_)                                        \
+            _Pragma("unroll") for (int i = 0; i < WM; ++i)                                      \
+                _Pragma("unroll") for (int j = 0; j < WN; ++j)                                  \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][s_], bv[j][s_], acc[i][j], 0, 0, 0); \
+    }
+
+    if (nk > 0) {
+        GLOAD(a0, b0, 0);
+        GLOAD(a1, b1, 1);
+        LSTORE(a0, b0, 0);
+        CSUM(b0);
+        __syncthreads();
+        GLOAD(a0, b0, 2);
+        int tile = 0;
+        for (; tile + 1 < nk; tile += 2) {           // branch-free body
+            COMPUTE(0);                               // tile
+            LSTORE(a1, b1, 1);                        // tile + 1
+            CSUM(b1);
+            __syncthreads();
+            GLOAD(a1, b1, tile + 3);
+            COMPUTE(1);                               // tile + 1
+            LSTORE(a0, b0, 0);                        // tile + 2 (a clamped duplicate at the end)
+            if (tile + 2 < nk) CSUM(b0);
+            __syncthreads();
+            GLOAD(a0, b0, tile + 4);
+        }
+        if (nk & 1) COMPUTE(0);                       // odd count: the last tile sits in LDS[0]
+    }
+    if (tail) {                                       // guarded K-tail
+        const int k0 = kbeg + nk * BK;
+        __syncthreads();
 #pragma unroll
         for (int i = 0; i < WM; ++i)
-            ra[i] = AKC ? load_kc(g.A, g.lda, m0 + 64 * i + a_r, g.M, k0 + a_k, kend, g.a_vec)
+            a0[i] = AKC ? load_kc(g.A, g.lda, m0 + 64 * i + a_r, g.M, k0 + a_k, kend, g.a_vec)
                         : load_rc(g.A, g.lda, m0 + 64 * i + a_r, g.M, k0 + a_k, kend, g.a_vec);
 #pragma unroll
         for (int j = 0; j < WN; ++j)
-            rb[j] = BKC ? load_kc(g.B, g.ldb, n0 + 64 * j + b_r, g.N, k0 + b_k, kend, g.b_vec)
+            b0[j] = BKC ? load_kc(g.B, g.ldb, n0 + 64 * j + b_r, g.N, k0 + b_k, kend, g.b_vec)
                         : load_rc(g.B, g.ldb, n0 + 64 * j + b_r, g.N, k0 + b_k, kend, g.b_vec);
+        LSTORE(a0, b0, 0);
+        CSUM(b0);
+        __syncthreads();
+        COMPUTE(0);
+    }
+#undef GLOAD
+#undef LSTORE
+#undef CSUM
+#undef COMPUTE
+
+    gemm_epilogue<WM, WN>(g, acc, m0, n0, z, wm, wn, lane);
+
+    if (BSUM && !BKC && mt == 0) {
+        // reduce csum over the 16 k-lanes of the staging layout (thread = (k = t&15, q = t>>4))
+        __syncthreads();
+        float* red = &As[0][0][0];   // reuse: [16][BN]  (16*BN <= BM*LDK)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+            *reinterpret_cast<float4*>(&red[(t & 15) * BN + 64 * j + 4 * (t >> 4)]) = csum[j];
+        __syncthreads();
+        if (t < BN) {
+            float sum = 0.f;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) sum += red[k * BN + t];
+            if (n0 + t < g.N) g.colsum[(size_t)z * g.N + n0 + t] = sum;
+        }
+    }
+}
+
+// ---- generic kernel (any alignment / extent): guarded loads, single-stage prefetch ---------
+template <bool AKC, bool BKC, bool BSUM>
+__global__ __launch_bounds__(256) void gemm_f32_generic(GemmArgs g) {
+    constexpr int WM = 1, WN = 1, BM = 64, BN = 64;
+    __shared__ __attribute__((aligned(16))) float As[2][BM][LDK];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BN][LDK];
+    int mt, nt, z;
+    if (!gemm_decode(g, mt, nt, z)) return;
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = mt * BM, n0 = nt * BN;
+    const int kbeg = z * g.kchunk;
+    const int kend = min(g.K, kbeg + g.kchunk);
+    const int ntiles = (kend - kbeg + BK - 1) / BK;
+    const int a_r = AKC ? (t >> 2) : 4 * (t >> 4);
+    const int a_k = AKC ? 4 * (t & 3) : (t & 15);
+    const int b_r = BKC ? (t >> 2) : 4 * (t >> 4);
+    const int b_k = BKC ? 4 * (t & 3) : (t & 15);
+    f32x16 acc[1][1];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
+    float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 ra, rb;
+    auto gload = [&](int tile) {
+        const int k0 = kbeg + tile * BK;
+        ra = AKC ? load_kc(g.A, g.lda, m0 + a_r, g.M, k0 + a_k, kend, g.a_vec)
+                 : load_rc(g.A, g.lda, m0 + a_r, g.M, k0 + a_k, kend, g.a_vec);
+        rb = BKC ? load_kc(g.B, g.ldb, n0 + b_r, g.N, k0 + b_k, kend, g.b_vec)
+                 : load_rc(g.B, g.ldb, n0 + b_r, g.N, k0 + b_k, kend, g.b_vec);
     };
     auto lstore = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < WM; ++i) {
-            if (AKC) {
-                As[buf][a_k + 0][64 * i + a_r] = ra[i].x;
-                As[buf][a_k + 1][64 * i + a_r] = ra[i].y;
-                As[buf][a_k + 2][64 * i + a_r] = ra[i].z;
-                As[buf][a_k + 3][64 * i + a_r] = ra[i].w;
-            } else {
-                *reinterpret_cast<float4*>(&As[buf][a_k][64 * i + a_r]) = ra[i];
-            }
+        if (AKC) {
+            *reinterpret_cast<float4*>(&As[buf][a_r][a_k]) = ra;
+        } else {
+            As[buf][a_r + 0][a_k] = ra.x; As[buf][a_r + 1][a_k] = ra.y;
+            As[buf][a_r + 2][a_k] = ra.z; As[buf][a_r + 3][a_k] = ra.w;
         }
-#pragma unroll
-        for (int j = 0; j < WN; ++j) {
-            if (BKC) {
-                Bs[buf][b_k + 0][64 * j + b_r] = rb[j].x;
-                Bs[buf][b_k + 1][64 * j + b_r] = rb[j].y;
-                Bs[buf][b_k + 2][64 * j + b_r] = rb[j].z;
-                Bs[buf][b_k + 3][64 * j + b_r] = rb[j].w;
-            } else {
-                *reinterpret_cast<float4*>(&Bs[buf][b_k][64 * j + b_r]) = rb[j];
-            }
-            if (BSUM && !BKC) {   // column sums of B (db = sum_rows dz), first M-tile only
-                csum[j].x += rb[j].x;
-                csum[j].y += rb[j].y;
-                csum[j].z += rb[j].z;
-                csum[j].w += rb[j].w;
-            }
+        if (BKC) {
+            *reinterpret_cast<float4*>(&Bs[buf][b_r][b_k]) = rb;
+        } else {
+            Bs[buf][b_r + 0][b_k] = rb.x; Bs[buf][b_r + 1][b_k] = rb.y;
+            Bs[buf][b_r + 2][b_k] = rb.z; Bs[buf][b_r + 3][b_k] = rb.w;
+        }
+        if (BSUM && !BKC) {
+            csum.x += rb.x; csum.y += rb.y; csum.z += rb.z; csum.w += rb.w;
         }
     };
-
     if (ntiles > 0) {
         gload(0);
         lstore(0);
     }
     __syncthreads();
-
-    // wave (wm, wn) owns rows [wm*32*WM, ...) x cols [wn*32*WN, ...) of the block tile
-    const int ar = wm * 32 * WM + (lane & 31), br = wn * 32 * WN + (lane & 31), hi = lane >> 5;
+    const int ar = wm * 32 + (lane & 31), br = wn * 32 + (lane & 31), hi = lane >> 5;
     for (int tile = 0; tile < ntiles; ++tile) {
         const int buf = tile & 1;
         if (tile + 1 < ntiles) gload(tile + 1);
+        const float4* pa = reinterpret_cast<const float4*>(&As[buf][ar][8 * hi]);
+        const float4* pb = reinterpret_cast<const float4*>(&Bs[buf][br][8 * hi]);
+        const float4 al = pa[0], au = pa[1], bl = pb[0], bu = pb[1];
+        const float av[8] = {al.x, al.y, al.z, al.w, au.x, au.y, au.z, au.w};
+        const float bv[8] = {bl.x, bl.y, bl.z, bl.w, bu.x, bu.y, bu.z, bu.w};
 #pragma unroll
-        for (int kk = 0; kk < BK; kk += 2) {
-            float a[WM], b[WN];
-#pragma unroll
-            for (int i = 0; i < WM; ++i) a[i] = As[buf][kk + hi][ar + 32 * i];
-#pragma unroll
-            for (int j = 0; j < WN; ++j) b[j] = Bs[buf][kk + hi][br + 32 * j];
-#pragma unroll
-            for (int i = 0; i < WM; ++i)
-#pragma unroll
-                for (int j = 0; j < WN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
-        }
+        for (int s_ = 0; s_ < 8; ++s_)
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s_], bv[s_], acc[0][0], 0, 0, 0);
         if (tile + 1 < ntiles) lstore(buf ^ 1);
         __syncthreads();
     }
-
-    // ---- epilogue ---------------------------------------------------------------------
-    float* Cz = g.C + (size_t)blockIdx.z * ((gridDim.z > 1) ? (size_t)g.M * g.ldc : 0);
-#pragma unroll
-    for (int j = 0; j < WN; ++j) {
-        const int col = n0 + wn * 32 * WN + 32 * j + (lane & 31);
-        if (col >= g.N) continue;
-        const float bias = (g.epi == EPI_FWD && g.bias) ? g.bias[col] : 0.f;
-#pragma unroll
-        for (int i = 0; i < WM; ++i) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * 32 * WM + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                if (row < g.M) {
-                    const size_t o = (size_t)row * g.ldc + col;
-                    float v = acc[i][j][r];
-                    if (g.epi == EPI_FWD) {
-                        v = tn_act_fwd(v + bias, g.act, g.act_prm);
-                        if (g.mask) v *= (float)g.mask[o];
-                    } else if (g.epi == EPI_DGRAD) {
-                        if (g.prev_a) v *= tn_act_grad_from_out(g.prev_a[o], g.act, g.act_prm);
-                        if (g.mask) v *= (float)g.mask[o];
-                    }
-                    Cz[o] = v;
-                }
-            }
-        }
-    }
-
-    if (BSUM && !BKC && blockIdx.y == 0) {
-        // reduce csum over the 16 k-rows of the staging layout (thread = (k = t>>4, q = t&15))
+    gemm_epilogue<1, 1>(g, acc, m0, n0, z, wm, wn, lane);
+    if (BSUM && !BKC && mt == 0) {
         __syncthreads();
-        float* red = &As[0][0][0];   // reuse: [16][BN]  (16*BN <= BK*LDA)
-#pragma unroll
-        for (int j = 0; j < WN; ++j)
-            *reinterpret_cast<float4*>(&red[(t >> 4) * BN + 64 * j + 4 * (t & 15)]) = csum[j];
+        float* red = &As[0][0][0];
+        *reinterpret_cast<float4*>(&red[(t & 15) * BN + 4 * (t >> 4)]) = csum;
         __syncthreads();
         if (t < BN) {
-            float s = 0.f;
+            float sum = 0.f;
 #pragma unroll
-            for (int k = 0; k < 16; ++k) s += red[k * BN + t];
-            if (n0 + t < g.N) g.colsum[(size_t)blockIdx.z * g.N + n0 + t] = s;
+            for (int k = 0; k < 16; ++k) sum += red[k * BN + t];
+            if (n0 + t < g.N) g.colsum[(size_t)z * g.N + n0 + t] = sum;
         }
     }
 }
@@ -257,27 +448,41 @@ static inline int vec_ok(const void* p, int ld) {
     return ((reinterpret_cast<uintptr_t>(p) & 15) == 0) && (ld % 4 == 0);
 }
 
-// tile choice: 128x64 when that still gives >= ~200 blocks, else 64x64
-static inline bool big_tile(int M, int N, int S) {
-    return (long long)cdiv(M, 128) * cdiv(N, 64) * S >= 200;
+static int tn_tune_tile() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("TN_GEMM_TILE");   // 0 auto, 1 force 64x64, 2 force 128x64
+        v = e ? atoi(e) : 0;
+    }
+    return v;
 }
 
 template <bool AKC, bool BKC, bool BSUM>
 static void launch_gemm(tn_ctx* ctx, GemmArgs& g, int S) {
-    if (big_tile(g.M, g.N, S))
-        gemm_f32_kernel<AKC, BKC, BSUM, 2, 1><<<dim3(cdiv(g.N, 64), cdiv(g.M, 128), S), 256, 0, ctx->stream>>>(g);
+    // FAST needs aligned operands; row-contiguous operands also need an extent % 4 == 0 so that
+    // clamped float4 groups stay inside the matrix
+    const bool fast = g.a_vec && g.b_vec && (AKC || (g.M % 4 == 0 && g.M >= 4)) &&
+                      (BKC || (g.N % 4 == 0 && g.N >= 4)) && tn_tune_tile() != 9;
+    bool big = (long long)cdiv(g.M, 128) * cdiv(g.N, 64) * S >= 2 * ctx->num_cus;
+    if (tn_tune_tile() == 1) big = false;
+    if (tn_tune_tile() == 2) big = true;
+    if (!fast) big = false;
+    g.S = S;
+    g.NT = cdiv(g.N, 64);
+    g.MT = cdiv(g.M, big ? 128 : 64);
+    const int grid = (S == 1) ? 8 * cdiv(g.MT, 8) * g.NT : 8 * cdiv(S, 8) * g.MT * g.NT;
+    if (!fast)
+        gemm_f32_generic<AKC, BKC, BSUM><<<grid, 256, 0, ctx->stream>>>(g);
+    else if (big)
+        gemm_f32_fast<AKC, BKC, BSUM, 2, 1><<<grid, 256, 0, ctx->stream>>>(g);
     else
-        gemm_f32_kernel<AKC, BKC, BSUM, 1, 1><<<dim3(cdiv(g.N, 64), cdiv(g.M, 64), S), 256, 0, ctx->stream>>>(g);
+        gemm_f32_fast<AKC, BKC, BSUM, 1, 1><<<grid, 256, 0, ctx->stream>>>(g);
 }
 
 static int wgrad_splits(int B, int n_in, int n_out) {
-    const int tiles = cdiv(n_in, 128) * cdiv(n_out, 64);
-    int S = cdiv(256, tiles);             // about one block per CU
-    const int max_s = cdiv(B, 8 * BK);    // at least 8 K-tiles per split
-    if (S > max_s) S = max_s;
-    if (S < 1) S = 1;
-    if (S > 16) S = 16;
-    return S;
+    // one K-slab per XCD (8) once the batch is long enough for >= 8 K-tiles per slab
+    if (B >= 8 * 8 * BK) return 8;
+    return 1;
 }
 
 // =====================================================================================
@@ -285,110 +490,132 @@ static int wgrad_splits(int B, int n_in, int n_out) {
 // =====================================================================================
 #define SK_MAX 16
 
-// forward: one wave per row; lanes split K (coalesced x reads), W staged in LDS (row stride
-// n_out+1 words: conflict-free), per-lane partial sums reduced across the wave with DPP.
 template <int CTRL>
 __device__ __forceinline__ float gdpp(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
 }
-__device__ __forceinline__ float wave_allsum(float v) {
-    v += gdpp<0xB1>(v);
-    v += gdpp<0x4E>(v);
-    v += gdpp<0x141>(v);
-    v += gdpp<0x140>(v);
-    const int iv = __float_as_int(v);
-    return __int_as_float(__builtin_amdgcn_readlane(iv, 0)) + __int_as_float(__builtin_amdgcn_readlane(iv, 16)) +
-           __int_as_float(__builtin_amdgcn_readlane(iv, 32)) + __int_as_float(__builtin_amdgcn_readlane(iv, 48));
+// sum over each aligned group of 32 lanes (result valid in every lane of the group)
+__device__ __forceinline__ float half_allsum(float v) {
+    v += gdpp<0xB1>(v);     // quad xor 1
+    v += gdpp<0x4E>(v);     // quad xor 2
+    v += gdpp<0x141>(v);    // row_half_mirror
+    v += gdpp<0x140>(v);    // row_mirror: 16-lane row sums
+    v += __shfl_xor(v, 16, 64);
+    return v;
 }
 
+// forward: block = 8 rows x 32 k-lanes.  Every lane owns k = kl, kl+32, ... : its x values are
+// loaded up front (all in flight), W sits in LDS with row stride n_out+1 (conflict-free), the
+// n_out partial sums are reduced over the 32 lanes with DPP.
+#define SK_XPL 16     // x values per lane and pass (covers n_in <= 512 in one pass)
 __global__ __launch_bounds__(256) void fc_skinny_fwd_kernel(
     const float* __restrict__ x, const float* __restrict__ W, const float* __restrict__ b,
     float* __restrict__ a, int B, int n_in, int n_out, int act, float prm,
-    const uint8_t* __restrict__ mask, int rows_per_wave) {
+    const uint8_t* __restrict__ mask) {
     extern __shared__ float sW[];       // [n_in][n_out+1]
     const int ldw = n_out + 1;
+    const int kl = threadIdx.x & 31;
+    const int row = min(blockIdx.x * 8 + (threadIdx.x >> 5), B - 1);
+    const float* xr = x + (size_t)row * n_in;
+    float xv[SK_XPL];
+#pragma unroll
+    for (int i = 0; i < SK_XPL; ++i) xv[i] = xr[min(kl + 32 * i, n_in - 1)];   // in flight with W
     for (int t = threadIdx.x; t < n_in * n_out; t += 256) {
-        const int k = t / n_out, n = t - k * n_out;
-        sW[k * ldw + n] = W[t];
+        const int k = t / n_out;
+        sW[t + k] = W[t];                                  // k*ldw + n == t + k
     }
     __syncthreads();
-    const int lane = threadIdx.x & 63;
-    const int wave_global = blockIdx.x * 4 + (threadIdx.x >> 6);
-    for (int rr = 0; rr < rows_per_wave; ++rr) {
-        const int row = wave_global * rows_per_wave + rr;
-        if (row >= B) return;
-        float acc[SK_MAX];
+    float acc[SK_MAX];
 #pragma unroll
-        for (int n = 0; n < SK_MAX; ++n) acc[n] = 0.f;
-        const float* xr = x + (size_t)row * n_in;
-        for (int k = lane; k < n_in; k += 64) {
-            const float xv = xr[k];
-            const float* wr = sW + k * ldw;
+    for (int n = 0; n < SK_MAX; ++n) acc[n] = 0.f;
+    for (int k0 = 0; k0 < n_in; k0 += 32 * SK_XPL) {
+        if (k0 > 0) {
+#pragma unroll
+            for (int i = 0; i < SK_XPL; ++i) xv[i] = xr[min(k0 + kl + 32 * i, n_in - 1)];
+        }
+#pragma unroll
+        for (int i = 0; i < SK_XPL; ++i) {
+            const int k = k0 + kl + 32 * i;
+            const float xx = (k < n_in) ? xv[i] : 0.f;
+            const float* wr = sW + min(k, n_in - 1) * ldw;
 #pragma unroll
             for (int n = 0; n < SK_MAX; ++n)
-                if (n < n_out) acc[n] = fmaf(xv, wr[n], acc[n]);
+                if (n < n_out) acc[n] = fmaf(xx, wr[n], acc[n]);
         }
-        float mine = 0.f;
+    }
+    float mine = 0.f;
 #pragma unroll
-        for (int n = 0; n < SK_MAX; ++n) {
-            if (n < n_out) {       // wave-uniform
-                const float s = wave_allsum(acc[n]);
-                if (lane == n) mine = s;
-            }
+    for (int n = 0; n < SK_MAX; ++n) {
+        if (n < n_out) {       // block-uniform
+            const float s = half_allsum(acc[n]);
+            if (kl == n) mine = s;
         }
-        if (lane < n_out) {
-            const size_t o = (size_t)row * n_out + lane;
-            float v = tn_act_fwd(mine + (b ? b[lane] : 0.f), act, prm);
-            if (mask) v *= (float)mask[o];
-            a[o] = v;
-        }
+    }
+    if (kl < n_out && blockIdx.x * 8 + (threadIdx.x >> 5) < B) {
+        const size_t o = (size_t)row * n_out + kl;
+        float v = tn_act_fwd(mine + (b ? b[kl] : 0.f), act, prm);
+        if (mask) v *= (float)mask[o];
+        a[o] = v;
     }
 }
 
-// dgrad: thread = one (row, k) element: n_out FMAs with the row's dz (broadcast) and W[k,:]
+// dgrad: thread = one input feature k for 16 rows: side loads (prev_a, mask) are all issued
+// first, the rows' dz values are wave-uniform scalar loads.
 __global__ __launch_bounds__(256) void fc_skinny_dgrad_kernel(
     const float* __restrict__ dz, const float* __restrict__ W, float* __restrict__ dx, int B, int n_in,
     int n_out, const float* __restrict__ prev_a, int act, float prm, const uint8_t* __restrict__ mask) {
-    const int k = blockIdx.x * 256 + threadIdx.x;
+    const int k = min(blockIdx.x * 256 + threadIdx.x, n_in - 1);
+    const bool live = blockIdx.x * 256 + threadIdx.x < n_in;
     const int row0 = blockIdx.y * 16;
-    if (k >= n_in) return;
     float w[SK_MAX];
 #pragma unroll
     for (int n = 0; n < SK_MAX; ++n) w[n] = (n < n_out) ? W[(size_t)k * n_out + n] : 0.f;
+    float pa[16], pm[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const size_t o = (size_t)min(row0 + r, B - 1) * n_in + k;
+        pa[r] = prev_a ? prev_a[o] : 0.f;
+        pm[r] = mask ? (float)mask[o] : 1.f;
+    }
+#pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int row = row0 + r;
-        if (row >= B) break;
-        const float* dzr = dz + (size_t)row * n_out;     // wave-uniform -> scalar loads
+        const float* dzr = dz + (size_t)min(row, B - 1) * n_out;     // wave-uniform -> scalar loads
         float s = 0.f;
 #pragma unroll
         for (int n = 0; n < SK_MAX; ++n)
             if (n < n_out) s = fmaf(dzr[n], w[n], s);
-        const size_t o = (size_t)row * n_in + k;
-        if (prev_a) s *= tn_act_grad_from_out(prev_a[o], act, prm);
-        if (mask) s *= (float)mask[o];
-        dx[o] = s;
+        if (prev_a) s *= tn_act_grad_from_out(pa[r], act, prm);
+        s *= pm[r];
+        if (live && row < B) dx[(size_t)row * n_in + k] = s;
     }
 }
 
-// wgrad: thread = one input feature k, block = a chunk of rows; partial[chunk][k][n]
+// wgrad: thread = one input feature k, block.y = a chunk of 32 rows; the 32 x values are
+// loaded up front, dz rows are wave-uniform.  partial[chunk][k][n], dbpartial[chunk][n].
+#define SK_WROWS 32
 __global__ __launch_bounds__(256) void fc_skinny_wgrad_kernel(
     const float* __restrict__ x, const float* __restrict__ dz, float* __restrict__ partial,
-    float* __restrict__ dbpartial, int B, int n_in, int n_out, int rows_per_blk) {
-    const int k = blockIdx.x * 256 + threadIdx.x;
-    const int row0 = blockIdx.y * rows_per_blk;
-    const int row1 = min(B, row0 + rows_per_blk);
+    float* __restrict__ dbpartial, int B, int n_in, int n_out) {
+    const int k = min(blockIdx.x * 256 + threadIdx.x, n_in - 1);
+    const bool live = blockIdx.x * 256 + threadIdx.x < n_in;
+    const int row0 = blockIdx.y * SK_WROWS;
+    float xv[SK_WROWS];
+#pragma unroll
+    for (int r = 0; r < SK_WROWS; ++r) xv[r] = x[(size_t)min(row0 + r, B - 1) * n_in + k];
     float acc[SK_MAX], accb[SK_MAX];
 #pragma unroll
     for (int n = 0; n < SK_MAX; ++n) acc[n] = accb[n] = 0.f;
-    const bool live = k < n_in;
-    for (int row = row0; row < row1; ++row) {
-        const float xv = live ? x[(size_t)row * n_in + k] : 0.f;
-        const float* dzr = dz + (size_t)row * n_out;     // wave-uniform
+#pragma unroll
+    for (int r = 0; r < SK_WROWS; ++r) {
+        const bool rok = row0 + r < B;                                 // uniform
+        const float* dzr = dz + (size_t)min(row0 + r, B - 1) * n_out;  // wave-uniform
+        const float xx = rok ? xv[r] : 0.f;
 #pragma unroll
         for (int n = 0; n < SK_MAX; ++n)
             if (n < n_out) {
-                const float d = dzr[n];
-                acc[n] = fmaf(xv, d, acc[n]);
+                const float d = rok ? dzr[n] : 0.f;
+                acc[n] = fmaf(xx, d, acc[n]);
                 accb[n] += d;
             }
     }
@@ -398,11 +625,27 @@ __global__ __launch_bounds__(256) void fc_skinny_wgrad_kernel(
         for (int n = 0; n < SK_MAX; ++n)
             if (n < n_out) p[n] = acc[n];
     }
-    if (k == 0) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
 #pragma unroll
         for (int n = 0; n < SK_MAX; ++n)
             if (n < n_out) dbpartial[(size_t)blockIdx.y * n_out + n] = accb[n];
     }
+}
+
+// out[i] = sum_s slabs[s][i]: one block per 64 outputs, 4 slab groups per output, fixed order
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slabs,
+                                                         float* __restrict__ out, int n, int S) {
+    __shared__ float red[4][64];
+    const int i = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int grp = threadIdx.x >> 6;
+    float s = 0.f;
+    if (i < n) {
+#pragma unroll 8
+        for (int z = grp; z < S; z += 4) s += slabs[(size_t)z * n + i];
+    }
+    red[grp][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (grp == 0 && i < n) out[i] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
 extern "C" {
@@ -412,9 +655,8 @@ int tn_fc_fwd(tn_ctx* ctx, const float* x, const float* W, const float* b, float
     TN_REQUIRE(B > 0 && n_in > 0 && n_out > 0, "tn_fc_fwd: bad shape");
     const size_t sk_lds = (size_t)n_in * (n_out + 1) * sizeof(float);
     if (n_out <= SK_MAX && sk_lds <= 60 * 1024) {
-        const int rpw = 4;
-        fc_skinny_fwd_kernel<<<cdiv(B, 4 * rpw), 256, sk_lds, ctx->stream>>>(
-            x, W, b, a, B, n_in, n_out, act, act_param, mask, rpw);
+        fc_skinny_fwd_kernel<<<cdiv(B, 8), 256, sk_lds, ctx->stream>>>(
+            x, W, b, a, B, n_in, n_out, act, act_param, mask);
         TN_LAUNCH_CHECK();
         return TN_OK;
     }
@@ -432,7 +674,7 @@ int tn_fc_fwd(tn_ctx* ctx, const float* x, const float* W, const float* b, float
 
 size_t tn_fc_wgrad_ws_bytes(int B, int n_in, int n_out) {
     if (n_out <= SK_MAX) {
-        const int chunks = cdiv(B, 256);
+        const int chunks = cdiv(B, SK_WROWS);
         return ((size_t)chunks * n_in * n_out + (size_t)chunks * n_out) * sizeof(float) + 64;
     }
     const int S = wgrad_splits(B, n_in, n_out);
@@ -443,14 +685,16 @@ int tn_fc_wgrad(tn_ctx* ctx, const float* x, const float* dz, float* dW, float* 
                 int n_out, void* ws) {
     TN_REQUIRE(B > 0 && n_in > 0 && n_out > 0 && ws != nullptr, "tn_fc_wgrad: bad arguments");
     if (n_out <= SK_MAX) {
-        const int chunks = cdiv(B, 256);
+        const int chunks = cdiv(B, SK_WROWS);
         float* wsC = (float*)ws;
         float* wsB = wsC + (size_t)chunks * n_in * n_out;
         fc_skinny_wgrad_kernel<<<dim3(cdiv(n_in, 256), chunks), 256, 0, ctx->stream>>>(
-            x, dz, wsC, wsB, B, n_in, n_out, 256);
+            x, dz, wsC, wsB, B, n_in, n_out);
         TN_LAUNCH_CHECK();
-        const size_t MN = (size_t)n_in * n_out;
-        splitk_reduce_kernel<<<cdiv(cdiv(MN, 4), 256), 256, 0, ctx->stream>>>(wsC, dW, MN, chunks, wsB, db, n_out);
+        const int MN = n_in * n_out;
+        slab_reduce_kernel<<<cdiv(MN, 64), 256, 0, ctx->stream>>>(wsC, dW, MN, chunks);
+        TN_LAUNCH_CHECK();
+        slab_reduce_kernel<<<cdiv(n_out, 64), 256, 0, ctx->stream>>>(wsB, db, n_out, chunks);
         TN_LAUNCH_CHECK();
         return TN_OK;
     }
