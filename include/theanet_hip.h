@@ -119,6 +119,15 @@ int tn_convpool_bwd(tn_ctx* ctx, const float* x, const float* W, const float* b,
                     float* dz, float* dW, float* db, int N, int C, int H, int Wd, int K, int f,
                     int pad_lo, int Ho, int Wo, int p, int Hp, int Wp, int act, float act_param);
 
+/* LDS-resident backward of the same fused block for MANY filter elements (K*C*f*f in the
+ * hundreds, e.g. mnist.prms conv2): a block keeps G whole images' x and dz in LDS, so dz never
+ * reaches HBM and dx (= dcost/dx, may be NULL) comes out of the same kernel as dW/db.
+ * tn_convblock_supported returns the group size G (0 = use tn_convpool_bwd + tn_conv2d_dgrad). */
+int tn_convblock_supported(int C, int K, int f, int stride, int p, int Ho, int Wo);
+int tn_convblock_bwd(tn_ctx* ctx, const float* x, const float* W, const float* b, const float* g,
+                     float* dx, float* dW, float* db, int N, int C, int H, int Wd, int K, int f,
+                     int pad_lo, int Ho, int Wo, int p, int Hp, int Wp, int act, float act_param);
+
 /* ---- pool / mean (replaces pool.pool_2d + MaxPoolGrad, tt.mean; convpool.py:106-107,131) ----
  * max over p x p, stride p, no padding; Ho = ceil(H/p) unless ignore_border (floor).   */
 int tn_pool_fwd(tn_ctx* ctx, const float* x, float* y, int NC, int H, int Wd, int p,

@@ -122,6 +122,40 @@ def test_convpool_fused_fwd_bwd(case):
     assert_close(dW.get_value(), dW_w, atol=2e-4, what="convpool dW (no dz) %s" % (case,))
 
 
+@pytest.mark.parametrize("case", [
+    (9, 4, 13, 20, 3, "valid", "relu05", False),      # mnist.prms conv2 (partial last window)
+    (5, 4, 13, 20, 3, "valid", "relu05", True),       # ignore_border: last row/col in no window
+    (6, 3, 12, 16, 3, "same", "relu10", False),
+    (3, 2, 10, 30, 3, "same", "tanh", False),
+    (2, 4, 8, 21, 3, "valid", "relu", False),
+])
+def test_convblock_lds_backward(case):
+    N, C, H, K, f, mode, act, ib = case
+    pad_lo, _, Ho = O.conv_geometry(H, f, 1, mode)
+    assert ctx().lib.tn_convblock_supported(C, K, f, 1, 2, Ho, Ho) > 0
+    rng = np.random.RandomState(N * 7 + K)
+    x = rng.randn(N, C, H, H).astype(np.float32)
+    W = (rng.randn(K, C, f, f) / np.sqrt(C * f * f)).astype(np.float32)
+    b = rng.randn(K).astype(np.float32)
+    Hp = O.pool_out_sz(Ho, 2, ib)
+    fa, dfa = O.activation(act)
+    x64, W64, b64 = x.astype(np.float64), W.astype(np.float64), b.astype(np.float64)
+    z = O.conv2d_fwd(x64, W64, b64, 1, mode)
+    g = rng.randn(N, K, Hp, Hp).astype(np.float32)
+    dz_w = O.pool_bwd(fa(z), g.astype(np.float64), 2, ib) * dfa(z)
+    dx_w, dW_w, db_w = O.conv2d_bwd(x64, W64, dz_w, 1, mode)
+    kind, prm = act_code(act)
+    dx, dW, db = empty(x.shape), empty(W.shape), empty((K,))
+    geom = (N, C, H, H, K, f, pad_lo, Ho, Ho, 2, Hp, Hp, kind, prm)
+    call("tn_convblock_bwd", dev(x).ptr, dev(W).ptr, dev(b).ptr, dev(g).ptr, dx.ptr, dW.ptr, db.ptr, *geom)
+    assert_close(dx.get_value(), dx_w, atol=2e-5, what="convblock dx %s" % (case,))
+    assert_close(dW.get_value(), dW_w, atol=2e-4, what="convblock dW %s" % (case,))
+    assert_close(db.get_value(), db_w, atol=2e-4, what="convblock db %s" % (case,))
+    dW.fill_bytes(0)
+    call("tn_convblock_bwd", dev(x).ptr, dev(W).ptr, dev(b).ptr, dev(g).ptr, None, dW.ptr, db.ptr, *geom)
+    assert_close(dW.get_value(), dW_w, atol=2e-4, what="convblock dW (no dx) %s" % (case,))
+
+
 def test_convpool_tie_rule():
     # constant image, zero weights -> every conv output equals the bias: all four tie
     x = np.ones((1, 1, 6, 6), np.float32)

@@ -67,6 +67,8 @@ SIGNATURES = {
     "tn_sgd_update_multi": (c_int, [CTX, P, c_int, c_size_t, P, c_float]),
     "tn_convpool_supported": (c_int, [c_int, c_int, c_int, c_int]),
     "tn_convpool_fwd": (c_int, [CTX, P, P, P, P] + [c_int] * 12 + [c_int, c_float]),
+    "tn_convblock_supported": (c_int, [c_int] * 7),
+    "tn_convblock_bwd": (c_int, [CTX, P, P, P, P, P, P, P] + [c_int] * 12 + [c_int, c_float]),
     "tn_convpool_bwd": (c_int, [CTX, P, P, P, P, P, P, P] + [c_int] * 12 + [c_int, c_float]),
     "tn_elastic_draws_count": (c_size_t, [c_int, c_int]),
     "tn_elastic_draws": (c_int, [CTX, P, c_int, c_int, c_uint64, c_uint32, P]),

@@ -103,6 +103,20 @@ class ConvLayer(Layer):
         """gpool = d cost / d (pooled output).  One kernel recomputes the windows, routes the
         gradient through max-pool and activation and reduces dW/db; dz is only materialised
         when the layer below needs a gradient."""
+        pool = self.fused_pool
+        if self.ctx.lib.tn_convblock_supported(self.num_prev_maps, self.num_maps, self.filter_sz,
+                                               self.stride, pool.pool_sz, self.out_sz, self.out_sz):
+            # LDS-resident variant: dW/db AND the gradient w.r.t. the input in one kernel
+            b_out, b_act, b_prm, b_mask = below.act_info() if below is not None else (None, 0, 0., None)
+            if not (need_gin and b_out is not None and b_act != _lib.TN_ACT_LINEAR):
+                if need_gin and self.gin is None:
+                    self.gin = self.ctx.empty(self.inpt.shape)
+                self.ctx.call("tn_convblock_bwd", self.inpt.ptr, self.W.ptr, self.b.ptr, gpool.ptr,
+                              self.gin.ptr if need_gin else None, self.grads[0].ptr,
+                              self.grads[1].ptr, *self._fused_geom())
+                self._gin_done = True
+                return self.gin if need_gin else None
+        self._gin_done = False
         if need_gin and self.dz is None:
             self.dz = self.ctx.empty(self.output.shape)
         self.ctx.call("tn_convpool_bwd", self.inpt.ptr, self.W.ptr, self.b.ptr, gpool.ptr,
@@ -116,6 +130,8 @@ class ConvLayer(Layer):
             gout = self._backward_fused(gout, need_gin, below)
             if not need_gin:
                 return None
+            if self._gin_done:
+                return gout
         elif self.has_updates():
             self.ctx.call("tn_conv2d_wgrad", self.inpt.ptr, gout.ptr, self.grads[0].ptr,
                           self.grads[1].ptr, *self._geom())

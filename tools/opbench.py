@@ -100,6 +100,12 @@ def _():
              2, 6, 6, LEAKY, .05)
 
 
+@op("convblock2_bwd", 6 * B * 121 * 20 * 36, 4 * B * (676 + 720 + 676))
+def _():
+    ctx.call("tn_convblock_bwd", p1.ptr, W2.ptr, b2.ptr, g2.ptr, g1.ptr, dW2.ptr, db2.ptr, *c2, 0, 11, 11,
+             2, 6, 6, LEAKY, .05)
+
+
 @op("conv2_dgrad", 2 * B * 121 * 20 * 36, 4 * B * (2420 + 676))
 def _():
     ctx.call("tn_conv2d_dgrad", dz2.ptr, W2.ptr, g1.ptr, *c2, 1, 0, 11, 11, None, 0, 0.0)
