@@ -56,6 +56,12 @@ int tn_ctx_create(int device, tn_ctx** ctx);
 int tn_ctx_destroy(tn_ctx* ctx);
 const char* tn_last_error(tn_ctx* ctx);
 int tn_sync(tn_ctx* ctx);
+/* Two streams per context: 0 = main (the dependent chain), 1 = side (leaf work such as weight
+ * gradients, which only the update needs).  tn_stream_select picks the stream the following
+ * ops are enqueued on; tn_stream_wait(w, s) makes stream w wait for everything enqueued on s
+ * so far.  Both calls are legal inside tn_graph_begin/_end (cross-stream capture).           */
+int tn_stream_select(tn_ctx* ctx, int idx);
+int tn_stream_wait(tn_ctx* ctx, int waiter, int signaler);
 /* name_len bytes are written to name; cus = compute units; hbm_bytes = total memory */
 int tn_device_info(tn_ctx* ctx, char* name, int name_len, int* cus, size_t* hbm_bytes);
 

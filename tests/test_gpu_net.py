@@ -288,3 +288,32 @@ def test_train_py_end_to_end(tmp_path):
     with open(tmp_path / pk[0], "rb") as fh:
         ck = pickle.load(fh)
     assert ck["training_params"]["CUR_EPOCH"] >= 2 and len(ck["allwts"]) == 7
+
+
+def test_graph_replay_equals_eager():
+    """The captured HIP graph must reproduce the eager step bit for bit (same kernels, same
+    order; minibatch row, RNG step and learning rate come from device memory)."""
+    from theanet_amd import NeuralNet
+    import copy
+    prms = load_prms("mnist.prms", 28, batch=64)
+    rng = np.random.RandomState(0)
+    x = rng.rand(4 * 64, 1, 28, 28).astype(np.float32)
+    y = rng.randint(0, 10, 4 * 64).astype(np.int32)
+    nets = []
+    for use_graph in (False, True):
+        net = NeuralNet(copy.deepcopy(prms["layers"]), dict(prms["training_params"]))
+        net.use_graph = use_graph
+        fn = net.get_trin_model(x, y)
+        outs = []
+        for s in range(7):
+            if s == 4:
+                net.inc_epoch_set_rate()          # lr lives on the device: no recapture needed
+            outs.append(fn(s % 4))
+        assert (fn._graph is not None) == use_graph
+        nets.append((net, outs))
+    for (c0, _, l0), (c1, _, l1) in zip(nets[0][1], nets[1][1]):
+        assert c0 == c1
+        np.testing.assert_array_equal(l0, l1)
+    for la, lb in zip(nets[0][0].tr_layers, nets[1][0].tr_layers):
+        for wa, wb in zip(la.get_wts(), lb.get_wts()):
+            np.testing.assert_array_equal(wa, wb)

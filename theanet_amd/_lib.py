@@ -26,6 +26,8 @@ SIGNATURES = {
     "tn_ctx_destroy": (c_int, [CTX]),
     "tn_last_error": (c_char_p, [CTX]),
     "tn_sync": (c_int, [CTX]),
+    "tn_stream_select": (c_int, [CTX, c_int]),
+    "tn_stream_wait": (c_int, [CTX, c_int, c_int]),
     "tn_device_info": (c_int, [CTX, c_char_p, c_int, POINTER(c_int), POINTER(c_size_t)]),
     "tn_alloc": (c_int, [CTX, c_size_t, POINTER(c_void_p)]),
     "tn_free": (c_int, [CTX, P]),

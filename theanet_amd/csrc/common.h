@@ -12,7 +12,9 @@
 
 struct tn_ctx {
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;          // the stream ops are currently issued on
+    hipStream_t streams[2] = {nullptr, nullptr};   // [0] main, [1] side (leaf work: weight gradients)
+    hipEvent_t sync_ev[2] = {nullptr, nullptr};
     int num_cus = 256;
     char err[512] = {0};
     // RCCL (loaded lazily, comm.hip)

@@ -281,11 +281,19 @@ static int launch_cb(tn_ctx* ctx, const float* x, const float* W, const float* b
     float* dbpartial = ctx->scratch + (size_t)nslab * KCFF;
     if (act == TN_ACT_LEAKY) {
         auto kern = convblock_bwd_lds<F, C, TN_ACT_LEAKY>;
-        TN_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        static size_t set_for = 0;      // the attribute call is not a stream op: do it once per size
+        if (set_for < lds) {
+            TN_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            set_for = lds;
+        }
         kern<<<nblk, CB_NT, lds, ctx->stream>>>(x, W, b, g, dx, partial, dbpartial, q, act, prm);
     } else {
         auto kern = convblock_bwd_lds<F, C, -1>;
-        TN_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        static size_t set_for = 0;
+        if (set_for < lds) {
+            TN_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            set_for = lds;
+        }
         kern<<<nblk, CB_NT, lds, ctx->stream>>>(x, W, b, g, dx, partial, dbpartial, q, act, prm);
     }
     TN_LAUNCH_CHECK();

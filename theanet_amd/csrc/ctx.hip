@@ -24,11 +24,15 @@ int tn_ctx_create(int device, tn_ctx** out) {
     TN_HIP(hipSetDevice(device));
     tn_ctx* c = new tn_ctx();
     c->device = device;
-    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    hipError_t e = hipStreamCreateWithFlags(&c->streams[0], hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->streams[1], hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->sync_ev[0], hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->sync_ev[1], hipEventDisableTiming);
     if (e != hipSuccess) {
         delete c;
         return tn_fail(nullptr, TN_E_HIP, "hipStreamCreate -> %s", hipGetErrorString(e));
     }
+    c->stream = c->streams[0];
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->num_cus = prop.multiProcessorCount;
     c->scratch_bytes = 1 << 20;
@@ -46,9 +50,13 @@ int tn_ctx_destroy(tn_ctx* ctx) {
     if (!ctx) return TN_OK;
     hipSetDevice(ctx->device);
     tn_comm_destroy(ctx);
-    hipStreamSynchronize(ctx->stream);
+    hipStreamSynchronize(ctx->streams[0]);
+    hipStreamSynchronize(ctx->streams[1]);
     if (ctx->scratch) hipFree(ctx->scratch);
-    hipStreamDestroy(ctx->stream);
+    hipEventDestroy(ctx->sync_ev[0]);
+    hipEventDestroy(ctx->sync_ev[1]);
+    hipStreamDestroy(ctx->streams[0]);
+    hipStreamDestroy(ctx->streams[1]);
     delete ctx;
     return TN_OK;
 }
@@ -56,7 +64,22 @@ int tn_ctx_destroy(tn_ctx* ctx) {
 const char* tn_last_error(tn_ctx* ctx) { return ctx ? ctx->err : g_tn_err; }
 
 int tn_sync(tn_ctx* ctx) {
-    TN_HIP(hipStreamSynchronize(ctx->stream));
+    TN_HIP(hipStreamSynchronize(ctx->streams[1]));
+    TN_HIP(hipStreamSynchronize(ctx->streams[0]));
+    return TN_OK;
+}
+
+int tn_stream_select(tn_ctx* ctx, int idx) {
+    TN_REQUIRE(idx == 0 || idx == 1, "tn_stream_select: idx %d", idx);
+    ctx->stream = ctx->streams[idx];
+    return TN_OK;
+}
+
+int tn_stream_wait(tn_ctx* ctx, int waiter, int signaler) {
+    TN_REQUIRE((waiter == 0 || waiter == 1) && (signaler == 0 || signaler == 1) && waiter != signaler,
+               "tn_stream_wait: bad stream ids");
+    TN_HIP(hipEventRecord(ctx->sync_ev[signaler], ctx->streams[signaler]));
+    TN_HIP(hipStreamWaitEvent(ctx->streams[waiter], ctx->sync_ev[signaler], 0));
     return TN_OK;
 }
 
@@ -96,8 +119,9 @@ int tn_h2d(tn_ctx* ctx, void* dst, const void* src, size_t bytes) {
 
 int tn_d2h(tn_ctx* ctx, void* dst, const void* src, size_t bytes) {
     if (!bytes) return TN_OK;
-    TN_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
-    TN_HIP(hipStreamSynchronize(ctx->stream));
+    TN_HIP(hipStreamSynchronize(ctx->streams[1]));
+    TN_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->streams[0]));
+    TN_HIP(hipStreamSynchronize(ctx->streams[0]));
     return TN_OK;
 }
 
@@ -146,13 +170,15 @@ int tn_add_u32(tn_ctx* ctx, uint32_t* d, uint32_t inc) {
 
 // ---- graph capture -------------------------------------------------------------
 int tn_graph_begin(tn_ctx* ctx) {
-    TN_HIP(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+    ctx->stream = ctx->streams[0];
+    TN_HIP(hipStreamBeginCapture(ctx->streams[0], hipStreamCaptureModeThreadLocal));
     return TN_OK;
 }
 
 int tn_graph_end(tn_ctx* ctx, void** graph_exec) {
     hipGraph_t g = nullptr;
-    TN_HIP(hipStreamEndCapture(ctx->stream, &g));
+    ctx->stream = ctx->streams[0];
+    TN_HIP(hipStreamEndCapture(ctx->streams[0], &g));
     hipGraphExec_t ge = nullptr;
     hipError_t e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
     hipGraphDestroy(g);
@@ -163,7 +189,7 @@ int tn_graph_end(tn_ctx* ctx, void** graph_exec) {
 }
 
 int tn_graph_launch(tn_ctx* ctx, void* graph_exec) {
-    TN_HIP(hipGraphLaunch((hipGraphExec_t)graph_exec, ctx->stream));
+    TN_HIP(hipGraphLaunch((hipGraphExec_t)graph_exec, ctx->streams[0]));
     return TN_OK;
 }
 

@@ -11,6 +11,8 @@ from .weights import init_wb
 
 
 class HiddenLayer(Layer):
+    side_stream = True        # overlap the weight-gradient GEMM with the backward chain
+
     def __init__(self, inpt, wts,
                  rand_gen=None,
                  n_in=None,
@@ -84,9 +86,17 @@ class HiddenLayer(Layer):
             if self.wgrad_ws is None:
                 nbytes = self.ctx.lib.tn_fc_wgrad_ws_bytes(self.batch_sz, self.n_in, self.n_out)
                 self.wgrad_ws = self.ctx.empty((nbytes + 3) // 4)
+            # dW/db only feed the update: run them on the side stream, concurrently with the
+            # dgrad chain on the main stream (joined again before the all-reduce / update)
+            side = self.side_stream and need_gin
+            if side:
+                self.ctx.call("tn_stream_wait", 1, 0)
+                self.ctx.call("tn_stream_select", 1)
             self.ctx.call("tn_fc_wgrad", self.inpt.ptr, gout.ptr, self.grads[0].ptr,
                           self.grads[1].ptr, self.batch_sz, self.n_in, self.n_out,
                           self.wgrad_ws.ptr)
+            if side:
+                self.ctx.call("tn_stream_select", 0)
         if not need_gin:
             return None
         if self.gin is None:

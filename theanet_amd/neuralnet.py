@@ -67,6 +67,7 @@ class _TrainFn:
     def __init__(self, net, x_data, y_data, take_index_list):
         self.net, self.x_data, self.y_data = net, x_data, y_data
         self.take_index_list = take_index_list
+        self._graph, self._warm = None, False
         ctx = net.ctx
         if take_index_list:
             row = int(np.prod(x_data.shape[1:]))
@@ -75,10 +76,52 @@ class _TrainFn:
             self.idx_dev = ctx.empty((net.local_bsz,), np.int32)
             self.row_bytes = row * 4
 
+    # -- HIP-graph replay ---------------------------------------------------------------
+    def _graph_ok(self):
+        net = self.net
+        if not net.use_graph or self.take_index_list or net.ctx.ev_hook is not None:
+            return False
+        for lyr in net.tr_layers:               # injected draws change buffers: stay eager
+            drop = getattr(lyr, "drop", None)
+            if drop is not None and drop.injected:
+                return False
+            if getattr(lyr, "_inj_draws", False) or getattr(lyr, "_inj_flip", None) is not None:
+                return False
+        return True
+
+    def _enqueue_graph(self, i):
+        """Step = one tiny kernel that stores the minibatch's first row on the device + one
+        graph launch (the ~25 kernels of the step were captured once; every per-step value --
+        row offset, RNG step counter, learning rate -- is read from device memory)."""
+        net, ctx = self.net, self.net.ctx
+        slot = net.x
+        row0 = int(i) * net.batch_sz + net.shard_lo
+        if self._graph is None:
+            if not self._warm:                  # first call runs eagerly: sizes every lazy buffer
+                self._warm = True
+                return False
+            slot.bind(self.x_data)
+            slot.row0, slot.d_row0, slot.row_global0 = 0, net.d_row0, net.shard_lo
+            ctx.call("tn_graph_begin")
+            try:
+                net._train_step(self.y_data, 0, net.d_row0)
+            finally:
+                import ctypes
+                g = ctypes.c_void_p()
+                ctx.call("tn_graph_end", ctypes.byref(g))
+            slot.d_row0 = None
+            self._graph = g
+        ctx.call("tn_set_i64", net.d_row0.ptr, row0)
+        ctx.call("tn_graph_launch", self._graph)
+        return True
+
     def enqueue(self, i):
         net, ctx = self.net, self.net.ctx
         B, lo = net.batch_sz, net.shard_lo
         slot = net.x
+        if self._graph_ok() and self._enqueue_graph(i):
+            return
+        slot.d_row0 = None
         if self.take_index_list:
             idx = np.ascontiguousarray(np.asarray(i, np.int32)[lo:lo + net.local_bsz])
             self.idx_dev.set_value(idx)
@@ -173,9 +216,13 @@ class NeuralNet():
             self.test_x = InputSlot(self.local_bsz)
             self.test_x.bind(share(test_x))
 
-        # device-side step state
+        # device-side step state (read by the kernels, so a captured graph can be replayed)
         self.d_step = self.ctx.zeros((1,), np.uint32)       # RNG step counter
+        self.d_row0 = self.ctx.zeros((1,), np.int64)        # first dataset row of the minibatch
         self.cur_learn_rate = self.ctx.zeros((1,), np.float32)
+        import os
+        env = os.environ.get("TN_GRAPH")
+        self.use_graph = (self.world.size == 1) if env is None else (env == "1")
 
         # Input Layer
         input_layer_type = getattr(layer, layers[0][0])
@@ -341,14 +388,14 @@ class NeuralNet():
             self._group()
         self._grads_ready = True
 
-    def _train_step(self, y, y_row0):
+    def _train_step(self, y, y_row0, d_row0=None):
         """forward + backward + all-reduce + update for the minibatch the input slot
         currently points at.  Everything is enqueued; nothing is read back."""
         ctx = self.ctx
         out = self.tr_layers[-1]
         for lyr in self.tr_layers[:-1]:
             lyr.forward(True)
-        out.forward(True, y=y, y_row0=y_row0)
+        out.forward(True, y=y, y_row0=y_row0, d_row0=d_row0)
         # cost = -mean logprob[n, y_n]  (this rank's share of the global mean)
         ctx.call("tn_reduce_sum", out.rowloss.ptr, self.local_bsz, 1.0 / self.batch_sz,
                  self.d_cost.ptr, 0)
@@ -359,6 +406,7 @@ class NeuralNet():
             g = lyr.backward(g, self._need_gin[idx], below)
             if g is None:
                 break
+        ctx.call("tn_stream_wait", 0, 1)          # join the side stream (leaf weight gradients)
         if self.world.size > 1:
             self._group().allreduce_sum(self.flat_grads, self.n_flat)
         for lyr in self.tr_layers:
