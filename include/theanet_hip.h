@@ -178,6 +178,15 @@ int tn_scale_mask(tn_ctx* ctx, const float* x, const uint8_t* mask, float scale,
 int tn_softmax_nll(tn_ctx* ctx, const float* z, const int32_t* y, int64_t y_row0,
                    const int64_t* d_row0, float* logprob, float* rowloss, int32_t* pred,
                    float* rowp, float* dz, int B, int n_out, float inv_batch);
+/* Same, plus cost[0] = cost_scale * sum(rowloss) produced by the LAST block to finish (fixed
+ * summation order: deterministic), which saves a separate reduction launch.  ws: scratch of
+ * tn_softmax_cost_ws_bytes(B) bytes that must be zero before the first call (the kernel leaves
+ * it ready for the next one).                                                               */
+size_t tn_softmax_cost_ws_bytes(int B);
+int tn_softmax_nll_cost(tn_ctx* ctx, const float* z, const int32_t* y, int64_t y_row0,
+                        const int64_t* d_row0, float* logprob, float* rowloss, int32_t* pred,
+                        float* rowp, float* dz, int B, int n_out, float inv_batch,
+                        float cost_scale, float* cost, void* ws);
 /* out[0] = scale * sum(v[0..n))  (+ out[0] if accumulate) -- cost and error-rate scalars */
 int tn_reduce_sum(tn_ctx* ctx, const float* v, size_t n, float scale, float* out, int accumulate);
 /* out[0] (+)= L1*sum|p| + L2*sum p^2  (layer.py:109-117)                                 */
@@ -204,7 +213,7 @@ typedef struct tn_sgd_seg {
     float momentum, rate, L1, L2;
 } tn_sgd_seg;
 int tn_sgd_update_multi(tn_ctx* ctx, const tn_sgd_seg* d_segs, int nseg, size_t max_n,
-                        const float* d_lr, float gscale);
+                        const float* d_lr, float gscale, uint32_t* d_step_inc /* ++ if not NULL */);
 
 /* ---- elastic input stage (replaces ElasticLayer's graph; inlayers.py:63-144) ----
  * draws layout (float32, device): [0:2] translation u(-1,1) ; [2:4] origin u(.25,.75) ;

@@ -303,6 +303,7 @@ def test_graph_replay_equals_eager():
     for use_graph in (False, True):
         net = NeuralNet(copy.deepcopy(prms["layers"]), dict(prms["training_params"]))
         net.use_graph = use_graph
+        net.side_stream = True
         fn = net.get_trin_model(x, y)
         outs = []
         for s in range(7):

@@ -200,31 +200,32 @@ __global__ __launch_bounds__(256) void conv_bgrad_generic(const float* __restric
     if (threadIdx.x == 0) db[k] = red[0] + red[1] + red[2] + red[3];
 }
 
-// reduce partials over blocks (one wave per output element, fixed order -> deterministic);
-// flip (u,v) -> (f-1-u, f-1-v)
+// reduce partials over blocks: one 256-thread block per output element, fixed strided order ->
+// deterministic; flip (u,v) -> (f-1-u, f-1-v)
 __global__ __launch_bounds__(256) void conv_wgrad_finish(const float* __restrict__ partial,
                                                         const float* __restrict__ dbpartial,
                                                         float* __restrict__ dW, float* __restrict__ db,
                                                         int nblk, int K, int C, int f) {
+    __shared__ float red[4];
     const int ff = f * f;
     const int KCFF = K * C * ff;
-    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (t < KCFF) {
-        float s = 0.f;
-        for (int bk = lane; bk < nblk; bk += 64) s += partial[(size_t)bk * KCFF + t];
-        s = wave_sum_f(s);
-        if (lane == 0) {
+    const int t = blockIdx.x;
+    const float* src = (t < KCFF) ? partial + t : dbpartial + (t - KCFF);
+    const int stride = (t < KCFF) ? KCFF : K;
+    float s = 0.f;
+    for (int bk = threadIdx.x; bk < nblk; bk += 256) s += src[(size_t)bk * stride];
+    s = wave_sum_f(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float r = red[0] + red[1] + red[2] + red[3];
+        if (t < KCFF) {
             const int uv = t % ff, kc = t / ff;
             const int u = uv / f, v = uv % f;
-            dW[(size_t)kc * ff + (f - 1 - u) * f + (f - 1 - v)] = s;
+            dW[(size_t)kc * ff + (f - 1 - u) * f + (f - 1 - v)] = r;
+        } else {
+            db[t - KCFF] = r;
         }
-    } else if (t < KCFF + K) {
-        const int k = t - KCFF;
-        float s = 0.f;
-        for (int bk = lane; bk < nblk; bk += 64) s += dbpartial[(size_t)bk * K + k];
-        s = wave_sum_f(s);
-        if (lane == 0) db[k] = s;
     }
 }
 
@@ -402,7 +403,7 @@ int tn_ensure_scratch(tn_ctx* ctx, size_t bytes) {
 int tn_conv_wgrad_finish(tn_ctx* ctx, const float* partial, const float* dbpartial, float* dW,
                          float* db, int nblk, int K, int C, int f) {
     const int outs = K * C * f * f + K;
-    conv_wgrad_finish<<<cdiv(outs, 4), 256, 0, ctx->stream>>>(partial, dbpartial, dW, db, nblk, K, C, f);
+    conv_wgrad_finish<<<outs, 256, 0, ctx->stream>>>(partial, dbpartial, dW, db, nblk, K, C, f);
     TN_LAUNCH_CHECK();
     return TN_OK;
 }

@@ -238,7 +238,7 @@ __global__ __launch_bounds__(CB_NT) void convblock_bwd_lds(
             }
         }
     }
-    if (wlive) {
+    if (wlive) {        // one partial slab per (block, image slot); conv_wgrad_finish sums them
         const size_t slab = (size_t)blockIdx.x * G + wg;
         float* p = partial + slab * K * C * FF + ((size_t)wk * C + wc) * FF + wu * F;
 #pragma unroll

@@ -591,33 +591,39 @@ __global__ __launch_bounds__(256) void fc_skinny_dgrad_kernel(
     }
 }
 
-// wgrad: thread = one input feature k, block.y = a chunk of 32 rows; the 32 x values are
-// loaded up front, dz rows are wave-uniform.  partial[chunk][k][n], dbpartial[chunk][n].
-#define SK_WROWS 32
+// wgrad: thread = one input feature k, block.y = a chunk of SK_WROWS rows.  The chunk's dz rows
+// are staged in LDS (read back as wave broadcasts), the x values are loaded 32 at a time (all
+// in flight).  partial[chunk][k][n], dbpartial[chunk][n].
+#define SK_WROWS 64
 __global__ __launch_bounds__(256) void fc_skinny_wgrad_kernel(
     const float* __restrict__ x, const float* __restrict__ dz, float* __restrict__ partial,
     float* __restrict__ dbpartial, int B, int n_in, int n_out) {
+    __shared__ float sdz[SK_WROWS * SK_MAX];
     const int k = min(blockIdx.x * 256 + threadIdx.x, n_in - 1);
     const bool live = blockIdx.x * 256 + threadIdx.x < n_in;
     const int row0 = blockIdx.y * SK_WROWS;
-    float xv[SK_WROWS];
+    const int nrow = min(SK_WROWS, B - row0);
+    for (int t = threadIdx.x; t < SK_WROWS * SK_MAX; t += 256) {
+        const int r = t / SK_MAX, n = t - r * SK_MAX;
+        sdz[t] = (r < nrow && n < n_out) ? dz[(size_t)(row0 + r) * n_out + n] : 0.f;
+    }
+    __syncthreads();
+    float acc[SK_MAX];
 #pragma unroll
-    for (int r = 0; r < SK_WROWS; ++r) xv[r] = x[(size_t)min(row0 + r, B - 1) * n_in + k];
-    float acc[SK_MAX], accb[SK_MAX];
+    for (int n = 0; n < SK_MAX; ++n) acc[n] = 0.f;
 #pragma unroll
-    for (int n = 0; n < SK_MAX; ++n) acc[n] = accb[n] = 0.f;
+    for (int half = 0; half < SK_WROWS / 32; ++half) {
+        float xv[32];
 #pragma unroll
-    for (int r = 0; r < SK_WROWS; ++r) {
-        const bool rok = row0 + r < B;                                 // uniform
-        const float* dzr = dz + (size_t)min(row0 + r, B - 1) * n_out;  // wave-uniform
-        const float xx = rok ? xv[r] : 0.f;
+        for (int r = 0; r < 32; ++r)
+            xv[r] = x[(size_t)min(row0 + 32 * half + r, B - 1) * n_in + k];
 #pragma unroll
-        for (int n = 0; n < SK_MAX; ++n)
-            if (n < n_out) {
-                const float d = rok ? dzr[n] : 0.f;
-                acc[n] = fmaf(xx, d, acc[n]);
-                accb[n] += d;
-            }
+        for (int r = 0; r < 32; ++r) {
+            const float* dr = sdz + (32 * half + r) * SK_MAX;       // zero rows beyond nrow
+#pragma unroll
+            for (int n = 0; n < SK_MAX; ++n)
+                if (n < n_out) acc[n] = fmaf(xv[r], dr[n], acc[n]);
+        }
     }
     if (live) {
         float* p = partial + ((size_t)blockIdx.y * n_in + k) * n_out;
@@ -625,10 +631,10 @@ __global__ __launch_bounds__(256) void fc_skinny_wgrad_kernel(
         for (int n = 0; n < SK_MAX; ++n)
             if (n < n_out) p[n] = acc[n];
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-#pragma unroll
-        for (int n = 0; n < SK_MAX; ++n)
-            if (n < n_out) dbpartial[(size_t)blockIdx.y * n_out + n] = accb[n];
+    if (blockIdx.x == 0 && threadIdx.x < n_out) {
+        float sb = 0.f;
+        for (int r = 0; r < SK_WROWS; ++r) sb += sdz[r * SK_MAX + threadIdx.x];
+        dbpartial[(size_t)blockIdx.y * n_out + threadIdx.x] = sb;
     }
 }
 

@@ -2,14 +2,19 @@
 // Semantics: theanet/layer/outlayers.py:50-51 (nll), :69-80 (error stats), :87-95 (SoftmaxLayer).
 #include "common.h"
 
+template <bool COST>
 __global__ __launch_bounds__(256) void softmax_nll_kernel(
     const float* __restrict__ z, const int32_t* __restrict__ y, int64_t y_row0,
     const int64_t* __restrict__ d_row0, float* __restrict__ logprob, float* __restrict__ rowloss,
     int32_t* __restrict__ pred, float* __restrict__ rowp, float* __restrict__ dz, int B, int n_out,
-    float inv_batch) {
+    float inv_batch, float cost_scale, float* __restrict__ cost, float* __restrict__ blk_part,
+    unsigned* __restrict__ counter) {
+    __shared__ float wl[4];
+    __shared__ unsigned ticket_s;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    if (row >= B) return;
+    float myloss = 0.f;
+    if (row < B) {
     const float* zr = z + (size_t)row * n_out;
     // max + first argmax (numpy argmax semantics: first maximal index)
     float m = -INFINITY;
@@ -44,9 +49,39 @@ __global__ __launch_bounds__(256) void softmax_nll_kernel(
         if (c == label) {
             if (rowloss) rowloss[row] = -lp;
             if (rowp) rowp[row] = expf(lp);
+            myloss = -lp;
         }
     }
     if (lane == 0 && pred) pred[row] = am;
+    }
+    if (COST) {
+        // block partial -> global; the last block to arrive sums all partials in index order
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) myloss += __shfl_xor(myloss, o, 64);
+        if (lane == 0) wl[threadIdx.x >> 6] = myloss;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            blk_part[blockIdx.x] = wl[0] + wl[1] + wl[2] + wl[3];
+            __threadfence();
+            ticket_s = atomicAdd(counter, 1u);
+        }
+        __syncthreads();
+        if (ticket_s == gridDim.x - 1) {
+            __threadfence();
+            float s = 0.f;
+            for (int i = threadIdx.x; i < (int)gridDim.x; i += 256)
+                s += __hip_atomic_load(&blk_part[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+            __syncthreads();
+            if (lane == 0) wl[threadIdx.x >> 6] = s;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                cost[0] = cost_scale * (wl[0] + wl[1] + wl[2] + wl[3]);
+                *counter = 0;                    // ready for the next launch
+            }
+        }
+    }
 }
 
 extern "C" int tn_softmax_nll(tn_ctx* ctx, const float* z, const int32_t* y, int64_t y_row0,
@@ -55,8 +90,25 @@ extern "C" int tn_softmax_nll(tn_ctx* ctx, const float* z, const int32_t* y, int
     TN_REQUIRE(B > 0 && n_out > 0, "tn_softmax_nll: bad shape");
     TN_REQUIRE(y != nullptr || (rowloss == nullptr && dz == nullptr && rowp == nullptr),
                "tn_softmax_nll: labels required for loss/gradient outputs");
-    softmax_nll_kernel<<<cdiv(B, 4), 256, 0, ctx->stream>>>(z, y, y_row0, d_row0, logprob, rowloss,
-                                                           pred, rowp, dz, B, n_out, inv_batch);
+    softmax_nll_kernel<false><<<cdiv(B, 4), 256, 0, ctx->stream>>>(
+        z, y, y_row0, d_row0, logprob, rowloss, pred, rowp, dz, B, n_out, inv_batch, 0.f, nullptr,
+        nullptr, nullptr);
+    TN_LAUNCH_CHECK();
+    return TN_OK;
+}
+
+extern "C" size_t tn_softmax_cost_ws_bytes(int B) { return ((size_t)cdiv(B, 4) + 4) * sizeof(float); }
+
+extern "C" int tn_softmax_nll_cost(tn_ctx* ctx, const float* z, const int32_t* y, int64_t y_row0,
+                                   const int64_t* d_row0, float* logprob, float* rowloss,
+                                   int32_t* pred, float* rowp, float* dz, int B, int n_out,
+                                   float inv_batch, float cost_scale, float* cost, void* ws) {
+    TN_REQUIRE(B > 0 && n_out > 0 && y && cost && ws, "tn_softmax_nll_cost: bad arguments");
+    unsigned* counter = (unsigned*)ws;
+    float* part = (float*)ws + 4;
+    softmax_nll_kernel<true><<<cdiv(B, 4), 256, 0, ctx->stream>>>(
+        z, y, y_row0, d_row0, logprob, rowloss, pred, rowp, dz, B, n_out, inv_batch, cost_scale, cost,
+        part, counter);
     TN_LAUNCH_CHECK();
     return TN_OK;
 }

@@ -24,7 +24,9 @@ __global__ __launch_bounds__(256) void sgd_update_kernel(float* __restrict__ p, 
 // all parameter tensors of the net in ONE launch: blockIdx.y selects the segment descriptor
 __global__ __launch_bounds__(256) void sgd_update_multi_kernel(const tn_sgd_seg* __restrict__ segs,
                                                               const float* __restrict__ d_lr,
-                                                              float gscale) {
+                                                              float gscale, uint32_t* d_step_inc) {
+    if (d_step_inc && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
+        *d_step_inc += 1;                       // the RNG step counter advances with the update
     const tn_sgd_seg sg = segs[blockIdx.y];
     const float step = sg.rate * d_lr[0];
     float* __restrict__ p = sg.p;
@@ -103,13 +105,13 @@ int tn_sgd_update(tn_ctx* ctx, float* p, float* v, const float* g, size_t n, flo
 }
 
 int tn_sgd_update_multi(tn_ctx* ctx, const tn_sgd_seg* d_segs, int nseg, size_t max_n,
-                        const float* d_lr, float gscale) {
+                        const float* d_lr, float gscale, uint32_t* d_step_inc) {
     if (nseg <= 0) return TN_OK;
     TN_REQUIRE(d_segs != nullptr && d_lr != nullptr, "tn_sgd_update_multi: NULL argument");
     int bx = cdiv(max_n, 1024);
     if (bx > 256) bx = 256;
     if (bx < 1) bx = 1;
-    sgd_update_multi_kernel<<<dim3(bx, nseg), 256, 0, ctx->stream>>>(d_segs, d_lr, gscale);
+    sgd_update_multi_kernel<<<dim3(bx, nseg), 256, 0, ctx->stream>>>(d_segs, d_lr, gscale, d_step_inc);
     TN_LAUNCH_CHECK();
     return TN_OK;
 }

@@ -23,6 +23,7 @@ class DropStream:
             else int(np.random.randint(0, 1e6))
         self.mask = ctx.empty(shape, np.uint8)
         self.injected = False
+        self.ready = False          # mask of the current step already generated (side stream)
         self.d_step = None          # device step counter (set by the net)
         self.elem0 = 0              # global index of this shard's first element
 
@@ -37,6 +38,9 @@ class DropStream:
 
     def generate(self):
         if self.injected:
+            return
+        if self.ready:              # produced ahead of time by NeuralNet._train_step
+            self.ready = False
             return
         self.ctx.call("tn_dropout_mask", self.mask.ptr, self.mask.size, self.pdrop, self.seed,
                       0, self.d_step.ptr if self.d_step is not None else None, self.elem0)

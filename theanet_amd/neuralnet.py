@@ -222,7 +222,12 @@ class NeuralNet():
         self.cur_learn_rate = self.ctx.zeros((1,), np.float32)
         import os
         env = os.environ.get("TN_GRAPH")
-        self.use_graph = (self.world.size == 1) if env is None else (env == "1")
+        # measured on MI355X: replaying the captured step is NOT faster than eager launches (the
+        # ~1.5-2 us kernel boundaries are GPU-side either way) and loses ~12 % with the
+        # two-stream backward, so capture is opt-in (TN_GRAPH=1)
+        self.use_graph = (env == "1")
+        self.side_stream = os.environ.get("TN_SIDE", "1") == "1"
+        HiddenLayer.side_stream = self.side_stream
 
         # Input Layer
         input_layer_type = getattr(layer, layers[0][0])
@@ -393,12 +398,26 @@ class NeuralNet():
         currently points at.  Everything is enqueued; nothing is read back."""
         ctx = self.ctx
         out = self.tr_layers[-1]
+        # Random inputs that depend only on the step counter are produced on the side stream,
+        # off the critical path: dropout masks now, the NEXT step's elastic field later on.
+        pre = [l for l in self.tr_layers if getattr(l, "drop", None) is not None and not l.drop.injected] \
+            if self.side_stream else []
+        if pre:
+            ctx.call("tn_stream_wait", 1, 0)
+            ctx.call("tn_stream_select", 1)
+            for lyr in pre:
+                lyr.drop.generate()
+                lyr.drop.ready = True
+            ctx.call("tn_stream_select", 0)
+        joined = not pre
         for lyr in self.tr_layers[:-1]:
+            if not joined and getattr(lyr, "drop", None) is not None:
+                ctx.call("tn_stream_wait", 0, 1)
+                joined = True
             lyr.forward(True)
-        out.forward(True, y=y, y_row0=y_row0, d_row0=d_row0)
-        # cost = -mean logprob[n, y_n]  (this rank's share of the global mean)
-        ctx.call("tn_reduce_sum", out.rowloss.ptr, self.local_bsz, 1.0 / self.batch_sz,
-                 self.d_cost.ptr, 0)
+        # logits, softmax, per-row loss and cost = -mean logprob[n, y_n] (this rank's share of
+        # the global mean) in one launch
+        out.forward(True, y=y, y_row0=y_row0, d_row0=d_row0, cost_scale=1.0 / self.batch_sz)
         g = out.dlogits
         for idx in range(len(self.tr_layers) - 1, -1, -1):
             lyr = self.tr_layers[idx]
@@ -411,12 +430,13 @@ class NeuralNet():
             self._group().allreduce_sum(self.flat_grads, self.n_flat)
         for lyr in self.tr_layers:
             lyr.get_wtcost(self.d_cost)
-        if self._n_segs:
+        if self._n_segs:                          # also advances the RNG step counter
             ctx.call("tn_sgd_update_multi", self._d_segs.ptr, self._n_segs, self._max_seg,
-                     self.cur_learn_rate.ptr, 1.0)
+                     self.cur_learn_rate.ptr, 1.0, self.d_step.ptr)
+        else:
+            ctx.call("tn_add_u32", self.d_step.ptr, 1)
         for lyr in self.tr_layers:
             lyr.apply_maxnorm()
-        ctx.call("tn_add_u32", self.d_step.ptr, 1)
 
     # ------------------------------------------------------------------------------
     def get_trin_model(self, x_data, y_data, aux_data=None,
