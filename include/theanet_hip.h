@@ -110,6 +110,10 @@ int tn_conv2d_dgrad(tn_ctx* ctx, const float* dz, const float* W, float* dx,
                     int N, int C, int H, int Wd, int K, int f, int stride, int pad_lo,
                     int Ho, int Wo, const float* prev_a, int prev_act, float prev_act_param);
 
+/* 1 if tn_conv2d_* run this shape on the implicit-im2col fp32-MFMA kernels (stride 1, reduction
+ * C*f*f >= 32, >= 16 output maps); otherwise the direct VALU kernels are used.              */
+int tn_conv_mfma_supported(int C, int K, int f, int stride);
+
 /* ---- fused conv + bias + act + max-pool for small feature maps (same reference call sites as
  * tn_conv2d_* followed by tn_pool_*: convpool.py:54-72 then :106-107).  The conv activation
  * never reaches HBM: fwd writes only the pooled map y (N,K,Hp,Wp); bwd takes g = dcost/dy,

@@ -23,6 +23,13 @@ CONV_CASES = [
     (2, 3, 9, 4, 2, 1, "valid", "scaled_tanh"),
     (2, 2, 7, 3, 1, 1, "valid", "softplus"),
     (2, 9, 8, 16, 3, 1, "same", "relu10"),
+    # implicit-im2col MFMA path (C*f*f >= 32, K >= 16)
+    (3, 16, 12, 32, 3, 1, "same", "relu10"),
+    (2, 32, 9, 64, 3, 1, "valid", "relu10"),
+    (2, 17, 10, 70, 3, 1, "same", "tanh"),          # ragged: Kd = 153 (not % 4), K = 70
+    (1, 8, 14, 16, 5, 1, "same", "relu05"),
+    (5, 64, 8, 96, 3, 1, "same", "relu10"),
+    (2, 24, 7, 40, 2, 1, "valid", "linear"),
 ]
 
 

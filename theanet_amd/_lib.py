@@ -70,6 +70,7 @@ SIGNATURES = {
     "tn_softmax_cost_ws_bytes": (c_size_t, [c_int]),
     "tn_softmax_nll_cost": (c_int, [CTX, P, P, c_int64, P, P, P, P, P, P, c_int, c_int, c_float,
                                     c_float, P, P]),
+    "tn_conv_mfma_supported": (c_int, [c_int] * 4),
     "tn_convpool_supported": (c_int, [c_int, c_int, c_int, c_int]),
     "tn_convpool_fwd": (c_int, [CTX, P, P, P, P] + [c_int] * 12 + [c_int, c_float]),
     "tn_convblock_supported": (c_int, [c_int] * 7),

@@ -400,6 +400,16 @@ int tn_ensure_scratch(tn_ctx* ctx, size_t bytes) {
     return TN_OK;
 }
 
+// MFMA implicit-GEMM path (conv_mfma.hip)
+int tn_conv_mfma_fwd(tn_ctx* ctx, const float* x, const float* W, const float* b, float* a, int N,
+                     int C, int H, int Wd, int K, int f, int pad, int Ho, int Wo, int act, float prm);
+int tn_conv_mfma_dgrad(tn_ctx* ctx, const float* dz, const float* W, float* dx, int N, int C, int H,
+                       int Wd, int K, int f, int pad, int Ho, int Wo, const float* prev_a, int act,
+                       float prm);
+int tn_conv_mfma_wgrad(tn_ctx* ctx, const float* x, const float* dz, float* dW, float* db, int N,
+                       int C, int H, int Wd, int K, int f, int pad, int Ho, int Wo);
+extern "C" int tn_conv_mfma_supported(int C, int K, int f, int stride);
+
 int tn_conv_wgrad_finish(tn_ctx* ctx, const float* partial, const float* dbpartial, float* dW,
                          float* db, int nblk, int K, int C, int f) {
     const int outs = K * C * f * f + K;
@@ -415,6 +425,8 @@ int tn_conv2d_fwd(tn_ctx* ctx, const float* x, const float* W, const float* b, f
                   int act, float act_param) {
     TN_REQUIRE(N > 0 && C > 0 && K > 0 && f > 0 && stride > 0 && Ho > 0 && Wo > 0,
                "tn_conv2d_fwd: bad shape");
+    if (tn_conv_mfma_supported(C, K, f, stride))
+        return tn_conv_mfma_fwd(ctx, x, W, b, a, N, C, H, Wd, K, f, pad_lo, Ho, Wo, act, act_param);
     const long long M = (long long)N * Ho * Wo;
     const int gx = cdiv(M, 256);
 #define LAUNCH_FWD(F_, KT_)                                                                     \
@@ -436,6 +448,8 @@ int tn_conv2d_fwd(tn_ctx* ctx, const float* x, const float* W, const float* b, f
 int tn_conv2d_wgrad(tn_ctx* ctx, const float* x, const float* dz, float* dW, float* db, int N, int C,
                     int H, int Wd, int K, int f, int stride, int pad_lo, int Ho, int Wo) {
     TN_REQUIRE(N > 0 && C > 0 && K > 0 && f > 0 && stride > 0, "tn_conv2d_wgrad: bad shape");
+    if (tn_conv_mfma_supported(C, K, f, stride))
+        return tn_conv_mfma_wgrad(ctx, x, dz, dW, db, N, C, H, Wd, K, f, pad_lo, Ho, Wo);
     const long long M = (long long)N * Ho * Wo;
     if (f == 3 || f == 5 || f == 1 || f == 2) {
         int nblk = cdiv(M, 256 * 16);
@@ -479,6 +493,9 @@ int tn_conv2d_dgrad(tn_ctx* ctx, const float* dz, const float* W, float* dx, int
                     int Wd, int K, int f, int stride, int pad_lo, int Ho, int Wo, const float* prev_a,
                     int prev_act, float prev_act_param) {
     TN_REQUIRE(N > 0 && C > 0 && K > 0 && f > 0 && stride > 0, "tn_conv2d_dgrad: bad shape");
+    if (tn_conv_mfma_supported(K, C, f, stride))     // reduction K*f*f, rows = C input maps
+        return tn_conv_mfma_dgrad(ctx, dz, W, dx, N, C, H, Wd, K, f, pad_lo, Ho, Wo, prev_a, prev_act,
+                                  prev_act_param);
     if (f == 3 && stride == 1) {
         const size_t per = (size_t)K * (Ho + 4) * (Wo + 4) * sizeof(float);
         const size_t wbytes = (size_t)K * 9 * 16;

@@ -167,6 +167,31 @@ def _():
     ctx.call("tn_dropout_mask", mask.ptr, B * 500, .5, 77, 0, None, 0)
 
 
+# ---- a wide6-like layer: 64 -> 64 maps, 3x3 same, 64x64 images, 128 images/GPU ------------
+WB = int(os.environ.get("OPBENCH_WB", 128))
+wx = dev((WB, 64, 64, 64)); wW, wb_ = dev((64, 64, 3, 3)), dev((64,))
+wa = dev((WB, 64, 64, 64)); wdz = dev((WB, 64, 64, 64)); wdx = dev((WB, 64, 64, 64))
+wdW, wdb = dev((64, 64, 3, 3)), dev((64,))
+cw = (WB, 64, 64, 64, 64, 3)
+WFL = 2 * WB * 64 * 64 * 64 * 64 * 9
+WBY = 4 * (2 * WB * 64 * 64 * 64 + 64 * 64 * 9)
+
+
+@op("wide_conv_fwd", WFL, WBY)
+def _():
+    ctx.call("tn_conv2d_fwd", wx.ptr, wW.ptr, wb_.ptr, wa.ptr, *cw, 1, 1, 64, 64, LEAKY, .1)
+
+
+@op("wide_conv_dgrad", WFL, WBY)
+def _():
+    ctx.call("tn_conv2d_dgrad", wdz.ptr, wW.ptr, wdx.ptr, *cw, 1, 1, 64, 64, wa.ptr, LEAKY, .1)
+
+
+@op("wide_conv_wgrad", WFL, WBY)
+def _():
+    ctx.call("tn_conv2d_wgrad", wx.ptr, wdz.ptr, wdW.ptr, wdb.ptr, *cw, 1, 1, 64, 64)
+
+
 def main():
     flt = [a for a in sys.argv[1:] if not a.startswith("--")]
     iters = 20
