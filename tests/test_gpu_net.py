@@ -318,3 +318,38 @@ def test_graph_replay_equals_eager():
     for la, lb in zip(nets[0][0].tr_layers, nets[1][0].tr_layers):
         for wa, wb in zip(la.get_wts(), lb.get_wts()):
             np.testing.assert_array_equal(wa, wb)
+
+
+@pytest.mark.parametrize("name,img,B", [("cifar_like.prms", 32, 16), ("wide6.prms", 16, 4)])
+def test_baseline_config_nets_match_oracle(name, img, B):
+    """BASELINE.json configs 4 and 5 (MFMA conv path, dropout + maxnorm): two training steps at
+    a reduced batch against the float64 oracle."""
+    import copy
+    from theanet_amd import NeuralNet
+    prms = load_prms(name, img, batch=B)
+    tr = prms["training_params"]
+    rng = np.random.RandomState(1)
+    x = rng.rand(2 * B, 3, img, img).astype(np.float32)
+    y = rng.randint(0, 10, 2 * B).astype(np.int32)
+    net = NeuralNet(copy.deepcopy(prms["layers"]), dict(tr))
+    ora = O.OracleNet(copy.deepcopy(prms["layers"]), dict(tr), dtype=np.float64)
+    fn = net.get_trin_model(x, y)
+    for s in range(2):
+        draws = {}
+        for i, l in enumerate(ora.L):
+            if l.kind == "Elastic" and l.stage.active:
+                d = l.stage.draw((B, 3, img, img))
+                draws[i] = d
+                net.tr_layers[i].inject(**{k: getattr(d, k) for k in d.__slots__})
+            if getattr(l, "mask_rv", None) is not None:
+                m = l.mask_rv.draw((B, l.n_out))
+                draws[i] = m
+                net.tr_layers[i].drop.inject(m)
+        cost_w, lp_w, _ = ora.train_step(x[s * B:(s + 1) * B], y[s * B:(s + 1) * B], draws)
+        cost, _, lp = fn(s)
+        assert_close(lp, lp_w, 1e-4, 2e-5, what="%s logprob step %d" % (name, s))
+        assert_close(cost, cost_w, 1e-4, 1e-5, what="%s cost step %d" % (name, s))
+        np.testing.assert_array_equal(lp.argmax(1), lp_w.argmax(1))
+    for i, (lyr, ol) in enumerate(zip(net.tr_layers, ora.L)):
+        for j, w in enumerate(lyr.get_wts()):
+            assert_close(w, ol.params[j], 2e-4, 2e-6, what="%s w %d %d" % (name, i, j))

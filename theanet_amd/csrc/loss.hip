@@ -61,13 +61,15 @@ __global__ __launch_bounds__(256) void softmax_nll_kernel(
         if (lane == 0) wl[threadIdx.x >> 6] = myloss;
         __syncthreads();
         if (threadIdx.x == 0) {
-            blk_part[blockIdx.x] = wl[0] + wl[1] + wl[2] + wl[3];
-            __threadfence();
-            ticket_s = atomicAdd(counter, 1u);
+            // write-through (sc1) store of the partial, drained before the ticket: no L2
+            // write-back fence needed (cdna_hip_programming.md G16, form R1)
+            __hip_atomic_store(&blk_part[blockIdx.x], wl[0] + wl[1] + wl[2] + wl[3], __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            ticket_s = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();
         if (ticket_s == gridDim.x - 1) {
-            __threadfence();
             float s = 0.f;
             for (int i = threadIdx.x; i < (int)gridDim.x; i += 256)
                 s += __hip_atomic_load(&blk_part[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -1,0 +1,17 @@
+#!/bin/bash
+# Runs ON THE GPU BOX (via gpurun): kernel-trace stats and the HBM-traffic PMC passes for the
+# headline workload, written under gpurun_out/ (copy the summaries into profiles/ afterwards).
+#   FETCH_SIZE / WRITE_SIZE are collected in their own passes (TCC has 4 slots: 3 + 2 do not
+#   fit together), exactly as /opt/skills/guides/MI355X_MICROARCH.md prescribes.
+set -e
+TAG=${1:-r01}
+OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o mnist -- \
+    python $GRAFT_REPO_ROOT/bench.py --steps 50 --warmup 5 --no-cpu-baseline > $OUT/stats.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -o p -- \
+    python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -o p -- \
+    python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/write.log 2>&1
+tail -1 $OUT/stats.log | cut -c1-200
