@@ -112,10 +112,14 @@ class ElasticLayer(Layer):
         h = w = img_sz
         n_draws = ctx.lib.tn_elastic_draws_count(h, w)
         self.draws = ctx.zeros((n_draws,))
-        self.map_idx = ctx.empty((h * w,), np.int32)
-        self.map_fy = ctx.empty((h * w,))
-        self.map_fx = ctx.empty((h * w,))
-        self.target = ctx.empty((2, h, w), np.float64)     # debugout[1] + indices (:146)
+        # two sample maps: while the minibatch of step t is resampled through one, the field of
+        # step t+1 (it depends only on the step counter) is built into the other on the side stream
+        self._maps = [(ctx.empty((h * w,), np.int32), ctx.empty((h * w,)), ctx.empty((h * w,)),
+                       ctx.empty((2, h, w), np.float64)) for _ in range(2)]
+        self._cur = 0
+        self._pre_valid = False
+        self.precompute = False         # set by NeuralNet (needs the side stream, eager launches)
+        self.map_idx, self.map_fy, self.map_fx, self.target = self._maps[0]
 
     def TestVersion(self, te_inpt):
         return ElasticLayer(te_inpt, self.img_sz,
@@ -166,13 +170,16 @@ class ElasticLayer(Layer):
                           None, None, None, 0.0, None, 0, 0, None, rg0)
             return
         d_step_ptr = self.d_step.ptr if self.d_step is not None else None
+        ahead = self.precompute and self.has_field and not self._inj_draws and self.d_step is not None
         if self.has_field:
-            if not self._inj_draws:
-                self.ctx.call("tn_elastic_draws", self.draws.ptr, h, w, self.seed, 0, d_step_ptr)
-            self.ctx.call("tn_elastic_field", self.draws.ptr, h, w, float(self.translation),
-                          float(self.zoom), float(self.magnitude), int(self.sigma),
-                          float(self.angle), int(self.nearest), self.map_idx.ptr,
-                          self.map_fy.ptr, self.map_fx.ptr, self.target.ptr)
+            self.map_idx, self.map_fy, self.map_fx, self.target = self._maps[self._cur]
+            if ahead and self._pre_valid:
+                self.ctx.call("tn_stream_wait", 0, 1)        # the side stream built this map
+            else:
+                if not self._inj_draws:
+                    self.ctx.call("tn_elastic_draws", self.draws.ptr, h, w, self.seed, 0, d_step_ptr)
+                self._field(self._maps[self._cur])
+            self._pre_valid = False
         self.ctx.call("tn_elastic_apply", x_ptr, row0, d_row0_ptr, self.output.ptr,
                       self.batch_sz, self.num_maps, h, w, int(self.invert), int(self.nearest),
                       self.map_idx.ptr if self.has_field else None,
@@ -180,6 +187,22 @@ class ElasticLayer(Layer):
                       float(self.pflip) if self._inj_flip is None else 0.0,
                       self._inj_flip.ptr if self._inj_flip is not None else None,
                       self.seed, 0, d_step_ptr, rg0)
+        if ahead:
+            # next step's field: draws keyed by (seed, *d_step + 1); the step counter only
+            # advances in the update, which the net issues after joining the side stream
+            nxt = 1 - self._cur
+            self.ctx.call("tn_stream_wait", 1, 0)
+            self.ctx.call("tn_stream_select", 1)
+            self.ctx.call("tn_elastic_draws", self.draws.ptr, h, w, self.seed, 1, d_step_ptr)
+            self._field(self._maps[nxt])
+            self.ctx.call("tn_stream_select", 0)
+            self._cur, self._pre_valid = nxt, True
+
+    def _field(self, m):
+        h = w = self.img_sz
+        self.ctx.call("tn_elastic_field", self.draws.ptr, h, w, float(self.translation),
+                      float(self.zoom), float(self.magnitude), int(self.sigma),
+                      float(self.angle), int(self.nearest), m[0].ptr, m[1].ptr, m[2].ptr, m[3].ptr)
 
     @property
     def debugout(self):
