@@ -13,6 +13,8 @@
 //            per block is written at the end and reduced (fixed order) by conv_wgrad_finish.
 // HBM traffic: x, g read once, dx written once.  Semantics: theanet/layer/convpool.py:54-72,
 // :106-112; Theano MaxPoolGrad tie rule.
+#include <cstdlib>
+
 #include "common.h"
 
 int tn_conv_wgrad_finish(tn_ctx* ctx, const float* partial, const float* dbpartial, float* dW,
@@ -39,6 +41,7 @@ struct CbGeom {
     int N, H, Wd, K, pad, Ho, Wo, Hp, Wp, G;
     int Hx, Wx;      // x tile:  Hx = Ho+F-1 rows of Wx floats
     int Hh, Wh;      // dz tile: Hh = Ho+2(F-1) rows of Wh floats
+    int dbg;         // ablation (TN_CB_DBG): 1 skip phase 1, 2 skip phase 2, 4 skip phase 3, 8 skip staging
 };
 
 #define CB_NT 1024     // 16 waves per block: four per SIMD hide the LDS latency of the phases
@@ -92,7 +95,7 @@ __global__ __launch_bounds__(CB_NT) void convblock_bwd_lds(
         const int gcnt = min(G, q.N - n0);
         __syncthreads();                       // previous group's readers are done
         // ---- stage x (zero padded) ------------------------------------------------------
-        for (int t = tid; t < gcnt * C * xplane; t += CB_NT) {
+        for (int t = tid; t < ((q.dbg & 8) ? 0 : gcnt * C * xplane); t += CB_NT) {
             const int gc = t / xplane, r = t - gc * xplane;
             const int yy = r / q.Wx - q.pad, xx = r % q.Wx - q.pad;     // cols beyond the data are zero
             const bool in = ((unsigned)yy < (unsigned)q.H) && ((unsigned)xx < (unsigned)q.Wd);
@@ -103,7 +106,7 @@ __global__ __launch_bounds__(CB_NT) void convblock_bwd_lds(
         __syncthreads();
         // ---- phase 1: dz into the haloed LDS tile ------------------------------------------
         const int nwin = gcnt * HpWp;
-        for (int it = tid; it < nwin * KG; it += CB_NT) {
+        for (int it = tid; it < ((q.dbg & 1) ? 0 : nwin * KG); it += CB_NT) {
             const int kg = it / nwin, w = it - kg * nwin;     // window fastest: a wave shares kg
             const int gi = w / HpWp, wq = w - gi * HpWp;
             const int pi = wq / q.Wp, pj = wq - pi * q.Wp;
@@ -172,16 +175,18 @@ __global__ __launch_bounds__(CB_NT) void convblock_bwd_lds(
                     for (int di = 0; di < 2; ++di)
 #pragma unroll
                         for (int dj = 0; dj < 2; ++dj) {
+                            // invalid positions fall on the (zero) halo: storing their 0 is harmless,
+                            // and the unconditional store keeps the phase branch-free
                             const float d = (vld[di][dj] && z[kk][di][dj] == m)
                                                 ? gk[kk] * cb_actg<ACT>(z[kk][di][dj], act, prm) : 0.f;
-                            if (vld[di][dj]) dzk[di * q.Wh + dj] = d;
+                            dzk[di * q.Wh + dj] = d;
                         }
                 }
             }
         }
         __syncthreads();
         // ---- phase 2: dgrad --------------------------------------------------------------
-        if (dx) {
+        if (dx && !(q.dbg & 2)) {
             for (int t = tid; t < gcnt * HW; t += CB_NT) {
                 const int gi = t / HW, p = t - gi * HW;
                 const int y = p / q.Wd, xq = p - y * q.Wd;
@@ -211,7 +216,7 @@ __global__ __launch_bounds__(CB_NT) void convblock_bwd_lds(
             }
         }
         // ---- phase 3: wgrad (registers persist over the groups) ------------------------------
-        if (wlive && wg < gcnt) {
+        if (wlive && wg < gcnt && !(q.dbg & 4)) {
             {
                 const int gi = wg;
                 const float* dzp = sdz + ((size_t)gi * K + wk) * hplane + (F - 1) * q.Wh + CB_LP;
@@ -230,8 +235,8 @@ __global__ __launch_bounds__(CB_NT) void convblock_bwd_lds(
                         for (int e = 0; e < 4; ++e) {
 #pragma unroll
                             for (int v = 0; v < F; ++v) wacc[v] = fmaf(dd[e], xs[e + v], wacc[v]);
-                            bacc += dd[e];
                         }
+                        if (wc == 0 && wu == 0) bacc += (dd[0] + dd[1]) + (dd[2] + dd[3]);
                         xa = xb;
                     }
                 }
@@ -310,6 +315,14 @@ extern "C" int tn_convblock_bwd(tn_ctx* ctx, const float* x, const float* W, con
     CbGeom q;
     q.N = N; q.H = H; q.Wd = Wd; q.K = K; q.pad = pad_lo; q.Ho = Ho; q.Wo = Wo; q.Hp = Hp; q.Wp = Wp;
     q.G = G;
+    {
+        static int dbg = -1;
+        if (dbg < 0) {
+            const char* e = getenv("TN_CB_DBG");
+            dbg = e ? atoi(e) : 0;
+        }
+        q.dbg = dbg;
+    }
     q.Hx = Ho + f - 1; q.Hh = Ho + 2 * f - 2;
     q.Wh = 4 * ((Wo + 3) / 4) + 4;
     q.Wx = q.Wh + 4;      // x rows 4 floats wider: de-phases the (c, u) b128 reads of phase 3
