@@ -20,6 +20,12 @@
 int tn_conv_wgrad_finish(tn_ctx* ctx, const float* partial, const float* dbpartial, float* dW,
                          float* db, int nblk, int K, int C, int f);
 int tn_ensure_scratch(tn_ctx* ctx, size_t bytes);
+// convblock_mfma.hip: matrix-core variant of the same backward
+int tn_convblock_mfma_supported(int C, int K, int f, int stride, int p, int H, int Wd, int pad_lo,
+                                int Ho, int Wo, int Hp, int Wp);
+int tn_convblock_mfma_bwd(tn_ctx* ctx, const float* x, const float* W, const float* b, const float* g,
+                          float* dx, float* dW, float* db, int N, int C, int H, int Wd, int K,
+                          int pad_lo, int Ho, int Wo, int Hp, int Wp, int act, float act_param);
 
 template <int ACT>
 __device__ __forceinline__ float cb_act(float z, int act, float prm) {
@@ -312,6 +318,9 @@ extern "C" int tn_convblock_bwd(tn_ctx* ctx, const float* x, const float* W, con
                                 int act, float act_param) {
     const int G = tn_convblock_supported(C, K, f, 1, p, Ho, Wo);
     TN_REQUIRE(G > 0, "tn_convblock_bwd: unsupported C=%d K=%d f=%d p=%d", C, K, f, p);
+    if (tn_convblock_mfma_supported(C, K, f, 1, p, H, Wd, pad_lo, Ho, Wo, Hp, Wp))
+        return tn_convblock_mfma_bwd(ctx, x, W, b, g, dx, dW, db, N, C, H, Wd, K, pad_lo, Ho, Wo, Hp, Wp,
+                                     act, act_param);
     CbGeom q;
     q.N = N; q.H = H; q.Wd = Wd; q.K = K; q.pad = pad_lo; q.Ho = Ho; q.Wo = Wo; q.Hp = Hp; q.Wp = Wp;
     q.G = G;

@@ -1,0 +1,440 @@
+// Matrix-core backward of a conv(3x3) + act + 2x2-max-pool block with few channels and a few
+// dozen filters (mnist.prms conv2: 20 x 4 x 3 x 3).  Same contract as convblock.hip; this is the
+// path tn_convblock_bwd takes when the shape fits.
+//
+// One 64-lane WAVE owns one image at a time and never synchronises with other waves inside
+// the image loop: its x tile, dz tile and dx tile live in a private LDS slice, ordered only by
+// the in-order LDS pipe.  All three products run on v_mfma_f32_16x16x4_f32 (exact f32):
+//
+//   conv recompute  z[pix][k]     = sum_ckk patch[pix][ckk] * Wf[k][ckk]       M=pix  N=k    red=ckk
+//   wgrad           dWf[k][ckk]  += sum_pix dz[k][pix] * patch[pix][ckk]       M=k    N=ckk  red=pix
+//   dgrad           T[ckk][x']    = sum_k  Wf[k][ckk] * dz[k][y][x']           M=ckk  N=x'   red=k
+//                   dx[c][y+a][x'+b] += T[(c,a,b)][x']: b by DPP lane shifts, a by a rolling row sum
+//
+// ckk = (c, a, b) indexes the FLIPPED filter Wf[k][c][a][b] = W[k][c][2-a][2-b], so that
+// z[k][y][x] = sum Wf * x[c][y+a][x+b] (true convolution, theanet/layer/convpool.py:54-72).
+// Pixels are enumerated pooling window by pooling window (4 per window): the conv result of a
+// 16-pixel tile leaves the matrix core with one window's 4 outputs in the 4 accumulator
+// registers of a lane, so act / max / tie mask (Theano MaxPoolGrad: every tie gets the
+// gradient) are in-lane, and the same registers are the A operand of the wgrad product -- dz
+// goes to LDS only for the dgrad product, never to HBM.  The filter operands of all three
+// products stay in registers for the whole kernel; the next image's x and g are prefetched
+// into registers while the current one is computed.  HBM traffic: x, g read once, dx written once.
+#include <cstdlib>
+
+#include "common.h"
+
+int tn_conv_wgrad_finish(tn_ctx* ctx, const float* partial, const float* dbpartial, float* dW,
+                         float* db, int nblk, int K, int C, int f);
+int tn_ensure_scratch(tn_ctx* ctx, size_t bytes);
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define CM_XR 12        // prefetch registers per lane for x (C*H*W <= 64*CM_XR) and for g (K*Hp*Wp)
+
+struct CmGeom {
+    int N, H, Wd, K, pad, Ho, Wo, Hp, Wp;
+    int Wx, xplane;      // x / dx tile: C planes of (Ho+3) rows of Wx = Wo+3 floats (one spare row and col)
+    int xf;              // floats per x tile incl. the two constant cells (multiple of 4)
+    int PT;              // 16-pixel tiles per image = ceil(Hp*Wp / 4)
+    int npixp;           // dz row stride (floats), npixp/4 odd
+    int dzf;             // floats of the dz tile
+    int tabf;            // floats of the per-block tables
+    int wavef;           // floats of one wave's slice
+    int dbg;             // ablation (TN_CM_DBG): 1 no wgrad, 2 no dgrad, 4 no scatter, 8 no conv product
+};
+
+__device__ __forceinline__ void cm_wave_sync() {
+    // LDS operations of one wave complete in order; only the compiler has to be told
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ f32x4 cm_mfma(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// value of the lane N places to the left inside the 16-lane DPP row, 0 beyond its start
+template <int N>
+__device__ __forceinline__ float cm_shr(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x110 + N, 0xf, 0xf, false));
+}
+
+template <int ACT>
+__device__ __forceinline__ float cm_act(float z, int act, float prm) {
+    if (ACT == TN_ACT_LEAKY) return fmaxf(0.f, z) + fminf(0.f, z) * prm;
+    return tn_act_fwd(z, act, prm);
+}
+template <int ACT>
+__device__ __forceinline__ float cm_actg(float a, int act, float prm) {
+    if (ACT == TN_ACT_LEAKY) return a > 0.f ? 1.f : (a < 0.f ? prm : (prm > 0.f ? 1.f + prm : 0.f));
+    return tn_act_grad_from_out(a, act, prm);
+}
+
+template <int C, int NKT, int ACT>
+__global__ __launch_bounds__(256, 2) void convblock_bwd_mfma(
+    const float* __restrict__ x, const float* __restrict__ W, const float* __restrict__ b,
+    const float* __restrict__ g, float* __restrict__ dx, float* __restrict__ partial,
+    float* __restrict__ dbpartial, CmGeom q, int act, float prm) {
+    constexpr int F = 3, FF = 9, CKK = C * FF;
+    constexpr int KS1 = (CKK + 3) / 4;        // reduction steps of the conv product
+    constexpr int NT = (CKK + 16) / 16;       // 16-wide ckk tiles incl. the bias column ckk == CKK
+    constexpr int KS2 = NKT * 4;              // max reduction steps of the dgrad product
+    constexpr int NTD = 3;                    // dgrad product rows: (c = row>>2 & 3, ab = 4*tile + (row & 3))
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lo = lane & 15, qd = lane >> 4;
+    const int K = q.K, HW = q.H * q.Wd, CHW = C * HW, HpWp = q.Hp * q.Wp, KHW = K * HpWp;
+    const int ks2 = (K + 3) >> 2;
+
+    int* wtab = reinterpret_cast<int*>(sm);           // [4*PT] window -> (tile offset << 4) | valid bits
+    float* wbase = sm + q.tabf + wv * q.wavef;
+    float* sx = wbase;                                // x tile (zero padded)
+    float* sdx = sx + q.xf;                           // dx tile; doubles as the g tile during phase 1
+    float* sg = sdx;
+    float* sdz = sdx + q.xf;                          // [4*ks2][npixp], pixels in window order
+    const int ZERO = q.xf - 4, ONE = q.xf - 3;        // constant cells behind the x tile
+
+    for (int i = threadIdx.x; i < 4 * q.PT; i += 256) {
+        int e = 0;
+        if (i < HpWp) {
+            const int wy = i / q.Wp, wx = i - wy * q.Wp;
+            const bool vx = 2 * wx + 1 < q.Wo, vy = 2 * wy + 1 < q.Ho;
+            e = ((2 * wy * q.Wx + 2 * wx) << 4) | 1 | (vx ? 2 : 0) | (vy ? 4 : 0) | (vx && vy ? 8 : 0);
+        }
+        wtab[i] = e;
+    }
+    for (int i = lane; i < q.xf; i += 64) sx[i] = 0.f;       // pads stay zero for the whole kernel
+    for (int i = lane; i < q.dzf; i += 64) sdz[i] = 0.f;     // rows K..4*ks2-1 and the row pads stay zero
+    __syncthreads();
+    if (lane == 0) sx[ONE] = 1.f;
+
+    // ---- loop-invariant operands ------------------------------------------------------------
+    auto ckk_off = [&](int ckk) {
+        const int c = ckk / FF, ab = ckk - c * FF, a = ab / F, bb = ab - a * F;
+        return c * q.xplane + a * q.Wx + bb;
+    };
+    auto wf = [&](int k, int c, int ab) -> float {       // flipped filter, 0 outside
+        const bool ok = k < K && c < C && ab < FF;
+        const float v = W[((size_t)min(k, K - 1) * C + min(c, C - 1)) * FF + (FF - 1 - min(ab, FF - 1))];
+        return ok ? v : 0.f;
+    };
+    float Bw1[NKT][KS1];       // conv product B operand: Wf[k = 16kt+lo][ckk = 4s+qd]
+    int off1[KS1];             // conv product A operand: tile offset of ckk = 4s+qd
+#pragma unroll
+    for (int s = 0; s < KS1; ++s) {
+        const int ckk = 4 * s + qd;
+        off1[s] = ckk < CKK ? ckk_off(ckk) : 0;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) Bw1[kt][s] = wf(16 * kt + lo, ckk < CKK ? ckk / FF : C, ckk % FF);
+    }
+    int off3[NT], msk3[NT];    // wgrad B operand: ckk = 16nt+lo (bias column reads the 1.0 cell)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int ckk = 16 * nt + lo;
+        off3[nt] = ckk < CKK ? ckk_off(ckk) : (ckk == CKK ? ONE : ZERO);
+        msk3[nt] = ckk < CKK ? -1 : 0;
+    }
+    float Aw2[NTD][KS2];       // dgrad product A operand: Wf[k = 4s+qd][c = lo>>2][ab = 4mt + (lo&3)]
+#pragma unroll
+    for (int mt = 0; mt < NTD; ++mt)
+#pragma unroll
+        for (int s = 0; s < KS2; ++s) Aw2[mt][s] = wf(4 * s + qd, lo >> 2, 4 * mt + (lo & 3));
+    float bk[NKT];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) bk[kt] = b[min(16 * kt + lo, K - 1)];
+    int tabr[CM_XR];           // image element lane+64j -> offset in the x / dx tile
+#pragma unroll
+    for (int j = 0; j < CM_XR; ++j) {
+        const int i = min(lane + 64 * j, CHW - 1);
+        const int c = i / HW, r = i - c * HW, y = r / q.Wd, xx = r - y * q.Wd;
+        tabr[j] = c * q.xplane + (y + q.pad) * q.Wx + xx + q.pad;
+    }
+    // Pin the operands: they are complete here, so the tile loops never wait on the vector-memory
+    // counter and the image prefetch below stays in flight across them.
+    __builtin_amdgcn_s_waitcnt(0x0f70);     // vmcnt(0)
+#pragma unroll
+    for (int s = 0; s < KS1; ++s)
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) asm volatile("" : "+v"(Bw1[kt][s]));
+#pragma unroll
+    for (int mt = 0; mt < NTD; ++mt)
+#pragma unroll
+        for (int s = 0; s < KS2; ++s) asm volatile("" : "+v"(Aw2[mt][s]));
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) asm volatile("" : "+v"(bk[kt]));
+
+    f32x4 accW[NKT][NT];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) accW[kt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int gw = blockIdx.x * 4 + wv, nw = gridDim.x * 4;
+    float xr[CM_XR], gr[CM_XR];
+#define CM_PREFETCH(N_)                                                                     \
+    {                                                                                       \
+        const float* xp_ = x + (size_t)(N_) * CHW;                                          \
+        const float* gp_ = g + (size_t)(N_) * KHW;                                          \
+        _Pragma("unroll") for (int j = 0; j < CM_XR; ++j) {                                 \
+            xr[j] = xp_[min(lane + 64 * j, CHW - 1)];                                       \
+            gr[j] = gp_[min(lane + 64 * j, KHW - 1)];                                       \
+        }                                                                                   \
+    }
+    int n = gw;
+    if (n < q.N) CM_PREFETCH(n);
+    const int dyo = ((lo >> 1) & 1) * q.Wx + (lo & 1);      // sub-pixel offset of conv-product row lo
+    const float tie = prm > 0.f ? 1.f + prm : 0.f;          // leaky slope at an exact 0
+    // dgrad product column lo = tile column x': the dz pixel (y, x') in window order, or the zero pad
+    const int dcol = lo < q.Wo ? 4 * (lo >> 1) + (lo & 1) : 16 * q.PT;
+    const int dmsk = lo < q.Wo ? -1 : 0;
+    for (; n < q.N; n += nw) {
+#pragma unroll
+        for (int j = 0; j < CM_XR; ++j) {
+            const int i = lane + 64 * j;
+            if (i < CHW) sx[tabr[j]] = xr[j];
+            if (i < KHW) sg[i] = gr[j];
+        }
+        if (n + nw < q.N) CM_PREFETCH(n + nw);
+        cm_wave_sync();
+        // ---- conv recompute -> dz (registers + LDS) -> wgrad ---------------------------------
+        float av[KS1];
+        {
+            const int poff = (wtab[lo >> 2] >> 4) + dyo;
+#pragma unroll
+            for (int s = 0; s < KS1; ++s) av[s] = sx[poff + off1[s]];
+        }
+#pragma unroll 1
+        for (int t = 0; t < q.PT; ++t) {
+            f32x4 z[NKT];
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt) z[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (!(q.dbg & 8)) {
+#pragma unroll
+            for (int s = 0; s < KS1; ++s)
+#pragma unroll
+                for (int kt = 0; kt < NKT; ++kt) z[kt] = cm_mfma(av[s], Bw1[kt][s], z[kt]);
+            }
+            // operands of the next tile's conv product and of this tile's wgrad product: issued
+            // now, they arrive while the matrix core and the epilogue below are busy
+            {
+                const int tn = min(t + 1, q.PT - 1);
+                const int poff = (wtab[4 * tn + (lo >> 2)] >> 4) + dyo;
+#pragma unroll
+                for (int s = 0; s < KS1; ++s) av[s] = sx[poff + off1[s]];
+            }
+            // lane (lo = filter, qd = window 4t+qd): the 4 registers are the window's 4 outputs
+            const int wi = 4 * t + qd;
+            const int e2 = wtab[wi];
+            const int woff = e2 >> 4;
+            float bv[4][NT];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int pw = woff + (r >> 1) * q.Wx + (r & 1);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) bv[r][nt] = sx[off3[nt] + (pw & msk3[nt])];
+            }
+            float dzv[NKT][4];
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt) {
+                const int k = 16 * kt + lo;
+                float gv = sg[min(k, K - 1) * HpWp + min(wi, HpWp - 1)];
+                gv = k < K ? gv : 0.f;
+                float a[4];
+                float m = -INFINITY;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    a[r] = cm_act<ACT>(z[kt][r] + bk[kt], act, prm);
+                    m = (e2 >> r & 1) ? fmaxf(m, a[r]) : m;
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float gp;
+                    if (ACT == TN_ACT_LEAKY) {
+                        gp = a[r] < 0.f ? prm : tie;
+                        gp = a[r] > 0.f ? 1.f : gp;
+                    } else {
+                        gp = tn_act_grad_from_out(a[r], act, prm);
+                    }
+                    const float sel = ((e2 >> r & 1) && a[r] == m) ? gv : 0.f;
+                    dzv[kt][r] = sel * gp;
+                }
+                if (k < K)
+                    *reinterpret_cast<float4*>(sdz + k * q.npixp + 16 * t + 4 * qd) =
+                        make_float4(dzv[kt][0], dzv[kt][1], dzv[kt][2], dzv[kt][3]);
+            }
+            if (!(q.dbg & 1)) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        accW[kt][nt] = cm_mfma(dzv[kt][r], bv[r][nt], accW[kt][nt]);
+            }
+        }
+        if (dx && !(q.dbg & 2)) {
+            // ---- dgrad: one dz row y per step.  T[(c,a,b)][x'] = sum_k Wf[k][c][a][b] dz[k][y][x']
+            // on the matrix core; lane (x', c) then owns all 9 taps of its channel: the b shifts
+            // are DPP lane shifts inside the 16-lane row, the a shifts a rolling 3-row sum, so every
+            // dx row is produced complete, in registers, and stored once.
+            cm_wave_sync();
+            float R1 = 0.f, R2 = 0.f;
+            float* dxo = sdx + qd * q.xplane + lo;
+            const bool dlive = (qd < C) && (lo < q.Wo + 2);
+#pragma unroll 1
+            for (int y = 0; y < q.Ho; ++y) {
+                const int prow = 4 * (y >> 1) * q.Wp + 2 * (y & 1);
+                const float* dzp = sdz + qd * q.npixp + dcol + (prow & dmsk);
+                float bvv[KS2];
+#pragma unroll
+                for (int s = 0; s < KS2; ++s) bvv[s] = dzp[4 * min(s, ks2 - 1) * q.npixp];
+                f32x4 T[NTD];
+#pragma unroll
+                for (int mt = 0; mt < NTD; ++mt) T[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < KS2; ++s) {
+                    if (s < ks2) {
+#pragma unroll
+                        for (int mt = 0; mt < NTD; ++mt) T[mt] = cm_mfma(Aw2[mt][s], bvv[s], T[mt]);
+                    }
+                }
+                // T[mt][r] <-> tap ab = 4mt + r = 3a + b
+                const float S0 = T[0][0] + cm_shr<1>(T[0][1]) + cm_shr<2>(T[0][2]);
+                const float S1 = T[0][3] + cm_shr<1>(T[1][0]) + cm_shr<2>(T[1][1]);
+                const float S2 = T[1][2] + cm_shr<1>(T[1][3]) + cm_shr<2>(T[2][0]);
+                const float out = S0 + R1;
+                R1 = S1 + R2;
+                R2 = S2;
+                if (dlive) dxo[y * q.Wx] = out;
+            }
+            if (dlive) {
+                dxo[q.Ho * q.Wx] = R1;
+                dxo[(q.Ho + 1) * q.Wx] = R2;
+            }
+            cm_wave_sync();
+            float* dxp = dx + (size_t)n * CHW;
+#pragma unroll
+            for (int j = 0; j < CM_XR; ++j) {
+                const int i = lane + 64 * j;
+                if (i < CHW) dxp[i] = sdx[tabr[j]];
+            }
+        }
+        cm_wave_sync();
+    }
+#undef CM_PREFETCH
+    // ---- one partial slab per block: sum the 4 waves' accumulators in wave order ---------------
+    __syncthreads();
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) wbase[((kt * NT + nt) * 4 + r) * 64 + lane] = accW[kt][nt][r];
+    __syncthreads();
+    for (int e = threadIdx.x; e < K * (CKK + 1); e += 256) {
+        const int k = e / (CKK + 1), ckk = e - k * (CKK + 1);
+        // accumulator (kt, nt): rows = filters 4*qd + r, cols = ckk-in-tile
+        const int idx = (((k >> 4) * NT + (ckk >> 4)) * 4 + (k & 3)) * 64 + ((k & 15) >> 2) * 16 + (ckk & 15);
+        const float* src = sm + q.tabf + idx;
+        const float s = ((src[0] + src[q.wavef]) + src[2 * q.wavef]) + src[3 * q.wavef];
+        if (ckk < CKK)
+            partial[(size_t)blockIdx.x * K * CKK + k * CKK + ckk] = s;
+        else
+            dbpartial[(size_t)blockIdx.x * K + k] = s;
+    }
+}
+
+static void cm_geometry(CmGeom& q, int C, int K) {
+    q.Wx = q.Wo + 3;
+    q.xplane = (q.Ho + 3) * q.Wx;
+    q.xf = ((C * q.xplane + 3) & ~3) + 4;
+    q.PT = (q.Hp * q.Wp + 3) / 4;
+    q.npixp = 16 * q.PT + 4;                    // npixp/4 odd: filters land on distinct b128 banks
+    q.dzf = 4 * ((K + 3) / 4) * q.npixp;
+    q.tabf = (4 * q.PT + 3) & ~3;
+    const int red = 2 * ((C * 9 + 16) / 16) * 4 * 64;     // final accumulator exchange
+    q.wavef = 2 * q.xf + q.dzf;
+    if (q.wavef < red) q.wavef = red;
+}
+
+static size_t cm_lds_bytes(const CmGeom& q) { return ((size_t)q.tabf + 4 * (size_t)q.wavef) * sizeof(float); }
+
+// 1 if the matrix-core backward applies to this block shape
+int tn_convblock_mfma_supported(int C, int K, int f, int stride, int p, int H, int Wd, int pad_lo,
+                                int Ho, int Wo, int Hp, int Wp) {
+    static int enabled = -1;
+    if (enabled < 0) {
+        const char* e = getenv("TN_CB_MFMA");
+        enabled = e ? atoi(e) : 1;
+    }
+    if (!enabled) return 0;
+    if (f != 3 || stride != 1 || p != 2 || C < 1 || C > 4 || K < 1 || K > 32) return 0;
+    if (C * H * Wd > 64 * CM_XR || K * Hp * Wp > 64 * CM_XR) return 0;
+    if (H + 2 * pad_lo > Ho + 2 || Wd + 2 * pad_lo > Wo + 2) return 0;     // the padded image is the tile
+    if (Wo + 2 > 16) return 0;                   // a dz row (+ its 2-pixel spill) is one 16-lane DPP row
+    if (Hp != (Ho + 1) / 2 || Wp != (Wo + 1) / 2) return 0;
+    CmGeom q;
+    q.H = H; q.Wd = Wd; q.Ho = Ho; q.Wo = Wo; q.Hp = Hp; q.Wp = Wp; q.dbg = 0;
+    cm_geometry(q, C, K);
+    if (K * Hp * Wp > q.xf) return 0;            // the g tile borrows the dx tile
+    return cm_lds_bytes(q) <= 78 * 1024;         // two blocks per CU
+}
+
+template <int C, int NKT>
+static int launch_cm(tn_ctx* ctx, const float* x, const float* W, const float* b, const float* g,
+                     float* dx, float* dW, float* db, CmGeom q, int act, float prm) {
+    const size_t lds = cm_lds_bytes(q);
+    int nblk = 2 * ctx->num_cus;
+    if (nblk > cdiv(q.N, 4)) nblk = cdiv(q.N, 4);
+    const size_t KCFF = (size_t)q.K * C * 9;
+    int rc = tn_ensure_scratch(ctx, (size_t)nblk * (KCFF + q.K) * sizeof(float));
+    if (rc) return rc;
+    float* partial = ctx->scratch;
+    float* dbpartial = ctx->scratch + (size_t)nblk * KCFF;
+    if (act == TN_ACT_LEAKY) {
+        auto kern = convblock_bwd_mfma<C, NKT, TN_ACT_LEAKY>;
+        static size_t set_for = 0;      // the attribute call is not a stream op: do it once per size
+        if (set_for < lds) {
+            TN_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            set_for = lds;
+        }
+        kern<<<nblk, 256, lds, ctx->stream>>>(x, W, b, g, dx, partial, dbpartial, q, act, prm);
+    } else {
+        auto kern = convblock_bwd_mfma<C, NKT, -1>;
+        static size_t set_for = 0;
+        if (set_for < lds) {
+            TN_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            set_for = lds;
+        }
+        kern<<<nblk, 256, lds, ctx->stream>>>(x, W, b, g, dx, partial, dbpartial, q, act, prm);
+    }
+    TN_LAUNCH_CHECK();
+    return tn_conv_wgrad_finish(ctx, partial, dbpartial, dW, db, nblk, q.K, C, 3);
+}
+
+int tn_convblock_mfma_bwd(tn_ctx* ctx, const float* x, const float* W, const float* b, const float* g,
+                          float* dx, float* dW, float* db, int N, int C, int H, int Wd, int K,
+                          int pad_lo, int Ho, int Wo, int Hp, int Wp, int act, float act_param) {
+    CmGeom q;
+    q.N = N; q.H = H; q.Wd = Wd; q.K = K; q.pad = pad_lo; q.Ho = Ho; q.Wo = Wo; q.Hp = Hp; q.Wp = Wp;
+    cm_geometry(q, C, K);
+    {
+        static int dbg = -1;
+        if (dbg < 0) {
+            const char* e = getenv("TN_CM_DBG");
+            dbg = e ? atoi(e) : 0;
+        }
+        q.dbg = dbg;
+    }
+#define CM_GO(C_)                                                                                  \
+    return K > 16 ? launch_cm<C_, 2>(ctx, x, W, b, g, dx, dW, db, q, act, act_param)               \
+                  : launch_cm<C_, 1>(ctx, x, W, b, g, dx, dW, db, q, act, act_param)
+    switch (C) {
+        case 1: CM_GO(1);
+        case 2: CM_GO(2);
+        case 3: CM_GO(3);
+        default: CM_GO(4);
+    }
+#undef CM_GO
+}

@@ -160,11 +160,14 @@ __device__ __forceinline__ bool gemm_decode(const GemmArgs& g, int& mt, int& nt,
 // branch-free, so hipcc emits counted vmcnt waits and the two-tile look-ahead really overlaps:
 //   registers R0/R1 hold tiles t+1 / t+2, LDS buffers 0/1 hold tiles t / t+1.
 // A K-tail (K % 16 != 0, e.g. dgrad with n_out = 500) is one guarded tile after the loop.
-template <bool AKC, bool BKC, bool BSUM, int WM, int WN>
+template <bool AKC, bool BKC, bool BSUM, int WM, int WN, int BKT>
 __global__ __launch_bounds__(256) void gemm_f32_fast(GemmArgs g) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
-    __shared__ __attribute__((aligned(16))) float As[2][BM][LDK];
-    __shared__ __attribute__((aligned(16))) float Bs[2][BN][LDK];
+    constexpr int NP = BKT / 16;        // 16-wide k passes per tile
+    constexpr int KH = BKT / 2;         // k-values per lane and tile
+    constexpr int LDT = BKT + 4;        // LDS row stride (20 or 36 floats: odd multiple of 16 B)
+    __shared__ __attribute__((aligned(16))) float As[2][BM][LDT];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BN][LDT];
     int mt, nt, z;
     if (!gemm_decode(g, mt, nt, z)) return;
 
@@ -174,8 +177,8 @@ __global__ __launch_bounds__(256) void gemm_f32_fast(GemmArgs g) {
     const int m0 = mt * BM, n0 = nt * BN;
     const int kbeg = z * g.kchunk;
     const int kend = min(g.K, kbeg + g.kchunk);
-    const int nk = (kend - kbeg) / BK;               // full tiles
-    const bool tail = (kend - kbeg) % BK != 0;
+    const int nk = (kend - kbeg) / BKT;              // full tiles
+    const bool tail = (kend - kbeg) % BKT != 0;
 
     const int a_r = AKC ? (t >> 2) : 4 * (t >> 4);
     const int a_k = AKC ? 4 * (t & 3) : (t & 15);
@@ -195,8 +198,10 @@ __global__ __launch_bounds__(256) void gemm_f32_fast(GemmArgs g) {
         const int r = min(n0 + 64 * j + b_r, BKC ? g.N - 1 : g.N - 4);
         pB[j] = BKC ? g.B + (size_t)r * g.ldb + kbeg + b_k : g.B + (size_t)(kbeg + b_k) * g.ldb + r;
     }
-    const size_t stepA = AKC ? BK : (size_t)BK * g.lda;
-    const size_t stepB = BKC ? BK : (size_t)BK * g.ldb;
+    const size_t stepA = AKC ? BKT : (size_t)BKT * g.lda;
+    const size_t stepB = BKC ? BKT : (size_t)BKT * g.ldb;
+    const size_t passA = AKC ? 16 : (size_t)16 * g.lda;      // offset of the second 16-wide k pass
+    const size_t passB = BKC ? 16 : (size_t)16 * g.ldb;
 
     f32x16 acc[WM][WN];
 #pragma unroll
@@ -209,105 +214,132 @@ __global__ __launch_bounds__(256) void gemm_f32_fast(GemmArgs g) {
 #pragma unroll
     for (int j = 0; j < WN; ++j) csum[j] = make_float4(0.f, 0.f, 0.f, 0.f);
 
-    float4 a0[WM], b0[WN], a1[WM], b1[WN];          // staging sets R0 / R1
+    float4 a0[WM][NP], b0[WN][NP], a1[WM][NP], b1[WN][NP];          // staging sets R0 / R1
     const int last = max(nk - 1, 0);
 #define GLOAD(RA, RB, TILE)                                                                     \
     {                                                                                           \
         const int tl_ = min((TILE), last);                                                      \
         _Pragma("unroll") for (int i = 0; i < WM; ++i)                                          \
-            RA[i] = *reinterpret_cast<const float4*>(pA[i] + tl_ * stepA);                      \
+            _Pragma("unroll") for (int p = 0; p < NP; ++p)                                      \
+                RA[i][p] = *reinterpret_cast<const float4*>(pA[i] + tl_ * stepA + p * passA);   \
         _Pragma("unroll") for (int j = 0; j < WN; ++j)                                          \
-            RB[j] = *reinterpret_cast<const float4*>(pB[j] + tl_ * stepB);                      \
+            _Pragma("unroll") for (int p = 0; p < NP; ++p)                                      \
+                RB[j][p] = *reinterpret_cast<const float4*>(pB[j] + tl_ * stepB + p * passB);   \
     }
 #define LSTORE(RA, RB, BUF)                                                                     \
     {                                                                                           \
-        _Pragma("unroll") for (int i = 0; i < WM; ++i) {                                        \
-            if (AKC) {                                                                          \
-                *reinterpret_cast<float4*>(&As[BUF][64 * i + a_r][a_k]) = RA[i];                \
-            } else {                                                                            \
-                As[BUF][64 * i + a_r + 0][a_k] = RA[i].x;                                       \
-                As[BUF][64 * i + a_r + 1][a_k] = RA[i].y;                                       \
-                As[BUF][64 * i + a_r + 2][a_k] = RA[i].z;                                       \
-                As[BUF][64 * i + a_r + 3][a_k] = RA[i].w;                                       \
+        _Pragma("unroll") for (int i = 0; i < WM; ++i)                                          \
+            _Pragma("unroll") for (int p = 0; p < NP; ++p) {                                    \
+                if (AKC) {                                                                      \
+                    *reinterpret_cast<float4*>(&As[BUF][64 * i + a_r][16 * p + a_k]) = RA[i][p]; \
+                } else {                                                                        \
+                    As[BUF][64 * i + a_r + 0][16 * p + a_k] = RA[i][p].x;                       \
+                    As[BUF][64 * i + a_r + 1][16 * p + a_k] = RA[i][p].y;                       \
+                    As[BUF][64 * i + a_r + 2][16 * p + a_k] = RA[i][p].z;                       \
+                    As[BUF][64 * i + a_r + 3][16 * p + a_k] = RA[i][p].w;                       \
+                }                                                                               \
             }                                                                                   \
-        }                                                                                       \
-        _Pragma("unroll") for (int j = 0; j < WN; ++j) {                                        \
-            if (BKC) {                                                                          \
-                *reinterpret_cast<float4*>(&Bs[BUF][64 * j + b_r][b_k]) = RB[j];                \
-            } else {                                                                            \
-                Bs[BUF][64 * j + b_r + 0][b_k] = RB[j].x;                                       \
-                Bs[BUF][64 * j + b_r + 1][b_k] = RB[j].y;                                       \
-                Bs[BUF][64 * j + b_r + 2][b_k] = RB[j].z;                                       \
-                Bs[BUF][64 * j + b_r + 3][b_k] = RB[j].w;                                       \
+        _Pragma("unroll") for (int j = 0; j < WN; ++j)                                          \
+            _Pragma("unroll") for (int p = 0; p < NP; ++p) {                                    \
+                if (BKC) {                                                                      \
+                    *reinterpret_cast<float4*>(&Bs[BUF][64 * j + b_r][16 * p + b_k]) = RB[j][p]; \
+                } else {                                                                        \
+                    Bs[BUF][64 * j + b_r + 0][16 * p + b_k] = RB[j][p].x;                       \
+                    Bs[BUF][64 * j + b_r + 1][16 * p + b_k] = RB[j][p].y;                       \
+                    Bs[BUF][64 * j + b_r + 2][16 * p + b_k] = RB[j][p].z;                       \
+                    Bs[BUF][64 * j + b_r + 3][16 * p + b_k] = RB[j][p].w;                       \
+                }                                                                               \
             }                                                                                   \
-        }                                                                                       \
     }
 #define CSUM(RB)                                                                                \
     if (BSUM && !BKC) {                                                                         \
-        _Pragma("unroll") for (int j = 0; j < WN; ++j) {                                        \
-            csum[j].x += RB[j].x; csum[j].y += RB[j].y; csum[j].z += RB[j].z; csum[j].w += RB[j].w; \
-        }                                                                                       \
+        _Pragma("unroll") for (int j = 0; j < WN; ++j)                                          \
+            _Pragma("unroll") for (int p = 0; p < NP; ++p) {                                    \
+                csum[j].x += RB[j][p].x; csum[j].y += RB[j][p].y;                               \
+                csum[j].z += RB[j][p].z; csum[j].w += RB[j][p].w;                               \
+            }                                                                                   \
     }
     const int ar = wm * 32 * WM + (lane & 31), br = wn * 32 * WN + (lane & 31), hi = lane >> 5;
-#define COMPUTE(BUF)                                                                            \
+    // fragments of a K-tile: 8 k-values per lane and operand row (two b128 reads each)
+#define LDFRAG(BUF, AV, BV)                                                                     \
     {                                                                                           \
-        float av[WM][8], bv[WN][8];                                                             \
         _Pragma("unroll") for (int i = 0; i < WM; ++i) {                                        \
-            const float4* p_ = reinterpret_cast<const float4*>(&As[BUF][ar + 32 * i][8 * hi]);  \
-            const float4 lo = p_[0], up = p_[1];                                                \
-            av[i][0] = lo.x; av[i][1] = lo.y; av[i][2] = lo.z; av[i][3] = lo.w;                 \
-            av[i][4] = up.x; av[i][5] = up.y; av[i][6] = up.z; av[i][7] = up.w;                 \
+            const float4* p_ = reinterpret_cast<const float4*>(&As[BUF][ar + 32 * i][KH * hi]); \
+            _Pragma("unroll") for (int q_ = 0; q_ < KH / 4; ++q_) {                             \
+                const float4 v_ = p_[q_];                                                       \
+                AV[i][4 * q_] = v_.x; AV[i][4 * q_ + 1] = v_.y;                                 \
+                AV[i][4 * q_ + 2] = v_.z; AV[i][4 * q_ + 3] = v_.w;                             \
+            }                                                                                   \
         }                                                                                       \
         _Pragma("unroll") for (int j = 0; j < WN; ++j) {                                        \
-            const float4* p_ = reinterpret_cast<const float4*>(&Bs[BUF][br + 32 * j][8 * hi]);  \
-            const float4 lo = p_[0], up = p_[1];                                                \
-            bv[j][0] = lo.x; bv[j][1] = lo.y; bv[j][2] = lo.z; bv[j][3] = lo.w;                 \
-            bv[j][4] = up.x; bv[j][5] = up.y; bv[j][6] = up.z; bv[j][7] = up.w;                 \
+            const float4* p_ = reinterpret_cast<const float4*>(&Bs[BUF][br + 32 * j][KH * hi]); \
+            _Pragma("unroll") for (int q_ = 0; q_ < KH / 4; ++q_) {                             \
+                const float4 v_ = p_[q_];                                                       \
+                BV[j][4 * q_] = v_.x; BV[j][4 * q_ + 1] = v_.y;                                 \
+                BV[j][4 * q_ + 2] = v_.z; BV[j][4 * q_ + 3] = v_.w;                             \
+            }                                                                                   \
         }                                                                                       \
-        _Pragma("unroll") for (int s_ = 0; s_ < 8; ++s_)                                        \
+    }
+#define MMA(AV, BV)                                                                             \
+    {                                                                                           \
+        _Pragma("unroll") for (int s_ = 0; s_ < KH; ++s_)                                       \
             _Pragma("unroll") for (int i = 0; i < WM; ++i)                                      \
                 _Pragma("unroll") for (int j = 0; j < WN; ++j)                                  \
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][s_], bv[j][s_], acc[i][j], 0, 0, 0); \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(AV[i][s_], BV[j][s_], acc[i][j], 0, 0, 0); \
     }
+    float avA[WM][KH], bvA[WN][KH], avB[WM][KH], bvB[WN][KH];
 
+    // Software pipeline: the fragments of tile t+1 are read from LDS (asynchronously) BEFORE
+    // the MFMAs of tile t are issued, so the matrix pipe never waits for an LDS round trip:
+    //   store(t+1) ; barrier ; read frags(t+1) ; issue global loads(t+3) ; MFMA(t)
     if (nk > 0) {
         GLOAD(a0, b0, 0);
         GLOAD(a1, b1, 1);
         LSTORE(a0, b0, 0);
         CSUM(b0);
         __syncthreads();
+        LDFRAG(0, avA, bvA);
         GLOAD(a0, b0, 2);
         int tile = 0;
         for (; tile + 1 < nk; tile += 2) {           // branch-free body
-            COMPUTE(0);                               // tile
             LSTORE(a1, b1, 1);                        // tile + 1
             CSUM(b1);
             __syncthreads();
+            LDFRAG(1, avB, bvB);
             GLOAD(a1, b1, tile + 3);
-            COMPUTE(1);                               // tile + 1
+            MMA(avA, bvA);                            // tile
             LSTORE(a0, b0, 0);                        // tile + 2 (a clamped duplicate at the end)
             if (tile + 2 < nk) CSUM(b0);
             __syncthreads();
+            LDFRAG(0, avA, bvA);
             GLOAD(a0, b0, tile + 4);
+            MMA(avB, bvB);                            // tile + 1
         }
-        if (nk & 1) COMPUTE(0);                       // odd count: the last tile sits in LDS[0]
+        if (nk & 1) MMA(avA, bvA);                    // odd count: the last tile is already in avA
     }
     if (tail) {                                       // guarded K-tail
-        const int k0 = kbeg + nk * BK;
+        const int k0 = kbeg + nk * BKT;
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < WM; ++i)
-            a0[i] = AKC ? load_kc(g.A, g.lda, m0 + 64 * i + a_r, g.M, k0 + a_k, kend, g.a_vec)
-                        : load_rc(g.A, g.lda, m0 + 64 * i + a_r, g.M, k0 + a_k, kend, g.a_vec);
+#pragma unroll
+            for (int p = 0; p < NP; ++p)
+                a0[i][p] = AKC ? load_kc(g.A, g.lda, m0 + 64 * i + a_r, g.M, k0 + 16 * p + a_k, kend, g.a_vec)
+                               : load_rc(g.A, g.lda, m0 + 64 * i + a_r, g.M, k0 + 16 * p + a_k, kend, g.a_vec);
 #pragma unroll
         for (int j = 0; j < WN; ++j)
-            b0[j] = BKC ? load_kc(g.B, g.ldb, n0 + 64 * j + b_r, g.N, k0 + b_k, kend, g.b_vec)
-                        : load_rc(g.B, g.ldb, n0 + 64 * j + b_r, g.N, k0 + b_k, kend, g.b_vec);
+#pragma unroll
+            for (int p = 0; p < NP; ++p)
+                b0[j][p] = BKC ? load_kc(g.B, g.ldb, n0 + 64 * j + b_r, g.N, k0 + 16 * p + b_k, kend, g.b_vec)
+                               : load_rc(g.B, g.ldb, n0 + 64 * j + b_r, g.N, k0 + 16 * p + b_k, kend, g.b_vec);
         LSTORE(a0, b0, 0);
         CSUM(b0);
         __syncthreads();
-        COMPUTE(0);
+        LDFRAG(0, avA, bvA);
+        MMA(avA, bvA);
     }
+#undef LDFRAG
+#undef MMA
 #undef GLOAD
 #undef LSTORE
 #undef CSUM
@@ -318,7 +350,7 @@ __global__ __launch_bounds__(256) void gemm_f32_fast(GemmArgs g) {
     if (BSUM && !BKC && mt == 0) {
         // reduce csum over the 16 k-lanes of the staging layout (thread = (k = t&15, q = t>>4))
         __syncthreads();
-        float* red = &As[0][0][0];   // reuse: [16][BN]  (16*BN <= BM*LDK)
+        float* red = &As[0][0][0];   // reuse: [16][BN]  (16*BN <= BM*LDT)
 #pragma unroll
         for (int j = 0; j < WN; ++j)
             *reinterpret_cast<float4*>(&red[(t & 15) * BN + 64 * j + 4 * (t >> 4)]) = csum[j];
@@ -457,6 +489,15 @@ static int tn_tune_tile() {
     return v;
 }
 
+static int tn_tune_bk() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("TN_GEMM_BK");
+        v = e ? atoi(e) : 16;
+    }
+    return v;
+}
+
 template <bool AKC, bool BKC, bool BSUM>
 static void launch_gemm(tn_ctx* ctx, GemmArgs& g, int S) {
     // FAST needs aligned operands; row-contiguous operands also need an extent % 4 == 0 so that
@@ -474,9 +515,11 @@ static void launch_gemm(tn_ctx* ctx, GemmArgs& g, int S) {
     if (!fast)
         gemm_f32_generic<AKC, BKC, BSUM><<<grid, 256, 0, ctx->stream>>>(g);
     else if (big)
-        gemm_f32_fast<AKC, BKC, BSUM, 2, 1><<<grid, 256, 0, ctx->stream>>>(g);
+        gemm_f32_fast<AKC, BKC, BSUM, 2, 1, 16><<<grid, 256, 0, ctx->stream>>>(g);
+    else if (tn_tune_bk() == 32)
+        gemm_f32_fast<AKC, BKC, BSUM, 1, 1, 32><<<grid, 256, 0, ctx->stream>>>(g);
     else
-        gemm_f32_fast<AKC, BKC, BSUM, 1, 1><<<grid, 256, 0, ctx->stream>>>(g);
+        gemm_f32_fast<AKC, BKC, BSUM, 1, 1, 16><<<grid, 256, 0, ctx->stream>>>(g);
 }
 
 static int wgrad_splits(int B, int n_in, int n_out) {

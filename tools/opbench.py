@@ -192,6 +192,26 @@ def _():
     ctx.call("tn_conv2d_wgrad", wx.ptr, wdz.ptr, wdW.ptr, wdb.ptr, *cw, 1, 1, 64, 64)
 
 
+# ---- calibration: launch boundary and GEMM fixed cost ------------------------------------------
+tiny = dev((16,))
+xk16, Wk16 = dev((B, 16)), dev((16, 500))
+
+
+@op("empty_kernel", 0, 0)
+def _():
+    ctx.call("tn_axpby", tiny.ptr, tiny.ptr, 1, 1.0, 0.0)
+
+
+@op("fc_fwd_K16", 2 * B * 16 * 500, 4 * (B * 16 + 16 * 500 + B * 500))
+def _():
+    ctx.call("tn_fc_fwd", xk16.ptr, Wk16.ptr, bf.ptr, h.ptr, B, 16, 500, LEAKY, .01, mask.ptr)
+
+
+@op("fc_fwd_K16_nomask", 2 * B * 16 * 500, 4 * (B * 16 + 16 * 500 + B * 500))
+def _():
+    ctx.call("tn_fc_fwd", xk16.ptr, Wk16.ptr, bf.ptr, h.ptr, B, 16, 500, 0, .0, None)
+
+
 def main():
     flt = [a for a in sys.argv[1:] if not a.startswith("--")]
     iters = 20
