@@ -128,6 +128,13 @@ int tn_convpool_fwd(tn_ctx* ctx, const float* x, const float* W, const float* b,
 int tn_convpool_bwd(tn_ctx* ctx, const float* x, const float* W, const float* b, const float* g,
                     float* dz, float* dW, float* db, int N, int C, int H, int Wd, int K, int f,
                     int pad_lo, int Ho, int Wo, int p, int Hp, int Wp, int act, float act_param);
+/* tn_convpool_fwd that also records WHERE each pooled value came from: bit 2*di+dj of
+ * mask[n,k,i,j] (uint8, shape of y) is set iff window element (di,dj) exists and attains the
+ * maximum -- all of them on a tie, the elements Theano's MaxPoolGrad routes the gradient to
+ * (convpool.py:106-107).  mask == NULL is plain tn_convpool_fwd.                            */
+int tn_convpool_fwd_mask(tn_ctx* ctx, const float* x, const float* W, const float* b, float* y,
+                         uint8_t* mask, int N, int C, int H, int Wd, int K, int f, int pad_lo,
+                         int Ho, int Wo, int p, int Hp, int Wp, int act, float act_param);
 
 /* LDS-resident backward of the same fused block for MANY filter elements (K*C*f*f in the
  * hundreds, e.g. mnist.prms conv2): a block keeps G whole images' x and dz in LDS, so dz never
@@ -137,6 +144,17 @@ int tn_convblock_supported(int C, int K, int f, int stride, int p, int Ho, int W
 int tn_convblock_bwd(tn_ctx* ctx, const float* x, const float* W, const float* b, const float* g,
                      float* dx, float* dW, float* db, int N, int C, int H, int Wd, int K, int f,
                      int pad_lo, int Ho, int Wo, int p, int Hp, int Wp, int act, float act_param);
+/* The same backward driven by the forward's record instead of a conv recompute: y and mask are
+ * tn_convpool_fwd_mask's outputs, so dz = mask bit ? g * act'(y) : 0.  One wave per image on
+ * the fp32 matrix cores (wgrad and dgrad products), dz lives in LDS only.  dx may be NULL;
+ * dW/db are OVERWRITTEN.  Shapes: f == 3, stride 1, p == 2 keeping the border, C <= 4, K <= 32,
+ * Wo <= 14, image and pooled map <= 768 elements (tn_convblock_mask_supported).             */
+int tn_convblock_mask_supported(int C, int K, int f, int stride, int p, int H, int Wd, int pad_lo,
+                                int Ho, int Wo, int Hp, int Wp);
+int tn_convblock_bwd_mask(tn_ctx* ctx, const float* x, const float* W, const float* g,
+                          const float* y, const uint8_t* mask, float* dx, float* dW, float* db,
+                          int N, int C, int H, int Wd, int K, int f, int pad_lo, int Ho, int Wo,
+                          int p, int Hp, int Wp, int act, float act_param);
 
 /* ---- pool / mean (replaces pool.pool_2d + MaxPoolGrad, tt.mean; convpool.py:106-107,131) ----
  * max over p x p, stride p, no padding; Ho = ceil(H/p) unless ignore_border (floor).   */

@@ -163,6 +163,60 @@ def test_convblock_lds_backward(case):
     assert_close(dW.get_value(), dW_w, atol=2e-4, what="convblock dW (no dx) %s" % (case,))
 
 
+@pytest.mark.parametrize("case", [
+    (9, 4, 13, 20, 3, "valid", "relu05"),       # mnist.prms conv2 (partial last window)
+    (70, 4, 13, 20, 3, "valid", "relu05"),      # more images than one block's waves
+    (6, 3, 12, 16, 3, "same", "relu10"),
+    (3, 2, 10, 30, 3, "same", "tanh"),
+    (2, 4, 8, 21, 3, "valid", "relu"),
+    (5, 1, 14, 7, 3, "valid", "sigmoid"),
+])
+def test_convblock_mask_backward(case):
+    """tn_convpool_fwd_mask + tn_convblock_bwd_mask (matrix-core backward driven by the forward's
+    pooling mask) against the oracle's conv -> act -> pool backward."""
+    N, C, H, K, f, mode, act = case
+    pad_lo, _, Ho = O.conv_geometry(H, f, 1, mode)
+    Hp = O.pool_out_sz(Ho, 2, False)
+    assert ctx().lib.tn_convblock_mask_supported(C, K, f, 1, 2, H, H, pad_lo, Ho, Ho, Hp, Hp)
+    rng = np.random.RandomState(N * 11 + K)
+    x = rng.randn(N, C, H, H).astype(np.float32)
+    W = (rng.randn(K, C, f, f) / np.sqrt(C * f * f)).astype(np.float32)
+    b = rng.randn(K).astype(np.float32)
+    fa, dfa = O.activation(act)
+    x64, W64, b64 = x.astype(np.float64), W.astype(np.float64), b.astype(np.float64)
+    z = O.conv2d_fwd(x64, W64, b64, 1, mode)
+    a = fa(z)
+    want_y = O.pool_fwd(a, 2, False)
+    g = rng.randn(N, K, Hp, Hp).astype(np.float32)
+    dz_w = O.pool_bwd(a, g.astype(np.float64), 2, False) * dfa(z)
+    dx_w, dW_w, db_w = O.conv2d_bwd(x64, W64, dz_w, 1, mode)
+    kind, prm = act_code(act)
+    xd, Wd, bd, gd = dev(x), dev(W), dev(b), dev(g)
+    y = empty((N, K, Hp, Hp))
+    mask = empty((N, K, Hp, Hp), np.uint8)
+    geom = (N, C, H, H, K, f, pad_lo, Ho, Ho, 2, Hp, Hp, kind, prm)
+    call("tn_convpool_fwd_mask", xd.ptr, Wd.ptr, bd.ptr, y.ptr, mask.ptr, *geom)
+    assert_close(y.get_value(), want_y, what="convpool fwd (mask) %s" % (case,))
+    # the mask marks exactly the window elements equal to the pooled value
+    m = mask.get_value()
+    ap = np.full((N, K, 2 * Hp, 2 * Hp), -np.inf)
+    ap[:, :, :Ho, :Ho] = a
+    for r in range(4):
+        sub = ap[:, :, (r >> 1)::2, (r & 1)::2]
+        bit = (m >> r) & 1
+        clear = np.abs(sub - want_y) > 1e-5          # away from float ties the bit is determined
+        assert np.all(bit[clear] == 0), "mask bit %d set off the maximum" % r
+    assert np.all(m > 0) and np.all(m < 16)
+    dx, dW, db = empty(x.shape), empty(W.shape), empty((K,))
+    call("tn_convblock_bwd_mask", xd.ptr, Wd.ptr, gd.ptr, y.ptr, mask.ptr, dx.ptr, dW.ptr, db.ptr, *geom)
+    assert_close(dx.get_value(), dx_w, atol=2e-5, what="convblock(mask) dx %s" % (case,))
+    assert_close(dW.get_value(), dW_w, atol=2e-4, what="convblock(mask) dW %s" % (case,))
+    assert_close(db.get_value(), db_w, atol=2e-4, what="convblock(mask) db %s" % (case,))
+    dW.fill_bytes(0)
+    call("tn_convblock_bwd_mask", xd.ptr, Wd.ptr, gd.ptr, y.ptr, mask.ptr, None, dW.ptr, db.ptr, *geom)
+    assert_close(dW.get_value(), dW_w, atol=2e-4, what="convblock(mask) dW (no dx) %s" % (case,))
+
+
 def test_convpool_tie_rule():
     # constant image, zero weights -> every conv output equals the bias: all four tie
     x = np.ones((1, 1, 6, 6), np.float32)

@@ -94,8 +94,8 @@ __device__ __forceinline__ void window_conv(const Window<P + F - 1, C, PADDED>& 
 template <int F, int P, int C, int ACT, bool PADDED>
 __global__ __launch_bounds__(256) void convpool_fwd_kernel(
     const float* __restrict__ x, const float* __restrict__ W, const float* __restrict__ b,
-    float* __restrict__ y, int N, int H, int Wd, int K, int pad, int Ho, int Wo, int Hp, int Wp,
-    int act, float prm) {
+    float* __restrict__ y, uint8_t* __restrict__ mask, int N, int H, int Wd, int K, int pad, int Ho,
+    int Wo, int Hp, int Wp, int act, float prm) {
     const int HpWp = Hp * Wp;
     const unsigned total = (unsigned)N * HpWp;
     const unsigned t = blockIdx.x * 256u + threadIdx.x;
@@ -119,10 +119,19 @@ __global__ __launch_bounds__(256) void convpool_fwd_kernel(
         for (int di = 0; di < P; ++di)
 #pragma unroll
             for (int dj = 0; dj < P; ++dj) {
-                const float a = act_fwd_t<ACT>(z[di][dj], act, prm);
-                m = valid[di][dj] ? fmaxf(m, a) : m;
+                z[di][dj] = act_fwd_t<ACT>(z[di][dj], act, prm);
+                m = valid[di][dj] ? fmaxf(m, z[di][dj]) : m;
             }
         yn[(size_t)k * HpWp] = m;
+        if (mask) {       // bit di*P+dj: that window element attains the maximum (ties: all of them)
+            unsigned bits = 0;
+#pragma unroll
+            for (int di = 0; di < P; ++di)
+#pragma unroll
+                for (int dj = 0; dj < P; ++dj)
+                    bits |= (valid[di][dj] && z[di][dj] == m) ? (1u << (di * P + dj)) : 0u;
+            mask[((size_t)n * K + k) * HpWp + q] = (uint8_t)bits;
+        }
     }
 }
 
@@ -261,14 +270,14 @@ int tn_conv_wgrad_finish(tn_ctx* ctx, const float* partial, const float* dbparti
 int tn_ensure_scratch(tn_ctx* ctx, size_t bytes);
 
 template <int F, int P, int C>
-static int launch_fwd(tn_ctx* ctx, const float* x, const float* W, const float* b, float* y, int N,
-                      int H, int Wd, int K, int pad, int Ho, int Wo, int Hp, int Wp, int act,
+static int launch_fwd(tn_ctx* ctx, const float* x, const float* W, const float* b, float* y,
+                      uint8_t* mask, int N, int H, int Wd, int K, int pad, int Ho, int Wo, int Hp, int Wp, int act,
                       float prm) {
     const long long total = (long long)N * Hp * Wp;
     TN_REQUIRE(total < (1ll << 31), "tn_convpool_fwd: too many outputs for 32-bit indexing");
 #define CP_L(ACT_, PAD_)                                                                          \
     convpool_fwd_kernel<F, P, C, ACT_, PAD_><<<cdiv(total, 256), 256, 0, ctx->stream>>>(           \
-        x, W, b, y, N, H, Wd, K, pad, Ho, Wo, Hp, Wp, act, prm)
+        x, W, b, y, mask, N, H, Wd, K, pad, Ho, Wo, Hp, Wp, act, prm)
     if (act == TN_ACT_LEAKY) {
         if (pad) CP_L(TN_ACT_LEAKY, true); else CP_L(TN_ACT_LEAKY, false);
     } else {
@@ -337,9 +346,17 @@ int tn_convpool_supported(int C, int f, int stride, int p) {
 int tn_convpool_fwd(tn_ctx* ctx, const float* x, const float* W, const float* b, float* y, int N,
                     int C, int H, int Wd, int K, int f, int pad_lo, int Ho, int Wo, int p, int Hp,
                     int Wp, int act, float act_param) {
+    return tn_convpool_fwd_mask(ctx, x, W, b, y, nullptr, N, C, H, Wd, K, f, pad_lo, Ho, Wo, p, Hp, Wp,
+                                act, act_param);
+}
+
+int tn_convpool_fwd_mask(tn_ctx* ctx, const float* x, const float* W, const float* b, float* y,
+                         uint8_t* mask, int N, int C, int H, int Wd, int K, int f, int pad_lo, int Ho,
+                         int Wo, int p, int Hp, int Wp, int act, float act_param) {
     TN_REQUIRE(tn_convpool_supported(C, f, 1, p), "tn_convpool_fwd: unsupported C=%d f=%d p=%d", C, f, p);
 #define CP_FWD(F_, C_)                                                                            \
-    return launch_fwd<F_, 2, C_>(ctx, x, W, b, y, N, H, Wd, K, pad_lo, Ho, Wo, Hp, Wp, act, act_param)
+    return launch_fwd<F_, 2, C_>(ctx, x, W, b, y, mask, N, H, Wd, K, pad_lo, Ho, Wo, Hp, Wp, act,  \
+                                 act_param)
     if (f == 3) {
         switch (C) {
             case 1: CP_FWD(3, 1);

@@ -2,6 +2,9 @@
 Same constructor arguments, shape rules and ``representation`` strings; the
 compute is enqueued on the HIP backend (include/theanet_hip.h)."""
 import math
+import os
+
+import numpy as np
 
 from .. import _lib
 from .layer import Layer, activation_by_name
@@ -87,6 +90,13 @@ class ConvLayer(Layer):
         return bool(self.stride == 1 and self.ctx.lib.tn_convpool_supported(
             self.num_prev_maps, self.filter_sz, self.stride, pool.pool_sz))
 
+    def mask_backward_supported(self, pool):
+        """True if the fused block's backward can run from the forward's pooling mask
+        (tn_convblock_bwd_mask) instead of recomputing the convolution."""
+        return bool(self.stride == 1 and self.ctx.lib.tn_convblock_mask_supported(
+            self.num_prev_maps, self.num_maps, self.filter_sz, self.stride, pool.pool_sz,
+            self.in_sz, self.in_sz, self.pad_lo, self.out_sz, self.out_sz, pool.out_sz, pool.out_sz))
+
     def _fused_geom(self):
         pool = self.fused_pool
         return (self.batch_sz, self.num_prev_maps, self.in_sz, self.in_sz, self.num_maps,
@@ -104,6 +114,18 @@ class ConvLayer(Layer):
         gradient through max-pool and activation and reduces dW/db; dz is only materialised
         when the layer below needs a gradient."""
         pool = self.fused_pool
+        if pool.mask is not None:
+            # the forward recorded where every pooled value came from: no conv recompute, the
+            # weight and input gradients are matrix-core products over an LDS-resident dz
+            b_out, b_act, b_prm, b_mask = below.act_info() if below is not None else (None, 0, 0., None)
+            if not (need_gin and b_out is not None and b_act != _lib.TN_ACT_LINEAR):
+                if need_gin and self.gin is None:
+                    self.gin = self.ctx.empty(self.inpt.shape)
+                self.ctx.call("tn_convblock_bwd_mask", self.inpt.ptr, self.W.ptr, gpool.ptr,
+                              pool.output.ptr, pool.mask.ptr, self.gin.ptr if need_gin else None,
+                              self.grads[0].ptr, self.grads[1].ptr, *self._fused_geom())
+                self._gin_done = True
+                return self.gin if need_gin else None
         if self.ctx.lib.tn_convblock_supported(self.num_prev_maps, self.num_maps, self.filter_sz,
                                                self.stride, pool.pool_sz, self.out_sz, self.out_sz):
             # LDS-resident variant: dW/db AND the gradient w.r.t. the input in one kernel
@@ -168,6 +190,7 @@ class PoolLayer(Layer):
         self.output = self.ctx.empty((self.batch_sz, num_maps, self.out_sz, self.out_sz))
         self.gin = None
         self.fused_conv = None
+        self.mask = None           # uint8 pooling mask of the fused forward (training graphs only)
         self.representation = (
             "Pool Maps:{:2d} Pool_sz:{} Border:{} Output:{:2d}"
             "".format(num_maps, pool_sz,
@@ -180,8 +203,12 @@ class PoolLayer(Layer):
     def forward(self, train=True):
         conv = self.fused_conv
         if conv is not None:
-            self.ctx.call("tn_convpool_fwd", conv.inpt.ptr, conv.W.ptr, conv.b.ptr,
-                          self.output.ptr, *conv._fused_geom())
+            if train and self.mask is None and os.environ.get("TN_POOL_MASK", "1") != "0" and \
+                    conv.mask_backward_supported(self):
+                self.mask = self.ctx.empty(self.output.shape, np.uint8)
+            self.ctx.call("tn_convpool_fwd_mask", conv.inpt.ptr, conv.W.ptr, conv.b.ptr,
+                          self.output.ptr, self.mask.ptr if (train and self.mask is not None) else None,
+                          *conv._fused_geom())
             return
         self.ctx.call("tn_pool_fwd", self.inpt.ptr, self.output.ptr,
                       self.batch_sz * self.num_maps, self.in_sz, self.in_sz, self.pool_sz,

@@ -62,6 +62,7 @@ a1 = dev((B, 4, 26, 26)); p1 = dev((B, 4, 13, 13))
 W2, b2 = dev((20, 4, 3, 3)), dev((20,))
 a2 = dev((B, 20, 11, 11)); p2 = dev((B, 20, 6, 6))
 g2 = dev((B, 20, 6, 6)); dz2 = dev((B, 20, 11, 11)); dW2, db2 = dev((20, 4, 3, 3)), dev((20,))
+m2 = dev((B, 20, 6, 6), np.uint8, rand=False)
 g1 = dev((B, 4, 13, 13)); dz1 = dev((B, 4, 26, 26)); dW1, db1 = dev((4, 1, 3, 3)), dev((4,))
 Wf, bf = dev((720, 500)), dev((500,))
 h = dev((B, 500)); mask = dev((B, 500), np.uint8)
@@ -104,6 +105,17 @@ def _():
 def _():
     ctx.call("tn_convblock_bwd", p1.ptr, W2.ptr, b2.ptr, g2.ptr, g1.ptr, dW2.ptr, db2.ptr, *c2, 0, 11, 11,
              2, 6, 6, LEAKY, .05)
+
+
+@op("convpool2_fwd_mask", 2 * B * 121 * 20 * 36, 4 * B * (676 + 720) + B * 720)
+def _():
+    ctx.call("tn_convpool_fwd_mask", p1.ptr, W2.ptr, b2.ptr, p2.ptr, m2.ptr, *c2, 0, 11, 11, 2, 6, 6, LEAKY, .05)
+
+
+@op("convblock2_bwd_mask", 4 * B * 121 * 20 * 36, 4 * B * (676 + 720 + 720 + 676) + B * 720)
+def _():
+    ctx.call("tn_convblock_bwd_mask", p1.ptr, W2.ptr, g2.ptr, p2.ptr, m2.ptr, g1.ptr, dW2.ptr, db2.ptr, *c2,
+             0, 11, 11, 2, 6, 6, LEAKY, .05)
 
 
 @op("conv2_dgrad", 2 * B * 121 * 20 * 36, 4 * B * (2420 + 676))
