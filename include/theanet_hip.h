@@ -131,10 +131,16 @@ int tn_convpool_bwd(tn_ctx* ctx, const float* x, const float* W, const float* b,
 /* tn_convpool_fwd that also records WHERE each pooled value came from: bit 2*di+dj of
  * mask[n,k,i,j] (uint8, shape of y) is set iff window element (di,dj) exists and attains the
  * maximum -- all of them on a tie, the elements Theano's MaxPoolGrad routes the gradient to
- * (convpool.py:106-107).  mask == NULL is plain tn_convpool_fwd.                            */
+ * (convpool.py:106-107); bits 4 / 5 hold y > 0 / y < 0.  mask == NULL is plain tn_convpool_fwd.
+ * tn_convpool_bwd_mask is tn_convpool_bwd driven by that record (f == 3 only): dz = mask bit ?
+ * g * act'(y) : 0 with no conv recompute (y is read only when act is not leaky-relu).        */
 int tn_convpool_fwd_mask(tn_ctx* ctx, const float* x, const float* W, const float* b, float* y,
                          uint8_t* mask, int N, int C, int H, int Wd, int K, int f, int pad_lo,
                          int Ho, int Wo, int p, int Hp, int Wp, int act, float act_param);
+int tn_convpool_bwd_mask(tn_ctx* ctx, const float* x, const float* g, const float* y,
+                         const uint8_t* mask, float* dz, float* dW, float* db, int N, int C, int H,
+                         int Wd, int K, int f, int pad_lo, int Ho, int Wo, int p, int Hp, int Wp,
+                         int act, float act_param);
 
 /* LDS-resident backward of the same fused block for MANY filter elements (K*C*f*f in the
  * hundreds, e.g. mnist.prms conv2): a block keeps G whole images' x and dz in LDS, so dz never

@@ -206,7 +206,7 @@ def test_convblock_mask_backward(case):
         bit = (m >> r) & 1
         clear = np.abs(sub - want_y) > 1e-5          # away from float ties the bit is determined
         assert np.all(bit[clear] == 0), "mask bit %d set off the maximum" % r
-    assert np.all(m > 0) and np.all(m < 16)
+    assert np.all((m & 15) > 0) and np.all(m < 64)
     dx, dW, db = empty(x.shape), empty(W.shape), empty((K,))
     call("tn_convblock_bwd_mask", xd.ptr, Wd.ptr, gd.ptr, y.ptr, mask.ptr, dx.ptr, dW.ptr, db.ptr, *geom)
     assert_close(dx.get_value(), dx_w, atol=2e-5, what="convblock(mask) dx %s" % (case,))
@@ -215,6 +215,50 @@ def test_convblock_mask_backward(case):
     dW.fill_bytes(0)
     call("tn_convblock_bwd_mask", xd.ptr, Wd.ptr, gd.ptr, y.ptr, mask.ptr, None, dW.ptr, db.ptr, *geom)
     assert_close(dW.get_value(), dW_w, atol=2e-4, what="convblock(mask) dW (no dx) %s" % (case,))
+
+
+@pytest.mark.parametrize("case", [
+    (7, 1, 28, 4, "valid", "relu10", False),        # mnist.prms conv1
+    (3, 1, 15, 5, "valid", "relu05", True),         # ignore_border: last row/col in no window
+    (4, 3, 16, 6, "same", "tanh", False),
+    (2, 4, 11, 9, "same", "relu", False),
+    (3, 2, 9, 3, "valid", "sigmoid", False),
+])
+def test_convpool_mask_backward(case):
+    """tn_convpool_bwd_mask (window-per-thread backward from the pooling mask) vs the oracle."""
+    N, C, H, K, mode, act, ib = case
+    f = 3
+    pad_lo, _, Ho = O.conv_geometry(H, f, 1, mode)
+    Hp = O.pool_out_sz(Ho, 2, ib)
+    rng = np.random.RandomState(N * 13 + K)
+    x = rng.randn(N, C, H, H).astype(np.float32)
+    W = (rng.randn(K, C, f, f) / np.sqrt(C * f * f)).astype(np.float32)
+    b = rng.randn(K).astype(np.float32)
+    fa, dfa = O.activation(act)
+    x64, W64, b64 = x.astype(np.float64), W.astype(np.float64), b.astype(np.float64)
+    z = O.conv2d_fwd(x64, W64, b64, 1, mode)
+    a = fa(z)
+    g = rng.randn(N, K, Hp, Hp).astype(np.float32)
+    dz_w = O.pool_bwd(a, g.astype(np.float64), 2, ib) * dfa(z)
+    _, dW_w, db_w = O.conv2d_bwd(x64, W64, dz_w, 1, mode)
+    kind, prm = act_code(act)
+    xd, Wd, bd, gd = dev(x), dev(W), dev(b), dev(g)
+    y = empty((N, K, Hp, Hp))
+    mask = empty((N, K, Hp, Hp), np.uint8)
+    geom = (N, C, H, H, K, f, pad_lo, Ho, Ho, 2, Hp, Hp, kind, prm)
+    call("tn_convpool_fwd_mask", xd.ptr, Wd.ptr, bd.ptr, y.ptr, mask.ptr, *geom)
+    assert_close(y.get_value(), O.pool_fwd(a, 2, ib), what="convpool fwd (mask) %s" % (case,))
+    yv, m = y.get_value(), mask.get_value()
+    assert np.array_equal((m >> 4) & 1, yv > 0) and np.array_equal((m >> 5) & 1, yv < 0)
+    dz, dW, db = empty((N, K, Ho, Ho)), empty(W.shape), empty((K,))
+    dz.fill_bytes(0xff)
+    call("tn_convpool_bwd_mask", xd.ptr, gd.ptr, y.ptr, mask.ptr, dz.ptr, dW.ptr, db.ptr, *geom)
+    assert_close(dz.get_value(), dz_w, atol=1e-5, what="convpool(mask) dz %s" % (case,))
+    assert_close(dW.get_value(), dW_w, atol=2e-4, what="convpool(mask) dW %s" % (case,))
+    assert_close(db.get_value(), db_w, atol=2e-4, what="convpool(mask) db %s" % (case,))
+    dW.fill_bytes(0)
+    call("tn_convpool_bwd_mask", xd.ptr, gd.ptr, y.ptr, mask.ptr, None, dW.ptr, db.ptr, *geom)
+    assert_close(dW.get_value(), dW_w, atol=2e-4, what="convpool(mask) dW (no dz) %s" % (case,))
 
 
 def test_convpool_tie_rule():

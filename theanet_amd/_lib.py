@@ -74,6 +74,7 @@ SIGNATURES = {
     "tn_convpool_supported": (c_int, [c_int, c_int, c_int, c_int]),
     "tn_convpool_fwd": (c_int, [CTX, P, P, P, P] + [c_int] * 12 + [c_int, c_float]),
     "tn_convpool_fwd_mask": (c_int, [CTX, P, P, P, P, P] + [c_int] * 12 + [c_int, c_float]),
+    "tn_convpool_bwd_mask": (c_int, [CTX, P, P, P, P, P, P, P] + [c_int] * 12 + [c_int, c_float]),
     "tn_convblock_mask_supported": (c_int, [c_int] * 12),
     "tn_convblock_bwd_mask": (c_int, [CTX, P, P, P, P, P, P, P, P] + [c_int] * 12 + [c_int, c_float]),
     "tn_convblock_supported": (c_int, [c_int] * 7),

@@ -412,7 +412,7 @@ __global__ __launch_bounds__(256, 2) void convblock_bwd_mask_mfma(
         _Pragma("unroll") for (int j = 0; j < CM_XR; ++j) {                                 \
             xr[j] = xp_[min(lane + 64 * j, CHW - 1)];                                       \
             gr[j] = gp_[min(lane + 64 * j, KHW - 1)];                                       \
-            yr[j] = yp_[min(lane + 64 * j, KHW - 1)];                                       \
+            if (ACT != TN_ACT_LEAKY) yr[j] = yp_[min(lane + 64 * j, KHW - 1)];              \
             mr[j] = mp_[min(lane + 64 * j, KHW - 1)];                                       \
         }                                                                                   \
     }
@@ -503,15 +503,15 @@ __global__ __launch_bounds__(256, 2) void convblock_bwd_mask_mfma(
 #pragma unroll
         for (int j = 0; j < CM_XR; ++j) {
             sx[tabr[j]] = xr[j];
+            const int m = mr[j];
             float gp;
-            if (ACT == TN_ACT_LEAKY) {
-                gp = yr[j] < 0.f ? prm : tie;
-                gp = yr[j] > 0.f ? 1.f : gp;
+            if (ACT == TN_ACT_LEAKY) {      // the slope is in the mask's sign bits: y is not read
+                gp = (m & 32) ? prm : tie;
+                gp = (m & 16) ? 1.f : gp;
             } else {
                 gp = tn_act_grad_from_out(yr[j], act, prm);
             }
             const float gy = gr[j] * gp;
-            const int m = mr[j];
             *reinterpret_cast<float4*>(sdz + dzo[j]) =
                 make_float4((m & 1) ? gy : 0.f, (m & 2) ? gy : 0.f, (m & 4) ? gy : 0.f, (m & 8) ? gy : 0.f);
         }

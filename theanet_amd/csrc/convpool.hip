@@ -124,12 +124,14 @@ __global__ __launch_bounds__(256) void convpool_fwd_kernel(
             }
         yn[(size_t)k * HpWp] = m;
         if (mask) {       // bit di*P+dj: that window element attains the maximum (ties: all of them)
+                          // bits 4 / 5: y > 0 / y < 0 (all a leaky-relu backward needs of y)
             unsigned bits = 0;
 #pragma unroll
             for (int di = 0; di < P; ++di)
 #pragma unroll
                 for (int dj = 0; dj < P; ++dj)
                     bits |= (valid[di][dj] && z[di][dj] == m) ? (1u << (di * P + dj)) : 0u;
+            bits |= (m > 0.f ? 16u : 0u) | (m < 0.f ? 32u : 0u);      // sign of the pooled value
             mask[((size_t)n * K + k) * HpWp + q] = (uint8_t)bits;
         }
     }
@@ -264,6 +266,118 @@ __global__ __launch_bounds__(256) void convpool_bwd_kernel(
     }
 }
 
+// Backward of the fused block from the forward's pooling mask, f = 3, p = 2.  Thread = one POOLING
+// window: its 4 x 4 x C input patch is loaded once (16 C loads for 4 conv outputs), dz of the 4
+// window elements is mask bit ? g * act'(y) : 0 -- no conv recompute, no cross-lane max -- and
+// the wgrad FMAs run on the patch registers.  Same partial-slab contract as convpool_bwd_kernel.
+template <int C, int KT, int ACT, bool PADDED>
+__global__ __launch_bounds__(256) void convpool_bwd_mask_kernel(
+    const float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ y,
+    const uint8_t* __restrict__ mask, float* __restrict__ dz_out, float* __restrict__ partial,
+    float* __restrict__ dbpartial, int N, int H, int Wd, int K, int pad, int Ho, int Wo, int Hp,
+    int Wp, int act, float prm) {
+    constexpr int F = 3, FF = 9;
+    constexpr int NACC = KT * C * FF + KT;
+    __shared__ float red[4][NACC];
+    const int HpWp = Hp * Wp, HoWo = Ho * Wo;
+    const unsigned total = (unsigned)N * HpWp;
+    const int k0 = blockIdx.y * KT;
+    const float tie = prm > 0.f ? 1.f + prm : 0.f;
+
+    float acc[KT][C][FF];
+    float accb[KT];
+#pragma unroll
+    for (int kk = 0; kk < KT; ++kk) {
+        accb[kk] = 0.f;
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+#pragma unroll
+            for (int s = 0; s < FF; ++s) acc[kk][c][s] = 0.f;
+    }
+    const unsigned stride = gridDim.x * 256u;
+    for (unsigned base = blockIdx.x * 256u; base < total; base += stride) {
+        const unsigned t = base + threadIdx.x;
+        const bool live = t < total;
+        const unsigned tt = live ? t : total - 1;
+        const int n = (int)(tt / (unsigned)HpWp);
+        const int q = (int)(tt - (unsigned)n * HpWp);
+        const int pi = q / Wp, pj = q - pi * Wp;
+        Window<4, C, PADDED> pt;
+        pt.load(x + (size_t)n * C * H * Wd, H, Wd, 2 * pi - pad, 2 * pj - pad);
+        float gy[KT];
+        unsigned mk[KT];
+#pragma unroll
+        for (int kk = 0; kk < KT; ++kk) {
+            const size_t e = ((size_t)n * K + min(k0 + kk, K - 1)) * HpWp + q;
+            gy[kk] = g[e];
+            mk[kk] = mask[e];
+            if (ACT != TN_ACT_LEAKY) gy[kk] *= tn_act_grad_from_out(y[e], act, prm);
+        }
+#pragma unroll
+        for (int kk = 0; kk < KT; ++kk) {
+            const int k = k0 + kk;
+            if (k < K) {   // wave-uniform
+                if (ACT == TN_ACT_LEAKY) {
+                    float gp = (mk[kk] & 32u) ? prm : tie;
+                    gp = (mk[kk] & 16u) ? 1.f : gp;
+                    gy[kk] *= gp;
+                }
+                const float gl = live ? gy[kk] : 0.f;
+                float d[2][2];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) d[r >> 1][r & 1] = (mk[kk] >> r & 1u) ? gl : 0.f;
+                if (dz_out && live) {
+                    float* o = dz_out + ((size_t)n * K + k) * HoWo + (2 * pi) * Wo + 2 * pj;
+                    const bool vj = 2 * pj + 1 < Wo, vi = 2 * pi + 1 < Ho;
+                    o[0] = d[0][0];
+                    if (vj) o[1] = d[0][1];
+                    if (vi) o[Wo] = d[1][0];
+                    if (vi && vj) o[Wo + 1] = d[1][1];
+                }
+                accb[kk] += (d[0][0] + d[0][1]) + (d[1][0] + d[1][1]);
+#pragma unroll
+                for (int c = 0; c < C; ++c)
+#pragma unroll
+                    for (int u = 0; u < F; ++u)
+#pragma unroll
+                        for (int v = 0; v < F; ++v) {
+                            float a = acc[kk][c][u * F + v];
+                            a = fmaf(d[0][0], pt.v[c][u][v], a);
+                            a = fmaf(d[0][1], pt.v[c][u][v + 1], a);
+                            a = fmaf(d[1][0], pt.v[c][u + 1][v], a);
+                            a = fmaf(d[1][1], pt.v[c][u + 1][v + 1], a);
+                            acc[kk][c][u * F + v] = a;
+                        }
+            }
+        }
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int kk = 0; kk < KT; ++kk) {
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+#pragma unroll
+            for (int s = 0; s < FF; ++s) {
+                const float r = wave_sum_dpp(acc[kk][c][s]);
+                if (lane == 0) red[wave][(kk * C + c) * FF + s] = r;
+            }
+        const float rb = wave_sum_dpp(accb[kk]);
+        if (lane == 0) red[wave][KT * C * FF + kk] = rb;
+    }
+    __syncthreads();
+    const int KCFF = K * C * FF;
+    for (int s = threadIdx.x; s < NACC; s += 256) {
+        const float r = red[0][s] + red[1][s] + red[2][s] + red[3][s];
+        if (s < KT * C * FF) {
+            const int kk = s / (C * FF), rem = s - kk * C * FF;
+            if (k0 + kk < K) partial[(size_t)blockIdx.x * KCFF + (size_t)(k0 + kk) * C * FF + rem] = r;
+        } else {
+            const int kk = s - KT * C * FF;
+            if (k0 + kk < K) dbpartial[(size_t)blockIdx.x * K + k0 + kk] = r;
+        }
+    }
+}
+
 // shared with conv.hip
 int tn_conv_wgrad_finish(tn_ctx* ctx, const float* partial, const float* dbpartial, float* dW,
                          float* db, int nblk, int K, int C, int f);
@@ -334,7 +448,64 @@ static int launch_bwd(tn_ctx* ctx, const float* x, const float* W, const float* 
     return tn_conv_wgrad_finish(ctx, partial, dbpartial, dW, db, nblk, K, C, F);
 }
 
+static int tn_tune_mwin() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("TN_CONVPOOL_MWIN");
+        v = e ? atoi(e) : 4;
+    }
+    return v;
+}
+
+template <int C, int KT>
+static int launch_bwd_mask(tn_ctx* ctx, const float* x, const float* g, const float* y,
+                           const uint8_t* mask, float* dz, float* dW, float* db, int N, int H, int Wd,
+                           int K, int pad, int Ho, int Wo, int Hp, int Wp, int act, float prm) {
+    const long long total = (long long)N * Hp * Wp;
+    TN_REQUIRE(total < (1ll << 31), "tn_convpool_bwd_mask: too many outputs for 32-bit indexing");
+    int nblk = cdiv(total, 256 * tn_tune_mwin());      // windows per thread
+    if (nblk > 2048) nblk = 2048;
+    if (nblk < 1) nblk = 1;
+    const size_t KCFF = (size_t)K * C * 9;
+    int rc = tn_ensure_scratch(ctx, (size_t)nblk * (KCFF + K) * sizeof(float));
+    if (rc) return rc;
+    float* partial = ctx->scratch;
+    float* dbpartial = ctx->scratch + (size_t)nblk * KCFF;
+    const dim3 grid(nblk, cdiv(K, KT));
+#define CP_L(ACT_, PAD_)                                                                          \
+    convpool_bwd_mask_kernel<C, KT, ACT_, PAD_><<<grid, 256, 0, ctx->stream>>>(                     \
+        x, g, y, mask, dz, partial, dbpartial, N, H, Wd, K, pad, Ho, Wo, Hp, Wp, act, prm)
+    if (act == TN_ACT_LEAKY) {
+        if (pad) CP_L(TN_ACT_LEAKY, true); else CP_L(TN_ACT_LEAKY, false);
+    } else {
+        if (pad) CP_L(-1, true); else CP_L(-1, false);
+    }
+#undef CP_L
+    TN_LAUNCH_CHECK();
+    return tn_conv_wgrad_finish(ctx, partial, dbpartial, dW, db, nblk, K, C, 3);
+}
+
 extern "C" {
+
+int tn_convpool_bwd_mask(tn_ctx* ctx, const float* x, const float* g, const float* y,
+                         const uint8_t* mask, float* dz, float* dW, float* db, int N, int C, int H,
+                         int Wd, int K, int f, int pad_lo, int Ho, int Wo, int p, int Hp, int Wp,
+                         int act, float act_param) {
+    TN_REQUIRE(f == 3 && p == 2 && C >= 1 && C <= 4, "tn_convpool_bwd_mask: unsupported C=%d f=%d p=%d", C, f, p);
+    TN_REQUIRE(x && g && y && mask && dW && db, "tn_convpool_bwd_mask: null argument");
+    if (dz && (Hp * p < Ho || Wp * p < Wo))   // rows/cols outside every window (ignore_border)
+        TN_HIP(hipMemsetAsync(dz, 0, (size_t)N * K * Ho * Wo * sizeof(float), ctx->stream));
+#define CP_BWDM(C_, KT_)                                                                          \
+    return launch_bwd_mask<C_, KT_>(ctx, x, g, y, mask, dz, dW, db, N, H, Wd, K, pad_lo, Ho, Wo, Hp, Wp, \
+                                    act, act_param)
+    switch (C) {
+        case 1: CP_BWDM(1, 4);
+        case 2: CP_BWDM(2, 4);
+        case 3: CP_BWDM(3, 2);
+        default: CP_BWDM(4, 2);
+    }
+#undef CP_BWDM
+}
 
 int tn_convpool_supported(int C, int f, int stride, int p) {
     if (stride != 1 || p != 2) return 0;

@@ -54,6 +54,7 @@ class ConvLayer(Layer):
         self.output = self.ctx.empty((batch_sz, num_maps, self.out_sz, self.out_sz))
         self.gin = None
         self.fused_pool = None     # set by NeuralNet: conv+act+pool run as ONE kernel
+        self._mask_block = None
         self.dz = None
 
         self.params = [self.W, self.b]
@@ -91,11 +92,14 @@ class ConvLayer(Layer):
             self.num_prev_maps, self.filter_sz, self.stride, pool.pool_sz))
 
     def mask_backward_supported(self, pool):
-        """True if the fused block's backward can run from the forward's pooling mask
-        (tn_convblock_bwd_mask) instead of recomputing the convolution."""
-        return bool(self.stride == 1 and self.ctx.lib.tn_convblock_mask_supported(
-            self.num_prev_maps, self.num_maps, self.filter_sz, self.stride, pool.pool_sz,
-            self.in_sz, self.in_sz, self.pad_lo, self.out_sz, self.out_sz, pool.out_sz, pool.out_sz))
+        """True if the fused block's whole backward (dW, db and the input gradient) can run as
+        the one-kernel matrix-core variant tn_convblock_bwd_mask."""
+        if self._mask_block is None:
+            self._mask_block = bool(self.stride == 1 and self.ctx.lib.tn_convblock_mask_supported(
+                self.num_prev_maps, self.num_maps, self.filter_sz, self.stride, pool.pool_sz,
+                self.in_sz, self.in_sz, self.pad_lo, self.out_sz, self.out_sz, pool.out_sz,
+                pool.out_sz))
+        return self._mask_block
 
     def _fused_geom(self):
         pool = self.fused_pool
@@ -115,10 +119,12 @@ class ConvLayer(Layer):
         when the layer below needs a gradient."""
         pool = self.fused_pool
         if pool.mask is not None:
-            # the forward recorded where every pooled value came from: no conv recompute, the
-            # weight and input gradients are matrix-core products over an LDS-resident dz
+            # the forward recorded where every pooled value came from: no conv recompute
             b_out, b_act, b_prm, b_mask = below.act_info() if below is not None else (None, 0, 0., None)
-            if not (need_gin and b_out is not None and b_act != _lib.TN_ACT_LINEAR):
+            fuse_below = need_gin and b_out is not None and b_act != _lib.TN_ACT_LINEAR
+            if self.mask_backward_supported(pool) and not fuse_below:
+                # small maps: weight and input gradients as matrix-core products over an
+                # LDS-resident dz, one kernel
                 if need_gin and self.gin is None:
                     self.gin = self.ctx.empty(self.inpt.shape)
                 self.ctx.call("tn_convblock_bwd_mask", self.inpt.ptr, self.W.ptr, gpool.ptr,
@@ -126,6 +132,13 @@ class ConvLayer(Layer):
                               self.grads[0].ptr, self.grads[1].ptr, *self._fused_geom())
                 self._gin_done = True
                 return self.gin if need_gin else None
+            self._gin_done = False
+            if need_gin and self.dz is None:
+                self.dz = self.ctx.empty(self.output.shape)
+            self.ctx.call("tn_convpool_bwd_mask", self.inpt.ptr, gpool.ptr, pool.output.ptr,
+                          pool.mask.ptr, self.dz.ptr if need_gin else None, self.grads[0].ptr,
+                          self.grads[1].ptr, *self._fused_geom())
+            return self.dz if need_gin else None
         if self.ctx.lib.tn_convblock_supported(self.num_prev_maps, self.num_maps, self.filter_sz,
                                                self.stride, pool.pool_sz, self.out_sz, self.out_sz):
             # LDS-resident variant: dW/db AND the gradient w.r.t. the input in one kernel
@@ -204,7 +217,7 @@ class PoolLayer(Layer):
         conv = self.fused_conv
         if conv is not None:
             if train and self.mask is None and os.environ.get("TN_POOL_MASK", "1") != "0" and \
-                    conv.mask_backward_supported(self):
+                    conv.filter_sz == 3 and self.pool_sz == 2:
                 self.mask = self.ctx.empty(self.output.shape, np.uint8)
             self.ctx.call("tn_convpool_fwd_mask", conv.inpt.ptr, conv.W.ptr, conv.b.ptr,
                           self.output.ptr, self.mask.ptr if (train and self.mask is not None) else None,

@@ -62,7 +62,7 @@ a1 = dev((B, 4, 26, 26)); p1 = dev((B, 4, 13, 13))
 W2, b2 = dev((20, 4, 3, 3)), dev((20,))
 a2 = dev((B, 20, 11, 11)); p2 = dev((B, 20, 6, 6))
 g2 = dev((B, 20, 6, 6)); dz2 = dev((B, 20, 11, 11)); dW2, db2 = dev((20, 4, 3, 3)), dev((20,))
-m2 = dev((B, 20, 6, 6), np.uint8, rand=False)
+m2 = dev((B, 20, 6, 6), np.uint8, rand=False); m1 = dev((B, 4, 13, 13), np.uint8, rand=False)
 g1 = dev((B, 4, 13, 13)); dz1 = dev((B, 4, 26, 26)); dW1, db1 = dev((4, 1, 3, 3)), dev((4,))
 Wf, bf = dev((720, 500)), dev((500,))
 h = dev((B, 500)); mask = dev((B, 500), np.uint8)
@@ -105,6 +105,17 @@ def _():
 def _():
     ctx.call("tn_convblock_bwd", p1.ptr, W2.ptr, b2.ptr, g2.ptr, g1.ptr, dW2.ptr, db2.ptr, *c2, 0, 11, 11,
              2, 6, 6, LEAKY, .05)
+
+
+@op("convpool1_fwd_mask", 2 * B * 676 * 36, 4 * B * (784 + 676) + B * 676)
+def _():
+    ctx.call("tn_convpool_fwd_mask", x0.ptr, W1.ptr, b1.ptr, p1.ptr, m1.ptr, *c1, 0, 26, 26, 2, 13, 13, LEAKY, .1)
+
+
+@op("convpool1_bwd_mask", 2 * B * 676 * 36, 4 * B * (784 + 676) + B * 676)
+def _():
+    ctx.call("tn_convpool_bwd_mask", x0.ptr, g1.ptr, p1.ptr, m1.ptr, None, dW1.ptr, db1.ptr, *c1, 0, 26, 26,
+             2, 13, 13, LEAKY, .1)
 
 
 @op("convpool2_fwd_mask", 2 * B * 121 * 20 * 36, 4 * B * (676 + 720) + B * 720)
