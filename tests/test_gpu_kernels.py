@@ -330,7 +330,9 @@ def test_mean_fwd_bwd():
 
 
 FC_CASES = [(64, 720, 500, "relu01"), (33, 500, 10, "linear"), (5, 7, 3, "tanh"),
-            (128, 100, 64, "sigmoid"), (70, 33, 130, "relu10"), (256, 64, 457, "relu")]
+            (128, 100, 64, "sigmoid"), (70, 33, 130, "relu10"), (256, 64, 457, "relu"),
+            # few outputs, n_in % 4 == 0: the 16-byte-access kernels of fc_skinny.hip
+            (300, 500, 10, "linear"), (129, 64, 16, "tanh"), (17, 8, 1, "relu05"), (515, 1028, 7, "sigmoid")]
 
 
 @pytest.mark.parametrize("B,n_in,n_out,act", FC_CASES)

@@ -1,0 +1,244 @@
+// Fully-connected layers with a handful of outputs (n_out <= 16, e.g. mnist.prms' 500 -> 10
+// softmax layer: theanet/layer/outlayers.py:87-95, hidden.py:40-43).  Too skinny for the tiled
+// GEMM: every op is one pass over the (B, n_in) activation matrix, so the kernels are built
+// around 16-byte row-contiguous accesses of that matrix, all issued before the first use:
+//   fwd    out = act(x W + b) * mask     16x16x4 f32 MFMA, M = 16 rows, N = outputs, 4-way split of K
+//   wgrad  dW = x^T dz, db = 1^T dz      16x16x4 f32 MFMA, M = input features (+ a ones column),
+//                                        N = outputs, reduction over rows; slabs + one reduce
+//   dgrad  dx = (dz W^T) act'(a) mask    VALU: thread = 4 input features, dz rows as scalar loads
+// Requires n_in % 4 == 0 and 16-byte aligned rows (tn_fc_skinny_ok); anything else keeps the
+// scalar kernels in gemm.hip.
+#include <cstdlib>
+
+#include "common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define SK_MAX 16
+
+__device__ __forceinline__ f32x4 sk_mfma(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// ---- forward --------------------------------------------------------------------------------
+// block = 16 rows, 4 waves; wave w owns the 16-wide k chunks w, w+4, ...  Lane (lo, qd) loads
+// x[row lo][16c + 4qd .. +3] as one float4: component e is the A operand of reduction step
+// (c, e) with k = 16c + 4qd + e, and the B operand W[k][n = lo] follows the same enumeration.
+#define SKF_CH 8
+__global__ __launch_bounds__(256) void fc_skinny_fwd_mfma(
+    const float* __restrict__ x, const float* __restrict__ W, const float* __restrict__ b,
+    float* __restrict__ a, int B, int n_in, int n_out, int act, float prm,
+    const uint8_t* __restrict__ mask) {
+    __shared__ float red[4][256];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, lo = lane & 15, qd = lane >> 4;
+    const float* xr = x + (size_t)min(blockIdx.x * 16 + lo, B - 1) * n_in;
+    const int nch = (n_in + 15) >> 4;
+    const int nc = min(lo, n_out - 1);
+    const bool nlive = lo < n_out;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int c0 = w; c0 < nch; c0 += 4 * SKF_CH) {
+        float4 xv[SKF_CH];
+        float wv[SKF_CH][4];
+#pragma unroll
+        for (int i = 0; i < SKF_CH; ++i) {
+            const int k = 16 * (c0 + 4 * i) + 4 * qd;
+            const int kc = min(k, n_in - 4);
+            xv[i] = *reinterpret_cast<const float4*>(xr + kc);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) wv[i][e] = W[(size_t)(kc + e) * n_out + nc];
+        }
+#pragma unroll
+        for (int i = 0; i < SKF_CH; ++i) {
+            const bool live = nlive && (16 * (c0 + 4 * i) + 4 * qd < n_in);     // n_in % 4 == 0
+            acc = sk_mfma(xv[i].x, live ? wv[i][0] : 0.f, acc);
+            acc = sk_mfma(xv[i].y, live ? wv[i][1] : 0.f, acc);
+            acc = sk_mfma(xv[i].z, live ? wv[i][2] : 0.f, acc);
+            acc = sk_mfma(xv[i].w, live ? wv[i][3] : 0.f, acc);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[w][r * 64 + lane] = acc[r];
+    __syncthreads();
+    if (w == 0 && nlive) {
+        const float bias = b ? b[lo] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = blockIdx.x * 16 + 4 * qd + r;        // accumulator row of register r
+            const float s = ((red[0][r * 64 + lane] + red[1][r * 64 + lane]) + red[2][r * 64 + lane]) +
+                            red[3][r * 64 + lane];
+            if (row < B) {
+                const size_t o = (size_t)row * n_out + lo;
+                float v = tn_act_fwd(s + bias, act, prm);
+                if (mask) v *= (float)mask[o];
+                a[o] = v;
+            }
+        }
+    }
+}
+
+// ---- wgrad ----------------------------------------------------------------------------------
+// grid (T, RC): T = group of 64 input features (feature n_in is a virtual column of ones -> db),
+// RC = chunk of 128 rows, 32 per wave.  Lane (lo, qd) loads x[row 4s+qd][64T + 4lo .. +3]; its
+// component e feeds accumulator e, whose M rows are the features 64T + 4i + e.
+#define SKW_ST 8
+__global__ __launch_bounds__(256) void fc_skinny_wgrad_mfma(
+    const float* __restrict__ x, const float* __restrict__ dz, float* __restrict__ slab, int B,
+    int n_in, int n_out) {
+    __shared__ float red[4][1024];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, lo = lane & 15, qd = lane >> 4;
+    const int k0 = 64 * blockIdx.x + 4 * lo;
+    const int kc = min(k0, n_in - 4);
+    const int rowbase = 128 * blockIdx.y + 32 * w;
+    const int nc = min(lo, n_out - 1);
+    float4 xv[SKW_ST];
+    float dv[SKW_ST];
+#pragma unroll
+    for (int s = 0; s < SKW_ST; ++s) {
+        const int row = rowbase + 4 * s + qd;
+        const int rc = min(row, B - 1);
+        xv[s] = *reinterpret_cast<const float4*>(x + (size_t)rc * n_in + kc);
+        dv[s] = dz[(size_t)rc * n_out + nc];
+        dv[s] = (row < B && lo < n_out) ? dv[s] : 0.f;
+    }
+    // n_in % 4 == 0: the lane's 4 columns are all real, or (ones, 0, 0, 0), or beyond
+    const bool real = k0 < n_in, ones = k0 == n_in;
+    f32x4 acc[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < SKW_ST; ++s) {
+        acc[0] = sk_mfma(real ? xv[s].x : (ones ? 1.f : 0.f), dv[s], acc[0]);
+        acc[1] = sk_mfma(real ? xv[s].y : 0.f, dv[s], acc[1]);
+        acc[2] = sk_mfma(real ? xv[s].z : 0.f, dv[s], acc[2]);
+        acc[3] = sk_mfma(real ? xv[s].w : 0.f, dv[s], acc[3]);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[w][(e * 4 + r) * 64 + lane] = acc[e][r];
+    __syncthreads();
+    // accumulator e, register r, lane (n = lo, qd): feature 64T + 4(4qd + r) + e
+    const int per = (n_in + 1) * n_out;
+    for (int t = threadIdx.x; t < 1024; t += 256) {
+        const int l = t & 63, er = t >> 6, e = er >> 2, r = er & 3;
+        const int n = l & 15, k = 64 * blockIdx.x + 4 * (4 * (l >> 4) + r) + e;
+        if (n < n_out && k <= n_in)
+            slab[(size_t)blockIdx.y * per + (size_t)k * n_out + n] =
+                ((red[0][t] + red[1][t]) + red[2][t]) + red[3][t];
+    }
+}
+
+// dW[i] / db[i - MN] = sum_z slab[z][i], fixed order
+__global__ __launch_bounds__(256) void fc_skinny_slab_reduce(const float* __restrict__ slab,
+                                                            float* __restrict__ dW,
+                                                            float* __restrict__ db, int MN, int n_out,
+                                                            int S) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int per = MN + n_out;
+    if (i >= per) return;
+    float s = 0.f;
+#pragma unroll 8
+    for (int z = 0; z < S; ++z) s += slab[(size_t)z * per + i];
+    if (i < MN) dW[i] = s; else db[i - MN] = s;
+}
+
+// ---- dgrad ----------------------------------------------------------------------------------
+// thread = 4 consecutive input features for SKD_ROWS rows; the W rows stay in registers, every
+// prev_a / mask access is one 16-byte / 4-byte load issued up front, the dz rows are wave-uniform.
+#define SKD_ROWS 8
+template <int NOUT>
+__global__ __launch_bounds__(128) void fc_skinny_dgrad_v4(
+    const float* __restrict__ dz, const float* __restrict__ W, float* __restrict__ dx, int B, int n_in,
+    const float* __restrict__ prev_a, int act, float prm, const uint8_t* __restrict__ mask) {
+    const int nq = n_in >> 2;
+    const int q = blockIdx.x * 128 + threadIdx.x;
+    const bool live = q < nq;
+    const int k = 4 * min(q, nq - 1);
+    const int row0 = blockIdx.y * SKD_ROWS;
+    // the 4 W rows of this thread are 4*NOUT consecutive floats: NOUT 16-byte loads
+    float wf[4 * NOUT];
+#pragma unroll
+    for (int i = 0; i < NOUT; ++i) {
+        const float4 v = *reinterpret_cast<const float4*>(W + (size_t)k * NOUT + 4 * i);
+        wf[4 * i] = v.x; wf[4 * i + 1] = v.y; wf[4 * i + 2] = v.z; wf[4 * i + 3] = v.w;
+    }
+    float4 pa[SKD_ROWS];
+    uint32_t pm[SKD_ROWS];
+#pragma unroll
+    for (int r = 0; r < SKD_ROWS; ++r) {
+        const size_t o = (size_t)min(row0 + r, B - 1) * n_in + k;
+        pa[r] = prev_a ? *reinterpret_cast<const float4*>(prev_a + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+        pm[r] = mask ? *reinterpret_cast<const uint32_t*>(mask + o) : 0x01010101u;
+    }
+#pragma unroll
+    for (int r = 0; r < SKD_ROWS; ++r) {
+        const int row = row0 + r;
+        const float* dzr = dz + (size_t)min(row, B - 1) * NOUT;     // wave-uniform -> scalar loads
+        float s[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int n = 0; n < NOUT; ++n) {
+            const float d = dzr[n];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s[e] = fmaf(d, wf[e * NOUT + n], s[e]);
+        }
+        if (prev_a) {
+            s[0] *= tn_act_grad_from_out(pa[r].x, act, prm);
+            s[1] *= tn_act_grad_from_out(pa[r].y, act, prm);
+            s[2] *= tn_act_grad_from_out(pa[r].z, act, prm);
+            s[3] *= tn_act_grad_from_out(pa[r].w, act, prm);
+        }
+        s[0] *= (float)(pm[r] & 0xffu);
+        s[1] *= (float)((pm[r] >> 8) & 0xffu);
+        s[2] *= (float)((pm[r] >> 16) & 0xffu);
+        s[3] *= (float)(pm[r] >> 24);
+        if (live && row < B)
+            *reinterpret_cast<float4*>(dx + (size_t)row * n_in + k) = make_float4(s[0], s[1], s[2], s[3]);
+    }
+}
+
+// ---- host side (called from the tn_fc_* entry points in gemm.hip) -------------------------------
+static bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+bool tn_fc_skinny_ok(int n_in, int n_out, const void* p0, const void* p1, const void* p2) {
+    static int enabled = -1;
+    if (enabled < 0) {
+        const char* e = getenv("TN_FC_SKINNY");
+        enabled = e ? atoi(e) : 1;
+    }
+    return enabled && n_out <= SK_MAX && n_in % 4 == 0 && n_in >= 4 && al16(p0) && (!p1 || al16(p1)) &&
+           (!p2 || ((uintptr_t)p2 & 3) == 0);
+}
+
+int tn_fc_skinny_fwd(tn_ctx* ctx, const float* x, const float* W, const float* b, float* a, int B,
+                     int n_in, int n_out, int act, float prm, const uint8_t* mask) {
+    fc_skinny_fwd_mfma<<<cdiv(B, 16), 256, 0, ctx->stream>>>(x, W, b, a, B, n_in, n_out, act, prm, mask);
+    TN_LAUNCH_CHECK();
+    return TN_OK;
+}
+
+int tn_fc_skinny_wgrad(tn_ctx* ctx, const float* x, const float* dz, float* dW, float* db, int B,
+                       int n_in, int n_out, float* ws) {
+    const int S = cdiv(B, 128);
+    fc_skinny_wgrad_mfma<<<dim3(cdiv(n_in + 1, 64), S), 256, 0, ctx->stream>>>(x, dz, ws, B, n_in, n_out);
+    TN_LAUNCH_CHECK();
+    const int per = (n_in + 1) * n_out;
+    fc_skinny_slab_reduce<<<cdiv(per, 256), 256, 0, ctx->stream>>>(ws, dW, db, n_in * n_out, n_out, S);
+    TN_LAUNCH_CHECK();
+    return TN_OK;
+}
+
+int tn_fc_skinny_dgrad(tn_ctx* ctx, const float* dz, const float* W, float* dx, int B, int n_in,
+                       int n_out, const float* prev_a, int act, float prm, const uint8_t* mask) {
+    const dim3 grid(cdiv(n_in / 4, 128), cdiv(B, SKD_ROWS));
+#define SKD_GO(N_)                                                                              \
+    case N_:                                                                                    \
+        fc_skinny_dgrad_v4<N_><<<grid, 128, 0, ctx->stream>>>(dz, W, dx, B, n_in, prev_a, act, prm, mask); \
+        break
+    switch (n_out) {
+        SKD_GO(1); SKD_GO(2); SKD_GO(3); SKD_GO(4); SKD_GO(5); SKD_GO(6); SKD_GO(7); SKD_GO(8);
+        SKD_GO(9); SKD_GO(10); SKD_GO(11); SKD_GO(12); SKD_GO(13); SKD_GO(14); SKD_GO(15);
+        default: SKD_GO(16);
+    }
+#undef SKD_GO
+    TN_LAUNCH_CHECK();
+    return TN_OK;
+}

@@ -697,11 +697,22 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
     if (grp == 0 && i < n) out[i] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
+// fc_skinny.hip: 16-byte-access kernels for n_out <= 16
+bool tn_fc_skinny_ok(int n_in, int n_out, const void* p0, const void* p1, const void* p2);
+int tn_fc_skinny_fwd(tn_ctx* ctx, const float* x, const float* W, const float* b, float* a, int B,
+                     int n_in, int n_out, int act, float prm, const uint8_t* mask);
+int tn_fc_skinny_wgrad(tn_ctx* ctx, const float* x, const float* dz, float* dW, float* db, int B,
+                       int n_in, int n_out, float* ws);
+int tn_fc_skinny_dgrad(tn_ctx* ctx, const float* dz, const float* W, float* dx, int B, int n_in,
+                       int n_out, const float* prev_a, int act, float prm, const uint8_t* mask);
+
 extern "C" {
 
 int tn_fc_fwd(tn_ctx* ctx, const float* x, const float* W, const float* b, float* a, int B, int n_in,
               int n_out, int act, float act_param, const uint8_t* mask) {
     TN_REQUIRE(B > 0 && n_in > 0 && n_out > 0, "tn_fc_fwd: bad shape");
+    if (tn_fc_skinny_ok(n_in, n_out, x, nullptr, nullptr))
+        return tn_fc_skinny_fwd(ctx, x, W, b, a, B, n_in, n_out, act, act_param, mask);
     const size_t sk_lds = (size_t)n_in * (n_out + 1) * sizeof(float);
     if (n_out <= SK_MAX && sk_lds <= 60 * 1024) {
         fc_skinny_fwd_kernel<<<cdiv(B, 8), 256, sk_lds, ctx->stream>>>(
@@ -733,6 +744,8 @@ size_t tn_fc_wgrad_ws_bytes(int B, int n_in, int n_out) {
 int tn_fc_wgrad(tn_ctx* ctx, const float* x, const float* dz, float* dW, float* db, int B, int n_in,
                 int n_out, void* ws) {
     TN_REQUIRE(B > 0 && n_in > 0 && n_out > 0 && ws != nullptr, "tn_fc_wgrad: bad arguments");
+    if (tn_fc_skinny_ok(n_in, n_out, x, nullptr, nullptr))
+        return tn_fc_skinny_wgrad(ctx, x, dz, dW, db, B, n_in, n_out, (float*)ws);
     if (n_out <= SK_MAX) {
         const int chunks = cdiv(B, SK_WROWS);
         float* wsC = (float*)ws;
@@ -778,6 +791,9 @@ int tn_fc_wgrad(tn_ctx* ctx, const float* x, const float* dz, float* dW, float* 
 int tn_fc_dgrad(tn_ctx* ctx, const float* dz, const float* W, float* dx, int B, int n_in, int n_out,
                 const float* prev_a, int prev_act, float prev_act_param, const uint8_t* prev_mask) {
     TN_REQUIRE(B > 0 && n_in > 0 && n_out > 0, "tn_fc_dgrad: bad shape");
+    if (tn_fc_skinny_ok(n_in, n_out, dx, prev_a, prev_mask))
+        return tn_fc_skinny_dgrad(ctx, dz, W, dx, B, n_in, n_out, prev_a, prev_act, prev_act_param,
+                                  prev_mask);
     if (n_out <= SK_MAX) {
         fc_skinny_dgrad_kernel<<<dim3(cdiv(n_in, 256), cdiv(B, 16)), 256, 0, ctx->stream>>>(
             dz, W, dx, B, n_in, n_out, prev_a, prev_act, prev_act_param, prev_mask);
