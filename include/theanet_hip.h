@@ -242,6 +242,12 @@ typedef struct tn_sgd_seg {
 } tn_sgd_seg;
 int tn_sgd_update_multi(tn_ctx* ctx, const tn_sgd_seg* d_segs, int nseg, size_t max_n,
                         const float* d_lr, float gscale, uint32_t* d_step_inc /* ++ if not NULL */);
+/* ... with a rider: *d_cost = cost_scale * sum(rowloss[0:nrow]) (fixed summation order), the
+ * minibatch cost tt.mean(nll) of outlayers.py:50-51, computed by one extra block of the same
+ * launch instead of a reduction kernel of its own.  rowloss == NULL: no rider.            */
+int tn_sgd_update_multi_cost(tn_ctx* ctx, const tn_sgd_seg* d_segs, int nseg, size_t max_n,
+                             const float* d_lr, float gscale, uint32_t* d_step_inc,
+                             const float* rowloss, int nrow, float cost_scale, float* d_cost);
 
 /* ---- elastic input stage (replaces ElasticLayer's graph; inlayers.py:63-144) ----
  * draws layout (float32, device): [0:2] translation u(-1,1) ; [2:4] origin u(.25,.75) ;

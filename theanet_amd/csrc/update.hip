@@ -23,10 +23,27 @@ __global__ __launch_bounds__(256) void sgd_update_kernel(float* __restrict__ p, 
 
 // all parameter tensors of the net in ONE launch: blockIdx.y selects the segment descriptor
 __global__ __launch_bounds__(256) void sgd_update_multi_kernel(const tn_sgd_seg* __restrict__ segs,
-                                                              const float* __restrict__ d_lr,
-                                                              float gscale, uint32_t* d_step_inc) {
+                                                              int nseg, const float* __restrict__ d_lr,
+                                                              float gscale, uint32_t* d_step_inc,
+                                                              const float* __restrict__ rowloss,
+                                                              int nrow, float cost_scale,
+                                                              float* __restrict__ d_cost) {
     if (d_step_inc && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
         *d_step_inc += 1;                       // the RNG step counter advances with the update
+    if ((int)blockIdx.y == nseg) {
+        // rider: the minibatch cost = cost_scale * sum(rowloss), summed in a fixed order by ONE block
+        // (saves the separate reduction launch of the step)
+        if (blockIdx.x != 0) return;
+        __shared__ float red[4];
+        float s = 0.f;
+        for (int i = threadIdx.x; i < nrow; i += 256) s += rowloss[i];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) d_cost[0] = cost_scale * ((red[0] + red[1]) + (red[2] + red[3]));
+        return;
+    }
     const tn_sgd_seg sg = segs[blockIdx.y];
     const float step = sg.rate * d_lr[0];
     float* __restrict__ p = sg.p;
@@ -106,12 +123,23 @@ int tn_sgd_update(tn_ctx* ctx, float* p, float* v, const float* g, size_t n, flo
 
 int tn_sgd_update_multi(tn_ctx* ctx, const tn_sgd_seg* d_segs, int nseg, size_t max_n,
                         const float* d_lr, float gscale, uint32_t* d_step_inc) {
-    if (nseg <= 0) return TN_OK;
-    TN_REQUIRE(d_segs != nullptr && d_lr != nullptr, "tn_sgd_update_multi: NULL argument");
+    return tn_sgd_update_multi_cost(ctx, d_segs, nseg, max_n, d_lr, gscale, d_step_inc, nullptr, 0, 0.f,
+                                    nullptr);
+}
+
+int tn_sgd_update_multi_cost(tn_ctx* ctx, const tn_sgd_seg* d_segs, int nseg, size_t max_n,
+                             const float* d_lr, float gscale, uint32_t* d_step_inc,
+                             const float* rowloss, int nrow, float cost_scale, float* d_cost) {
+    const bool rider = rowloss != nullptr;
+    if (nseg <= 0 && !rider) return TN_OK;
+    TN_REQUIRE(nseg <= 0 || (d_segs != nullptr && d_lr != nullptr), "tn_sgd_update_multi: NULL argument");
+    TN_REQUIRE(!rider || (d_cost != nullptr && nrow > 0), "tn_sgd_update_multi_cost: bad cost arguments");
+    if (nseg < 0) nseg = 0;
     int bx = cdiv(max_n, 1024);
     if (bx > 256) bx = 256;
     if (bx < 1) bx = 1;
-    sgd_update_multi_kernel<<<dim3(bx, nseg), 256, 0, ctx->stream>>>(d_segs, d_lr, gscale, d_step_inc);
+    sgd_update_multi_kernel<<<dim3(bx, nseg + (rider ? 1 : 0)), 256, 0, ctx->stream>>>(
+        d_segs, nseg, d_lr, gscale, d_step_inc, rowloss, nrow, cost_scale, d_cost);
     TN_LAUNCH_CHECK();
     return TN_OK;
 }

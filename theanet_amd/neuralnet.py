@@ -11,6 +11,7 @@ Data-parallel: one process per GPU (RANK/WORLD_SIZE from torch.distributed.run);
 rank r works on rows [i*B + r*B/R, i*B + (r+1)*B/R) of minibatch i and the flat
 gradient buffer (+ the scalar cost) is sum-all-reduced once per step over RCCL.
 """
+import os
 from functools import reduce
 from operator import mul
 
@@ -226,7 +227,7 @@ class NeuralNet():
         # ~1.5-2 us kernel boundaries are GPU-side either way) and loses ~12 % with the
         # two-stream backward, so capture is opt-in (TN_GRAPH=1)
         self.use_graph = (env == "1")
-        self.side_stream = os.environ.get("TN_SIDE", "1") == "1"
+        self.side_stream = os.environ.get("TN_SIDE", "0") == "1"   # measured: contends with the matrix-core backward
         self.elastic_ahead = os.environ.get("TN_ELASTIC_AHEAD", "0") == "1"   # measured: -2 %
         HiddenLayer.side_stream = self.side_stream
 
@@ -381,6 +382,12 @@ class NeuralNet():
                     segs.append((p.ptr, v.ptr, g.ptr, p.size, lyr.reg['momentum'], lyr.reg['rate'],
                                  lyr.reg['L1'], lyr.reg['L2']))
         self._n_segs = len(segs)
+        # the minibatch cost can ride in the update launch unless something must be added to it
+        # first (weight costs) or it has to travel through the all-reduce (data-parallel ranks)
+        has_wtcost = any(getattr(l, 'reg', None) and l.params and (l.reg['L1'] or l.reg['L2'])
+                         for l in self.tr_layers)
+        self._cost_rider = (not has_wtcost) and self.world.size == 1 and \
+            os.environ.get("TN_COST_RIDER", "1") != "0"
         self._max_seg = max([sg[3] for sg in segs] or [0])
         if segs:
             host = np.array(segs, dtype=seg_dt)
@@ -421,16 +428,18 @@ class NeuralNet():
                 joined = True
             lyr.forward(True)
         out.forward(True, y=y, y_row0=y_row0, d_row0=d_row0)
-        # cost = -mean logprob[n, y_n] (this rank's share of the global mean): a leaf reduction,
-        # so it runs on the side stream while the backward chain proceeds (a returning-atomic
-        # "last block" fusion into the softmax kernel measured 3x slower: 1024 tickets on one word)
-        if self.side_stream:
-            ctx.call("tn_stream_wait", 1, 0)
-            ctx.call("tn_stream_select", 1)
-        ctx.call("tn_reduce_sum", out.rowloss.ptr, self.local_bsz, 1.0 / self.batch_sz,
-                 self.d_cost.ptr, 0)
-        if self.side_stream:
-            ctx.call("tn_stream_select", 0)
+        # cost = -mean logprob[n, y_n] (this rank's share of the global mean).  Without weight
+        # costs it rides in the update launch at the end of the step (tn_sgd_update_multi_cost);
+        # with them it must exist before tn_wtcost accumulates onto it: a leaf reduction here.
+        rider = self._cost_rider
+        if not rider:
+            if self.side_stream:
+                ctx.call("tn_stream_wait", 1, 0)
+                ctx.call("tn_stream_select", 1)
+            ctx.call("tn_reduce_sum", out.rowloss.ptr, self.local_bsz, 1.0 / self.batch_sz,
+                     self.d_cost.ptr, 0)
+            if self.side_stream:
+                ctx.call("tn_stream_select", 0)
         g = out.dlogits
         for idx in range(len(self.tr_layers) - 1, -1, -1):
             lyr = self.tr_layers[idx]
@@ -443,9 +452,11 @@ class NeuralNet():
             self._group().allreduce_sum(self.flat_grads, self.n_flat)
         for lyr in self.tr_layers:
             lyr.get_wtcost(self.d_cost)
-        if self._n_segs:                          # also advances the RNG step counter
-            ctx.call("tn_sgd_update_multi", self._d_segs.ptr, self._n_segs, self._max_seg,
-                     self.cur_learn_rate.ptr, 1.0, self.d_step.ptr)
+        if self._n_segs or rider:                 # also advances the RNG step counter
+            ctx.call("tn_sgd_update_multi_cost", self._d_segs.ptr if self._n_segs else None,
+                     self._n_segs, self._max_seg, self.cur_learn_rate.ptr, 1.0, self.d_step.ptr,
+                     out.rowloss.ptr if rider else None, self.local_bsz, 1.0 / self.batch_sz,
+                     self.d_cost.ptr if rider else None)
         else:
             ctx.call("tn_add_u32", self.d_step.ptr, 1)
         for lyr in self.tr_layers:
