@@ -267,6 +267,13 @@ int tn_elastic_field(tn_ctx* ctx, const float* draws, int h, int w,
  * if given, else Philox(seed, step, global element index) < pflip, else none (pflip=0).
  * x rows are read at x_row0 + (d_row0 ? *d_row0 : 0) + n ; row_global0 is the global
  * index of the first row (for sharding-independent noise).  map_idx == NULL -> identity. */
+/* tn_elastic_draws + tn_elastic_field in ONE launch: every block regenerates the (tiny) draws in
+ * LDS from Philox (seed, step [+ *d_step]); draws_out (may be NULL for h*w small enough to fit
+ * LDS) receives the same values tn_elastic_draws would have written.                         */
+int tn_elastic_field_gen(tn_ctx* ctx, float* draws_out, uint64_t seed, uint32_t step,
+                         const uint32_t* d_step, int h, int w, double translation, double zoom,
+                         double magnitude, int sigma, double angle, int nearest, int32_t* map_idx,
+                         float* map_fy, float* map_fx, double* target);
 int tn_elastic_apply(tn_ctx* ctx, const float* x, int64_t x_row0, const int64_t* d_row0,
                      float* out, int N, int C, int h, int w, int invert, int nearest,
                      const int32_t* map_idx, const float* map_fy, const float* map_fx,

@@ -133,3 +133,47 @@ def test_deformer_device_rng_batch():
     out2 = empty((8, 28, 28))
     call("tn_deformer_transform", dev(imgs[8:16]).ptr, out2.ptr, 8, 28, 28, 3.0, 2.0, 0.0, None, 11, 8)
     np.testing.assert_array_equal(out2.get_value(), a[8:16])          # keyed by global image index
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hw,nearest,sigma", [(28, 1, 15), (13, 0, 4), (32, 1, 2)])
+def test_elastic_field_gen_equals_two_launches(hw, nearest, sigma):
+    """tn_elastic_field_gen (draws generated inside the field launch) is bit-identical to
+    tn_elastic_draws followed by tn_elastic_field, and the 4-wide apply equals the scalar one."""
+    h = w = hw
+    lib = ctx().lib
+    n = lib.tn_elastic_draws_count(h, w)
+    seed, step = 0x1234_5678_9abc, 7
+    prm = dict(translation=2.0, zoom=1.1, magnitude=60.0, sigma=sigma, angle=5.0)
+    outs = []
+    for fused in (False, True):
+        draws = empty((n,))
+        mi, fy, fx = empty((h * w,), np.int32), empty((h * w,)), empty((h * w,))
+        tgt = empty((2 * h * w,), np.float64)
+        args = (h, w, prm["translation"], prm["zoom"], prm["magnitude"], prm["sigma"], prm["angle"],
+                nearest, mi.ptr, fy.ptr, fx.ptr, tgt.ptr)
+        if fused:
+            call("tn_elastic_field_gen", draws.ptr, seed, step, None, *args)
+        else:
+            call("tn_elastic_draws", draws.ptr, h, w, seed, step, None)
+            call("tn_elastic_field", draws.ptr, *args)
+        outs.append((draws.get_value(), mi.get_value(), tgt.get_value(),
+                     fy.get_value() if not nearest else None, mi, fy, fx))
+    a, b = outs
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    if not nearest:
+        assert np.array_equal(a[3], b[3])
+    # apply: odd pixel offset forces the scalar kernel (unaligned out), aligned call takes the 4-wide one
+    N, C = 5, 2
+    rng = np.random.RandomState(hw)
+    x = rng.rand(N + 1, C, h, w).astype(np.float32)
+    xd = dev(x)
+    mi, fy, fx = b[4], b[5], b[6]
+    out4 = empty((N, C, h, w))
+    call("tn_elastic_apply", xd.ptr, 1, None, out4.ptr, N, C, h, w, 1, nearest, mi.ptr, fy.ptr, fx.ptr,
+         0.03, None, seed, step, None, 3)
+    big = empty((N * C * h * w + 1,))
+    out1 = big.view(1, (N, C, h, w))
+    call("tn_elastic_apply", xd.ptr, 1, None, out1.ptr, N, C, h, w, 1, nearest, mi.ptr, fy.ptr, fx.ptr,
+         0.03, None, seed, step, None, 3)
+    assert np.array_equal(out4.get_value(), big.get_value()[1:].reshape(N, C, h, w))

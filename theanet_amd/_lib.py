@@ -85,6 +85,8 @@ SIGNATURES = {
     "tn_elastic_draws": (c_int, [CTX, P, c_int, c_int, c_uint64, c_uint32, P]),
     "tn_elastic_field": (c_int, [CTX, P, c_int, c_int, c_double, c_double, c_double, c_int, c_double,
                                  c_int, P, P, P, P]),
+    "tn_elastic_field_gen": (c_int, [CTX, P, c_uint64, c_uint32, P, c_int, c_int, c_double, c_double,
+                                     c_double, c_int, c_double, c_int, P, P, P, P]),
     "tn_elastic_apply": (c_int, [CTX, P, c_int64, P, P, c_int, c_int, c_int, c_int, c_int, c_int,
                                  P, P, P, c_float, P, c_uint64, c_uint32, P, c_int64]),
     "tn_deformer_transform": (c_int, [CTX, P, P, c_int, c_int, c_int, c_double, c_double, c_double,

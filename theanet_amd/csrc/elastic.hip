@@ -8,35 +8,54 @@
 
 #define EL_HDR 8   // draws: [0:2] transln, [2:4] origin, [4:6] zoom, [6] theta, [7] pad, [8:] noise
 
+__device__ __forceinline__ float elastic_draw(int i, uint32_t st, uint32_t k0, uint32_t k1) {
+    const u32x4 r = philox4x32((uint32_t)i, 0u, st, TN_STREAM_ELASTIC, k0, k1);
+    if (i < EL_HDR) {
+        const float u = tn_u01(r.x);
+        if (i == 2 || i == 3) return .25f + .5f * u;   // origin  U(.25,.75)
+        return -1.f + 2.f * u;                         // U(-1,1)
+    }
+    // N(0,1), Box-Muller
+    const float u1 = ((r.x >> 8) + 1) * (1.0f / 16777216.0f);
+    const float u2 = tn_u01(r.y);
+    return sqrtf(-2.f * logf(u1)) * cosf(6.28318530717958647692f * u2);
+}
+
 __global__ __launch_bounds__(256) void elastic_draws_kernel(float* __restrict__ draws, int total,
                                                            uint32_t k0, uint32_t k1, uint32_t step,
                                                            const uint32_t* d_step) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
     const uint32_t st = step + (d_step ? *d_step : 0u);
-    const u32x4 r = philox4x32((uint32_t)i, 0u, st, TN_STREAM_ELASTIC, k0, k1);
-    float v;
-    if (i < EL_HDR) {
-        const float u = tn_u01(r.x);
-        if (i == 2 || i == 3) v = .25f + .5f * u;   // origin  U(.25,.75)
-        else v = -1.f + 2.f * u;                    // U(-1,1)
-    } else {                                         // N(0,1), Box-Muller
-        const float u1 = ((r.x >> 8) + 1) * (1.0f / 16777216.0f);
-        const float u2 = tn_u01(r.y);
-        v = sqrtf(-2.f * logf(u1)) * cosf(6.28318530717958647692f * u2);
-    }
-    draws[i] = v;
+    draws[i] = elastic_draw(i, st, k0, k1);
 }
 
 // one 64-lane WAVE per output pixel (4 pixels per block): the lanes split the (2s+1)^2 taps of
 // the gaussian, so the 31x31 smoothing of mnist.prms is ~15 taps per lane instead of a
 // 961-tap serial loop; lane 0 then applies translation / zoom / rotation / clipping.
+// GEN: the draws are not read but generated -- every block fills its own LDS copy (a few Philox
+// calls per thread), block 0 also stores them to draws_out: saves the separate draws launch.
+template <bool GEN>
 __global__ __launch_bounds__(256) void elastic_field_kernel(
-    const float* __restrict__ draws, int h, int w, double translation, double zoom, double magnitude,
-    int sigma, double angle, int nearest, int32_t* __restrict__ map_idx, float* __restrict__ map_fy,
-    float* __restrict__ map_fx, double* __restrict__ target) {
-    extern __shared__ float filt[];   // (2s+1)^2, float32 like the reference's filter
+    const float* __restrict__ draws_in, float* __restrict__ draws_out, uint32_t k0, uint32_t k1,
+    uint32_t step, const uint32_t* __restrict__ d_step, int h, int w, double translation, double zoom,
+    double magnitude, int sigma, double angle, int nearest, int32_t* __restrict__ map_idx,
+    float* __restrict__ map_fy, float* __restrict__ map_fx, double* __restrict__ target) {
+    extern __shared__ float filt[];   // (2s+1)^2, float32 like the reference's filter [+ the draws]
     const int ks = 2 * sigma + 1;
+    const float* draws = draws_in;
+    if (GEN) {
+        float* sd = filt + ks * ks;
+        const uint32_t st = step + (d_step ? *d_step : 0u);
+        const int total = EL_HDR + 2 * h * w;
+        for (int i = threadIdx.x; i < total; i += 256) {
+            const float v = elastic_draw(i, st, k0, k1);
+            sd[i] = v;
+            if (draws_out && blockIdx.x == 0) draws_out[i] = v;
+        }
+        draws = sd;
+        if (magnitude == 0.0) __syncthreads();
+    }
     if (magnitude != 0.0) {
         const double var = (double)sigma * sigma;
         const float norm = (float)(2.0 * 3.14159265358979323846 * var);
@@ -161,6 +180,72 @@ __global__ __launch_bounds__(256) void elastic_apply_kernel(
     out[t] = v;
 }
 
+// The same gather, 4 consecutive output pixels per thread (h*w % 4 == 0): one 16-byte map load,
+// one Philox call (the 4 flip draws of an aligned quad share a counter) and one 16-byte store.
+__global__ __launch_bounds__(256) void elastic_apply4_kernel(
+    const float* __restrict__ x, int64_t x_row0, const int64_t* __restrict__ d_row0,
+    float* __restrict__ out, long long total4, int C, int hw, int w, int invert, int nearest,
+    const int32_t* __restrict__ map_idx, const float* __restrict__ map_fy,
+    const float* __restrict__ map_fx, float pflip, const uint8_t* __restrict__ flipmask, uint32_t k0,
+    uint32_t k1, uint32_t step, const uint32_t* d_step, int64_t row_global0) {
+    const long long t4 = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t4 >= total4) return;
+    const long long t = t4 * 4;
+    const long long img = t / hw;              // n*C + c
+    const int p = (int)(t - img * hw);
+    const int64_t row_off = x_row0 + (d_row0 ? *d_row0 : 0);
+    const float* xi = x + ((size_t)row_off * C + img) * hw;
+    float v[4];
+    if (!map_idx) {
+        const float4 q = *reinterpret_cast<const float4*>(xi + p);
+        v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+    } else {
+        const int4 mi = *reinterpret_cast<const int4*>(map_idx + p);
+        const int m[4] = {mi.x, mi.y, mi.z, mi.w};
+        if (nearest) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = xi[m[e]];
+        } else {
+            const float4 fy4 = *reinterpret_cast<const float4*>(map_fy + p);
+            const float4 fx4 = *reinterpret_cast<const float4*>(map_fx + p);
+            const float fy[4] = {fy4.x, fy4.y, fy4.z, fy4.w}, fx[4] = {fx4.x, fx4.y, fx4.z, fx4.w};
+            float a[4], b[4], c[4], d[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                a[e] = xi[m[e]]; b[e] = xi[m[e] + 1]; c[e] = xi[m[e] + w]; d[e] = xi[m[e] + w + 1];
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (invert) {
+                    a[e] = 1.f - a[e]; b[e] = 1.f - b[e]; c[e] = 1.f - c[e]; d[e] = 1.f - d[e];
+                }
+                // same association as inlayers.py:134-137
+                v[e] = a[e] * (1.f - fy[e]) * (1.f - fx[e]) + b[e] * (1.f - fy[e]) * fx[e] +
+                       c[e] * fy[e] * (1.f - fx[e]) + d[e] * fy[e] * fx[e];
+            }
+        }
+    }
+    if (invert && (!map_idx || nearest)) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = 1.f - v[e];
+    }
+    if (flipmask) {
+        const uint32_t fm = *reinterpret_cast<const uint32_t*>(flipmask + t);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if ((fm >> (8 * e)) & 0xffu) v[e] = 1.f - v[e];
+    } else if (pflip > 0.f) {
+        const uint32_t st = step + (d_step ? *d_step : 0u);
+        const uint64_t cq = ((uint64_t)row_global0 * C * hw + (uint64_t)t) >> 2;
+        const u32x4 r = philox4x32((uint32_t)cq, (uint32_t)(cq >> 32), st, TN_STREAM_FLIP, k0, k1);
+        if (tn_u01(r.x) < pflip) v[0] = 1.f - v[0];
+        if (tn_u01(r.y) < pflip) v[1] = 1.f - v[1];
+        if (tn_u01(r.z) < pflip) v[2] = 1.f - v[2];
+        if (tn_u01(r.w) < pflip) v[3] = 1.f - v[3];
+    }
+    *reinterpret_cast<float4*>(out + t) = make_float4(v[0], v[1], v[2], v[3]);
+}
+
 // ---- extras/deformer.py:7-18, one block per image, float64 like scipy -------------------
 __global__ __launch_bounds__(256) void deformer_kernel(const float* __restrict__ imgs,
                                                       float* __restrict__ out, int h, int w,
@@ -258,9 +343,32 @@ int tn_elastic_field(tn_ctx* ctx, const float* draws, int h, int w, double trans
     const int ks = 2 * sigma + 1;
     const size_t lds = (size_t)ks * ks * sizeof(float);
     TN_REQUIRE(lds <= 64 * 1024, "tn_elastic_field: sigma %d too large", sigma);
-    elastic_field_kernel<<<cdiv(h * w, 4), 256, lds, ctx->stream>>>(
-        draws, h, w, translation, zoom, magnitude, sigma, angle, nearest, map_idx, map_fy, map_fx,
-        target);
+    elastic_field_kernel<false><<<cdiv(h * w, 4), 256, lds, ctx->stream>>>(
+        draws, nullptr, 0u, 0u, 0u, nullptr, h, w, translation, zoom, magnitude, sigma, angle, nearest,
+        map_idx, map_fy, map_fx, target);
+    TN_LAUNCH_CHECK();
+    return TN_OK;
+}
+
+int tn_elastic_field_gen(tn_ctx* ctx, float* draws_out, uint64_t seed, uint32_t step,
+                         const uint32_t* d_step, int h, int w, double translation, double zoom,
+                         double magnitude, int sigma, double angle, int nearest, int32_t* map_idx,
+                         float* map_fy, float* map_fx, double* target) {
+    TN_REQUIRE(h > 0 && w > 0 && zoom > 0 && sigma >= 0 && map_idx != nullptr,
+               "tn_elastic_field_gen: bad arguments");
+    TN_REQUIRE(nearest || (map_fy && map_fx), "tn_elastic_field_gen: bilinear needs map_fy/map_fx");
+    const int ks = 2 * sigma + 1;
+    const size_t lds = ((size_t)ks * ks + tn_elastic_draws_count(h, w)) * sizeof(float);
+    if (lds > 64 * 1024) {      // big images: two launches
+        TN_REQUIRE(draws_out != nullptr, "tn_elastic_field_gen: %dx%d needs a draws buffer", h, w);
+        int rc = tn_elastic_draws(ctx, draws_out, h, w, seed, step, d_step);
+        if (rc) return rc;
+        return tn_elastic_field(ctx, draws_out, h, w, translation, zoom, magnitude, sigma, angle,
+                                nearest, map_idx, map_fy, map_fx, target);
+    }
+    elastic_field_kernel<true><<<cdiv(h * w, 4), 256, lds, ctx->stream>>>(
+        nullptr, draws_out, (uint32_t)seed, (uint32_t)(seed >> 32), step, d_step, h, w, translation,
+        zoom, magnitude, sigma, angle, nearest, map_idx, map_fy, map_fx, target);
     TN_LAUNCH_CHECK();
     return TN_OK;
 }
@@ -271,6 +379,15 @@ int tn_elastic_apply(tn_ctx* ctx, const float* x, int64_t x_row0, const int64_t*
                      uint64_t seed, uint32_t step, const uint32_t* d_step, int64_t row_global0) {
     TN_REQUIRE(N > 0 && C > 0 && h > 0 && w > 0, "tn_elastic_apply: bad shape");
     const long long total = (long long)N * C * h * w;
+    const bool al = (((uintptr_t)x | (uintptr_t)out | (uintptr_t)map_idx | (uintptr_t)map_fy |
+                      (uintptr_t)map_fx) & 15) == 0 && ((uintptr_t)flipmask & 3) == 0;
+    if ((h * w) % 4 == 0 && al) {
+        elastic_apply4_kernel<<<cdiv(total / 4, 256), 256, 0, ctx->stream>>>(
+            x, x_row0, d_row0, out, total / 4, C, h * w, w, invert, nearest, map_idx, map_fy, map_fx,
+            pflip, flipmask, (uint32_t)seed, (uint32_t)(seed >> 32), step, d_step, row_global0);
+        TN_LAUNCH_CHECK();
+        return TN_OK;
+    }
     elastic_apply_kernel<<<cdiv(total, 256), 256, 0, ctx->stream>>>(
         x, x_row0, d_row0, out, total, C, h * w, w, invert, nearest, map_idx, map_fy, map_fx, pflip,
         flipmask, (uint32_t)seed, (uint32_t)(seed >> 32), step, d_step, row_global0);

@@ -176,9 +176,14 @@ class ElasticLayer(Layer):
             if ahead and self._pre_valid:
                 self.ctx.call("tn_stream_wait", 0, 1)        # the side stream built this map
             else:
-                if not self._inj_draws:
-                    self.ctx.call("tn_elastic_draws", self.draws.ptr, h, w, self.seed, 0, d_step_ptr)
-                self._field(self._maps[self._cur])
+                if not self._inj_draws:      # draws generated inside the field launch
+                    m = self._maps[self._cur]
+                    self.ctx.call("tn_elastic_field_gen", self.draws.ptr, self.seed, 0, d_step_ptr,
+                                  h, w, float(self.translation), float(self.zoom),
+                                  float(self.magnitude), int(self.sigma), float(self.angle),
+                                  int(self.nearest), m[0].ptr, m[1].ptr, m[2].ptr, m[3].ptr)
+                else:
+                    self._field(self._maps[self._cur])
             self._pre_valid = False
         self.ctx.call("tn_elastic_apply", x_ptr, row0, d_row0_ptr, self.output.ptr,
                       self.batch_sz, self.num_maps, h, w, int(self.invert), int(self.nearest),
