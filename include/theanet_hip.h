@@ -223,6 +223,13 @@ int tn_wtcost(tn_ctx* ctx, const float* p, size_t n, float L1, float L2, float* 
 int tn_error_stats(tn_ctx* ctx, const int32_t* pred, const int32_t* y, int64_t y_row0,
                    const float* rowp, int B, float* out2);
 
+/* ---- finishing reductions of the weight-gradient ops ----
+ * tn_conv2d_wgrad, tn_convpool_bwd*, tn_convblock_bwd* and tn_fc_wgrad end with a fixed-order sum
+ * of partial slabs.  Between tn_defer_reductions(ctx, 1) and tn_defer_reductions(ctx, 0) those
+ * sums are only recorded; the closing call runs all of them as ONE launch (dW/db are valid after
+ * it, in stream order).  Outside such a window every op finishes its own gradient.          */
+int tn_defer_reductions(tn_ctx* ctx, int on);
+
 /* ---- momentum SGD + maxnorm (replaces Layer.get_updates; layer.py:70-107) ----
  * g' = g*gscale + L1*sign(p) + 2*L2*p ; v_new = m*v + (1-m)*g' ; p_new = p - rate*lr*v_OLD
  * (simultaneous Theano update: the OLD velocity moves p).  lr is read from *d_lr.

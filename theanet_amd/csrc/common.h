@@ -10,6 +10,14 @@
 
 #include "../../include/theanet_hip.h"
 
+// one finishing reduction out[i] = sum_{s<S} src[s*stride + i] (reduce.hip)
+#define TN_RED_MAX 12
+struct tn_red_rec {
+    const float* src;
+    float* out;
+    uint32_t n, S, stride, flip;
+};
+
 struct tn_ctx {
     int device = 0;
     hipStream_t stream = nullptr;          // the stream ops are currently issued on
@@ -24,7 +32,18 @@ struct tn_ctx {
     // small persistent scratch (reductions)
     float* scratch = nullptr;
     size_t scratch_bytes = 0;
+    // deferred finishing reductions (reduce.hip)
+    bool defer = false;
+    size_t scratch_off = 0;
+    int npend = 0;
+    tn_red_rec pend[TN_RED_MAX];
 };
+
+int tn_scratch_get(tn_ctx* ctx, size_t bytes, float** out);
+int tn_red_push(tn_ctx* ctx, const float* src, float* out, uint32_t n, uint32_t S, uint32_t stride,
+                uint32_t flip);
+int tn_red_commit(tn_ctx* ctx);
+int tn_red_flush(tn_ctx* ctx);
 
 extern char g_tn_err[512];
 

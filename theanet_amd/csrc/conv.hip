@@ -200,34 +200,6 @@ __global__ __launch_bounds__(256) void conv_bgrad_generic(const float* __restric
     if (threadIdx.x == 0) db[k] = red[0] + red[1] + red[2] + red[3];
 }
 
-// reduce partials over blocks: one 256-thread block per output element, fixed strided order ->
-// deterministic; flip (u,v) -> (f-1-u, f-1-v)
-__global__ __launch_bounds__(256) void conv_wgrad_finish(const float* __restrict__ partial,
-                                                        const float* __restrict__ dbpartial,
-                                                        float* __restrict__ dW, float* __restrict__ db,
-                                                        int nblk, int K, int C, int f) {
-    __shared__ float red[4];
-    const int ff = f * f;
-    const int KCFF = K * C * ff;
-    const int t = blockIdx.x;
-    const float* src = (t < KCFF) ? partial + t : dbpartial + (t - KCFF);
-    const int stride = (t < KCFF) ? KCFF : K;
-    float s = 0.f;
-    for (int bk = threadIdx.x; bk < nblk; bk += 256) s += src[(size_t)bk * stride];
-    s = wave_sum_f(s);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const float r = red[0] + red[1] + red[2] + red[3];
-        if (t < KCFF) {
-            const int uv = t % ff, kc = t / ff;
-            const int u = uv / f, v = uv % f;
-            dW[(size_t)kc * ff + (f - 1 - u) * f + (f - 1 - v)] = r;
-        } else {
-            db[t - KCFF] = r;
-        }
-    }
-}
 
 // ------------------------------------------------------------------------------------
 // dgrad: dx[n,c,y,x] = sum_{k,u,v} dz[n,k,(y+pad-u)/s,(x+pad-v)/s] * W[k,c,f-1-u,f-1-v]
@@ -387,18 +359,6 @@ __global__ __launch_bounds__(256) void conv_dgrad_lds(
 }
 
 // ------------------------------------------------------------------------------------
-int tn_ensure_scratch(tn_ctx* ctx, size_t bytes) {
-    if (bytes <= ctx->scratch_bytes) return TN_OK;
-    TN_HIP(hipStreamSynchronize(ctx->stream));
-    if (ctx->scratch) TN_HIP(hipFree(ctx->scratch));
-    ctx->scratch = nullptr;
-    ctx->scratch_bytes = 0;
-    size_t nb = bytes + (bytes >> 2);
-    hipError_t e = hipMalloc((void**)&ctx->scratch, nb);
-    if (e != hipSuccess) return tn_fail(ctx, TN_E_NOMEM, "scratch hipMalloc(%zu) failed", nb);
-    ctx->scratch_bytes = nb;
-    return TN_OK;
-}
 
 // MFMA implicit-GEMM path (conv_mfma.hip)
 int tn_conv_mfma_fwd(tn_ctx* ctx, const float* x, const float* W, const float* b, float* a, int N,
@@ -412,10 +372,13 @@ extern "C" int tn_conv_mfma_supported(int C, int K, int f, int stride);
 
 int tn_conv_wgrad_finish(tn_ctx* ctx, const float* partial, const float* dbpartial, float* dW,
                          float* db, int nblk, int K, int C, int f) {
-    const int outs = K * C * f * f + K;
-    conv_wgrad_finish<<<outs, 256, 0, ctx->stream>>>(partial, dbpartial, dW, db, nblk, K, C, f);
-    TN_LAUNCH_CHECK();
-    return TN_OK;
+    // slabs are in correlation layout: the sum flips every f x f block back (reduce.hip)
+    int rc = tn_red_push(ctx, partial, dW, (uint32_t)(K * C * f * f), (uint32_t)nblk,
+                         (uint32_t)(K * C * f * f), (uint32_t)(f * f));
+    if (rc) return rc;
+    rc = tn_red_push(ctx, dbpartial, db, (uint32_t)K, (uint32_t)nblk, (uint32_t)K, 0);
+    if (rc) return rc;
+    return tn_red_commit(ctx);
 }
 
 extern "C" {
@@ -457,10 +420,10 @@ int tn_conv2d_wgrad(tn_ctx* ctx, const float* x, const float* dz, float* dW, flo
         if (nblk < 1) nblk = 1;
         const size_t KCFF = (size_t)K * C * f * f;
         const size_t need = ((size_t)nblk * (KCFF + K)) * sizeof(float);
-        int rc = tn_ensure_scratch(ctx, need);
+        float* partial;
+        int rc = tn_scratch_get(ctx, need, &partial);
         if (rc) return rc;
-        float* partial = ctx->scratch;
-        float* dbpartial = ctx->scratch + (size_t)nblk * KCFF;
+        float* dbpartial = partial + (size_t)nblk * KCFF;
 #define LAUNCH_WG(F_, KT_, CT_)                                                                  \
     conv_wgrad_direct<F_, KT_, CT_><<<dim3(nblk, cdiv(K, KT_), cdiv(C, CT_)), 256, 0, ctx->stream>>>( \
         x, dz, partial, dbpartial, N, C, H, Wd, K, stride, pad_lo, Ho, Wo)

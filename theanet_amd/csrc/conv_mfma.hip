@@ -24,7 +24,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define CM_BK 16
 #define CM_LDK 20
 
-int tn_ensure_scratch(tn_ctx* ctx, size_t bytes);
 
 struct ConvMG {
     const float* x;        // gathered operand source (N, C, H, Wd)
@@ -389,9 +388,9 @@ int tn_conv_mfma_dgrad(tn_ctx* ctx, const float* dz, const float* W, float* dx, 
                        float prm) {
     // dx = conv_fwd(dz, Wt) with padding f-1-pad: gathered tensor = dz (N,K,Ho,Wo), rows = C maps
     const size_t wt_bytes = (size_t)K * C * f * f * sizeof(float);
-    int rc = tn_ensure_scratch(ctx, wt_bytes);
+    float* Wt;
+    int rc = tn_scratch_get(ctx, wt_bytes, &Wt);
     if (rc) return rc;
-    float* Wt = ctx->scratch;
     conv_wt_kernel<<<cdiv((long long)K * C * f * f, 256), 256, 0, ctx->stream>>>(W, Wt, K, C, f);
     TN_LAUNCH_CHECK();
     ConvMG g{};
@@ -422,10 +421,9 @@ int tn_conv_mfma_wgrad(tn_ctx* ctx, const float* x, const float* dz, float* dW, 
     g.S = S;
     g.mchunk = cdiv(cdiv(g.M, S), CM_BK) * CM_BK;
     const size_t n = (size_t)K * g.Kd;
-    int rc = tn_ensure_scratch(ctx, ((size_t)S * n + (size_t)S * K) * sizeof(float));
+    int rc = tn_scratch_get(ctx, ((size_t)S * n + (size_t)S * K) * sizeof(float), &g.ws);
     if (rc) return rc;
-    g.ws = ctx->scratch;
-    g.dbws = ctx->scratch + (size_t)S * n;
+    g.dbws = g.ws + (size_t)S * n;
     const int grid = S * g.KT * g.MT;
     if (pad > 0 || Ho + f - 1 > H || Wo + f - 1 > Wd)
         conv_mfma_wgrad_kernel<true><<<grid, 256, 0, ctx->stream>>>(g);

@@ -19,7 +19,6 @@
 
 int tn_conv_wgrad_finish(tn_ctx* ctx, const float* partial, const float* dbpartial, float* dW,
                          float* db, int nblk, int K, int C, int f);
-int tn_ensure_scratch(tn_ctx* ctx, size_t bytes);
 // convblock_mfma.hip: matrix-core variant of the same backward
 int tn_convblock_mfma_supported(int C, int K, int f, int stride, int p, int H, int Wd, int pad_lo,
                                 int Ho, int Wo, int Hp, int Wp);
@@ -286,10 +285,10 @@ static int launch_cb(tn_ctx* ctx, const float* x, const float* W, const float* b
     if (nblk > ngroups) nblk = ngroups;
     const size_t KCFF = (size_t)q.K * C * F * F;
     const int nslab = nblk * q.G;
-    int rc = tn_ensure_scratch(ctx, (size_t)nslab * (KCFF + q.K) * sizeof(float));
+    float* partial;
+    int rc = tn_scratch_get(ctx, (size_t)nslab * (KCFF + q.K) * sizeof(float), &partial);
     if (rc) return rc;
-    float* partial = ctx->scratch;
-    float* dbpartial = ctx->scratch + (size_t)nslab * KCFF;
+    float* dbpartial = partial + (size_t)nslab * KCFF;
     if (act == TN_ACT_LEAKY) {
         auto kern = convblock_bwd_lds<F, C, TN_ACT_LEAKY>;
         static size_t set_for = 0;      // the attribute call is not a stream op: do it once per size

@@ -26,7 +26,6 @@
 
 int tn_conv_wgrad_finish(tn_ctx* ctx, const float* partial, const float* dbpartial, float* dW,
                          float* db, int nblk, int K, int C, int f);
-int tn_ensure_scratch(tn_ctx* ctx, size_t bytes);
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -683,10 +682,10 @@ static int launch_cm(tn_ctx* ctx, const float* x, const float* W, const float* b
     int nblk = 2 * ctx->num_cus;
     if (nblk > cdiv(q.N, 4)) nblk = cdiv(q.N, 4);
     const size_t KCFF = (size_t)q.K * C * 9;
-    int rc = tn_ensure_scratch(ctx, (size_t)nblk * (KCFF + q.K) * sizeof(float));
+    float* partial;
+    int rc = tn_scratch_get(ctx, (size_t)nblk * (KCFF + q.K) * sizeof(float), &partial);
     if (rc) return rc;
-    float* partial = ctx->scratch;
-    float* dbpartial = ctx->scratch + (size_t)nblk * KCFF;
+    float* dbpartial = partial + (size_t)nblk * KCFF;
     if (act == TN_ACT_LEAKY) {
         auto kern = convblock_bwd_mfma<C, KS2, TN_ACT_LEAKY>;
         static size_t set_for = 0;      // the attribute call is not a stream op: do it once per size
@@ -719,10 +718,10 @@ static int launch_cm_mask(tn_ctx* ctx, const float* x, const float* W, const flo
     int nblk = 2 * ctx->num_cus;
     if (nblk > cdiv(q.N, 4)) nblk = cdiv(q.N, 4);
     const size_t KCFF = (size_t)q.K * C * 9;
-    int rc = tn_ensure_scratch(ctx, (size_t)nblk * (KCFF + q.K) * sizeof(float));
+    float* partial;
+    int rc = tn_scratch_get(ctx, (size_t)nblk * (KCFF + q.K) * sizeof(float), &partial);
     if (rc) return rc;
-    float* partial = ctx->scratch;
-    float* dbpartial = ctx->scratch + (size_t)nblk * KCFF;
+    float* dbpartial = partial + (size_t)nblk * KCFF;
     float* tdbg = (q.dbg & 16) ? db : nullptr;
     if (act == TN_ACT_LEAKY) {
         auto kern = convblock_bwd_mask_mfma<C, KS2, TN_ACT_LEAKY>;

@@ -381,7 +381,6 @@ __global__ __launch_bounds__(256) void convpool_bwd_mask_kernel(
 // shared with conv.hip
 int tn_conv_wgrad_finish(tn_ctx* ctx, const float* partial, const float* dbpartial, float* dW,
                          float* db, int nblk, int K, int C, int f);
-int tn_ensure_scratch(tn_ctx* ctx, size_t bytes);
 
 template <int F, int P, int C>
 static int launch_fwd(tn_ctx* ctx, const float* x, const float* W, const float* b, float* y,
@@ -429,10 +428,10 @@ static int launch_bwd(tn_ctx* ctx, const float* x, const float* W, const float* 
     if (nblk > 2048) nblk = 2048;
     if (nblk < 1) nblk = 1;
     const size_t KCFF = (size_t)K * C * F * F;
-    int rc = tn_ensure_scratch(ctx, (size_t)nblk * (KCFF + K) * sizeof(float));
+    float* partial;
+    int rc = tn_scratch_get(ctx, (size_t)nblk * (KCFF + K) * sizeof(float), &partial);
     if (rc) return rc;
-    float* partial = ctx->scratch;
-    float* dbpartial = ctx->scratch + (size_t)nblk * KCFF;
+    float* dbpartial = partial + (size_t)nblk * KCFF;
     TN_REQUIRE(total < (1ll << 31), "tn_convpool_bwd: too many outputs for 32-bit indexing");
     const dim3 grid(nblk, cdiv(K, KT));
 #define CP_L(ACT_, PAD_)                                                                          \
@@ -467,10 +466,10 @@ static int launch_bwd_mask(tn_ctx* ctx, const float* x, const float* g, const fl
     if (nblk > 2048) nblk = 2048;
     if (nblk < 1) nblk = 1;
     const size_t KCFF = (size_t)K * C * 9;
-    int rc = tn_ensure_scratch(ctx, (size_t)nblk * (KCFF + K) * sizeof(float));
+    float* partial;
+    int rc = tn_scratch_get(ctx, (size_t)nblk * (KCFF + K) * sizeof(float), &partial);
     if (rc) return rc;
-    float* partial = ctx->scratch;
-    float* dbpartial = ctx->scratch + (size_t)nblk * KCFF;
+    float* dbpartial = partial + (size_t)nblk * KCFF;
     const dim3 grid(nblk, cdiv(K, KT));
 #define CP_L(ACT_, PAD_)                                                                          \
     convpool_bwd_mask_kernel<C, KT, ACT_, PAD_><<<grid, 256, 0, ctx->stream>>>(                     \

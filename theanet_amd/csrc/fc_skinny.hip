@@ -4,7 +4,7 @@
 // around 16-byte row-contiguous accesses of that matrix, all issued before the first use:
 //   fwd    out = act(x W + b) * mask     16x16x4 f32 MFMA, M = 16 rows, N = outputs, 4-way split of K
 //   wgrad  dW = x^T dz, db = 1^T dz      16x16x4 f32 MFMA, M = input features (+ a ones column),
-//                                        N = outputs, reduction over rows; slabs + one reduce
+//                                        N = outputs, reduction over rows; slabs summed by reduce.hip
 //   dgrad  dx = (dz W^T) act'(a) mask    VALU: thread = 4 input features, dz rows as scalar loads
 // Requires n_in % 4 == 0 and 16-byte aligned rows (tn_fc_skinny_ok); anything else keeps the
 // scalar kernels in gemm.hip.
@@ -127,19 +127,6 @@ __global__ __launch_bounds__(256) void fc_skinny_wgrad_mfma(
     }
 }
 
-// dW[i] / db[i - MN] = sum_z slab[z][i], fixed order
-__global__ __launch_bounds__(256) void fc_skinny_slab_reduce(const float* __restrict__ slab,
-                                                            float* __restrict__ dW,
-                                                            float* __restrict__ db, int MN, int n_out,
-                                                            int S) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    const int per = MN + n_out;
-    if (i >= per) return;
-    float s = 0.f;
-#pragma unroll 8
-    for (int z = 0; z < S; ++z) s += slab[(size_t)z * per + i];
-    if (i < MN) dW[i] = s; else db[i - MN] = s;
-}
 
 // ---- dgrad ----------------------------------------------------------------------------------
 // thread = 4 consecutive input features for SKD_ROWS rows; the W rows stay in registers, every
@@ -220,10 +207,12 @@ int tn_fc_skinny_wgrad(tn_ctx* ctx, const float* x, const float* dz, float* dW, 
     const int S = cdiv(B, 128);
     fc_skinny_wgrad_mfma<<<dim3(cdiv(n_in + 1, 64), S), 256, 0, ctx->stream>>>(x, dz, ws, B, n_in, n_out);
     TN_LAUNCH_CHECK();
-    const int per = (n_in + 1) * n_out;
-    fc_skinny_slab_reduce<<<cdiv(per, 256), 256, 0, ctx->stream>>>(ws, dW, db, n_in * n_out, n_out, S);
-    TN_LAUNCH_CHECK();
-    return TN_OK;
+    const int per = (n_in + 1) * n_out, MN = n_in * n_out;
+    int rc = tn_red_push(ctx, ws, dW, (uint32_t)MN, (uint32_t)S, (uint32_t)per, 0);
+    if (rc) return rc;
+    rc = tn_red_push(ctx, ws + MN, db, (uint32_t)n_out, (uint32_t)S, (uint32_t)per, 0);
+    if (rc) return rc;
+    return tn_red_commit(ctx);
 }
 
 int tn_fc_skinny_dgrad(tn_ctx* ctx, const float* dz, const float* W, float* dx, int B, int n_in,

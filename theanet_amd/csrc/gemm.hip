@@ -447,34 +447,6 @@ __global__ __launch_bounds__(256) void gemm_f32_generic(GemmArgs g) {
     }
 }
 
-// sum split-K partial slabs (and the partial column sums) in a fixed order
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws,
-                                                           float* __restrict__ C, size_t MN, int S,
-                                                           const float* __restrict__ colsum_ws,
-                                                           float* __restrict__ colsum, int N) {
-    const size_t i4 = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
-    if (i4 + 3 < MN && (MN % 4 == 0)) {
-        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll 8
-        for (int z = 0; z < S; ++z) {
-            const float4 v = *reinterpret_cast<const float4*>(ws + (size_t)z * MN + i4);
-            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-        }
-        *reinterpret_cast<float4*>(C + i4) = s;
-    } else {
-        for (size_t i = i4; i < MN && i < i4 + 4; ++i) {
-            float s = 0.f;
-            for (int z = 0; z < S; ++z) s += ws[(size_t)z * MN + i];
-            C[i] = s;
-        }
-    }
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (colsum && i < (size_t)N) {
-        float s = 0.f;
-        for (int z = 0; z < S; ++z) s += colsum_ws[(size_t)z * N + i];
-        colsum[i] = s;
-    }
-}
 
 static inline int vec_ok(const void* p, int ld) {
     return ((reinterpret_cast<uintptr_t>(p) & 15) == 0) && (ld % 4 == 0);
@@ -681,21 +653,6 @@ __global__ __launch_bounds__(256) void fc_skinny_wgrad_kernel(
     }
 }
 
-// out[i] = sum_s slabs[s][i]: one block per 64 outputs, 4 slab groups per output, fixed order
-__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slabs,
-                                                         float* __restrict__ out, int n, int S) {
-    __shared__ float red[4][64];
-    const int i = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int grp = threadIdx.x >> 6;
-    float s = 0.f;
-    if (i < n) {
-#pragma unroll 8
-        for (int z = grp; z < S; z += 4) s += slabs[(size_t)z * n + i];
-    }
-    red[grp][threadIdx.x & 63] = s;
-    __syncthreads();
-    if (grp == 0 && i < n) out[i] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-}
 
 // fc_skinny.hip: 16-byte-access kernels for n_out <= 16
 bool tn_fc_skinny_ok(int n_in, int n_out, const void* p0, const void* p1, const void* p2);
@@ -754,11 +711,11 @@ int tn_fc_wgrad(tn_ctx* ctx, const float* x, const float* dz, float* dW, float* 
             x, dz, wsC, wsB, B, n_in, n_out);
         TN_LAUNCH_CHECK();
         const int MN = n_in * n_out;
-        slab_reduce_kernel<<<cdiv(MN, 64), 256, 0, ctx->stream>>>(wsC, dW, MN, chunks);
-        TN_LAUNCH_CHECK();
-        slab_reduce_kernel<<<cdiv(n_out, 64), 256, 0, ctx->stream>>>(wsB, db, n_out, chunks);
-        TN_LAUNCH_CHECK();
-        return TN_OK;
+        int rc = tn_red_push(ctx, wsC, dW, (uint32_t)MN, (uint32_t)chunks, (uint32_t)MN, 0);
+        if (rc) return rc;
+        rc = tn_red_push(ctx, wsB, db, (uint32_t)n_out, (uint32_t)chunks, (uint32_t)n_out, 0);
+        if (rc) return rc;
+        return tn_red_commit(ctx);
     }
     const int S = wgrad_splits(B, n_in, n_out);
     float* wsC = (float*)ws;
@@ -782,8 +739,12 @@ int tn_fc_wgrad(tn_ctx* ctx, const float* x, const float* dz, float* dW, float* 
         const size_t MN = (size_t)n_in * n_out;
         int blocks = cdiv(cdiv(MN, 4), 256);
         if (blocks < cdiv(n_out, 256)) blocks = cdiv(n_out, 256);
-        splitk_reduce_kernel<<<blocks, 256, 0, ctx->stream>>>(wsC, dW, MN, Sx, wsB, db, n_out);
-        TN_LAUNCH_CHECK();
+        (void)blocks;
+        int rc = tn_red_push(ctx, wsC, dW, (uint32_t)MN, (uint32_t)Sx, (uint32_t)MN, 0);
+        if (rc) return rc;
+        rc = tn_red_push(ctx, wsB, db, (uint32_t)n_out, (uint32_t)Sx, (uint32_t)n_out, 0);
+        if (rc) return rc;
+        return tn_red_commit(ctx);
     }
     return TN_OK;
 }

@@ -441,13 +441,18 @@ class NeuralNet():
             if self.side_stream:
                 ctx.call("tn_stream_select", 0)
         g = out.dlogits
-        for idx in range(len(self.tr_layers) - 1, -1, -1):
-            lyr = self.tr_layers[idx]
-            below = self.tr_layers[idx - 1] if idx > 0 else None
-            g = lyr.backward(g, self._need_gin[idx], below)
-            if g is None:
-                break
-        ctx.call("tn_stream_wait", 0, 1)          # join the side stream (leaf weight gradients)
+        # the weight-gradient ops only record their finishing slab sums; one launch does them all
+        ctx.call("tn_defer_reductions", 1)
+        try:
+            for idx in range(len(self.tr_layers) - 1, -1, -1):
+                lyr = self.tr_layers[idx]
+                below = self.tr_layers[idx - 1] if idx > 0 else None
+                g = lyr.backward(g, self._need_gin[idx], below)
+                if g is None:
+                    break
+        finally:
+            ctx.call("tn_stream_wait", 0, 1)      # join the side stream (leaf weight gradients)
+            ctx.call("tn_defer_reductions", 0)
         if self.world.size > 1:
             self._group().allreduce_sum(self.flat_grads, self.n_flat)
         for lyr in self.tr_layers:
