@@ -126,10 +126,13 @@ def main():
         B_ = per_gpu
         # algorithmic FLOPs / bytes per launch
         cb_flops = 2 * 2 * B_ * conv2.out_sz ** 2 * conv2.num_maps * conv2.num_prev_maps * 9   # wgrad + dgrad
-        cb_bytes = 4 * B_ * (2 * conv2.num_prev_maps * conv2.in_sz ** 2 + conv2.num_maps * 36)
+        pooled = conv2.num_maps * conv2.fused_pool.out_sz ** 2
+        # x and g read, dx written (f32), pooling mask read (u8); leaky-relu: y is not read
+        cb_bytes = B_ * (4 * (2 * conv2.num_prev_maps * conv2.in_sz ** 2 + pooled) + pooled)
         fl_fc, by_fc = roofline.kernel_cost("fc_fwd", B=B_, n_in=fc1.n_in, n_out=fc1.n_out)
-        specs = [("tn_convblock_bwd", 1, "convblock_bwd_lds (conv2 block backward: dz recompute + dgrad + wgrad)",
-                  cb_flops, cb_bytes),
+        specs = [("tn_convblock_bwd_mask", 1,
+                  "convblock_bwd_mask_mfma (conv2 block backward from the pooling mask: wgrad + dgrad "
+                  "on 16x16x4 f32 MFMA, dz in LDS only)", cb_flops, cb_bytes),
                  ("tn_fc_fwd", 1, "gemm_f32_fast NN (fc1 forward 4096x720x500)", fl_fc, by_fc),
                  ("tn_fc_dgrad", 2, "gemm_f32_fast NT (fc1 dgrad)", fl_fc, by_fc),
                  ("tn_fc_wgrad", 2, "gemm_f32_fast TN split-K (fc1 wgrad)", fl_fc, by_fc)]
