@@ -190,6 +190,14 @@ int tn_fc_dgrad(tn_ctx* ctx, const float* dz, const float* W, float* dx,
                 int B, int n_in, int n_out,
                 const float* prev_a, int prev_act, float prev_act_param, const uint8_t* prev_mask);
 
+/* tn_fc_fwd with the dropout mask DRAWN in the same launch: mask_out[i] is exactly what
+ * tn_dropout_mask(seed, step, d_step, elem0) would produce for a (B, n_out) tensor, the output is
+ * multiplied by it, and mask_out stays behind for the backward pass (hidden.py:40-43 + dropout.py:
+ * 9-13 as one op).  Shapes the fused epilogue cannot take run tn_dropout_mask + tn_fc_fwd.   */
+int tn_fc_fwd_dropout(tn_ctx* ctx, const float* x, const float* W, const float* b, float* a, int B,
+                      int n_in, int n_out, int act, float act_param, uint8_t* mask_out, float pdrop,
+                      uint64_t seed, uint32_t step, const uint32_t* d_step, uint64_t elem0);
+
 /* ---- dropout (replaces RandomStreams.binomial; dropout.py:9-31) ----
  * mask[i] = uniform(seed, *d_step + step, elem0 + i) >= pdrop  (Philox4x32-10), i < n.
  * elem0 = global index of element 0 so masks do not depend on how a batch is sharded.  */

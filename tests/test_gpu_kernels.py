@@ -353,6 +353,29 @@ def test_fc_fwd(B, n_in, n_out, act):
     assert_close(a.get_value(), want * mask, what="fc fwd masked")
 
 
+@pytest.mark.parametrize("B,n_in,n_out", [(64, 720, 500), (70, 36, 132), (33, 50, 10), (40, 64, 101)])
+def test_fc_fwd_dropout_matches_separate_mask(B, n_in, n_out):
+    """tn_fc_fwd_dropout draws the mask inside the GEMM epilogue (or falls back to two launches):
+    the mask must be bit-identical to tn_dropout_mask and the output the masked activation."""
+    rng = np.random.RandomState(B + n_out)
+    x = rng.randn(B, n_in).astype(np.float32)
+    W = (rng.randn(n_in, n_out) / np.sqrt(n_in)).astype(np.float32)
+    b = rng.randn(n_out).astype(np.float32)
+    kind, prm = act_code("relu01")
+    seed, step, elem0, p = 0xabcdef12345, 3, 4 * 25 * n_out, 0.5
+    want_mask = empty((B, n_out), np.uint8)
+    call("tn_dropout_mask", want_mask.ptr, B * n_out, p, seed, step, None, elem0)
+    a, mask = empty((B, n_out)), empty((B, n_out), np.uint8)
+    mask.fill_bytes(7)
+    call("tn_fc_fwd_dropout", dev(x).ptr, dev(W).ptr, dev(b).ptr, a.ptr, B, n_in, n_out, kind, prm,
+         mask.ptr, p, seed, step, None, elem0)
+    m = want_mask.get_value()
+    assert np.array_equal(mask.get_value(), m)
+    assert 0.3 < m.mean() < 0.7
+    z = x.astype(np.float64) @ W.astype(np.float64) + b
+    assert_close(a.get_value(), O.activation("relu01")[0](z) * m, what="fc fwd + inline dropout")
+
+
 @pytest.mark.parametrize("B,n_in,n_out,act", FC_CASES)
 def test_fc_bwd(B, n_in, n_out, act):
     rng = np.random.RandomState(B + 1)

@@ -50,6 +50,13 @@ struct GemmArgs {
     float act_prm;
     float* colsum;     // BSUM: [S][N] partial column sums of B
     int a_vec, b_vec;  // 16-byte vector loads allowed (ld % 4 == 0 and base aligned)
+    int c_vec;         // 16-byte epilogue: ldc % 4 == 0, N % 4 == 0, C / prev_a 16-byte, masks 4-byte aligned
+    // EPI_FWD dropout generated in the epilogue (c_vec only): keep = u01(philox(seed, step, e)) >= pdrop
+    uint8_t* drop_out; // mask bytes written for the backward pass (NULL: no inline dropout)
+    float pdrop;
+    uint32_t dk0, dk1, dstep;
+    const uint32_t* d_step;
+    uint64_t elem0;    // global index of C[0][0] (multiple of 4)
 };
 
 // ---- guarded tile loaders (edge tiles only) ------------------------------------------------
@@ -135,6 +142,84 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[W
     }
 }
 
+// ---- 16-byte epilogue (g.c_vec) ---------------------------------------------------------------
+// The accumulators go through LDS so that every thread owns 4 consecutive columns of a row:
+// one float4 store (plus one float4 / one 32-bit side load) instead of four scattered dwords,
+// and exactly one Philox counter per thread and row for the inline dropout mask.
+template <int WM, int WN>
+__device__ __forceinline__ void gemm_epilogue_vec(const GemmArgs& g, f32x16 (&acc)[WM][WN], float* sC,
+                                                  int m0, int n0, int z, int wm, int wn, int lane) {
+    constexpr int BM = 64 * WM, BN = 64 * WN, LDC = BN + 4;
+    const int hi = lane >> 5, t = threadIdx.x;
+    float* Cz = g.C + (size_t)z * ((g.S > 1) ? (size_t)g.M * g.ldc : 0);
+    __syncthreads();                                   // the operand tiles are dead
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                sC[(wm * 32 * WM + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * hi) * LDC + wn * 32 * WN + 32 * j +
+                   (lane & 31)] = acc[i][j][r];
+    __syncthreads();
+    constexpr int CQ = BN / 4;                         // float4 groups per tile row
+    constexpr int RP = 256 / CQ;                       // rows per pass
+    constexpr int NPASS = BM / RP;
+    const int c4 = 4 * (t % CQ), rl0 = t / CQ;
+    const int col = n0 + c4;
+    const bool cok = col < g.N;                        // N % 4 == 0: the whole group is inside
+    const int colc = min(col, g.N - 4);
+    float4 pa[NPASS];
+    uint32_t pm[NPASS];
+#pragma unroll
+    for (int p = 0; p < NPASS; ++p) {                  // side loads first (all in flight)
+        const size_t o = (size_t)min(m0 + rl0 + RP * p, g.M - 1) * g.ldc + colc;
+        if (g.epi == EPI_DGRAD && g.prev_a) pa[p] = *reinterpret_cast<const float4*>(g.prev_a + o);
+        pm[p] = g.mask ? *reinterpret_cast<const uint32_t*>(g.mask + o) : 0x01010101u;
+    }
+    float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (g.epi == EPI_FWD && g.bias) {
+        bias.x = g.bias[colc]; bias.y = g.bias[colc + 1]; bias.z = g.bias[colc + 2]; bias.w = g.bias[colc + 3];
+    }
+    const uint32_t dst = g.drop_out ? g.dstep + (g.d_step ? *g.d_step : 0u) : 0u;
+#pragma unroll
+    for (int p = 0; p < NPASS; ++p) {
+        const int rl = rl0 + RP * p, row = m0 + rl;
+        float4 v = *reinterpret_cast<const float4*>(sC + rl * LDC + c4);
+        const size_t o = (size_t)min(row, g.M - 1) * g.ldc + colc;
+        if (g.epi == EPI_FWD) {
+            v.x = tn_act_fwd(v.x + bias.x, g.act, g.act_prm);
+            v.y = tn_act_fwd(v.y + bias.y, g.act, g.act_prm);
+            v.z = tn_act_fwd(v.z + bias.z, g.act, g.act_prm);
+            v.w = tn_act_fwd(v.w + bias.w, g.act, g.act_prm);
+            if (g.drop_out) {
+                // element e = elem0 + row*N + col uses word (e & 3) of philox(e >> 2): same
+                // numbers as tn_dropout_mask (dropout_mask_kernel)
+                const uint64_t cq = (g.elem0 + (uint64_t)min(row, g.M - 1) * (uint64_t)g.N + (uint64_t)colc) >> 2;
+                const u32x4 rr = philox4x32((uint32_t)cq, (uint32_t)(cq >> 32), dst, TN_STREAM_DROPOUT,
+                                            g.dk0, g.dk1);
+                const uint32_t m = (tn_u01(rr.x) >= g.pdrop ? 1u : 0u) | (tn_u01(rr.y) >= g.pdrop ? 0x100u : 0u) |
+                                   (tn_u01(rr.z) >= g.pdrop ? 0x10000u : 0u) |
+                                   (tn_u01(rr.w) >= g.pdrop ? 0x1000000u : 0u);
+                pm[p] = m;
+                if (cok && row < g.M) *reinterpret_cast<uint32_t*>(g.drop_out + o) = m;
+            }
+        } else if (g.epi == EPI_DGRAD && g.prev_a) {
+            v.x *= tn_act_grad_from_out(pa[p].x, g.act, g.act_prm);
+            v.y *= tn_act_grad_from_out(pa[p].y, g.act, g.act_prm);
+            v.z *= tn_act_grad_from_out(pa[p].z, g.act, g.act_prm);
+            v.w *= tn_act_grad_from_out(pa[p].w, g.act, g.act_prm);
+        }
+        if (g.epi != EPI_PLAIN && (g.mask || g.drop_out)) {
+            v.x *= (float)(pm[p] & 0xffu);
+            v.y *= (float)((pm[p] >> 8) & 0xffu);
+            v.z *= (float)((pm[p] >> 16) & 0xffu);
+            v.w *= (float)(pm[p] >> 24);
+        }
+        if (cok && row < g.M) *reinterpret_cast<float4*>(Cz + (size_t)row * g.ldc + col) = v;
+    }
+}
+
 // XCD-aware decode of the 1-D block id; returns false for padding blocks
 __device__ __forceinline__ bool gemm_decode(const GemmArgs& g, int& mt, int& nt, int& z) {
     const int bid = blockIdx.x, xcd = bid & 7, idx = bid >> 3;
@@ -166,8 +251,11 @@ __global__ __launch_bounds__(256) void gemm_f32_fast(GemmArgs g) {
     constexpr int NP = BKT / 16;        // 16-wide k passes per tile
     constexpr int KH = BKT / 2;         // k-values per lane and tile
     constexpr int LDT = BKT + 4;        // LDS row stride (20 or 36 floats: odd multiple of 16 B)
-    __shared__ __attribute__((aligned(16))) float As[2][BM][LDT];
-    __shared__ __attribute__((aligned(16))) float Bs[2][BN][LDT];
+    // one buffer: the operand tiles of the main loop, then the C tile of the 16-byte epilogue
+    constexpr int SMF = 2 * (BM + BN) * LDT > BM * (BN + 4) ? 2 * (BM + BN) * LDT : BM * (BN + 4);
+    __shared__ __attribute__((aligned(16))) float smem[SMF];
+    float (*As)[BM][LDT] = reinterpret_cast<float (*)[BM][LDT]>(smem);
+    float (*Bs)[BN][LDT] = reinterpret_cast<float (*)[BN][LDT]>(smem + 2 * BM * LDT);
     int mt, nt, z;
     if (!gemm_decode(g, mt, nt, z)) return;
 
@@ -345,7 +433,10 @@ __global__ __launch_bounds__(256) void gemm_f32_fast(GemmArgs g) {
 #undef CSUM
 #undef COMPUTE
 
-    gemm_epilogue<WM, WN>(g, acc, m0, n0, z, wm, wn, lane);
+    if (g.c_vec)
+        gemm_epilogue_vec<WM, WN>(g, acc, smem, m0, n0, z, wm, wn, lane);
+    else
+        gemm_epilogue<WM, WN>(g, acc, m0, n0, z, wm, wn, lane);
 
     if (BSUM && !BKC && mt == 0) {
         // reduce csum over the 16 k-lanes of the staging layout (thread = (k = t&15, q = t>>4))
@@ -470,16 +561,35 @@ static int tn_tune_bk() {
     return v;
 }
 
+// FAST needs aligned operands; row-contiguous operands also need an extent % 4 == 0 so that
+// clamped float4 groups stay inside the matrix
+template <bool AKC, bool BKC>
+static bool gemm_fast_ok(const GemmArgs& g) {
+    return g.a_vec && g.b_vec && (AKC || (g.M % 4 == 0 && g.M >= 4)) &&
+           (BKC || (g.N % 4 == 0 && g.N >= 4)) && tn_tune_tile() != 9;
+}
+
+// the 16-byte epilogue (and with it the inline dropout) needs 4-column groups that never straddle
+// the matrix edge and aligned C / side operands
+static bool gemm_cvec_ok(const GemmArgs& g) {
+    static int vec_on = -1;
+    if (vec_on < 0) {
+        const char* e = getenv("TN_GEMM_VEC_EPI");
+        vec_on = e ? atoi(e) : 1;
+    }
+    auto al = [](const void* p, uintptr_t m) { return (reinterpret_cast<uintptr_t>(p) & m) == 0; };
+    return vec_on && g.ldc % 4 == 0 && g.N % 4 == 0 && g.N >= 4 && al(g.C, 15) && al(g.prev_a, 15) &&
+           al(g.mask, 3) && al(g.drop_out, 3) && (g.elem0 & 3) == 0;
+}
+
 template <bool AKC, bool BKC, bool BSUM>
 static void launch_gemm(tn_ctx* ctx, GemmArgs& g, int S) {
-    // FAST needs aligned operands; row-contiguous operands also need an extent % 4 == 0 so that
-    // clamped float4 groups stay inside the matrix
-    const bool fast = g.a_vec && g.b_vec && (AKC || (g.M % 4 == 0 && g.M >= 4)) &&
-                      (BKC || (g.N % 4 == 0 && g.N >= 4)) && tn_tune_tile() != 9;
+    const bool fast = gemm_fast_ok<AKC, BKC>(g);
     bool big = (long long)cdiv(g.M, 128) * cdiv(g.N, 64) * S >= 2 * ctx->num_cus;
     if (tn_tune_tile() == 1) big = false;
     if (tn_tune_tile() == 2) big = true;
     if (!fast) big = false;
+    g.c_vec = fast && gemm_cvec_ok(g);
     g.S = S;
     g.NT = cdiv(g.N, 64);
     g.MT = cdiv(g.M, big ? 128 : 64);
@@ -687,6 +797,29 @@ int tn_fc_fwd(tn_ctx* ctx, const float* x, const float* W, const float* b, float
     launch_gemm<true, false, false>(ctx, g, 1);
     TN_LAUNCH_CHECK();
     return TN_OK;
+}
+
+int tn_fc_fwd_dropout(tn_ctx* ctx, const float* x, const float* W, const float* b, float* a, int B,
+                      int n_in, int n_out, int act, float act_param, uint8_t* mask_out, float pdrop,
+                      uint64_t seed, uint32_t step, const uint32_t* d_step, uint64_t elem0) {
+    TN_REQUIRE(B > 0 && n_in > 0 && n_out > 0 && mask_out != nullptr, "tn_fc_fwd_dropout: bad arguments");
+    GemmArgs g{};
+    g.A = x; g.B = W; g.C = a;
+    g.M = B; g.N = n_out; g.K = n_in;
+    g.lda = n_in; g.ldb = n_out; g.ldc = n_out;
+    g.kchunk = cdiv(n_in, BK) * BK;
+    g.epi = EPI_FWD; g.bias = b; g.act = act; g.act_prm = act_param;
+    g.a_vec = vec_ok(x, n_in); g.b_vec = vec_ok(W, n_out);
+    g.drop_out = mask_out; g.pdrop = pdrop; g.dk0 = (uint32_t)seed; g.dk1 = (uint32_t)(seed >> 32);
+    g.dstep = step; g.d_step = d_step; g.elem0 = elem0;
+    if (n_out > SK_MAX && gemm_fast_ok<true, false>(g) && gemm_cvec_ok(g)) {
+        launch_gemm<true, false, false>(ctx, g, 1);      // mask drawn in the epilogue
+        TN_LAUNCH_CHECK();
+        return TN_OK;
+    }
+    int rc = tn_dropout_mask(ctx, mask_out, (size_t)B * n_out, pdrop, seed, step, d_step, elem0);
+    if (rc) return rc;
+    return tn_fc_fwd(ctx, x, W, b, a, B, n_in, n_out, act, act_param, mask_out);
 }
 
 size_t tn_fc_wgrad_ws_bytes(int B, int n_in, int n_out) {

@@ -71,11 +71,19 @@ class HiddenLayer(Layer):
                 self.drop.mask if self.drop is not None else None)
 
     def forward(self, train=True):
-        if self.drop is not None:
-            self.drop.generate()
-        self.ctx.call("tn_fc_fwd", self.inpt.ptr, self.w.ptr, self.b.ptr, self.output.ptr,
-                      self.batch_sz, self.n_in, self.n_out, self.act.kind, self.act.prm,
-                      self.drop.mask.ptr if self.drop is not None else None)
+        drop = self.drop
+        if drop is not None and not drop.injected and not drop.ready:
+            # the mask is drawn inside the layer's own launch (and kept for the backward pass)
+            self.ctx.call("tn_fc_fwd_dropout", self.inpt.ptr, self.w.ptr, self.b.ptr, self.output.ptr,
+                          self.batch_sz, self.n_in, self.n_out, self.act.kind, self.act.prm,
+                          drop.mask.ptr, drop.pdrop, drop.seed, 0,
+                          drop.d_step.ptr if drop.d_step is not None else None, drop.elem0)
+        else:
+            if drop is not None:
+                drop.generate()
+            self.ctx.call("tn_fc_fwd", self.inpt.ptr, self.w.ptr, self.b.ptr, self.output.ptr,
+                          self.batch_sz, self.n_in, self.n_out, self.act.kind, self.act.prm,
+                          drop.mask.ptr if drop is not None else None)
         if self.test_scale != 1.0:
             self.ctx.call("tn_scale_mask", self.output.ptr, None, float(self.test_scale),
                           self.output.ptr, self.output.size, None, _lib.TN_ACT_LINEAR, 0.0)

@@ -227,9 +227,9 @@ class NeuralNet():
         # ~1.5-2 us kernel boundaries are GPU-side either way) and loses ~12 % with the
         # two-stream backward, so capture is opt-in (TN_GRAPH=1)
         self.use_graph = (env == "1")
-        self.side_stream = os.environ.get("TN_SIDE", "0") == "1"   # measured: contends with the matrix-core backward
+        self.side_stream = os.environ.get("TN_SIDE", "0") in ("1", "2")   # measured: contends with the matrix-core backward
         self.elastic_ahead = os.environ.get("TN_ELASTIC_AHEAD", "0") == "1"   # measured: -2 %
-        HiddenLayer.side_stream = self.side_stream
+        HiddenLayer.side_stream = self.side_stream and os.environ.get("TN_SIDE") != "2"   # 2: light work only
 
         # Input Layer
         input_layer_type = getattr(layer, layers[0][0])
