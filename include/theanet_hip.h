@@ -190,6 +190,14 @@ int tn_fc_dgrad(tn_ctx* ctx, const float* dz, const float* W, float* dx,
                 int B, int n_in, int n_out,
                 const float* prev_a, int prev_act, float prev_act_param, const uint8_t* prev_mask);
 
+/* The whole SoftmaxLayer forward (outlayers.py:87-95 + :50-51) as one op: logits = x W + b
+ * followed by tn_softmax_nll on them.  With at most 16 classes it is one launch (the class
+ * logits of a row sit in one 16-lane DPP row of the matrix-core epilogue); wider heads run
+ * tn_fc_fwd + tn_softmax_nll.  Argument meaning as in those two.                            */
+int tn_fc_softmax_nll(tn_ctx* ctx, const float* x, const float* W, const float* b, float* logits, int B,
+                      int n_in, int n_out, const int32_t* y, int64_t y_row0, const int64_t* d_row0,
+                      float* logprob, float* rowloss, int32_t* pred, float* rowp, float* dz,
+                      float inv_batch);
 /* tn_fc_fwd with the dropout mask DRAWN in the same launch: mask_out[i] is exactly what
  * tn_dropout_mask(seed, step, d_step, elem0) would produce for a (B, n_out) tensor, the output is
  * multiplied by it, and mask_out stays behind for the backward pass (hidden.py:40-43 + dropout.py:

@@ -353,6 +353,36 @@ def test_fc_fwd(B, n_in, n_out, act):
     assert_close(a.get_value(), want * mask, what="fc fwd masked")
 
 
+@pytest.mark.parametrize("B,n_in,n_out", [(4096, 500, 10), (37, 64, 16), (50, 24, 3), (21, 30, 40), (19, 7, 5)])
+def test_fc_softmax_nll_fused(B, n_in, n_out):
+    """tn_fc_softmax_nll == tn_fc_fwd (linear) + tn_softmax_nll, against the oracle."""
+    rng = np.random.RandomState(B + n_out)
+    x = rng.randn(B, n_in).astype(np.float32)
+    W = (rng.randn(n_in, n_out) / np.sqrt(n_in)).astype(np.float32)
+    b = rng.randn(n_out).astype(np.float32)
+    y = rng.randint(0, n_out, size=B + 5).astype(np.int32)
+    z = x.astype(np.float64) @ W.astype(np.float64) + b
+    lp = O.log_softmax(z)
+    lab = y[5:]
+    logits, logprob, dz = empty((B, n_out)), empty((B, n_out)), empty((B, n_out))
+    rowloss, rowp, pred = empty((B,)), empty((B,)), empty((B,), np.int32)
+    call("tn_fc_softmax_nll", dev(x).ptr, dev(W).ptr, dev(b).ptr, logits.ptr, B, n_in, n_out,
+         dev(y).ptr, 5, None, logprob.ptr, rowloss.ptr, pred.ptr, rowp.ptr, dz.ptr, 1.0 / B)
+    assert_close(logits.get_value(), z, what="fused logits")
+    assert_close(logprob.get_value(), lp, what="fused logprob")
+    assert_close(rowloss.get_value(), -lp[np.arange(B), lab], what="fused rowloss")
+    assert_close(rowp.get_value(), np.exp(lp[np.arange(B), lab]), what="fused P(label)")
+    onehot = np.zeros((B, n_out)); onehot[np.arange(B), lab] = 1
+    assert_close(dz.get_value(), (np.exp(lp) - onehot) / B, atol=1e-7, what="fused dlogits")
+    got = pred.get_value()
+    best = z.max(1)
+    assert np.all(np.abs(z[np.arange(B), got] - best) <= 1e-5 * np.maximum(1, np.abs(best)))
+    # labels optional (test graphs)
+    call("tn_fc_softmax_nll", dev(x).ptr, dev(W).ptr, dev(b).ptr, logits.ptr, B, n_in, n_out,
+         None, 0, None, logprob.ptr, None, pred.ptr, None, None, 1.0 / B)
+    assert_close(logprob.get_value(), lp, what="fused logprob (no labels)")
+
+
 @pytest.mark.parametrize("B,n_in,n_out", [(64, 720, 500), (70, 36, 132), (33, 50, 10), (40, 64, 101)])
 def test_fc_fwd_dropout_matches_separate_mask(B, n_in, n_out):
     """tn_fc_fwd_dropout draws the mask inside the GEMM epilogue (or falls back to two launches):

@@ -19,6 +19,43 @@ __device__ __forceinline__ f32x4 sk_mfma(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+// optional softmax / NLL tail of the forward kernel (outlayers.py:50-51, :87-95)
+struct SkSoftmax {
+    const int32_t* y;          // labels (may be NULL: log-probabilities and argmax only)
+    int64_t y_row0;
+    const int64_t* d_row0;
+    float* logprob;            // NULL: plain fully-connected forward
+    float* rowloss;
+    int32_t* pred;
+    float* rowp;
+    float* dz;
+    float inv_batch;
+};
+
+template <int CTRL>
+__device__ __forceinline__ float sk_dpp(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+// all-reduce over the 16 lanes of a DPP row: quad xor 1, quad xor 2, half mirror, mirror
+__device__ __forceinline__ float sk_row_max(float v) {
+    v = fmaxf(v, sk_dpp<0xB1>(v));
+    v = fmaxf(v, sk_dpp<0x4E>(v));
+    v = fmaxf(v, sk_dpp<0x141>(v));
+    return fmaxf(v, sk_dpp<0x140>(v));
+}
+__device__ __forceinline__ float sk_row_min(float v) {
+    v = fminf(v, sk_dpp<0xB1>(v));
+    v = fminf(v, sk_dpp<0x4E>(v));
+    v = fminf(v, sk_dpp<0x141>(v));
+    return fminf(v, sk_dpp<0x140>(v));
+}
+__device__ __forceinline__ float sk_row_sum(float v) {
+    v += sk_dpp<0xB1>(v);
+    v += sk_dpp<0x4E>(v);
+    v += sk_dpp<0x141>(v);
+    return v + sk_dpp<0x140>(v);
+}
+
 // ---- forward --------------------------------------------------------------------------------
 // block = 16 rows, 4 waves; wave w owns the 16-wide k chunks w, w+4, ...  Lane (lo, qd) loads
 // x[row lo][16c + 4qd .. +3] as one float4: component e is the A operand of reduction step
@@ -27,7 +64,7 @@ __device__ __forceinline__ f32x4 sk_mfma(float a, float b, f32x4 c) {
 __global__ __launch_bounds__(256) void fc_skinny_fwd_mfma(
     const float* __restrict__ x, const float* __restrict__ W, const float* __restrict__ b,
     float* __restrict__ a, int B, int n_in, int n_out, int act, float prm,
-    const uint8_t* __restrict__ mask) {
+    const uint8_t* __restrict__ mask, SkSoftmax sm) {
     __shared__ float red[4][256];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, lo = lane & 15, qd = lane >> 4;
     const float* xr = x + (size_t)min(blockIdx.x * 16 + lo, B - 1) * n_in;
@@ -58,8 +95,10 @@ __global__ __launch_bounds__(256) void fc_skinny_fwd_mfma(
 #pragma unroll
     for (int r = 0; r < 4; ++r) red[w][r * 64 + lane] = acc[r];
     __syncthreads();
-    if (w == 0 && nlive) {
-        const float bias = b ? b[lo] : 0.f;
+    if (w != 0) return;
+    const float bias = (b && nlive) ? b[nc] : 0.f;
+    if (sm.logprob == nullptr) {
+        if (!nlive) return;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = blockIdx.x * 16 + 4 * qd + r;        // accumulator row of register r
@@ -71,6 +110,34 @@ __global__ __launch_bounds__(256) void fc_skinny_fwd_mfma(
                 if (mask) v *= (float)mask[o];
                 a[o] = v;
             }
+        }
+        return;
+    }
+    // softmax / NLL tail: a row's logits sit in the 16 lanes of one DPP row (lane lo = class)
+    const int64_t yoff = sm.y_row0 + (sm.d_row0 ? *sm.d_row0 : 0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = blockIdx.x * 16 + 4 * qd + r;
+        const int rowc = min(row, B - 1);
+        const float z = ((red[0][r * 64 + lane] + red[1][r * 64 + lane]) + red[2][r * 64 + lane]) +
+                        red[3][r * 64 + lane] + bias;
+        const float zv = nlive ? z : -INFINITY;
+        const float m = sk_row_max(zv);
+        // first maximal class (numpy argmax)
+        const float am = sk_row_min((nlive && zv == m) ? (float)lo : 1e9f);
+        const float se = sk_row_sum(nlive ? expf(zv - m) : 0.f);
+        const float lp = zv - m - logf(se);
+        const int label = sm.y ? sm.y[yoff + rowc] : -1;
+        if (nlive && row < B) {
+            const size_t o = (size_t)row * n_out + lo;
+            if (a) a[o] = z;
+            sm.logprob[o] = lp;
+            if (sm.dz) sm.dz[o] = (expf(lp) - (lo == label ? 1.f : 0.f)) * sm.inv_batch;
+            if (lo == label) {
+                if (sm.rowloss) sm.rowloss[row] = -lp;
+                if (sm.rowp) sm.rowp[row] = expf(lp);
+            }
+            if (lo == 0 && sm.pred) sm.pred[row] = (int)am;
         }
     }
 }
@@ -197,7 +264,22 @@ bool tn_fc_skinny_ok(int n_in, int n_out, const void* p0, const void* p1, const 
 
 int tn_fc_skinny_fwd(tn_ctx* ctx, const float* x, const float* W, const float* b, float* a, int B,
                      int n_in, int n_out, int act, float prm, const uint8_t* mask) {
-    fc_skinny_fwd_mfma<<<cdiv(B, 16), 256, 0, ctx->stream>>>(x, W, b, a, B, n_in, n_out, act, prm, mask);
+    SkSoftmax sm{};
+    fc_skinny_fwd_mfma<<<cdiv(B, 16), 256, 0, ctx->stream>>>(x, W, b, a, B, n_in, n_out, act, prm, mask, sm);
+    TN_LAUNCH_CHECK();
+    return TN_OK;
+}
+
+// logits = x W + b and the whole softmax / NLL row computation in one launch
+int tn_fc_skinny_softmax(tn_ctx* ctx, const float* x, const float* W, const float* b, float* logits,
+                         int B, int n_in, int n_out, const int32_t* y, int64_t y_row0,
+                         const int64_t* d_row0, float* logprob, float* rowloss, int32_t* pred,
+                         float* rowp, float* dz, float inv_batch) {
+    SkSoftmax sm{};
+    sm.y = y; sm.y_row0 = y_row0; sm.d_row0 = d_row0; sm.logprob = logprob; sm.rowloss = rowloss;
+    sm.pred = pred; sm.rowp = rowp; sm.dz = dz; sm.inv_batch = inv_batch;
+    fc_skinny_fwd_mfma<<<cdiv(B, 16), 256, 0, ctx->stream>>>(x, W, b, logits, B, n_in, n_out,
+                                                            TN_ACT_LINEAR, 0.f, nullptr, sm);
     TN_LAUNCH_CHECK();
     return TN_OK;
 }

@@ -773,7 +773,28 @@ int tn_fc_skinny_wgrad(tn_ctx* ctx, const float* x, const float* dz, float* dW, 
 int tn_fc_skinny_dgrad(tn_ctx* ctx, const float* dz, const float* W, float* dx, int B, int n_in,
                        int n_out, const float* prev_a, int act, float prm, const uint8_t* mask);
 
+int tn_fc_skinny_softmax(tn_ctx* ctx, const float* x, const float* W, const float* b, float* logits,
+                         int B, int n_in, int n_out, const int32_t* y, int64_t y_row0,
+                         const int64_t* d_row0, float* logprob, float* rowloss, int32_t* pred,
+                         float* rowp, float* dz, float inv_batch);
+
 extern "C" {
+
+int tn_fc_softmax_nll(tn_ctx* ctx, const float* x, const float* W, const float* b, float* logits, int B,
+                      int n_in, int n_out, const int32_t* y, int64_t y_row0, const int64_t* d_row0,
+                      float* logprob, float* rowloss, int32_t* pred, float* rowp, float* dz,
+                      float inv_batch) {
+    TN_REQUIRE(B > 0 && n_in > 0 && n_out > 0 && logits && logprob, "tn_fc_softmax_nll: bad arguments");
+    TN_REQUIRE(y != nullptr || (rowloss == nullptr && dz == nullptr && rowp == nullptr),
+               "tn_fc_softmax_nll: labels required for loss/gradient outputs");
+    if (tn_fc_skinny_ok(n_in, n_out, x, nullptr, nullptr))
+        return tn_fc_skinny_softmax(ctx, x, W, b, logits, B, n_in, n_out, y, y_row0, d_row0, logprob,
+                                    rowloss, pred, rowp, dz, inv_batch);
+    int rc = tn_fc_fwd(ctx, x, W, b, logits, B, n_in, n_out, TN_ACT_LINEAR, 0.f, nullptr);
+    if (rc) return rc;
+    return tn_softmax_nll(ctx, logits, y, y_row0, d_row0, logprob, rowloss, pred, rowp, dz, B, n_out,
+                          inv_batch);
+}
 
 int tn_fc_fwd(tn_ctx* ctx, const float* x, const float* W, const float* b, float* a, int B, int n_in,
               int n_out, int act, float act_param, const uint8_t* mask) {

@@ -67,22 +67,25 @@ class SoftmaxLayer(HiddenLayer, OutputLayer):
     def forward(self, train=True, y=None, y_row0=0, d_row0=None, cost_scale=None):
         """Logits GEMM + the fused softmax/NLL row kernel (+ the cost scalar when training:
         cost = cost_scale * sum_n -logprob[n, y_n], reduced inside the same launch)."""
+        have_y = y is not None
+        if not (have_y and train and cost_scale is not None and self.d_cost is not None):
+            # affine map + softmax / NLL rows as ONE op (one launch for <= 16 classes)
+            self.ctx.call("tn_fc_softmax_nll", self.inpt.ptr, self.w.ptr, self.b.ptr, self.logits.ptr,
+                          self.batch_sz, self.n_in, self.n_out, y.ptr if have_y else None, int(y_row0),
+                          d_row0.ptr if d_row0 is not None else None, self.logprob.ptr,
+                          self.rowloss.ptr if have_y else None, self.y_preds.ptr,
+                          self.rowp.ptr if have_y else None,
+                          self.dlogits.ptr if (have_y and train) else None, float(self.inv_batch))
+            return
+        # explicit in-launch cost reduction (kept for callers that ask for it; the training step
+        # lets the cost ride in the update launch instead)
         self.ctx.call("tn_fc_fwd", self.inpt.ptr, self.w.ptr, self.b.ptr, self.logits.ptr,
                       self.batch_sz, self.n_in, self.n_out, _lib.TN_ACT_LINEAR, 0.0, None)
-        have_y = y is not None
-        if have_y and train and cost_scale is not None and self.d_cost is not None:
-            if self.cost_ws is None:
-                n = self.ctx.lib.tn_softmax_cost_ws_bytes(self.batch_sz)
-                self.cost_ws = self.ctx.zeros(((n + 3) // 4,))
-            self.ctx.call("tn_softmax_nll_cost", self.logits.ptr, y.ptr, int(y_row0),
-                          d_row0.ptr if d_row0 is not None else None, self.logprob.ptr,
-                          self.rowloss.ptr, self.y_preds.ptr, self.rowp.ptr, self.dlogits.ptr,
-                          self.batch_sz, self.n_out, float(self.inv_batch), float(cost_scale),
-                          self.d_cost.ptr, self.cost_ws.ptr)
-            return
-        self.ctx.call("tn_softmax_nll", self.logits.ptr, y.ptr if have_y else None, int(y_row0),
+        if self.cost_ws is None:
+            n = self.ctx.lib.tn_softmax_cost_ws_bytes(self.batch_sz)
+            self.cost_ws = self.ctx.zeros(((n + 3) // 4,))
+        self.ctx.call("tn_softmax_nll_cost", self.logits.ptr, y.ptr, int(y_row0),
                       d_row0.ptr if d_row0 is not None else None, self.logprob.ptr,
-                      self.rowloss.ptr if have_y else None, self.y_preds.ptr,
-                      self.rowp.ptr if have_y else None,
-                      self.dlogits.ptr if (have_y and train) else None,
-                      self.batch_sz, self.n_out, float(self.inv_batch))
+                      self.rowloss.ptr, self.y_preds.ptr, self.rowp.ptr, self.dlogits.ptr,
+                      self.batch_sz, self.n_out, float(self.inv_batch), float(cost_scale),
+                      self.d_cost.ptr, self.cost_ws.ptr)
