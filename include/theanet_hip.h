@@ -190,6 +190,14 @@ int tn_fc_dgrad(tn_ctx* ctx, const float* dz, const float* W, float* dx,
                 int B, int n_in, int n_out,
                 const float* prev_a, int prev_act, float prev_act_param, const uint8_t* prev_mask);
 
+/* tn_fc_wgrad + tn_fc_dgrad of one layer as ONE op.  The two products only share dz, so their
+ * blocks are interleaved in a single launch (a kernel boundary less, and the prologue / epilogue
+ * of one product overlaps the main loop of the other).  Same arguments and results as the two
+ * ops; shapes the paired kernel cannot take run them one after the other.                    */
+int tn_fc_bwd(tn_ctx* ctx, const float* x, const float* dz, const float* W, float* dW, float* db,
+              float* dx, int B, int n_in, int n_out, void* ws, const float* prev_a, int prev_act,
+              float prev_act_param, const uint8_t* prev_mask);
+
 /* The whole SoftmaxLayer forward (outlayers.py:87-95 + :50-51) as one op: logits = x W + b
  * followed by tn_softmax_nll on them.  With at most 16 classes it is one launch (the class
  * logits of a row sit in one 16-lane DPP row of the matrix-core epilogue); wider heads run

@@ -332,7 +332,8 @@ def test_mean_fwd_bwd():
 FC_CASES = [(64, 720, 500, "relu01"), (33, 500, 10, "linear"), (5, 7, 3, "tanh"),
             (128, 100, 64, "sigmoid"), (70, 33, 130, "relu10"), (256, 64, 457, "relu"),
             # few outputs, n_in % 4 == 0: the 16-byte-access kernels of fc_skinny.hip
-            (300, 500, 10, "linear"), (129, 64, 16, "tanh"), (17, 8, 1, "relu05"), (515, 1028, 7, "sigmoid")]
+            (300, 500, 10, "linear"), (129, 64, 16, "tanh"), (17, 8, 1, "relu05"), (515, 1028, 7, "sigmoid"),
+            (1024, 128, 96, "relu01")]                   # long batch: split-K weight gradient
 
 
 @pytest.mark.parametrize("B,n_in,n_out,act", FC_CASES)
@@ -351,6 +352,31 @@ def test_fc_fwd(B, n_in, n_out, act):
     assert_close(a.get_value(), want, what="fc fwd")
     call("tn_fc_fwd", xd.ptr, Wd.ptr, bd.ptr, a.ptr, B, n_in, n_out, kind, prm, dev(mask).ptr)
     assert_close(a.get_value(), want * mask, what="fc fwd masked")
+
+
+@pytest.mark.parametrize("B,n_in,n_out,act", FC_CASES)
+def test_fc_bwd_paired(B, n_in, n_out, act):
+    """tn_fc_bwd (weight + input gradient as one op) == tn_fc_wgrad + tn_fc_dgrad."""
+    rng = np.random.RandomState(B + 2)
+    x = rng.randn(B, n_in).astype(np.float32)
+    W = (rng.randn(n_in, n_out) / np.sqrt(n_in)).astype(np.float32)
+    dz = rng.randn(B, n_out).astype(np.float32)
+    prev_a = rng.randn(B, n_in).astype(np.float32)
+    pm = (rng.rand(B, n_in) > .5).astype(np.uint8)
+    lib = ctx().lib
+    ws = empty((lib.tn_fc_wgrad_ws_bytes(B, n_in, n_out) // 4 + 1,))
+    dW, db, dx = empty((n_in, n_out)), empty((n_out,)), empty((B, n_in))
+    kind, prm = act_code("relu01")
+    call("tn_fc_bwd", dev(x).ptr, dev(dz).ptr, dev(W).ptr, dW.ptr, db.ptr, dx.ptr, B, n_in, n_out, ws.ptr,
+         dev(prev_a * pm).ptr, kind, prm, dev(pm).ptr)
+    assert_close(dW.get_value(), x.astype(np.float64).T @ dz.astype(np.float64), atol=1e-4, what="pair dW")
+    assert_close(db.get_value(), dz.astype(np.float64).sum(0), atol=1e-4, what="pair db")
+    g = np.where(prev_a > 0, 1.0, .01) * pm
+    assert_close(dx.get_value(), (dz.astype(np.float64) @ W.astype(np.float64).T) * g, atol=1e-4,
+                 what="pair dx * act' * mask")
+    call("tn_fc_bwd", dev(x).ptr, dev(dz).ptr, dev(W).ptr, dW.ptr, db.ptr, dx.ptr, B, n_in, n_out, ws.ptr,
+         None, 0, 0.0, None)
+    assert_close(dx.get_value(), dz.astype(np.float64) @ W.astype(np.float64).T, atol=1e-4, what="pair dx")
 
 
 @pytest.mark.parametrize("B,n_in,n_out", [(4096, 500, 10), (37, 64, 16), (50, 24, 3), (21, 30, 40), (19, 7, 5)])

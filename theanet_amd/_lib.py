@@ -57,6 +57,7 @@ SIGNATURES = {
     "tn_fc_fwd": (c_int, [CTX, P, P, P, P, c_int, c_int, c_int, c_int, c_float, P]),
     "tn_fc_fwd_dropout": (c_int, [CTX, P, P, P, P, c_int, c_int, c_int, c_int, c_float, P, c_float,
                                   c_uint64, c_uint32, P, c_uint64]),
+    "tn_fc_bwd": (c_int, [CTX, P, P, P, P, P, P, c_int, c_int, c_int, P, P, c_int, c_float, P]),
     "tn_fc_wgrad_ws_bytes": (c_size_t, [c_int, c_int, c_int]),
     "tn_fc_wgrad": (c_int, [CTX, P, P, P, P, c_int, c_int, c_int, P]),
     "tn_fc_dgrad": (c_int, [CTX, P, P, P, c_int, c_int, c_int, P, c_int, c_float, P]),

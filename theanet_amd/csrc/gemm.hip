@@ -221,8 +221,8 @@ __device__ __forceinline__ void gemm_epilogue_vec(const GemmArgs& g, f32x16 (&ac
 }
 
 // XCD-aware decode of the 1-D block id; returns false for padding blocks
-__device__ __forceinline__ bool gemm_decode(const GemmArgs& g, int& mt, int& nt, int& z) {
-    const int bid = blockIdx.x, xcd = bid & 7, idx = bid >> 3;
+__device__ __forceinline__ bool gemm_decode(const GemmArgs& g, int bid, int& mt, int& nt, int& z) {
+    const int xcd = bid & 7, idx = bid >> 3;
     if (g.S == 1) {
         mt = (idx / g.NT) * 8 + xcd;      // all N-tiles of an A row-panel on one XCD
         nt = idx % g.NT;
@@ -245,19 +245,23 @@ __device__ __forceinline__ bool gemm_decode(const GemmArgs& g, int& mt, int& nt,
 // branch-free, so hipcc emits counted vmcnt waits and the two-tile look-ahead really overlaps:
 //   registers R0/R1 hold tiles t+1 / t+2, LDS buffers 0/1 hold tiles t / t+1.
 // A K-tail (K % 16 != 0, e.g. dgrad with n_out = 500) is one guarded tile after the loop.
+// floats of LDS a block needs: the operand tiles of the main loop, later the C tile of the epilogue
+template <int WM, int WN, int BKT>
+constexpr int gemm_smem_floats() {
+    return 2 * (64 * WM + 64 * WN) * (BKT + 4) > 64 * WM * (64 * WN + 4) ? 2 * (64 * WM + 64 * WN) * (BKT + 4)
+                                                                         : 64 * WM * (64 * WN + 4);
+}
+
 template <bool AKC, bool BKC, bool BSUM, int WM, int WN, int BKT>
-__global__ __launch_bounds__(256) void gemm_f32_fast(GemmArgs g) {
+__device__ __forceinline__ void gemm_fast_body(const GemmArgs& g, float* __restrict__ smem, int bid) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
     constexpr int NP = BKT / 16;        // 16-wide k passes per tile
     constexpr int KH = BKT / 2;         // k-values per lane and tile
     constexpr int LDT = BKT + 4;        // LDS row stride (20 or 36 floats: odd multiple of 16 B)
-    // one buffer: the operand tiles of the main loop, then the C tile of the 16-byte epilogue
-    constexpr int SMF = 2 * (BM + BN) * LDT > BM * (BN + 4) ? 2 * (BM + BN) * LDT : BM * (BN + 4);
-    __shared__ __attribute__((aligned(16))) float smem[SMF];
     float (*As)[BM][LDT] = reinterpret_cast<float (*)[BM][LDT]>(smem);
     float (*Bs)[BN][LDT] = reinterpret_cast<float (*)[BN][LDT]>(smem + 2 * BM * LDT);
     int mt, nt, z;
-    if (!gemm_decode(g, mt, nt, z)) return;
+    if (!gemm_decode(g, bid, mt, nt, z)) return;
 
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
@@ -455,6 +459,35 @@ __global__ __launch_bounds__(256) void gemm_f32_fast(GemmArgs g) {
     }
 }
 
+template <bool AKC, bool BKC, bool BSUM, int WM, int WN, int BKT>
+__global__ __launch_bounds__(256) void gemm_f32_fast(GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) float smem[gemm_smem_floats<WM, WN, BKT>()];
+    gemm_fast_body<AKC, BKC, BSUM, WM, WN, BKT>(g, smem, (int)blockIdx.x);
+}
+
+// Two INDEPENDENT products in one launch (e.g. a layer's weight gradient and its input gradient,
+// which only share dz): groups of 8 blocks alternate between the problems, so blocks of both are
+// co-resident on every CU -- the prologue / epilogue of one product overlaps the main loop of the
+// other, and a kernel boundary disappears.
+template <bool A1, bool B1, bool S1, bool A2, bool B2, bool S2>
+__global__ __launch_bounds__(256) void gemm_f32_pair(GemmArgs g1, GemmArgs g2, int n1, int n2) {
+    __shared__ __attribute__((aligned(16))) float smem[gemm_smem_floats<1, 1, 16>()];
+    const int bid = blockIdx.x, grp = bid >> 3, l8 = bid & 7;
+    const int G1 = n1 >> 3, G2 = n2 >> 3, Gm = min(G1, G2);
+    int prob, idx;
+    if (grp < 2 * Gm) {
+        prob = grp & 1;
+        idx = grp >> 1;
+    } else {
+        prob = G1 > G2 ? 0 : 1;
+        idx = grp - Gm;
+    }
+    if (prob == 0)
+        gemm_fast_body<A1, B1, S1, 1, 1, 16>(g1, smem, idx * 8 + l8);
+    else
+        gemm_fast_body<A2, B2, S2, 1, 1, 16>(g2, smem, idx * 8 + l8);
+}
+
 // ---- generic kernel (any alignment / extent): guarded loads, single-stage prefetch ---------
 template <bool AKC, bool BKC, bool BSUM>
 __global__ __launch_bounds__(256) void gemm_f32_generic(GemmArgs g) {
@@ -462,7 +495,7 @@ __global__ __launch_bounds__(256) void gemm_f32_generic(GemmArgs g) {
     __shared__ __attribute__((aligned(16))) float As[2][BM][LDK];
     __shared__ __attribute__((aligned(16))) float Bs[2][BN][LDK];
     int mt, nt, z;
-    if (!gemm_decode(g, mt, nt, z)) return;
+    if (!gemm_decode(g, (int)blockIdx.x, mt, nt, z)) return;
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -602,6 +635,17 @@ static void launch_gemm(tn_ctx* ctx, GemmArgs& g, int S) {
         gemm_f32_fast<AKC, BKC, BSUM, 1, 1, 32><<<grid, 256, 0, ctx->stream>>>(g);
     else
         gemm_f32_fast<AKC, BKC, BSUM, 1, 1, 16><<<grid, 256, 0, ctx->stream>>>(g);
+}
+
+// prepares g for the 64 x 64 fast kernel; returns its grid size (0: not eligible)
+template <bool AKC, bool BKC>
+static int gemm_setup_small(GemmArgs& g, int S) {
+    if (!gemm_fast_ok<AKC, BKC>(g)) return 0;
+    g.c_vec = gemm_cvec_ok(g);
+    g.S = S;
+    g.NT = cdiv(g.N, 64);
+    g.MT = cdiv(g.M, 64);
+    return (S == 1) ? 8 * cdiv(g.MT, 8) * g.NT : 8 * cdiv(S, 8) * g.MT * g.NT;
 }
 
 static int wgrad_splits(int B, int n_in, int n_out) {
@@ -901,6 +945,60 @@ int tn_fc_wgrad(tn_ctx* ctx, const float* x, const float* dz, float* dW, float* 
         return tn_red_commit(ctx);
     }
     return TN_OK;
+}
+
+int tn_fc_bwd(tn_ctx* ctx, const float* x, const float* dz, const float* W, float* dW, float* db,
+              float* dx, int B, int n_in, int n_out, void* ws, const float* prev_a, int prev_act,
+              float prev_act_param, const uint8_t* prev_mask) {
+    TN_REQUIRE(B > 0 && n_in > 0 && n_out > 0 && ws != nullptr && dx != nullptr, "tn_fc_bwd: bad arguments");
+    static int pair_on = -1;
+    if (pair_on < 0) {
+        const char* e = getenv("TN_FC_PAIR");
+        pair_on = e ? atoi(e) : 1;
+    }
+    if (pair_on && n_out > SK_MAX) {
+        // weight gradient (split-K slabs) and input gradient as ONE launch of interleaved blocks
+        const int S = wgrad_splits(B, n_in, n_out);
+        float* wsC = (float*)ws;
+        float* wsB = wsC + (size_t)S * n_in * n_out;
+        GemmArgs g1{}, g2{};
+        g1.A = x; g1.B = dz;
+        g1.M = n_in; g1.N = n_out; g1.K = B;
+        g1.lda = n_in; g1.ldb = n_out; g1.ldc = n_out;
+        g1.kchunk = cdiv(cdiv(B, S), BK) * BK;
+        g1.epi = EPI_PLAIN;
+        g1.a_vec = vec_ok(x, n_in); g1.b_vec = vec_ok(dz, n_out);
+        const int Sx = cdiv(B, g1.kchunk);
+        if (Sx == 1) {
+            g1.C = dW; g1.colsum = db;
+        } else {
+            g1.C = wsC; g1.colsum = wsB;
+        }
+        g2.A = dz; g2.B = W; g2.C = dx;
+        g2.M = B; g2.N = n_in; g2.K = n_out;
+        g2.lda = n_out; g2.ldb = n_out; g2.ldc = n_in;
+        g2.kchunk = cdiv(n_out, BK) * BK;
+        g2.epi = EPI_DGRAD; g2.prev_a = prev_a; g2.mask = prev_mask; g2.act = prev_act;
+        g2.act_prm = prev_act_param;
+        g2.a_vec = vec_ok(dz, n_out); g2.b_vec = vec_ok(W, n_out);
+        const int n1 = gemm_setup_small<false, false>(g1, Sx), n2 = gemm_setup_small<true, true>(g2, 1);
+        if (n1 > 0 && n2 > 0) {
+            gemm_f32_pair<false, false, true, true, true, false><<<n1 + n2, 256, 0, ctx->stream>>>(g1, g2, n1, n2);
+            TN_LAUNCH_CHECK();
+            if (Sx > 1) {
+                const size_t MN = (size_t)n_in * n_out;
+                int rc = tn_red_push(ctx, wsC, dW, (uint32_t)MN, (uint32_t)Sx, (uint32_t)MN, 0);
+                if (rc) return rc;
+                rc = tn_red_push(ctx, wsB, db, (uint32_t)n_out, (uint32_t)Sx, (uint32_t)n_out, 0);
+                if (rc) return rc;
+                return tn_red_commit(ctx);
+            }
+            return TN_OK;
+        }
+    }
+    int rc = tn_fc_wgrad(ctx, x, dz, dW, db, B, n_in, n_out, ws);
+    if (rc) return rc;
+    return tn_fc_dgrad(ctx, dz, W, dx, B, n_in, n_out, prev_a, prev_act, prev_act_param, prev_mask);
 }
 
 int tn_fc_dgrad(tn_ctx* ctx, const float* dz, const float* W, float* dx, int B, int n_in, int n_out,

@@ -90,6 +90,20 @@ class HiddenLayer(Layer):
 
     def backward(self, gout, need_gin, below):
         """gout = d cost / d z (activation gradient and dropout mask already applied)."""
+        if self.has_updates() and need_gin and not self.side_stream:
+            # weight gradient and input gradient only share dz: one op, one launch
+            if self.wgrad_ws is None:
+                nbytes = self.ctx.lib.tn_fc_wgrad_ws_bytes(self.batch_sz, self.n_in, self.n_out)
+                self.wgrad_ws = self.ctx.empty((nbytes + 3) // 4)
+            if self.gin is None:
+                self.gin = self.ctx.empty(self.inpt.shape)
+            b_out, b_act, b_prm, b_mask = below.act_info()
+            fuse = b_out is not None and b_act != _lib.TN_ACT_LINEAR
+            self.ctx.call("tn_fc_bwd", self.inpt.ptr, gout.ptr, self.w.ptr, self.grads[0].ptr,
+                          self.grads[1].ptr, self.gin.ptr, self.batch_sz, self.n_in, self.n_out,
+                          self.wgrad_ws.ptr, b_out.ptr if fuse else None, b_act, b_prm,
+                          b_mask.ptr if b_mask is not None else None)
+            return self.gin
         if self.has_updates():
             if self.wgrad_ws is None:
                 nbytes = self.ctx.lib.tn_fc_wgrad_ws_bytes(self.batch_sz, self.n_in, self.n_out)
