@@ -147,14 +147,13 @@ __global__ __launch_bounds__(256) void fc_skinny_fwd_mfma(
 // RC = chunk of 128 rows, 32 per wave.  Lane (lo, qd) loads x[row 4s+qd][64T + 4lo .. +3]; its
 // component e feeds accumulator e, whose M rows are the features 64T + 4i + e.
 #define SKW_ST 8
-__global__ __launch_bounds__(256) void fc_skinny_wgrad_mfma(
+__device__ __forceinline__ void sk_wgrad_body(
     const float* __restrict__ x, const float* __restrict__ dz, float* __restrict__ slab, int B,
-    int n_in, int n_out) {
-    __shared__ float red[4][1024];
+    int n_in, int n_out, int bx, int by, float (*red)[1024]) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, lo = lane & 15, qd = lane >> 4;
-    const int k0 = 64 * blockIdx.x + 4 * lo;
+    const int k0 = 64 * bx + 4 * lo;
     const int kc = min(k0, n_in - 4);
-    const int rowbase = 128 * blockIdx.y + 32 * w;
+    const int rowbase = 128 * by + 32 * w;
     const int nc = min(lo, n_out - 1);
     float4 xv[SKW_ST];
     float dv[SKW_ST];
@@ -187,11 +186,18 @@ __global__ __launch_bounds__(256) void fc_skinny_wgrad_mfma(
     const int per = (n_in + 1) * n_out;
     for (int t = threadIdx.x; t < 1024; t += 256) {
         const int l = t & 63, er = t >> 6, e = er >> 2, r = er & 3;
-        const int n = l & 15, k = 64 * blockIdx.x + 4 * (4 * (l >> 4) + r) + e;
+        const int n = l & 15, k = 64 * bx + 4 * (4 * (l >> 4) + r) + e;
         if (n < n_out && k <= n_in)
-            slab[(size_t)blockIdx.y * per + (size_t)k * n_out + n] =
+            slab[(size_t)by * per + (size_t)k * n_out + n] =
                 ((red[0][t] + red[1][t]) + red[2][t]) + red[3][t];
     }
+}
+
+__global__ __launch_bounds__(256) void fc_skinny_wgrad_mfma(
+    const float* __restrict__ x, const float* __restrict__ dz, float* __restrict__ slab, int B,
+    int n_in, int n_out) {
+    __shared__ float red[4][1024];
+    sk_wgrad_body(x, dz, slab, B, n_in, n_out, blockIdx.x, blockIdx.y, red);
 }
 
 
@@ -200,14 +206,13 @@ __global__ __launch_bounds__(256) void fc_skinny_wgrad_mfma(
 // prev_a / mask access is one 16-byte / 4-byte load issued up front, the dz rows are wave-uniform.
 #define SKD_ROWS 8
 template <int NOUT>
-__global__ __launch_bounds__(128) void fc_skinny_dgrad_v4(
+__device__ __forceinline__ void sk_dgrad_body(
     const float* __restrict__ dz, const float* __restrict__ W, float* __restrict__ dx, int B, int n_in,
-    const float* __restrict__ prev_a, int act, float prm, const uint8_t* __restrict__ mask) {
+    const float* __restrict__ prev_a, int act, float prm, const uint8_t* __restrict__ mask, int q,
+    int row0) {
     const int nq = n_in >> 2;
-    const int q = blockIdx.x * 128 + threadIdx.x;
     const bool live = q < nq;
     const int k = 4 * min(q, nq - 1);
-    const int row0 = blockIdx.y * SKD_ROWS;
     // the 4 W rows of this thread are 4*NOUT consecutive floats: NOUT 16-byte loads
     float wf[4 * NOUT];
 #pragma unroll
@@ -249,6 +254,34 @@ __global__ __launch_bounds__(128) void fc_skinny_dgrad_v4(
     }
 }
 
+template <int NOUT>
+__global__ __launch_bounds__(128) void fc_skinny_dgrad_v4(
+    const float* __restrict__ dz, const float* __restrict__ W, float* __restrict__ dx, int B, int n_in,
+    const float* __restrict__ prev_a, int act, float prm, const uint8_t* __restrict__ mask) {
+    sk_dgrad_body<NOUT>(dz, W, dx, B, n_in, prev_a, act, prm, mask, blockIdx.x * 128 + threadIdx.x,
+                        blockIdx.y * SKD_ROWS);
+}
+
+// weight gradient and input gradient of one layer in ONE launch: they only share dz, so the blocks
+// of the first nW ids run the wgrad body and the rest two 128-thread dgrad bodies each
+template <int NOUT>
+__global__ __launch_bounds__(256) void fc_skinny_bwd_pair(
+    const float* __restrict__ x, const float* __restrict__ dz, const float* __restrict__ W,
+    float* __restrict__ slab, float* __restrict__ dx, int B, int n_in, const float* __restrict__ prev_a,
+    int act, float prm, const uint8_t* __restrict__ mask, int gxW, int nW, int gxD) {
+    __shared__ float red[4][1024];
+    const int bid = blockIdx.x;
+    if (bid < nW) {
+        sk_wgrad_body(x, dz, slab, B, n_in, NOUT, bid % gxW, bid / gxW, red);
+        return;
+    }
+    const int d = 2 * (bid - nW) + (threadIdx.x >> 7);      // 128-thread dgrad block id
+    const int by = d / gxD, bx = d - by * gxD;
+    if (by * SKD_ROWS >= B) return;
+    sk_dgrad_body<NOUT>(dz, W, dx, B, n_in, prev_a, act, prm, mask, bx * 128 + (threadIdx.x & 127),
+                        by * SKD_ROWS);
+}
+
 // ---- host side (called from the tn_fc_* entry points in gemm.hip) -------------------------------
 static bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
@@ -288,6 +321,32 @@ int tn_fc_skinny_wgrad(tn_ctx* ctx, const float* x, const float* dz, float* dW, 
                        int n_in, int n_out, float* ws) {
     const int S = cdiv(B, 128);
     fc_skinny_wgrad_mfma<<<dim3(cdiv(n_in + 1, 64), S), 256, 0, ctx->stream>>>(x, dz, ws, B, n_in, n_out);
+    TN_LAUNCH_CHECK();
+    const int per = (n_in + 1) * n_out, MN = n_in * n_out;
+    int rc = tn_red_push(ctx, ws, dW, (uint32_t)MN, (uint32_t)S, (uint32_t)per, 0);
+    if (rc) return rc;
+    rc = tn_red_push(ctx, ws + MN, db, (uint32_t)n_out, (uint32_t)S, (uint32_t)per, 0);
+    if (rc) return rc;
+    return tn_red_commit(ctx);
+}
+
+int tn_fc_skinny_bwd(tn_ctx* ctx, const float* x, const float* dz, const float* W, float* dW, float* db,
+                     float* dx, int B, int n_in, int n_out, float* ws, const float* prev_a, int act,
+                     float prm, const uint8_t* mask) {
+    const int S = cdiv(B, 128), gxW = cdiv(n_in + 1, 64), nW = gxW * S;
+    const int gxD = cdiv(n_in / 4, 128), nD = gxD * cdiv(B, SKD_ROWS);
+    const int grid = nW + cdiv(nD, 2);
+#define SKP_GO(N_)                                                                              \
+    case N_:                                                                                    \
+        fc_skinny_bwd_pair<N_><<<grid, 256, 0, ctx->stream>>>(x, dz, W, ws, dx, B, n_in, prev_a, act, prm, \
+                                                             mask, gxW, nW, gxD);               \
+        break
+    switch (n_out) {
+        SKP_GO(1); SKP_GO(2); SKP_GO(3); SKP_GO(4); SKP_GO(5); SKP_GO(6); SKP_GO(7); SKP_GO(8);
+        SKP_GO(9); SKP_GO(10); SKP_GO(11); SKP_GO(12); SKP_GO(13); SKP_GO(14); SKP_GO(15);
+        default: SKP_GO(16);
+    }
+#undef SKP_GO
     TN_LAUNCH_CHECK();
     const int per = (n_in + 1) * n_out, MN = n_in * n_out;
     int rc = tn_red_push(ctx, ws, dW, (uint32_t)MN, (uint32_t)S, (uint32_t)per, 0);

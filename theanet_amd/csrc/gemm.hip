@@ -817,6 +817,9 @@ int tn_fc_skinny_wgrad(tn_ctx* ctx, const float* x, const float* dz, float* dW, 
 int tn_fc_skinny_dgrad(tn_ctx* ctx, const float* dz, const float* W, float* dx, int B, int n_in,
                        int n_out, const float* prev_a, int act, float prm, const uint8_t* mask);
 
+int tn_fc_skinny_bwd(tn_ctx* ctx, const float* x, const float* dz, const float* W, float* dW, float* db,
+                     float* dx, int B, int n_in, int n_out, float* ws, const float* prev_a, int act,
+                     float prm, const uint8_t* mask);
 int tn_fc_skinny_softmax(tn_ctx* ctx, const float* x, const float* W, const float* b, float* logits,
                          int B, int n_in, int n_out, const int32_t* y, int64_t y_row0,
                          const int64_t* d_row0, float* logprob, float* rowloss, int32_t* pred,
@@ -956,6 +959,10 @@ int tn_fc_bwd(tn_ctx* ctx, const float* x, const float* dz, const float* W, floa
         const char* e = getenv("TN_FC_PAIR");
         pair_on = e ? atoi(e) : 1;
     }
+    if (pair_on && tn_fc_skinny_ok(n_in, n_out, x, nullptr, nullptr) &&
+        tn_fc_skinny_ok(n_in, n_out, dx, prev_a, prev_mask))
+        return tn_fc_skinny_bwd(ctx, x, dz, W, dW, db, dx, B, n_in, n_out, (float*)ws, prev_a, prev_act,
+                                prev_act_param, prev_mask);
     if (pair_on && n_out > SK_MAX) {
         // weight gradient (split-K slabs) and input gradient as ONE launch of interleaved blocks
         const int S = wgrad_splits(B, n_in, n_out);
