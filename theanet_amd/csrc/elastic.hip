@@ -8,26 +8,41 @@
 
 #define EL_HDR 8   // draws: [0:2] transln, [2:4] origin, [4:6] zoom, [6] theta, [7] pad, [8:] noise
 
-__device__ __forceinline__ float elastic_draw(int i, uint32_t st, uint32_t k0, uint32_t k1) {
-    const u32x4 r = philox4x32((uint32_t)i, 0u, st, TN_STREAM_ELASTIC, k0, k1);
-    if (i < EL_HDR) {
-        const float u = tn_u01(r.x);
-        if (i == 2 || i == 3) return .25f + .5f * u;   // origin  U(.25,.75)
-        return -1.f + 2.f * u;                         // U(-1,1)
+// draws quad q = elements 4q .. 4q+3 from ONE Philox call: header elements are uniforms of one word
+// each; the noise planes take both Box-Muller outputs of the word pairs (x,y) and (z,w)
+__device__ __forceinline__ void elastic_draw4(int q, uint32_t st, uint32_t k0, uint32_t k1, float (&v)[4]) {
+    const u32x4 r = philox4x32((uint32_t)q, 0u, st, TN_STREAM_ELASTIC, k0, k1);
+    const uint32_t wd[4] = {r.x, r.y, r.z, r.w};
+    if (4 * q < EL_HDR) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int i = 4 * q + e;
+            const float u = tn_u01(wd[e]);
+            v[e] = (i == 2 || i == 3) ? .25f + .5f * u : -1.f + 2.f * u;     // origin U(.25,.75), else U(-1,1)
+        }
+        return;
     }
-    // N(0,1), Box-Muller
-    const float u1 = ((r.x >> 8) + 1) * (1.0f / 16777216.0f);
-    const float u2 = tn_u01(r.y);
-    return sqrtf(-2.f * logf(u1)) * cosf(6.28318530717958647692f * u2);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const float u1 = ((wd[2 * h] >> 8) + 1) * (1.0f / 16777216.0f);
+        const float a = 6.28318530717958647692f * tn_u01(wd[2 * h + 1]);
+        const float rad = sqrtf(-2.f * logf(u1));
+        v[2 * h] = rad * cosf(a);
+        v[2 * h + 1] = rad * sinf(a);
+    }
 }
 
 __global__ __launch_bounds__(256) void elastic_draws_kernel(float* __restrict__ draws, int total,
                                                            uint32_t k0, uint32_t k1, uint32_t step,
                                                            const uint32_t* d_step) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= total) return;
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (4 * q >= total) return;
     const uint32_t st = step + (d_step ? *d_step : 0u);
-    draws[i] = elastic_draw(i, st, k0, k1);
+    float v[4];
+    elastic_draw4(q, st, k0, k1, v);
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        if (4 * q + e < total) draws[4 * q + e] = v[e];
 }
 
 // one 64-lane WAVE per output pixel (4 pixels per block): the lanes split the (2s+1)^2 taps of
@@ -48,10 +63,15 @@ __global__ __launch_bounds__(256) void elastic_field_kernel(
         float* sd = filt + ks * ks;
         const uint32_t st = step + (d_step ? *d_step : 0u);
         const int total = EL_HDR + 2 * h * w;
-        for (int i = threadIdx.x; i < total; i += 256) {
-            const float v = elastic_draw(i, st, k0, k1);
-            sd[i] = v;
-            if (draws_out && blockIdx.x == 0) draws_out[i] = v;
+        for (int q4 = threadIdx.x; 4 * q4 < total; q4 += 256) {
+            float v[4];
+            elastic_draw4(q4, st, k0, k1, v);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (4 * q4 + e < total) {
+                    sd[4 * q4 + e] = v[e];
+                    if (draws_out && blockIdx.x == 0) draws_out[4 * q4 + e] = v[e];
+                }
         }
         draws = sd;
         if (magnitude == 0.0) __syncthreads();
@@ -328,7 +348,7 @@ size_t tn_elastic_draws_count(int h, int w) { return (size_t)EL_HDR + 2 * (size_
 int tn_elastic_draws(tn_ctx* ctx, float* draws, int h, int w, uint64_t seed, uint32_t step,
                      const uint32_t* d_step) {
     const int total = (int)tn_elastic_draws_count(h, w);
-    elastic_draws_kernel<<<cdiv(total, 256), 256, 0, ctx->stream>>>(
+    elastic_draws_kernel<<<cdiv(cdiv(total, 4), 256), 256, 0, ctx->stream>>>(
         draws, total, (uint32_t)seed, (uint32_t)(seed >> 32), step, d_step);
     TN_LAUNCH_CHECK();
     return TN_OK;
