@@ -133,9 +133,10 @@ def main():
         specs = [("tn_convblock_bwd_mask", 1,
                   "convblock_bwd_mask_mfma (conv2 block backward from the pooling mask: wgrad + dgrad "
                   "on 16x16x4 f32 MFMA, dz in LDS only)", cb_flops, cb_bytes),
-                 ("tn_fc_fwd", 1, "gemm_f32_fast NN (fc1 forward 4096x720x500)", fl_fc, by_fc),
-                 ("tn_fc_dgrad", 2, "gemm_f32_fast NT (fc1 dgrad)", fl_fc, by_fc),
-                 ("tn_fc_wgrad", 2, "gemm_f32_fast TN split-K (fc1 wgrad)", fl_fc, by_fc)]
+                 ("tn_fc_fwd_dropout", 1, "gemm_f32_fast NN (fc1 forward 4096x720x500, bias + act + "
+                  "inline dropout epilogue)", fl_fc, by_fc + B_ * fc1.n_out),
+                 ("tn_fc_bwd", 2, "gemm_f32_pair (fc1 weight gradient, split-K, + input gradient in one "
+                  "launch)", 2 * fl_fc, 2 * by_fc)]
         if args.time_op:
             op, nth = (args.time_op.split(":") + ["1"])[:2]
             specs = [(op, int(nth), op, 0, 0)]
