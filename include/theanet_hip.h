@@ -206,6 +206,16 @@ int tn_fc_softmax_nll(tn_ctx* ctx, const float* x, const float* W, const float* 
                       int n_in, int n_out, const int32_t* y, int64_t y_row0, const int64_t* d_row0,
                       float* logprob, float* rowloss, int32_t* pred, float* rowp, float* dz,
                       float inv_batch);
+/* ... and the training step of that layer as ONE op: tn_fc_softmax_nll followed by tn_fc_bwd with
+ * dz = dlogits (dW, db OVERWRITTEN, dx = d cost / d (input) times act'(prev_a) * prev_mask of the
+ * layer below; prev_a, if given, is x itself).  With at most 16 classes the whole thing is one launch
+ * per 32 rows: logits, log-softmax / NLL, the input gradient and the rows' weight-gradient slab
+ * (ws >= tn_fc_wgrad_ws_bytes).                                                               */
+int tn_fc_softmax_train(tn_ctx* ctx, const float* x, const float* W, const float* b, float* logits, int B,
+                        int n_in, int n_out, const int32_t* y, int64_t y_row0, const int64_t* d_row0,
+                        float* logprob, float* rowloss, int32_t* pred, float* rowp, float* dz,
+                        float inv_batch, float* dW, float* db, float* dx, void* ws, const float* prev_a,
+                        int prev_act, float prev_act_param, const uint8_t* prev_mask);
 /* tn_fc_fwd with the dropout mask DRAWN in the same launch: mask_out[i] is exactly what
  * tn_dropout_mask(seed, step, d_step, elem0) would produce for a (B, n_out) tensor, the output is
  * multiplied by it, and mask_out stays behind for the backward pass (hidden.py:40-43 + dropout.py:

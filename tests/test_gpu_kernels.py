@@ -409,6 +409,40 @@ def test_fc_softmax_nll_fused(B, n_in, n_out):
     assert_close(logprob.get_value(), lp, what="fused logprob (no labels)")
 
 
+@pytest.mark.parametrize("B,n_in,n_out", [(4096, 500, 10), (45, 64, 16), (70, 24, 3), (21, 30, 40)])
+def test_fc_softmax_train_fused(B, n_in, n_out):
+    """tn_fc_softmax_train: logits, log-softmax/NLL, input gradient and weight gradient of the softmax
+    layer as one op, against the float64 oracle."""
+    rng = np.random.RandomState(B + 3 * n_out)
+    x = rng.randn(B, n_in).astype(np.float32)
+    pm = (rng.rand(B, n_in) > .5).astype(np.uint8)
+    x = x * pm                                       # output of a dropout layer: act(z) * mask
+    W = (rng.randn(n_in, n_out) / np.sqrt(n_in)).astype(np.float32)
+    b = rng.randn(n_out).astype(np.float32)
+    y = rng.randint(0, n_out, size=B).astype(np.int32)
+    z = x.astype(np.float64) @ W.astype(np.float64) + b
+    lp = O.log_softmax(z)
+    onehot = np.zeros((B, n_out)); onehot[np.arange(B), y] = 1
+    dz_w = (np.exp(lp) - onehot) / B
+    lib = ctx().lib
+    ws = empty((lib.tn_fc_wgrad_ws_bytes(B, n_in, n_out) // 4 + 1,))
+    logits, logprob, dz = empty((B, n_out)), empty((B, n_out)), empty((B, n_out))
+    rowloss, rowp, pred = empty((B,)), empty((B,)), empty((B,), np.int32)
+    dW, db, dx = empty((n_in, n_out)), empty((n_out,)), empty((B, n_in))
+    kind, prm = act_code("relu01")
+    xd = dev(x)
+    call("tn_fc_softmax_train", xd.ptr, dev(W).ptr, dev(b).ptr, logits.ptr, B, n_in, n_out, dev(y).ptr, 0,
+         None, logprob.ptr, rowloss.ptr, pred.ptr, rowp.ptr, dz.ptr, 1.0 / B, dW.ptr, db.ptr, dx.ptr,
+         ws.ptr, xd.ptr, kind, prm, dev(pm).ptr)
+    assert_close(logprob.get_value(), lp, what="train logprob")
+    assert_close(rowloss.get_value(), -lp[np.arange(B), y], what="train rowloss")
+    assert_close(dz.get_value(), dz_w, atol=1e-7, what="train dlogits")
+    assert_close(dW.get_value(), x.astype(np.float64).T @ dz_w, atol=1e-5, what="train dW")
+    assert_close(db.get_value(), dz_w.sum(0), atol=1e-5, what="train db")
+    g = np.where(x > 0, 1.0, np.where(x < 0, .01, 1.01)) * pm
+    assert_close(dx.get_value(), (dz_w @ W.astype(np.float64).T) * g, atol=1e-6, what="train dx")
+
+
 @pytest.mark.parametrize("B,n_in,n_out", [(64, 720, 500), (70, 36, 132), (33, 50, 10), (40, 64, 101)])
 def test_fc_fwd_dropout_matches_separate_mask(B, n_in, n_out):
     """tn_fc_fwd_dropout draws the mask inside the GEMM epilogue (or falls back to two launches):

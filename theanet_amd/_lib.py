@@ -65,6 +65,8 @@ SIGNATURES = {
     "tn_scale_mask": (c_int, [CTX, P, P, c_float, P, c_size_t, P, c_int, c_float]),
     "tn_fc_softmax_nll": (c_int, [CTX, P, P, P, P, c_int, c_int, c_int, P, c_int64, P, P, P, P, P, P,
                                   c_float]),
+    "tn_fc_softmax_train": (c_int, [CTX, P, P, P, P, c_int, c_int, c_int, P, c_int64, P, P, P, P, P, P,
+                                    c_float, P, P, P, P, P, c_int, c_float, P]),
     "tn_softmax_nll": (c_int, [CTX, P, P, c_int64, P, P, P, P, P, P, c_int, c_int, c_float]),
     "tn_reduce_sum": (c_int, [CTX, P, c_size_t, c_float, P, c_int]),
     "tn_wtcost": (c_int, [CTX, P, c_size_t, c_float, c_float, P, c_int]),

@@ -282,6 +282,168 @@ __global__ __launch_bounds__(256) void fc_skinny_bwd_pair(
                         by * SKD_ROWS);
 }
 
+// ---- the whole SoftmaxLayer training step in one launch -----------------------------------------
+// block = SKT_RB rows.  (1) logits on the matrix core + the softmax / NLL tail, twice 16 rows, dlogits
+// kept in LDS; (2) input gradient of the 32 rows (thread = 4 features, 16 rows); (3) the rows'
+// contribution to the weight gradient on the matrix core: wave w owns the 64-feature groups
+// w, w+4, ... and writes them straight into this block's slab.  h is read from HBM once (the two
+// later passes hit L2), dh is written once, and two kernel boundaries disappear.
+#define SKT_RB 16      // rows per block
+template <int NOUT>
+__global__ __launch_bounds__(256) void fc_skinny_softmax_train(
+    const float* __restrict__ x, const float* __restrict__ W, const float* __restrict__ b,
+    float* __restrict__ logits, SkSoftmax sm, float* __restrict__ slab, float* __restrict__ dx, int B,
+    int n_in, int act, float prm, const uint8_t* __restrict__ mask, int fuse_act) {
+    __shared__ float red[4][256];
+    __shared__ __attribute__((aligned(16))) float sdz[SKT_RB][16];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, lo = lane & 15, qd = lane >> 4;
+    const int base = blockIdx.x * SKT_RB;
+    const int nch = (n_in + 15) >> 4;
+    const int nc = min(lo, NOUT - 1);
+    const bool nlive = lo < NOUT;
+    const int64_t yoff = sm.y_row0 + (sm.d_row0 ? *sm.d_row0 : 0);
+    const float bias = (b && nlive) ? b[nc] : 0.f;
+    // ---- (1) forward ---------------------------------------------------------------------------
+    for (int tile = 0; tile < SKT_RB / 16; ++tile) {
+        const int rb = base + 16 * tile;
+        const float* xr = x + (size_t)min(rb + lo, B - 1) * n_in;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int c0 = w; c0 < nch; c0 += 4 * SKF_CH) {
+            float4 xv[SKF_CH];
+            float wv[SKF_CH][4];
+#pragma unroll
+            for (int i = 0; i < SKF_CH; ++i) {
+                const int kc = min(16 * (c0 + 4 * i) + 4 * qd, n_in - 4);
+                xv[i] = *reinterpret_cast<const float4*>(xr + kc);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) wv[i][e] = W[(size_t)(kc + e) * NOUT + nc];
+            }
+#pragma unroll
+            for (int i = 0; i < SKF_CH; ++i) {
+                const bool live = nlive && (16 * (c0 + 4 * i) + 4 * qd < n_in);
+                acc = sk_mfma(xv[i].x, live ? wv[i][0] : 0.f, acc);
+                acc = sk_mfma(xv[i].y, live ? wv[i][1] : 0.f, acc);
+                acc = sk_mfma(xv[i].z, live ? wv[i][2] : 0.f, acc);
+                acc = sk_mfma(xv[i].w, live ? wv[i][3] : 0.f, acc);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[w][r * 64 + lane] = acc[r];
+        __syncthreads();
+        if (w == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int rl = 16 * tile + 4 * qd + r, row = base + rl;
+                const int rowc = min(row, B - 1);
+                const float z = ((red[0][r * 64 + lane] + red[1][r * 64 + lane]) + red[2][r * 64 + lane]) +
+                                red[3][r * 64 + lane] + bias;
+                const float zv = nlive ? z : -INFINITY;
+                const float m = sk_row_max(zv);
+                const float am = sk_row_min((nlive && zv == m) ? (float)lo : 1e9f);
+                const float se = sk_row_sum(nlive ? expf(zv - m) : 0.f);
+                const float lp = zv - m - logf(se);
+                const int label = sm.y[yoff + rowc];
+                const float d = (nlive && row < B) ? (expf(lp) - (lo == label ? 1.f : 0.f)) * sm.inv_batch : 0.f;
+                sdz[rl][lo] = d;
+                if (nlive && row < B) {
+                    const size_t o = (size_t)row * NOUT + lo;
+                    if (logits) logits[o] = z;
+                    sm.logprob[o] = lp;
+                    if (sm.dz) sm.dz[o] = d;
+                    if (lo == label) {
+                        if (sm.rowloss) sm.rowloss[row] = -lp;
+                        if (sm.rowp) sm.rowp[row] = expf(lp);
+                    }
+                    if (lo == 0 && sm.pred) sm.pred[row] = (int)am;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // ---- (2) input gradient: dx = (dz W^T) * act'(x) * mask  (x IS the output of the layer below) ----
+    {
+        const int nq = n_in >> 2, half = threadIdx.x >> 7;
+        for (int q0 = 0; q0 < nq; q0 += 128) {
+            const int q = q0 + (threadIdx.x & 127);
+            const bool live = q < nq;
+            const int k = 4 * min(q, nq - 1);
+            float wf[4 * NOUT];
+#pragma unroll
+            for (int i = 0; i < NOUT; ++i) {
+                const float4 v = *reinterpret_cast<const float4*>(W + (size_t)k * NOUT + 4 * i);
+                wf[4 * i] = v.x; wf[4 * i + 1] = v.y; wf[4 * i + 2] = v.z; wf[4 * i + 3] = v.w;
+            }
+#pragma unroll
+            for (int g = 0; g < SKT_RB / 16; ++g) {
+                float4 pa[8];
+                uint32_t pm[8];
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const size_t o = (size_t)min(base + (SKT_RB / 2) * half + 8 * g + r, B - 1) * n_in + k;
+                    pa[r] = fuse_act ? *reinterpret_cast<const float4*>(x + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    pm[r] = mask ? *reinterpret_cast<const uint32_t*>(mask + o) : 0x01010101u;
+                }
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const int rl = (SKT_RB / 2) * half + 8 * g + r, row = base + rl;
+                    float s[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int n = 0; n < NOUT; ++n) {
+                        const float d = sdz[rl][n];            // wave-uniform LDS broadcast
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) s[e] = fmaf(d, wf[e * NOUT + n], s[e]);
+                    }
+                    if (fuse_act) {
+                        s[0] *= tn_act_grad_from_out(pa[r].x, act, prm);
+                        s[1] *= tn_act_grad_from_out(pa[r].y, act, prm);
+                        s[2] *= tn_act_grad_from_out(pa[r].z, act, prm);
+                        s[3] *= tn_act_grad_from_out(pa[r].w, act, prm);
+                    }
+                    s[0] *= (float)(pm[r] & 0xffu);
+                    s[1] *= (float)((pm[r] >> 8) & 0xffu);
+                    s[2] *= (float)((pm[r] >> 16) & 0xffu);
+                    s[3] *= (float)(pm[r] >> 24);
+                    if (live && row < B)
+                        *reinterpret_cast<float4*>(dx + (size_t)row * n_in + k) = make_float4(s[0], s[1], s[2], s[3]);
+                }
+            }
+        }
+    }
+    // ---- (3) weight gradient of the block's 32 rows -> slab[blockIdx.x] ------------------------------
+    {
+        const int per = (n_in + 1) * NOUT, ngrp = (n_in + 1 + 63) >> 6;
+        for (int T = w; T < ngrp; T += 4) {
+            const int k0 = 64 * T + 4 * lo;
+            const int kc = min(k0, n_in - 4);
+            const bool real = k0 < n_in, ones = k0 == n_in;
+            f32x4 acc[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+            float4 xv[SKT_RB / 4];
+#pragma unroll
+            for (int s2 = 0; s2 < SKT_RB / 4; ++s2)
+                xv[s2] = *reinterpret_cast<const float4*>(x + (size_t)min(base + 4 * s2 + qd, B - 1) * n_in + kc);
+#pragma unroll
+            for (int s2 = 0; s2 < SKT_RB / 4; ++s2) {
+                const float dv = sdz[4 * s2 + qd][lo];         // 0 for rows >= B and classes >= NOUT
+                acc[0] = sk_mfma(real ? xv[s2].x : (ones ? 1.f : 0.f), dv, acc[0]);
+                acc[1] = sk_mfma(real ? xv[s2].y : 0.f, dv, acc[1]);
+                acc[2] = sk_mfma(real ? xv[s2].z : 0.f, dv, acc[2]);
+                acc[3] = sk_mfma(real ? xv[s2].w : 0.f, dv, acc[3]);
+            }
+            if (nlive) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int k = 64 * T + 4 * (4 * qd + r) + e;
+                        if (k <= n_in) slab[(size_t)blockIdx.x * per + (size_t)k * NOUT + lo] = acc[e][r];
+                    }
+            }
+        }
+    }
+}
+
 // ---- host side (called from the tn_fc_* entry points in gemm.hip) -------------------------------
 static bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
@@ -347,6 +509,36 @@ int tn_fc_skinny_bwd(tn_ctx* ctx, const float* x, const float* dz, const float* 
         default: SKP_GO(16);
     }
 #undef SKP_GO
+    TN_LAUNCH_CHECK();
+    const int per = (n_in + 1) * n_out, MN = n_in * n_out;
+    int rc = tn_red_push(ctx, ws, dW, (uint32_t)MN, (uint32_t)S, (uint32_t)per, 0);
+    if (rc) return rc;
+    rc = tn_red_push(ctx, ws + MN, db, (uint32_t)n_out, (uint32_t)S, (uint32_t)per, 0);
+    if (rc) return rc;
+    return tn_red_commit(ctx);
+}
+
+// ws must hold cdiv(B, 16) slabs of (n_in + 1) * n_out floats (tn_fc_wgrad_ws_bytes provides it)
+int tn_fc_skinny_softmax_train(tn_ctx* ctx, const float* x, const float* W, const float* b, float* logits,
+                               int B, int n_in, int n_out, const int32_t* y, int64_t y_row0,
+                               const int64_t* d_row0, float* logprob, float* rowloss, int32_t* pred,
+                               float* rowp, float* dz, float inv_batch, float* dW, float* db, float* dx,
+                               float* ws, int fuse_act, int act, float prm, const uint8_t* mask) {
+    SkSoftmax sm{};
+    sm.y = y; sm.y_row0 = y_row0; sm.d_row0 = d_row0; sm.logprob = logprob; sm.rowloss = rowloss;
+    sm.pred = pred; sm.rowp = rowp; sm.dz = dz; sm.inv_batch = inv_batch;
+    const int S = cdiv(B, SKT_RB);
+#define SKT_GO(N_)                                                                              \
+    case N_:                                                                                    \
+        fc_skinny_softmax_train<N_><<<S, 256, 0, ctx->stream>>>(x, W, b, logits, sm, ws, dx, B, n_in, act, \
+                                                                prm, mask, fuse_act);           \
+        break
+    switch (n_out) {
+        SKT_GO(1); SKT_GO(2); SKT_GO(3); SKT_GO(4); SKT_GO(5); SKT_GO(6); SKT_GO(7); SKT_GO(8);
+        SKT_GO(9); SKT_GO(10); SKT_GO(11); SKT_GO(12); SKT_GO(13); SKT_GO(14); SKT_GO(15);
+        default: SKT_GO(16);
+    }
+#undef SKT_GO
     TN_LAUNCH_CHECK();
     const int per = (n_in + 1) * n_out, MN = n_in * n_out;
     int rc = tn_red_push(ctx, ws, dW, (uint32_t)MN, (uint32_t)S, (uint32_t)per, 0);

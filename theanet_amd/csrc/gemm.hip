@@ -820,12 +820,41 @@ int tn_fc_skinny_dgrad(tn_ctx* ctx, const float* dz, const float* W, float* dx, 
 int tn_fc_skinny_bwd(tn_ctx* ctx, const float* x, const float* dz, const float* W, float* dW, float* db,
                      float* dx, int B, int n_in, int n_out, float* ws, const float* prev_a, int act,
                      float prm, const uint8_t* mask);
+int tn_fc_skinny_softmax_train(tn_ctx* ctx, const float* x, const float* W, const float* b, float* logits,
+                               int B, int n_in, int n_out, const int32_t* y, int64_t y_row0,
+                               const int64_t* d_row0, float* logprob, float* rowloss, int32_t* pred,
+                               float* rowp, float* dz, float inv_batch, float* dW, float* db, float* dx,
+                               float* ws, int fuse_act, int act, float prm, const uint8_t* mask);
 int tn_fc_skinny_softmax(tn_ctx* ctx, const float* x, const float* W, const float* b, float* logits,
                          int B, int n_in, int n_out, const int32_t* y, int64_t y_row0,
                          const int64_t* d_row0, float* logprob, float* rowloss, int32_t* pred,
                          float* rowp, float* dz, float inv_batch);
 
 extern "C" {
+
+int tn_fc_softmax_train(tn_ctx* ctx, const float* x, const float* W, const float* b, float* logits, int B,
+                        int n_in, int n_out, const int32_t* y, int64_t y_row0, const int64_t* d_row0,
+                        float* logprob, float* rowloss, int32_t* pred, float* rowp, float* dz,
+                        float inv_batch, float* dW, float* db, float* dx, void* ws, const float* prev_a,
+                        int prev_act, float prev_act_param, const uint8_t* prev_mask) {
+    TN_REQUIRE(B > 0 && n_in > 0 && n_out > 0 && logits && logprob && y && dz && dW && db && dx && ws,
+               "tn_fc_softmax_train: bad arguments");
+    TN_REQUIRE(prev_a == nullptr || prev_a == x, "tn_fc_softmax_train: prev_a must be the layer input");
+    static int fused_on = -1;
+    if (fused_on < 0) {
+        const char* e = getenv("TN_SOFTMAX_TRAIN");
+        fused_on = e ? atoi(e) : 1;
+    }
+    if (fused_on && tn_fc_skinny_ok(n_in, n_out, x, dx, prev_mask))
+        return tn_fc_skinny_softmax_train(ctx, x, W, b, logits, B, n_in, n_out, y, y_row0, d_row0, logprob,
+                                          rowloss, pred, rowp, dz, inv_batch, dW, db, dx, (float*)ws,
+                                          prev_a != nullptr, prev_act, prev_act_param, prev_mask);
+    int rc = tn_fc_softmax_nll(ctx, x, W, b, logits, B, n_in, n_out, y, y_row0, d_row0, logprob, rowloss,
+                               pred, rowp, dz, inv_batch);
+    if (rc) return rc;
+    return tn_fc_bwd(ctx, x, dz, W, dW, db, dx, B, n_in, n_out, ws, prev_a, prev_act, prev_act_param,
+                     prev_mask);
+}
 
 int tn_fc_softmax_nll(tn_ctx* ctx, const float* x, const float* W, const float* b, float* logits, int B,
                       int n_in, int n_out, const int32_t* y, int64_t y_row0, const int64_t* d_row0,
@@ -893,7 +922,9 @@ int tn_fc_fwd_dropout(tn_ctx* ctx, const float* x, const float* W, const float* 
 size_t tn_fc_wgrad_ws_bytes(int B, int n_in, int n_out) {
     if (n_out <= SK_MAX) {
         const int chunks = cdiv(B, SK_WROWS);
-        return ((size_t)chunks * n_in * n_out + (size_t)chunks * n_out) * sizeof(float) + 64;
+        const size_t a = ((size_t)chunks * n_in * n_out + (size_t)chunks * n_out) * sizeof(float) + 64;
+        const size_t t = (size_t)cdiv(B, 16) * (n_in + 1) * n_out * sizeof(float) + 64;   // softmax_train slabs
+        return a > t ? a : t;
     }
     const int S = wgrad_splits(B, n_in, n_out);
     return ((size_t)S * n_in * n_out + (size_t)S * n_out) * sizeof(float) + 64;

@@ -64,10 +64,38 @@ class SoftmaxLayer(HiddenLayer, OutputLayer):
     def act_info(self):
         return None, _lib.TN_ACT_LINEAR, 0.0, None
 
-    def forward(self, train=True, y=None, y_row0=0, d_row0=None, cost_scale=None):
+    def backward(self, gout, need_gin, below):
+        if getattr(self, "_bwd_done", False):       # produced by the fused forward of this step
+            self._bwd_done = False
+            return self.gin if need_gin else None
+        return HiddenLayer.backward(self, gout, need_gin, below)
+
+    def forward(self, train=True, y=None, y_row0=0, d_row0=None, cost_scale=None, below=None):
         """Logits GEMM + the fused softmax/NLL row kernel (+ the cost scalar when training:
-        cost = cost_scale * sum_n -logprob[n, y_n], reduced inside the same launch)."""
+        cost = cost_scale * sum_n -logprob[n, y_n], reduced inside the same launch).
+
+        ``below`` (training only): the layer under this one -- the forward then also produces this
+        layer's weight gradients and the gradient w.r.t. its input (one op, tn_fc_softmax_train);
+        ``backward`` returns that result."""
         have_y = y is not None
+        self._bwd_done = False
+        if have_y and train and below is not None and cost_scale is None and self.has_updates():
+            if self.wgrad_ws is None:
+                nbytes = self.ctx.lib.tn_fc_wgrad_ws_bytes(self.batch_sz, self.n_in, self.n_out)
+                self.wgrad_ws = self.ctx.empty((nbytes + 3) // 4)
+            if self.gin is None:
+                self.gin = self.ctx.empty(self.inpt.shape)
+            b_out, b_act, b_prm, b_mask = below.act_info()
+            fuse = b_out is not None and b_act != _lib.TN_ACT_LINEAR
+            self.ctx.call("tn_fc_softmax_train", self.inpt.ptr, self.w.ptr, self.b.ptr, self.logits.ptr,
+                          self.batch_sz, self.n_in, self.n_out, y.ptr, int(y_row0),
+                          d_row0.ptr if d_row0 is not None else None, self.logprob.ptr,
+                          self.rowloss.ptr, self.y_preds.ptr, self.rowp.ptr, self.dlogits.ptr,
+                          float(self.inv_batch), self.grads[0].ptr, self.grads[1].ptr, self.gin.ptr,
+                          self.wgrad_ws.ptr, b_out.ptr if fuse else None, b_act, b_prm,
+                          b_mask.ptr if b_mask is not None else None)
+            self._bwd_done = True
+            return
         if not (have_y and train and cost_scale is not None and self.d_cost is not None):
             # affine map + softmax / NLL rows as ONE op (one launch for <= 16 classes)
             self.ctx.call("tn_fc_softmax_nll", self.inpt.ptr, self.w.ptr, self.b.ptr, self.logits.ptr,

@@ -427,7 +427,17 @@ class NeuralNet():
                 ctx.call("tn_stream_wait", 0, 1)
                 joined = True
             lyr.forward(True)
-        out.forward(True, y=y, y_row0=y_row0, d_row0=d_row0)
+        # the weight-gradient ops only record their finishing slab sums; one launch does them all
+        ctx.call("tn_defer_reductions", 1)
+        n_lyr = len(self.tr_layers)
+        fuse_out = n_lyr >= 2 and self._need_gin[n_lyr - 1] and not self.side_stream and \
+            os.environ.get("TN_SOFTMAX_TRAIN", "1") != "0"
+        try:
+            out.forward(True, y=y, y_row0=y_row0, d_row0=d_row0,
+                        below=self.tr_layers[-2] if fuse_out else None)
+        except Exception:
+            ctx.call("tn_defer_reductions", 0)
+            raise
         # cost = -mean logprob[n, y_n] (this rank's share of the global mean).  Without weight
         # costs it rides in the update launch at the end of the step (tn_sgd_update_multi_cost);
         # with them it must exist before tn_wtcost accumulates onto it: a leaf reduction here.
@@ -441,8 +451,6 @@ class NeuralNet():
             if self.side_stream:
                 ctx.call("tn_stream_select", 0)
         g = out.dlogits
-        # the weight-gradient ops only record their finishing slab sums; one launch does them all
-        ctx.call("tn_defer_reductions", 1)
         try:
             for idx in range(len(self.tr_layers) - 1, -1, -1):
                 lyr = self.tr_layers[idx]
