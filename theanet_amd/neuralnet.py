@@ -459,7 +459,8 @@ class NeuralNet():
                 if g is None:
                     break
         finally:
-            ctx.call("tn_stream_wait", 0, 1)      # join the side stream (leaf weight gradients)
+            if self.side_stream:
+                ctx.call("tn_stream_wait", 0, 1)  # join the side stream (leaf weight gradients)
             ctx.call("tn_defer_reductions", 0)
         if self.world.size > 1:
             self._group().allreduce_sum(self.flat_grads, self.n_flat)
