@@ -263,6 +263,9 @@ int tn_error_stats(tn_ctx* ctx, const int32_t* pred, const int32_t* y, int64_t y
  * sums are only recorded; the closing call runs all of them as ONE launch (dW/db are valid after
  * it, in stream order).  Outside such a window every op finishes its own gradient.          */
 int tn_defer_reductions(tn_ctx* ctx, int on);
+/* tn_defer_reductions(ctx, 0) that also advances a device counter (the RNG step counter) in the same
+ * launch, so that everything enqueued afterwards already sees the next step's value.            */
+int tn_defer_flush_step(tn_ctx* ctx, uint32_t* d_step);
 
 /* ---- momentum SGD + maxnorm (replaces Layer.get_updates; layer.py:70-107) ----
  * g' = g*gscale + L1*sign(p) + 2*L2*p ; v_new = m*v + (1-m)*g' ; p_new = p - rate*lr*v_OLD
@@ -315,6 +318,14 @@ int tn_elastic_field_gen(tn_ctx* ctx, float* draws_out, uint64_t seed, uint32_t 
                          const uint32_t* d_step, int h, int w, double translation, double zoom,
                          double magnitude, int sigma, double angle, int nearest, int32_t* map_idx,
                          float* map_fy, float* map_fx, double* target);
+/* The closing launch of a training step: tn_sgd_update_multi_cost (without the counter increment)
+ * and tn_elastic_field_gen for the NEXT minibatch side by side in one kernel -- the field depends only
+ * on *d_step, which the caller has already advanced (tn_defer_flush_step).  Arguments as in the two. */
+int tn_step_tail(tn_ctx* ctx, const tn_sgd_seg* d_segs, int nseg, size_t max_n, const float* d_lr,
+                 float gscale, const float* rowloss, int nrow, float cost_scale, float* d_cost,
+                 float* draws_out, uint64_t seed, const uint32_t* d_step, int h, int w,
+                 double translation, double zoom, double magnitude, int sigma, double angle, int nearest,
+                 int32_t* map_idx, float* map_fy, float* map_fx, double* target);
 int tn_elastic_apply(tn_ctx* ctx, const float* x, int64_t x_row0, const int64_t* d_row0,
                      float* out, int N, int C, int h, int w, int invert, int nearest,
                      const int32_t* map_idx, const float* map_fy, const float* map_fx,

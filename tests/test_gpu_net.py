@@ -320,6 +320,31 @@ def test_graph_replay_equals_eager():
             np.testing.assert_array_equal(wa, wb)
 
 
+def test_step_tail_equals_separate_launches(monkeypatch):
+    """Building the next minibatch's elastic field beside the update (tn_step_tail) is a pure
+    re-scheduling: costs, log-probabilities and weights must match the plain schedule bit for bit."""
+    from theanet_amd import NeuralNet
+    import copy
+    prms = load_prms("mnist.prms", 28, batch=64)
+    rng = np.random.RandomState(3)
+    x = rng.rand(4 * 64, 1, 28, 28).astype(np.float32)
+    y = rng.randint(0, 10, 4 * 64).astype(np.int32)
+    nets = []
+    for tail in ("1", "0"):
+        monkeypatch.setenv("TN_STEP_TAIL", tail)
+        net = NeuralNet(copy.deepcopy(prms["layers"]), dict(prms["training_params"]))
+        fn = net.get_trin_model(x, y)
+        outs = [fn(s % 4) for s in range(6)]
+        assert net.tr_layers[0]._pre_valid == (tail == "1")
+        nets.append((net, outs))
+    for (c0, _, l0), (c1, _, l1) in zip(nets[0][1], nets[1][1]):
+        assert c0 == c1
+        np.testing.assert_array_equal(l0, l1)
+    for la, lb in zip(nets[0][0].tr_layers, nets[1][0].tr_layers):
+        for wa, wb in zip(la.get_wts(), lb.get_wts()):
+            np.testing.assert_array_equal(wa, wb)
+
+
 @pytest.mark.parametrize("name,img,B", [("cifar_like.prms", 32, 16), ("wide6.prms", 16, 4)])
 def test_baseline_config_nets_match_oracle(name, img, B):
     """BASELINE.json configs 4 and 5 (MFMA conv path, dropout + maxnorm): two training steps at

@@ -74,6 +74,10 @@ SIGNATURES = {
     "tn_sgd_update": (c_int, [CTX, P, P, P, c_size_t, c_float, c_float, P, c_float, c_float, c_float]),
     "tn_maxnorm": (c_int, [CTX, P, c_int, c_int, c_int, c_float]),
     "tn_defer_reductions": (c_int, [CTX, c_int]),
+    "tn_defer_flush_step": (c_int, [CTX, P]),
+    "tn_step_tail": (c_int, [CTX, P, c_int, c_size_t, P, c_float, P, c_int, c_float, P,
+                             P, c_uint64, P, c_int, c_int, c_double, c_double, c_double, c_int, c_double,
+                             c_int, P, P, P, P]),
     "tn_sgd_update_multi": (c_int, [CTX, P, c_int, c_size_t, P, c_float, P]),
     "tn_sgd_update_multi_cost": (c_int, [CTX, P, c_int, c_size_t, P, c_float, P, P, c_int, c_float, P]),
     "tn_softmax_cost_ws_bytes": (c_size_t, [c_int]),

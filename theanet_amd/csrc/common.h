@@ -44,6 +44,7 @@ int tn_red_push(tn_ctx* ctx, const float* src, float* out, uint32_t n, uint32_t 
                 uint32_t flip);
 int tn_red_commit(tn_ctx* ctx);
 int tn_red_flush(tn_ctx* ctx);
+int tn_red_flush_inc(tn_ctx* ctx, uint32_t* inc);
 
 extern char g_tn_err[512];
 

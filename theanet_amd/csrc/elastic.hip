@@ -5,6 +5,7 @@
 // float32 random inputs upcast to float64); the field is tiny (2 x h x w) so fp64 is free.
 // The gather kernel is the HBM-bound part: x read once, out written once.
 #include "common.h"
+#include "update_body.h"
 
 #define EL_HDR 8   // draws: [0:2] transln, [2:4] origin, [4:6] zoom, [6] theta, [7] pad, [8:] noise
 
@@ -50,13 +51,35 @@ __global__ __launch_bounds__(256) void elastic_draws_kernel(float* __restrict__ 
 // 961-tap serial loop; lane 0 then applies translation / zoom / rotation / clipping.
 // GEN: the draws are not read but generated -- every block fills its own LDS copy (a few Philox
 // calls per thread), block 0 also stores them to draws_out: saves the separate draws launch.
+struct ElField {       // arguments of the field computation (shared by its two launchers)
+    const float* draws_in;
+    float* draws_out;
+    uint32_t k0, k1, step;
+    const uint32_t* d_step;
+    int h, w;
+    double translation, zoom, magnitude;
+    int sigma;
+    double angle;
+    int nearest;
+    int32_t* map_idx;
+    float* map_fy;
+    float* map_fx;
+    double* target;
+};
+
 template <bool GEN>
-__global__ __launch_bounds__(256) void elastic_field_kernel(
-    const float* __restrict__ draws_in, float* __restrict__ draws_out, uint32_t k0, uint32_t k1,
-    uint32_t step, const uint32_t* __restrict__ d_step, int h, int w, double translation, double zoom,
-    double magnitude, int sigma, double angle, int nearest, int32_t* __restrict__ map_idx,
-    float* __restrict__ map_fy, float* __restrict__ map_fx, double* __restrict__ target) {
-    extern __shared__ float filt[];   // (2s+1)^2, float32 like the reference's filter [+ the draws]
+__device__ __forceinline__ void elastic_field_block(const ElField& f, float* filt, int bx) {
+    const float* __restrict__ draws_in = f.draws_in;
+    float* __restrict__ draws_out = f.draws_out;
+    const uint32_t k0 = f.k0, k1 = f.k1, step = f.step;
+    const uint32_t* __restrict__ d_step = f.d_step;
+    const int h = f.h, w = f.w, sigma = f.sigma, nearest = f.nearest;
+    const double translation = f.translation, zoom = f.zoom, magnitude = f.magnitude, angle = f.angle;
+    int32_t* __restrict__ map_idx = f.map_idx;
+    float* __restrict__ map_fy = f.map_fy;
+    float* __restrict__ map_fx = f.map_fx;
+    double* __restrict__ target = f.target;
+    // filt: (2s+1)^2 floats, float32 like the reference's filter [+ the draws]
     const int ks = 2 * sigma + 1;
     const float* draws = draws_in;
     if (GEN) {
@@ -70,7 +93,7 @@ __global__ __launch_bounds__(256) void elastic_field_kernel(
             for (int e = 0; e < 4; ++e)
                 if (4 * q4 + e < total) {
                     sd[4 * q4 + e] = v[e];
-                    if (draws_out && blockIdx.x == 0) draws_out[4 * q4 + e] = v[e];
+                    if (draws_out && bx == 0) draws_out[4 * q4 + e] = v[e];
                 }
         }
         draws = sd;
@@ -85,7 +108,7 @@ __global__ __launch_bounds__(256) void elastic_field_kernel(
         }
         __syncthreads();
     }
-    const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int p = bx * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (p >= h * w) return;
     const int y = p / w, x = p - y * w;
@@ -153,6 +176,32 @@ __global__ __launch_bounds__(256) void elastic_field_kernel(
         map_fy[p] = (float)(cy - top);
         map_fx[p] = (float)(cx - left);
     }
+}
+
+template <bool GEN>
+__global__ __launch_bounds__(256) void elastic_field_kernel(ElField f) {
+    extern __shared__ float filt[];
+    elastic_field_block<GEN>(f, filt, (int)blockIdx.x);
+}
+
+// The last launch of a training step: the momentum-SGD update of every tensor (+ the cost rider),
+// and -- in the extra row blockIdx.y == n_upd -- the elastic field of the NEXT minibatch, which only
+// depends on the RNG step counter (already advanced by the step's reduction launch).  The two are
+// independent, so they share one kernel boundary.
+__global__ __launch_bounds__(256) void step_tail_kernel(const tn_sgd_seg* __restrict__ segs, int nseg,
+                                                       const float* __restrict__ d_lr, float gscale,
+                                                       const float* __restrict__ rowloss, int nrow,
+                                                       float cost_scale, float* __restrict__ d_cost,
+                                                       int n_upd, int nbx_upd, ElField f) {
+    extern __shared__ float filt[];
+    if ((int)blockIdx.y == n_upd) {
+        if ((int)blockIdx.x * 4 < f.h * f.w) elastic_field_block<true>(f, filt, (int)blockIdx.x);
+        return;
+    }
+    if ((int)blockIdx.x >= nbx_upd) return;
+    __shared__ float red[4];
+    sgd_update_multi_block(segs, nseg, d_lr, gscale, nullptr, rowloss, nrow, cost_scale, d_cost,
+                           blockIdx.x, blockIdx.y, nbx_upd, red);
 }
 
 __global__ __launch_bounds__(256) void elastic_apply_kernel(
@@ -363,9 +412,9 @@ int tn_elastic_field(tn_ctx* ctx, const float* draws, int h, int w, double trans
     const int ks = 2 * sigma + 1;
     const size_t lds = (size_t)ks * ks * sizeof(float);
     TN_REQUIRE(lds <= 64 * 1024, "tn_elastic_field: sigma %d too large", sigma);
-    elastic_field_kernel<false><<<cdiv(h * w, 4), 256, lds, ctx->stream>>>(
-        draws, nullptr, 0u, 0u, 0u, nullptr, h, w, translation, zoom, magnitude, sigma, angle, nearest,
-        map_idx, map_fy, map_fx, target);
+    ElField f{draws, nullptr, 0u, 0u, 0u, nullptr, h, w, translation, zoom, magnitude, sigma, angle, nearest,
+              map_idx, map_fy, map_fx, target};
+    elastic_field_kernel<false><<<cdiv(h * w, 4), 256, lds, ctx->stream>>>(f);
     TN_LAUNCH_CHECK();
     return TN_OK;
 }
@@ -386,9 +435,43 @@ int tn_elastic_field_gen(tn_ctx* ctx, float* draws_out, uint64_t seed, uint32_t 
         return tn_elastic_field(ctx, draws_out, h, w, translation, zoom, magnitude, sigma, angle,
                                 nearest, map_idx, map_fy, map_fx, target);
     }
-    elastic_field_kernel<true><<<cdiv(h * w, 4), 256, lds, ctx->stream>>>(
-        nullptr, draws_out, (uint32_t)seed, (uint32_t)(seed >> 32), step, d_step, h, w, translation,
-        zoom, magnitude, sigma, angle, nearest, map_idx, map_fy, map_fx, target);
+    ElField f{nullptr, draws_out, (uint32_t)seed, (uint32_t)(seed >> 32), step, d_step, h, w, translation,
+              zoom, magnitude, sigma, angle, nearest, map_idx, map_fy, map_fx, target};
+    elastic_field_kernel<true><<<cdiv(h * w, 4), 256, lds, ctx->stream>>>(f);
+    TN_LAUNCH_CHECK();
+    return TN_OK;
+}
+
+int tn_step_tail(tn_ctx* ctx, const tn_sgd_seg* d_segs, int nseg, size_t max_n, const float* d_lr,
+                 float gscale, const float* rowloss, int nrow, float cost_scale, float* d_cost,
+                 float* draws_out, uint64_t seed, const uint32_t* d_step, int h, int w,
+                 double translation, double zoom, double magnitude, int sigma, double angle, int nearest,
+                 int32_t* map_idx, float* map_fy, float* map_fx, double* target) {
+    TN_REQUIRE(h > 0 && w > 0 && zoom > 0 && sigma >= 0 && map_idx != nullptr && d_step != nullptr,
+               "tn_step_tail: bad field arguments");
+    TN_REQUIRE(nearest || (map_fy && map_fx), "tn_step_tail: bilinear needs map_fy/map_fx");
+    TN_REQUIRE(nseg <= 0 || (d_segs != nullptr && d_lr != nullptr), "tn_step_tail: NULL update argument");
+    const bool rider = rowloss != nullptr;
+    TN_REQUIRE(!rider || (d_cost != nullptr && nrow > 0), "tn_step_tail: bad cost arguments");
+    if (nseg < 0) nseg = 0;
+    const int ks = 2 * sigma + 1;
+    const size_t lds = ((size_t)ks * ks + tn_elastic_draws_count(h, w)) * sizeof(float);
+    if (lds > 48 * 1024) {      // the field does not fit beside the update: two launches
+        int rc = tn_sgd_update_multi_cost(ctx, d_segs, nseg, max_n, d_lr, gscale, nullptr, rowloss, nrow,
+                                          cost_scale, d_cost);
+        if (rc) return rc;
+        return tn_elastic_field_gen(ctx, draws_out, seed, 0, d_step, h, w, translation, zoom, magnitude,
+                                    sigma, angle, nearest, map_idx, map_fy, map_fx, target);
+    }
+    int bx = cdiv(max_n, 1024);
+    if (bx > 256) bx = 256;
+    if (bx < 1) bx = 1;
+    const int n_upd = nseg + (rider ? 1 : 0);
+    const int gx = bx > cdiv(h * w, 4) ? bx : cdiv(h * w, 4);
+    ElField f{nullptr, draws_out, (uint32_t)seed, (uint32_t)(seed >> 32), 0u, d_step, h, w, translation,
+              zoom, magnitude, sigma, angle, nearest, map_idx, map_fy, map_fx, target};
+    step_tail_kernel<<<dim3(gx, n_upd + 1), 256, lds, ctx->stream>>>(d_segs, nseg, d_lr, gscale, rowloss,
+                                                                    nrow, cost_scale, d_cost, n_upd, bx, f);
     TN_LAUNCH_CHECK();
     return TN_OK;
 }

@@ -18,7 +18,8 @@ struct RedBatch {
 // tall (S  > 32): block = 16 outputs x 16 slab lanes, lane l sums slabs l, l+16, ...; the 16 lane
 //                 sums are added in lane order.
 // flip = f*f > 0: conv slabs are in correlation layout, out[kc*ff + uv] = sum src[kc*ff + ff-1-uv].
-__global__ __launch_bounds__(256) void slab_sum_multi_kernel(RedBatch b) {
+__global__ __launch_bounds__(256) void slab_sum_multi_kernel(RedBatch b, uint32_t* inc) {
+    if (inc && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *inc += 1;     // rider: step counter
     const tn_red_rec rec = b.r[blockIdx.y];
     const uint32_t n = rec.n, S = rec.S, stride = rec.stride;
     const float* __restrict__ src = rec.src;
@@ -82,8 +83,18 @@ static uint32_t red_blocks(const tn_red_rec& r) {
     return vec ? (r.n / 4 + 255) / 256 : (r.n + 255) / 256;
 }
 
-int tn_red_flush(tn_ctx* ctx) {
-    if (ctx->npend == 0) return TN_OK;
+__global__ void red_inc_kernel(uint32_t* inc) { *inc += 1; }
+
+int tn_red_flush(tn_ctx* ctx) { return tn_red_flush_inc(ctx, nullptr); }
+
+int tn_red_flush_inc(tn_ctx* ctx, uint32_t* inc) {
+    if (ctx->npend == 0) {
+        if (inc) {
+            red_inc_kernel<<<1, 1, 0, ctx->stream>>>(inc);
+            TN_LAUNCH_CHECK();
+        }
+        return TN_OK;
+    }
     RedBatch b;
     b.nrec = ctx->npend;
     uint32_t gx = 1;
@@ -94,7 +105,7 @@ int tn_red_flush(tn_ctx* ctx) {
     }
     ctx->npend = 0;
     ctx->scratch_off = 0;          // the slabs are consumed in stream order
-    slab_sum_multi_kernel<<<dim3(gx, b.nrec), 256, 0, ctx->stream>>>(b);
+    slab_sum_multi_kernel<<<dim3(gx, b.nrec), 256, 0, ctx->stream>>>(b, inc);
     TN_LAUNCH_CHECK();
     return TN_OK;
 }
@@ -138,6 +149,11 @@ int tn_scratch_get(tn_ctx* ctx, size_t bytes, float** out) {
     *out = reinterpret_cast<float*>(reinterpret_cast<char*>(ctx->scratch) + off);
     if (ctx->defer) ctx->scratch_off = off + bytes;
     return TN_OK;
+}
+
+extern "C" int tn_defer_flush_step(tn_ctx* ctx, uint32_t* d_step) {
+    ctx->defer = false;
+    return tn_red_flush_inc(ctx, d_step);
 }
 
 extern "C" int tn_defer_reductions(tn_ctx* ctx, int on) {

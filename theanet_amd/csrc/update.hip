@@ -2,6 +2,7 @@
 // Semantics: theanet/layer/layer.py:70-107 -- simultaneous Theano updates:
 //   v' = m*v + (1-m)*g ;  p' = p - rate*lr*v   (the OLD velocity moves p) ; maxnorm(p').
 #include "common.h"
+#include "update_body.h"
 
 __global__ __launch_bounds__(256) void sgd_update_kernel(float* __restrict__ p, float* __restrict__ v,
                                                         const float* __restrict__ g, size_t n,
@@ -28,37 +29,9 @@ __global__ __launch_bounds__(256) void sgd_update_multi_kernel(const tn_sgd_seg*
                                                               const float* __restrict__ rowloss,
                                                               int nrow, float cost_scale,
                                                               float* __restrict__ d_cost) {
-    if (d_step_inc && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
-        *d_step_inc += 1;                       // the RNG step counter advances with the update
-    if ((int)blockIdx.y == nseg) {
-        // rider: the minibatch cost = cost_scale * sum(rowloss), summed in a fixed order by ONE block
-        // (saves the separate reduction launch of the step)
-        if (blockIdx.x != 0) return;
-        __shared__ float red[4];
-        float s = 0.f;
-        for (int i = threadIdx.x; i < nrow; i += 256) s += rowloss[i];
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
-        __syncthreads();
-        if (threadIdx.x == 0) d_cost[0] = cost_scale * ((red[0] + red[1]) + (red[2] + red[3]));
-        return;
-    }
-    const tn_sgd_seg sg = segs[blockIdx.y];
-    const float step = sg.rate * d_lr[0];
-    float* __restrict__ p = sg.p;
-    float* __restrict__ v = sg.v;
-    const float* __restrict__ g = sg.g;
-    const size_t n = sg.n;
-    const float m = sg.momentum, L1 = sg.L1, L2 = sg.L2;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        const float pv = p[i], vv = v[i];
-        float gg = g[i] * gscale;
-        if (L1 != 0.f) gg += L1 * ((pv > 0.f) - (pv < 0.f));
-        if (L2 != 0.f) gg += 2.f * L2 * pv;
-        v[i] = m * vv + (1.f - m) * gg;
-        p[i] = pv - step * vv;
-    }
+    __shared__ float red[4];
+    sgd_update_multi_block(segs, nseg, d_lr, gscale, d_step_inc, rowloss, nrow, cost_scale, d_cost,
+                           blockIdx.x, blockIdx.y, gridDim.x, red);
 }
 
 __global__ __launch_bounds__(256) void clip_kernel(float* __restrict__ p, size_t n, float mx) {

@@ -173,8 +173,10 @@ class ElasticLayer(Layer):
         ahead = self.precompute and self.has_field and not self._inj_draws and self.d_step is not None
         if self.has_field:
             self.map_idx, self.map_fy, self.map_fx, self.target = self._maps[self._cur]
-            if ahead and self._pre_valid:
-                self.ctx.call("tn_stream_wait", 0, 1)        # the side stream built this map
+            if self._pre_valid and not self._inj_draws:
+                if ahead:
+                    self.ctx.call("tn_stream_wait", 0, 1)    # the side stream built this map
+                # else: built by the previous step's closing launch (NeuralNet._train_step)
             else:
                 if not self._inj_draws:      # draws generated inside the field launch
                     m = self._maps[self._cur]

@@ -461,12 +461,33 @@ class NeuralNet():
         finally:
             if self.side_stream:
                 ctx.call("tn_stream_wait", 0, 1)  # join the side stream (leaf weight gradients)
-            ctx.call("tn_defer_reductions", 0)
+            # Step tail: the elastic field of the NEXT minibatch only depends on the step counter, so
+            # the counter advances with the reduction launch and the field is built beside the update.
+            tail = (isinstance(first, ElasticLayer) and first.active and first.has_field and
+                    not first._inj_draws and first.d_step is not None and not self.side_stream and
+                    not self.use_graph and (self._n_segs or rider) and
+                    os.environ.get("TN_STEP_TAIL", "1") != "0")
+            if tail:
+                ctx.call("tn_defer_flush_step", self.d_step.ptr)
+            else:
+                ctx.call("tn_defer_reductions", 0)
         if self.world.size > 1:
             self._group().allreduce_sum(self.flat_grads, self.n_flat)
         for lyr in self.tr_layers:
             lyr.get_wtcost(self.d_cost)
-        if self._n_segs or rider:                 # also advances the RNG step counter
+        if tail:
+            nxt = 1 - first._cur
+            m = first._maps[nxt]
+            hw = first.img_sz
+            ctx.call("tn_step_tail", self._d_segs.ptr if self._n_segs else None, self._n_segs,
+                     self._max_seg, self.cur_learn_rate.ptr, 1.0,
+                     out.rowloss.ptr if rider else None, self.local_bsz, 1.0 / self.batch_sz,
+                     self.d_cost.ptr if rider else None, first.draws.ptr, first.seed, self.d_step.ptr,
+                     hw, hw, float(first.translation), float(first.zoom), float(first.magnitude),
+                     int(first.sigma), float(first.angle), int(first.nearest), m[0].ptr, m[1].ptr,
+                     m[2].ptr, m[3].ptr)
+            first._cur, first._pre_valid = nxt, True
+        elif self._n_segs or rider:               # also advances the RNG step counter
             ctx.call("tn_sgd_update_multi_cost", self._d_segs.ptr if self._n_segs else None,
                      self._n_segs, self._max_seg, self.cur_learn_rate.ptr, 1.0, self.d_step.ptr,
                      out.rowloss.ptr if rider else None, self.local_bsz, 1.0 / self.batch_sz,
