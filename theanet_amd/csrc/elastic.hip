@@ -97,7 +97,28 @@ __device__ __forceinline__ void elastic_field_block(const ElField& f, float* fil
                 }
         }
         draws = sd;
-        if (magnitude == 0.0) __syncthreads();
+    }
+    // The zoom factors and the rotation (double-precision exp / cos / sin of three header draws) are
+    // the same for every pixel: four threads work them out while the others fill the filter table,
+    // instead of every wave's lane 0 doing all four after its smoothing sum.
+    double* aux = reinterpret_cast<double*>(filt + ((ks * ks + (GEN ? EL_HDR + 2 * h * w : 0) + 1) & ~1));
+    if (threadIdx.x >= 192 && threadIdx.x < 196 && (zoom != 1.0 || angle != 0.0)) {
+        float hd[4];                               // draws[4..7]: zoom u (2), theta u, pad
+        if (GEN) {
+            elastic_draw4(1, step + (d_step ? *d_step : 0u), k0, k1, hd);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) hd[e] = draws_in[4 + e];
+        }
+        const int j = threadIdx.x - 192;
+        double r;
+        if (j < 2) {
+            r = zoom != 1.0 ? exp(log(zoom) * (double)hd[j]) : 1.0;
+        } else {
+            const double theta = (angle * 3.14159265358979323846 / 180.0) * (double)hd[2];
+            r = j == 2 ? cos(theta) : sin(theta);
+        }
+        aux[j] = r;
     }
     if (magnitude != 0.0) {
         const double var = (double)sigma * sigma;
@@ -106,8 +127,8 @@ __device__ __forceinline__ void elastic_field_block(const ElField& f, float* fil
             const int i = t % ks - sigma, j = t / ks - sigma;
             filt[t] = (float)exp(-.5 * (i * i + j * j) / var) / norm;
         }
-        __syncthreads();
     }
+    __syncthreads();
     const int p = bx * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (p >= h * w) return;
@@ -146,13 +167,11 @@ __device__ __forceinline__ void elastic_field_block(const ElField& f, float* fil
         ty -= oy;
         tx -= ox;
         if (zoom != 1.0) {
-            const double lz = log(zoom);
-            ty *= exp(lz * (double)draws[4]);
-            tx *= exp(lz * (double)draws[5]);
+            ty *= aux[0];          // exp(log(zoom) * draws[4])
+            tx *= aux[1];          // exp(log(zoom) * draws[5])
         }
         if (angle != 0.0) {
-            const double theta = (angle * 3.14159265358979323846 / 180.0) * (double)draws[6];
-            const double c = cos(theta), s = sin(theta);
+            const double c = aux[2], s = aux[3];      // cos / sin(angle * pi/180 * draws[6])
             // tensordot(R, target, axes=(0,0)) with R=[[c,-s],[s,c]] -> R^T applied
             const double ry = c * ty + s * tx;
             const double rx = -s * ty + c * tx;
@@ -410,7 +429,7 @@ int tn_elastic_field(tn_ctx* ctx, const float* draws, int h, int w, double trans
                "tn_elastic_field: bad arguments");
     TN_REQUIRE(nearest || (map_fy && map_fx), "tn_elastic_field: bilinear needs map_fy/map_fx");
     const int ks = 2 * sigma + 1;
-    const size_t lds = (size_t)ks * ks * sizeof(float);
+    const size_t lds = ((size_t)ks * ks + 16) * sizeof(float);      // filter table + 4 doubles
     TN_REQUIRE(lds <= 64 * 1024, "tn_elastic_field: sigma %d too large", sigma);
     ElField f{draws, nullptr, 0u, 0u, 0u, nullptr, h, w, translation, zoom, magnitude, sigma, angle, nearest,
               map_idx, map_fy, map_fx, target};
@@ -427,7 +446,7 @@ int tn_elastic_field_gen(tn_ctx* ctx, float* draws_out, uint64_t seed, uint32_t 
                "tn_elastic_field_gen: bad arguments");
     TN_REQUIRE(nearest || (map_fy && map_fx), "tn_elastic_field_gen: bilinear needs map_fy/map_fx");
     const int ks = 2 * sigma + 1;
-    const size_t lds = ((size_t)ks * ks + tn_elastic_draws_count(h, w)) * sizeof(float);
+    const size_t lds = ((size_t)ks * ks + tn_elastic_draws_count(h, w) + 16) * sizeof(float);
     if (lds > 64 * 1024) {      // big images: two launches
         TN_REQUIRE(draws_out != nullptr, "tn_elastic_field_gen: %dx%d needs a draws buffer", h, w);
         int rc = tn_elastic_draws(ctx, draws_out, h, w, seed, step, d_step);
@@ -455,7 +474,7 @@ int tn_step_tail(tn_ctx* ctx, const tn_sgd_seg* d_segs, int nseg, size_t max_n, 
     TN_REQUIRE(!rider || (d_cost != nullptr && nrow > 0), "tn_step_tail: bad cost arguments");
     if (nseg < 0) nseg = 0;
     const int ks = 2 * sigma + 1;
-    const size_t lds = ((size_t)ks * ks + tn_elastic_draws_count(h, w)) * sizeof(float);
+    const size_t lds = ((size_t)ks * ks + tn_elastic_draws_count(h, w) + 16) * sizeof(float);
     if (lds > 48 * 1024) {      // the field does not fit beside the update: two launches
         int rc = tn_sgd_update_multi_cost(ctx, d_segs, nseg, max_n, d_lr, gscale, nullptr, rowloss, nrow,
                                           cost_scale, d_cost);
