@@ -318,6 +318,17 @@ int tn_elastic_field_gen(tn_ctx* ctx, float* draws_out, uint64_t seed, uint32_t 
                          const uint32_t* d_step, int h, int w, double translation, double zoom,
                          double magnitude, int sigma, double angle, int nearest, int32_t* map_idx,
                          float* map_fy, float* map_fx, double* target);
+/* Rider: the same field computation, not launched but left with the context; the next paired
+ * GEMM launch (tn_fc_bwd) carries it as extra blocks, so it costs no kernel boundary of its own.
+ * step is the offset added to *d_step (1 = the minibatch after the one in flight).  tn_rider_pending
+ * tells whether it is still waiting, tn_rider_cancel drops it (the caller then runs tn_step_tail or
+ * tn_elastic_field_gen itself).                                                              */
+int tn_rider_elastic_field(tn_ctx* ctx, float* draws_out, uint64_t seed, uint32_t step,
+                           const uint32_t* d_step, int h, int w, double translation, double zoom,
+                           double magnitude, int sigma, double angle, int nearest, int32_t* map_idx,
+                           float* map_fy, float* map_fx, double* target);
+int tn_rider_pending(tn_ctx* ctx);
+int tn_rider_cancel(tn_ctx* ctx);
 /* The closing launch of a training step: tn_sgd_update_multi_cost (without the counter increment)
  * and tn_elastic_field_gen for the NEXT minibatch side by side in one kernel -- the field depends only
  * on *d_step, which the caller has already advanced (tn_defer_flush_step).  Arguments as in the two. */

@@ -330,19 +330,22 @@ def test_step_tail_equals_separate_launches(monkeypatch):
     x = rng.rand(4 * 64, 1, 28, 28).astype(np.float32)
     y = rng.randint(0, 10, 4 * 64).astype(np.int32)
     nets = []
-    for tail in ("1", "0"):
+    # rider in the paired GEMM launch / beside the update (tn_step_tail) / a launch of its own
+    for tail, rider in (("1", "1"), ("1", "0"), ("0", "0")):
         monkeypatch.setenv("TN_STEP_TAIL", tail)
+        monkeypatch.setenv("TN_FIELD_RIDER", rider)
         net = NeuralNet(copy.deepcopy(prms["layers"]), dict(prms["training_params"]))
         fn = net.get_trin_model(x, y)
         outs = [fn(s % 4) for s in range(6)]
         assert net.tr_layers[0]._pre_valid == (tail == "1")
         nets.append((net, outs))
-    for (c0, _, l0), (c1, _, l1) in zip(nets[0][1], nets[1][1]):
-        assert c0 == c1
-        np.testing.assert_array_equal(l0, l1)
-    for la, lb in zip(nets[0][0].tr_layers, nets[1][0].tr_layers):
-        for wa, wb in zip(la.get_wts(), lb.get_wts()):
-            np.testing.assert_array_equal(wa, wb)
+    for other in nets[1:]:
+        for (c0, _, l0), (c1, _, l1) in zip(nets[0][1], other[1]):
+            assert c0 == c1
+            np.testing.assert_array_equal(l0, l1)
+        for la, lb in zip(nets[0][0].tr_layers, other[0].tr_layers):
+            for wa, wb in zip(la.get_wts(), lb.get_wts()):
+                np.testing.assert_array_equal(wa, wb)
 
 
 @pytest.mark.parametrize("name,img,B", [("cifar_like.prms", 32, 16), ("wide6.prms", 16, 4)])

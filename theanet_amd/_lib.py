@@ -75,6 +75,10 @@ SIGNATURES = {
     "tn_maxnorm": (c_int, [CTX, P, c_int, c_int, c_int, c_float]),
     "tn_defer_reductions": (c_int, [CTX, c_int]),
     "tn_defer_flush_step": (c_int, [CTX, P]),
+    "tn_rider_elastic_field": (c_int, [CTX, P, c_uint64, c_uint32, P, c_int, c_int, c_double, c_double,
+                                       c_double, c_int, c_double, c_int, P, P, P, P]),
+    "tn_rider_pending": (c_int, [CTX]),
+    "tn_rider_cancel": (c_int, [CTX]),
     "tn_step_tail": (c_int, [CTX, P, c_int, c_size_t, P, c_float, P, c_int, c_float, P,
                              P, c_uint64, P, c_int, c_int, c_double, c_double, c_double, c_int, c_double,
                              c_int, P, P, P, P]),

@@ -10,6 +10,23 @@
 
 #include "../../include/theanet_hip.h"
 
+// arguments of the elastic field computation (elastic_field.h)
+struct ElField {       // arguments of the field computation (shared by its two launchers)
+    const float* draws_in;
+    float* draws_out;
+    uint32_t k0, k1, step;
+    const uint32_t* d_step;
+    int h, w;
+    double translation, zoom, magnitude;
+    int sigma;
+    double angle;
+    int nearest;
+    int32_t* map_idx;
+    float* map_fy;
+    float* map_fx;
+    double* target;
+};
+
 // one finishing reduction out[i] = sum_{s<S} src[s*stride + i] (reduce.hip)
 #define TN_RED_MAX 12
 struct tn_red_rec {
@@ -37,6 +54,10 @@ struct tn_ctx {
     size_t scratch_off = 0;
     int npend = 0;
     tn_red_rec pend[TN_RED_MAX];
+    // a light independent job waiting for a heavy launch to ride in (tn_rider_elastic_field)
+    bool rider_valid = false;
+    ElField rider;
+    size_t rider_lds = 0;
 };
 
 int tn_scratch_get(tn_ctx* ctx, size_t bytes, float** out);

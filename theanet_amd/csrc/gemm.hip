@@ -25,6 +25,7 @@
 #include <cstdlib>
 
 #include "common.h"
+#include "elastic_field.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -470,9 +471,16 @@ __global__ __launch_bounds__(256) void gemm_f32_fast(GemmArgs g) {
 // co-resident on every CU -- the prologue / epilogue of one product overlaps the main loop of the
 // other, and a kernel boundary disappears.
 template <bool A1, bool B1, bool S1, bool A2, bool B2, bool S2>
-__global__ __launch_bounds__(256) void gemm_f32_pair(GemmArgs g1, GemmArgs g2, int n1, int n2) {
+__global__ __launch_bounds__(256) void gemm_f32_pair(GemmArgs g1, GemmArgs g2, int n1, int n2, ElField rider) {
     __shared__ __attribute__((aligned(16))) float smem[gemm_smem_floats<1, 1, 16>()];
     const int bid = blockIdx.x, grp = bid >> 3, l8 = bid & 7;
+    if (bid >= n1 + n2) {
+        // rider blocks behind the two products: a light independent job of the step (the elastic
+        // field of the next minibatch) that disappears under the GEMMs instead of owning a launch
+        extern __shared__ float rider_lds[];
+        elastic_field_block<true>(rider, rider_lds, bid - n1 - n2);
+        return;
+    }
     const int G1 = n1 >> 3, G2 = n2 >> 3, Gm = min(G1, G2);
     int prob, idx;
     if (grp < 2 * Gm) {
@@ -1021,7 +1029,17 @@ int tn_fc_bwd(tn_ctx* ctx, const float* x, const float* dz, const float* W, floa
         g2.a_vec = vec_ok(dz, n_out); g2.b_vec = vec_ok(W, n_out);
         const int n1 = gemm_setup_small<false, false>(g1, Sx), n2 = gemm_setup_small<true, true>(g2, 1);
         if (n1 > 0 && n2 > 0) {
-            gemm_f32_pair<false, false, true, true, true, false><<<n1 + n2, 256, 0, ctx->stream>>>(g1, g2, n1, n2);
+            int nrider = 0;
+            size_t rlds = 0;
+            ElField rider{};
+            if (ctx->rider_valid) {
+                rider = ctx->rider;
+                nrider = cdiv(rider.h * rider.w, 4);
+                rlds = ctx->rider_lds;
+                ctx->rider_valid = false;
+            }
+            gemm_f32_pair<false, false, true, true, true, false><<<n1 + n2 + nrider, 256, rlds, ctx->stream>>>(
+                g1, g2, n1, n2, rider);
             TN_LAUNCH_CHECK();
             if (Sx > 1) {
                 const size_t MN = (size_t)n_in * n_out;

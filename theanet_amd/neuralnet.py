@@ -451,6 +451,25 @@ class NeuralNet():
             if self.side_stream:
                 ctx.call("tn_stream_select", 0)
         g = out.dlogits
+        # The elastic field of the NEXT minibatch only depends on the step counter.  It is left with
+        # the context as a rider (offset +1: the counter advances at the end of the step) and
+        # travels as extra blocks of the backward pass's paired GEMM launch; nets without such a
+        # launch build it beside the update instead (tn_step_tail).
+        ahead = (isinstance(first, ElasticLayer) and first.active and first.has_field and
+                 not first._inj_draws and first.d_step is not None and not self.side_stream and
+                 not self.use_graph and (self._n_segs or rider) and
+                 os.environ.get("TN_STEP_TAIL", "1") != "0")
+        if ahead:
+            nxt = 1 - first._cur
+            m = first._maps[nxt]
+            hw = first.img_sz
+            field_args = (hw, hw, float(first.translation), float(first.zoom), float(first.magnitude),
+                          int(first.sigma), float(first.angle), int(first.nearest), m[0].ptr, m[1].ptr,
+                          m[2].ptr, m[3].ptr)
+            if os.environ.get("TN_FIELD_RIDER", "1") != "0":
+                ctx.call("tn_rider_elastic_field", first.draws.ptr, first.seed, 1, self.d_step.ptr,
+                         *field_args)
+        tail = False
         try:
             for idx in range(len(self.tr_layers) - 1, -1, -1):
                 lyr = self.tr_layers[idx]
@@ -461,14 +480,13 @@ class NeuralNet():
         finally:
             if self.side_stream:
                 ctx.call("tn_stream_wait", 0, 1)  # join the side stream (leaf weight gradients)
-            # Step tail: the elastic field of the NEXT minibatch only depends on the step counter, so
-            # the counter advances with the reduction launch and the field is built beside the update.
-            tail = (isinstance(first, ElasticLayer) and first.active and first.has_field and
-                    not first._inj_draws and first.d_step is not None and not self.side_stream and
-                    not self.use_graph and (self._n_segs or rider) and
-                    os.environ.get("TN_STEP_TAIL", "1") != "0")
+            waiting = bool(ctx.lib.tn_rider_pending(ctx.h))
+            if waiting:
+                ctx.call("tn_rider_cancel")       # nobody carried it: it joins the update launch
+            rode = ahead and not waiting and os.environ.get("TN_FIELD_RIDER", "1") != "0"
+            tail = ahead and not rode
             if tail:
-                ctx.call("tn_defer_flush_step", self.d_step.ptr)
+                ctx.call("tn_defer_flush_step", self.d_step.ptr)      # the counter advances here
             else:
                 ctx.call("tn_defer_reductions", 0)
         if self.world.size > 1:
@@ -476,17 +494,11 @@ class NeuralNet():
         for lyr in self.tr_layers:
             lyr.get_wtcost(self.d_cost)
         if tail:
-            nxt = 1 - first._cur
-            m = first._maps[nxt]
-            hw = first.img_sz
             ctx.call("tn_step_tail", self._d_segs.ptr if self._n_segs else None, self._n_segs,
                      self._max_seg, self.cur_learn_rate.ptr, 1.0,
                      out.rowloss.ptr if rider else None, self.local_bsz, 1.0 / self.batch_sz,
                      self.d_cost.ptr if rider else None, first.draws.ptr, first.seed, self.d_step.ptr,
-                     hw, hw, float(first.translation), float(first.zoom), float(first.magnitude),
-                     int(first.sigma), float(first.angle), int(first.nearest), m[0].ptr, m[1].ptr,
-                     m[2].ptr, m[3].ptr)
-            first._cur, first._pre_valid = nxt, True
+                     *field_args)
         elif self._n_segs or rider:               # also advances the RNG step counter
             ctx.call("tn_sgd_update_multi_cost", self._d_segs.ptr if self._n_segs else None,
                      self._n_segs, self._max_seg, self.cur_learn_rate.ptr, 1.0, self.d_step.ptr,
@@ -494,6 +506,8 @@ class NeuralNet():
                      self.d_cost.ptr if rider else None)
         else:
             ctx.call("tn_add_u32", self.d_step.ptr, 1)
+        if ahead:
+            first._cur, first._pre_valid = nxt, True
         for lyr in self.tr_layers:
             lyr.apply_maxnorm()
 
