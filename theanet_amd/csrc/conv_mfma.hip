@@ -252,15 +252,23 @@ __global__ __launch_bounds__(256) void conv_mfma_wgrad_kernel(ConvMG g) {
         pj[e] = p_ - pi[e] * g.Wo;
     }
     int next_m = mbeg + a_m;          // pixel index of element 0 of the NEXT load
+    // dz rows of 4 pixels never straddle a plane when the plane size is a multiple of 4 (mbeg and the
+    // tile step are multiples of 4 too) and the tensor is 16-byte aligned
+    const bool avec = (HoWo & 3) == 0 && (g.mchunk & 3) == 0 && ((reinterpret_cast<uintptr_t>(g.W) & 15) == 0);
     float asum = 0.f;                 // row sum of dz (bias gradient), first kk-tile only
 #define CW_GLOAD(RA, RB, TILE)                                                                   \
     {                                                                                            \
         bool aok_[4], bok_[4];                                                                   \
+        if (avec) {      /* 4 consecutive pixels of one (image, filter) plane: one 16-byte load */ \
+            const float4 a4_ = *reinterpret_cast<const float4*>(                                 \
+                g.W + ((size_t)min(pn[0], g.N - 1) * g.K + arow) * HoWo + pi[0] * g.Wo + pj[0]); \
+            RA[0] = a4_.x; RA[1] = a4_.y; RA[2] = a4_.z; RA[3] = a4_.w;                          \
+        }                                                                                        \
         _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                          \
             const bool mok_ = next_m + e < mend;                                                 \
             const int n_ = min(pn[e], g.N - 1), i_ = pi[e], j_ = pj[e];                          \
             const int p_ = i_ * g.Wo + j_;                                                       \
-            RA[e] = g.W[((size_t)n_ * g.K + arow) * HoWo + p_];                                  \
+            if (!avec) RA[e] = g.W[((size_t)n_ * g.K + arow) * HoWo + p_];                       \
             aok_[e] = mok_ && arow_ok;                                                           \
             int off_ = n_ * g.C * HW + (i_ - g.pad) * g.Wd + (j_ - g.pad) + tap;                 \
             bok_[e] = mok_ && kk_ok;                                                             \
