@@ -318,6 +318,19 @@ int tn_elastic_field_gen(tn_ctx* ctx, float* draws_out, uint64_t seed, uint32_t 
                          const uint32_t* d_step, int h, int w, double translation, double zoom,
                          double magnitude, int sigma, double angle, int nearest, int32_t* map_idx,
                          float* map_fy, float* map_fx, double* target);
+/* tn_elastic_apply fused into the forward of the conv block that consumes it (single-channel
+ * images, f == 3, p == 2, at most 16 filters): out (N,1,h,w) is still written (the backward pass
+ * reads it), y / mask are tn_convpool_fwd_mask's outputs.  Arguments as in the two ops.        */
+int tn_elastic_convpool_supported(int h, int w, int K, int f, int pad_lo, int Ho, int Wo, int p, int Hp,
+                                  int Wp);
+int tn_elastic_convpool_fwd_mask(tn_ctx* ctx, const float* x, int64_t x_row0, const int64_t* d_row0,
+                                 float* out, int N, int h, int w, int invert, int nearest,
+                                 const int32_t* map_idx, const float* map_fy, const float* map_fx,
+                                 float pflip, const uint8_t* flipmask, uint64_t seed, uint32_t step,
+                                 const uint32_t* d_step, int64_t row_global0, const float* W,
+                                 const float* b, float* y, uint8_t* mask, int K, int f, int pad_lo, int Ho,
+                                 int Wo, int p, int Hp, int Wp, int act, float act_param);
+
 /* Rider: the same field computation, not launched but left with the context; the next paired
  * GEMM launch (tn_fc_bwd) carries it as extra blocks, so it costs no kernel boundary of its own.
  * step is the offset added to *d_step (1 = the minibatch after the one in flight).  tn_rider_pending

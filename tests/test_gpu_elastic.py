@@ -177,3 +177,45 @@ def test_elastic_field_gen_equals_two_launches(hw, nearest, sigma):
     call("tn_elastic_apply", xd.ptr, 1, None, out1.ptr, N, C, h, w, 1, nearest, mi.ptr, fy.ptr, fx.ptr,
          0.03, None, seed, step, None, 3)
     assert np.array_equal(out4.get_value(), big.get_value()[1:].reshape(N, C, h, w))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hw,nearest,K,mode,act", [(28, 1, 4, "valid", "relu10"), (16, 0, 7, "same", "tanh"),
+                                                    (12, 1, 16, "valid", "relu")])
+def test_elastic_convpool_fused_equals_separate_ops(hw, nearest, K, mode, act):
+    """tn_elastic_convpool_fwd_mask == tn_elastic_apply followed by tn_convpool_fwd_mask, bit for bit
+    (resampled image, pooled output and pooling mask)."""
+    from tests.gpu_util import act_code
+    h = w = hw
+    lib = ctx().lib
+    pad_lo, _, Ho = O.conv_geometry(h, 3, 1, mode)
+    Hp = O.pool_out_sz(Ho, 2, False)
+    assert lib.tn_elastic_convpool_supported(h, w, K, 3, pad_lo, Ho, Ho, 2, Hp, Hp)
+    n = lib.tn_elastic_draws_count(h, w)
+    seed, step = 99, 3
+    draws = empty((n,))
+    mi, fy, fx = empty((h * w,), np.int32), empty((h * w,)), empty((h * w,))
+    call("tn_elastic_field_gen", draws.ptr, seed, step, None, h, w, 2.0, 1.1, 20.0, 3, 5.0, nearest,
+         mi.ptr, fy.ptr, fx.ptr, None)
+    N = 9
+    rng = np.random.RandomState(hw + K)
+    x = rng.rand(N + 2, 1, h, w).astype(np.float32)
+    Wt = (rng.randn(K, 1, 3, 3) / 3).astype(np.float32)
+    b = rng.randn(K).astype(np.float32)
+    kind, prm = act_code(act)
+    xd, Wd, bd = dev(x), dev(Wt), dev(b)
+    apply_args = (xd.ptr, 2, None)
+    tail_args = (N, 1, h, w, 1, nearest, mi.ptr, fy.ptr, fx.ptr, 0.05, None, seed, step, None, 40)
+    out_a = empty((N, 1, h, w))
+    call("tn_elastic_apply", *apply_args, out_a.ptr, *tail_args)
+    y_a, m_a = empty((N, K, Hp, Hp)), empty((N, K, Hp, Hp), np.uint8)
+    geom = (N, 1, h, w, K, 3, pad_lo, Ho, Ho, 2, Hp, Hp, kind, prm)
+    call("tn_convpool_fwd_mask", out_a.ptr, Wd.ptr, bd.ptr, y_a.ptr, m_a.ptr, *geom)
+    out_b = empty((N, 1, h, w))
+    y_b, m_b = empty((N, K, Hp, Hp)), empty((N, K, Hp, Hp), np.uint8)
+    call("tn_elastic_convpool_fwd_mask", *apply_args, out_b.ptr, N, h, w, 1, nearest, mi.ptr, fy.ptr,
+         fx.ptr, 0.05, None, seed, step, None, 40, Wd.ptr, bd.ptr, y_b.ptr, m_b.ptr, K, 3, pad_lo, Ho, Ho,
+         2, Hp, Hp, kind, prm)
+    assert np.array_equal(out_a.get_value(), out_b.get_value())
+    assert np.array_equal(y_a.get_value(), y_b.get_value())
+    assert np.array_equal(m_a.get_value(), m_b.get_value())

@@ -4,6 +4,8 @@
 // Coordinates are computed in float64 exactly as the Theano CPU path does (int64 indices +
 // float32 random inputs upcast to float64); the field is tiny (2 x h x w) so fp64 is free.
 // The gather kernel is the HBM-bound part: x read once, out written once.
+#include <cstdlib>
+
 #include "common.h"
 #include "update_body.h"
 #include "elastic_field.h"
@@ -162,6 +164,144 @@ __global__ __launch_bounds__(256) void elastic_apply4_kernel(
         if (tn_u01(r.w) < pflip) v[3] = 1.f - v[3];
     }
     *reinterpret_cast<float4*>(out + t) = make_float4(v[0], v[1], v[2], v[3]);
+}
+
+// ---- ElasticLayer resampling fused into the first conv block's forward --------------------------
+// One block per single-channel image: the 4-wide gather of elastic_apply4_kernel fills a zero-padded
+// LDS tile (and writes the resampled image out once -- the conv backward reads it), then one thread
+// per pooling window runs conv(3x3) + bias + act + 2x2 max-pool + pooling mask of convpool.hip on
+// the tile.  The resampled image is not read back from HBM and a kernel boundary disappears.
+// KT > 0: exactly KT filters, their taps are fetched (scalar loads) before the resampling phase and
+// the filter loop is unrolled; KT == 0: any K <= 16, taps fetched per filter.
+template <int ACT, int KT>
+__global__ __launch_bounds__(256) void elastic_convpool_fwd_kernel(
+    const float* __restrict__ x, int64_t x_row0, const int64_t* __restrict__ d_row0,
+    float* __restrict__ xd, int N, int h, int w, int invert, int nearest,
+    const int32_t* __restrict__ map_idx, const float* __restrict__ map_fy,
+    const float* __restrict__ map_fx, float pflip, const uint8_t* __restrict__ flipmask, uint32_t k0,
+    uint32_t k1, uint32_t step, const uint32_t* d_step, int64_t row_global0,
+    const float* __restrict__ W, const float* __restrict__ b, float* __restrict__ y,
+    uint8_t* __restrict__ mask, int K, int pad, int Ho, int Wo, int Hp, int Wp, int act, float prm) {
+    extern __shared__ __attribute__((aligned(16))) float tile[];     // [2Hp+2][2Wp+2], zero padded
+    const int Hx = 2 * Hp + 2, Wx = 2 * Wp + 2, hw = h * w;
+    const int n = blockIdx.x;
+    float wk[KT > 0 ? KT * 9 : 1], bk[KT > 0 ? KT : 1];
+    if (KT > 0) {
+#pragma unroll
+        for (int i = 0; i < KT * 9; ++i) wk[i] = W[i];
+#pragma unroll
+        for (int i = 0; i < KT; ++i) bk[i] = b[i];
+    }
+    if (Hx != h || Wx != w) {          // block-uniform: a tile larger than the image needs its zero frame
+        for (int i = threadIdx.x * 4; i < Hx * Wx; i += 1024)
+            *reinterpret_cast<float4*>(tile + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+        __syncthreads();
+    }
+    const int64_t row_off = x_row0 + (d_row0 ? *d_row0 : 0);
+    const float* xi = x + (size_t)(row_off + n) * hw;
+    const uint32_t st = step + (d_step ? *d_step : 0u);
+    for (int q4 = threadIdx.x; 4 * q4 < hw; q4 += 256) {
+        const int p = 4 * q4;
+        float v[4];
+        if (!map_idx) {
+            const float4 q = *reinterpret_cast<const float4*>(xi + p);
+            v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+        } else {
+            const int4 mi = *reinterpret_cast<const int4*>(map_idx + p);
+            const int m[4] = {mi.x, mi.y, mi.z, mi.w};
+            if (nearest) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = xi[m[e]];
+            } else {
+                const float4 fy4 = *reinterpret_cast<const float4*>(map_fy + p);
+                const float4 fx4 = *reinterpret_cast<const float4*>(map_fx + p);
+                const float fy[4] = {fy4.x, fy4.y, fy4.z, fy4.w}, fx[4] = {fx4.x, fx4.y, fx4.z, fx4.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float a = xi[m[e]], bb = xi[m[e] + 1], c = xi[m[e] + w], d = xi[m[e] + w + 1];
+                    if (invert) {
+                        a = 1.f - a; bb = 1.f - bb; c = 1.f - c; d = 1.f - d;
+                    }
+                    // same association as inlayers.py:134-137
+                    v[e] = a * (1.f - fy[e]) * (1.f - fx[e]) + bb * (1.f - fy[e]) * fx[e] +
+                           c * fy[e] * (1.f - fx[e]) + d * fy[e] * fx[e];
+                }
+            }
+        }
+        if (invert && (!map_idx || nearest)) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = 1.f - v[e];
+        }
+        const size_t t = (size_t)n * hw + p;                 // element index within the local batch
+        if (flipmask) {
+            const uint32_t fm = *reinterpret_cast<const uint32_t*>(flipmask + t);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if ((fm >> (8 * e)) & 0xffu) v[e] = 1.f - v[e];
+        } else if (pflip > 0.f) {
+            const uint64_t cq = ((uint64_t)row_global0 * hw + (uint64_t)t) >> 2;
+            const u32x4 r = philox4x32((uint32_t)cq, (uint32_t)(cq >> 32), st, TN_STREAM_FLIP, k0, k1);
+            if (tn_u01(r.x) < pflip) v[0] = 1.f - v[0];
+            if (tn_u01(r.y) < pflip) v[1] = 1.f - v[1];
+            if (tn_u01(r.z) < pflip) v[2] = 1.f - v[2];
+            if (tn_u01(r.w) < pflip) v[3] = 1.f - v[3];
+        }
+        *reinterpret_cast<float4*>(xd + t) = make_float4(v[0], v[1], v[2], v[3]);
+        const int yy = p / w, xx = p - yy * w;               // w % 4 == 0: the 4 pixels share a row
+        float* dst = tile + (yy + pad) * Wx + xx + pad;
+        dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2]; dst[3] = v[3];
+    }
+    __syncthreads();
+    const int HpWp = Hp * Wp;
+    for (int q = threadIdx.x; q < HpWp; q += 256) {
+        const int pi = q / Wp, pj = q - pi * Wp;
+        float pt[4][4];
+        const float* base = tile + (2 * pi) * Wx + 2 * pj;     // 8-byte aligned: Wx even
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float2 lo = *reinterpret_cast<const float2*>(base + r * Wx);
+            const float2 hi = *reinterpret_cast<const float2*>(base + r * Wx + 2);
+            pt[r][0] = lo.x; pt[r][1] = lo.y; pt[r][2] = hi.x; pt[r][3] = hi.y;
+        }
+        const bool v01 = 2 * pj + 1 < Wo, v10 = 2 * pi + 1 < Ho;
+        const bool valid[2][2] = {{true, v01}, {v10, v10 && v01}};
+#pragma unroll
+        for (int k = 0; k < (KT > 0 ? KT : K); ++k) {
+            const float* Wk = W + (size_t)k * 9;              // block-uniform: scalar loads
+            const float bias = KT > 0 ? bk[k] : b[k];
+            float z[2][2] = {{bias, bias}, {bias, bias}};
+#pragma unroll
+            for (int u = 0; u < 3; ++u)
+#pragma unroll
+                for (int vv = 0; vv < 3; ++vv) {
+                    const float wt = KT > 0 ? wk[k * 9 + (2 - u) * 3 + (2 - vv)] : Wk[(2 - u) * 3 + (2 - vv)];
+#pragma unroll
+                    for (int di = 0; di < 2; ++di)
+#pragma unroll
+                        for (int dj = 0; dj < 2; ++dj) z[di][dj] = fmaf(pt[di + u][dj + vv], wt, z[di][dj]);
+                }
+            float m = -INFINITY;
+#pragma unroll
+            for (int di = 0; di < 2; ++di)
+#pragma unroll
+                for (int dj = 0; dj < 2; ++dj) {
+                    z[di][dj] = (ACT == TN_ACT_LEAKY) ? fmaxf(0.f, z[di][dj]) + fminf(0.f, z[di][dj]) * prm
+                                                      : tn_act_fwd(z[di][dj], act, prm);
+                    m = valid[di][dj] ? fmaxf(m, z[di][dj]) : m;
+                }
+            const size_t o = ((size_t)n * K + k) * HpWp + q;
+            y[o] = m;
+            if (mask) {
+                unsigned bits = (m > 0.f ? 16u : 0u) | (m < 0.f ? 32u : 0u);
+#pragma unroll
+                for (int di = 0; di < 2; ++di)
+#pragma unroll
+                    for (int dj = 0; dj < 2; ++dj)
+                        bits |= (valid[di][dj] && z[di][dj] == m) ? (1u << (di * 2 + dj)) : 0u;
+                mask[o] = (uint8_t)bits;
+            }
+        }
+    }
 }
 
 // ---- extras/deformer.py:7-18, one block per image, float64 like scipy -------------------
@@ -370,6 +510,47 @@ int tn_elastic_apply(tn_ctx* ctx, const float* x, int64_t x_row0, const int64_t*
     elastic_apply_kernel<<<cdiv(total, 256), 256, 0, ctx->stream>>>(
         x, x_row0, d_row0, out, total, C, h * w, w, invert, nearest, map_idx, map_fy, map_fx, pflip,
         flipmask, (uint32_t)seed, (uint32_t)(seed >> 32), step, d_step, row_global0);
+    TN_LAUNCH_CHECK();
+    return TN_OK;
+}
+
+int tn_elastic_convpool_supported(int h, int w, int K, int f, int pad_lo, int Ho, int Wo, int p, int Hp,
+                                  int Wp) {
+    static int on = -1;
+    if (on < 0) {
+        const char* e = getenv("TN_ELASTIC_CONV");
+        on = e ? atoi(e) : 1;
+    }
+    if (!on || f != 3 || p != 2 || K < 1 || K > 16 || w % 4 != 0) return 0;
+    if (h + 2 * pad_lo > 2 * Hp + 2 || w + 2 * pad_lo > 2 * Wp + 2) return 0;      // image fits the tile
+    if (Hp != (Ho + 1) / 2 || Wp != (Wo + 1) / 2) return 0;
+    return (size_t)(2 * Hp + 2) * (2 * Wp + 2) * sizeof(float) <= 48 * 1024;
+}
+
+int tn_elastic_convpool_fwd_mask(tn_ctx* ctx, const float* x, int64_t x_row0, const int64_t* d_row0,
+                                 float* xd, int N, int h, int w, int invert, int nearest,
+                                 const int32_t* map_idx, const float* map_fy, const float* map_fx,
+                                 float pflip, const uint8_t* flipmask, uint64_t seed, uint32_t step,
+                                 const uint32_t* d_step, int64_t row_global0, const float* W,
+                                 const float* b, float* y, uint8_t* mask, int K, int f, int pad_lo, int Ho,
+                                 int Wo, int p, int Hp, int Wp, int act, float act_param) {
+    TN_REQUIRE(tn_elastic_convpool_supported(h, w, K, f, pad_lo, Ho, Wo, p, Hp, Wp),
+               "tn_elastic_convpool_fwd_mask: unsupported shape %dx%d K=%d f=%d p=%d", h, w, K, f, p);
+    TN_REQUIRE(N > 0 && x && xd && W && b && y, "tn_elastic_convpool_fwd_mask: bad arguments");
+    const size_t lds = (((size_t)(2 * Hp + 2) * (2 * Wp + 2) + 3) & ~(size_t)3) * sizeof(float);
+#define EC_GO(ACT_)                                                                              \
+    if (K == 4)                                                                                  \
+        elastic_convpool_fwd_kernel<ACT_, 4><<<N, 256, lds, ctx->stream>>>(                      \
+            x, x_row0, d_row0, xd, N, h, w, invert, nearest, map_idx, map_fy, map_fx, pflip, flipmask, \
+            (uint32_t)seed, (uint32_t)(seed >> 32), step, d_step, row_global0, W, b, y, mask, K, pad_lo, \
+            Ho, Wo, Hp, Wp, act, act_param);                                                     \
+    else                                                                                         \
+    elastic_convpool_fwd_kernel<ACT_, 0><<<N, 256, lds, ctx->stream>>>(                           \
+        x, x_row0, d_row0, xd, N, h, w, invert, nearest, map_idx, map_fy, map_fx, pflip, flipmask, \
+        (uint32_t)seed, (uint32_t)(seed >> 32), step, d_step, row_global0, W, b, y, mask, K, pad_lo, \
+        Ho, Wo, Hp, Wp, act, act_param)
+    if (act == TN_ACT_LEAKY) EC_GO(TN_ACT_LEAKY); else EC_GO(-1);
+#undef EC_GO
     TN_LAUNCH_CHECK();
     return TN_OK;
 }

@@ -204,6 +204,7 @@ class PoolLayer(Layer):
         self.gin = None
         self.fused_conv = None
         self.mask = None           # uint8 pooling mask of the fused forward (training graphs only)
+        self.fused_elastic = None  # ElasticLayer whose resampling this block's forward performs
         self.representation = (
             "Pool Maps:{:2d} Pool_sz:{} Border:{} Output:{:2d}"
             "".format(num_maps, pool_sz,
@@ -219,6 +220,17 @@ class PoolLayer(Layer):
             if train and self.mask is None and os.environ.get("TN_POOL_MASK", "1") != "0" and \
                     conv.filter_sz == 3 and self.pool_sz == 2:
                 self.mask = self.ctx.empty(self.output.shape, np.uint8)
+            el = self.fused_elastic
+            if el is not None and train and el._apply_args is not None:
+                # ElasticLayer -> conv -> act -> pool in one launch (the resampled image is still
+                # written to el.output for the backward pass)
+                a = el._apply_args
+                g = conv._fused_geom()          # (N, C, H, W, K, f, pad, Ho, Wo, p, Hp, Wp, act, prm)
+                self.ctx.call("tn_elastic_convpool_fwd_mask", a[0], a[1], a[2], a[3], a[4], a[6], a[7],
+                              *a[8:], conv.W.ptr, conv.b.ptr, self.output.ptr,
+                              self.mask.ptr if self.mask is not None else None, g[4], g[5], g[6], g[7],
+                              g[8], g[9], g[10], g[11], g[12], g[13])
+                return
             self.ctx.call("tn_convpool_fwd_mask", conv.inpt.ptr, conv.W.ptr, conv.b.ptr,
                           self.output.ptr, self.mask.ptr if (train and self.mask is not None) else None,
                           *conv._fused_geom())

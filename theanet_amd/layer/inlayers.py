@@ -103,6 +103,8 @@ class ElasticLayer(Layer):
         self.d_step = None
         self._inj_draws = False
         self._inj_flip = None
+        self.fused_conv = None          # set by NeuralNet: the first conv block resamples on the fly
+        self._apply_args = None
         if not self.active:
             return
 
@@ -187,13 +189,17 @@ class ElasticLayer(Layer):
                 else:
                     self._field(self._maps[self._cur])
             self._pre_valid = False
-        self.ctx.call("tn_elastic_apply", x_ptr, row0, d_row0_ptr, self.output.ptr,
-                      self.batch_sz, self.num_maps, h, w, int(self.invert), int(self.nearest),
-                      self.map_idx.ptr if self.has_field else None,
-                      self.map_fy.ptr, self.map_fx.ptr,
-                      float(self.pflip) if self._inj_flip is None else 0.0,
-                      self._inj_flip.ptr if self._inj_flip is not None else None,
-                      self.seed, 0, d_step_ptr, rg0)
+        # arguments of the resampling (tn_elastic_apply / the conv block it may be fused into)
+        self._apply_args = (x_ptr, row0, d_row0_ptr, self.output.ptr, self.batch_sz, self.num_maps, h, w,
+                            int(self.invert), int(self.nearest),
+                            self.map_idx.ptr if self.has_field else None,
+                            self.map_fy.ptr, self.map_fx.ptr,
+                            float(self.pflip) if self._inj_flip is None else 0.0,
+                            self._inj_flip.ptr if self._inj_flip is not None else None,
+                            self.seed, 0, d_step_ptr, rg0)
+        if self.fused_conv is not None and train:
+            return                      # the conv block's forward resamples while it loads (PoolLayer)
+        self.ctx.call("tn_elastic_apply", *self._apply_args)
         if ahead:
             # next step's field: draws keyed by (seed, *d_step + 1); the step counter only
             # advances in the update, which the net issues after joining the side stream

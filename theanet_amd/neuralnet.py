@@ -347,6 +347,16 @@ class NeuralNet():
             if isinstance(conv, ConvLayer) and isinstance(pool, PoolLayer) \
                     and conv.can_fuse_with(pool):
                 conv.fused_pool, pool.fused_conv = pool, conv
+        # an active single-channel ElasticLayer feeding such a block: the block's forward resamples
+        # the raw images itself (tn_elastic_convpool_fwd_mask)
+        if len(lyrs) >= 3 and isinstance(lyrs[0], ElasticLayer) and lyrs[0].active and \
+                lyrs[0].num_maps == 1 and isinstance(lyrs[1], ConvLayer) and \
+                lyrs[1].fused_pool is lyrs[2]:
+            el, conv, pool = lyrs[0], lyrs[1], lyrs[2]
+            if conv.ctx.lib.tn_elastic_convpool_supported(
+                    el.img_sz, el.img_sz, conv.num_maps, conv.filter_sz, conv.pad_lo, conv.out_sz,
+                    conv.out_sz, pool.pool_sz, pool.out_sz, pool.out_sz) and not pool.ignore_border:
+                el.fused_conv, pool.fused_elastic = conv, el
 
     # ------------------------------------------------------------------------------
     def _group(self):
