@@ -196,14 +196,28 @@ def main():
 
 
 if __name__ == "__main__":
-    # stdout carries exactly ONE line (the JSON record); the library's progress prints
-    # ("Compiling training function..." like the reference) go to stderr
+    # stdout carries exactly ONE line (the JSON record).  Everything else -- the library's progress
+    # prints ("Compiling training function..." like the reference) and whatever native libraries write
+    # to file descriptor 1 (RCCL's version banner) -- is sent to stderr: fd 1 is pointed at fd 2 for
+    # the whole run and the record goes out through a private duplicate of the real stdout.
     import contextlib
     import io
 
-    _real_stdout = sys.stdout
+    sys.stdout.flush()
+    _real_fd = os.dup(1)
+    os.dup2(2, 1)
     _buf = io.StringIO()
-    with contextlib.redirect_stdout(_buf):
-        main()
-    for _line in _buf.getvalue().splitlines():
-        print(_line, file=_real_stdout if _line.startswith("{") else sys.stderr)
+    try:
+        with contextlib.redirect_stdout(_buf):
+            main()
+    finally:
+        sys.stdout.flush()
+        _lines = _buf.getvalue().splitlines()
+        for _line in _lines:
+            if not _line.startswith("{"):
+                print(_line, file=sys.stderr)
+        sys.stderr.flush()
+        with os.fdopen(_real_fd, "w") as _out:
+            for _line in _lines:
+                if _line.startswith("{"):
+                    _out.write(_line + "\n")

@@ -264,6 +264,37 @@ def test_rccl_single_rank_allreduce_and_dp_plumbing():
     ctx().call("tn_comm_destroy")
 
 
+def test_dp_overlap_schedule_equals_plain(monkeypatch):
+    """The data-parallel step (forced with a 1-rank RCCL communicator): reducing the FC gradients on
+    the second stream under the conv backward must give the same weights as the single all-reduce at
+    the end of the step, and as the single-GPU schedule."""
+    from theanet_amd import NeuralNet
+    import copy
+    prms = load_prms("mnist.prms", 28, batch=64)
+    rng = np.random.RandomState(5)
+    x = rng.rand(4 * 64, 1, 28, 28).astype(np.float32)
+    y = rng.randint(0, 10, 4 * 64).astype(np.int32)
+    nets = []
+    for force, overlap in (("0", "1"), ("1", "1"), ("1", "0")):
+        monkeypatch.setenv("TN_DP_FORCE", force)
+        monkeypatch.setenv("TN_DP_OVERLAP", overlap)
+        net = NeuralNet(copy.deepcopy(prms["layers"]), dict(prms["training_params"]))
+        fn = net.get_trin_model(x, y)
+        outs = [fn(s % 4) for s in range(5)]
+        assert (net._dp_split is not None) == (force == "1" and overlap == "1")
+        nets.append((net, outs))
+        if force == "1":
+            net.ctx.call("tn_comm_destroy")
+            net._dev_group = None
+    for other in nets[1:]:
+        for (c0, _, l0), (c1, _, l1) in zip(nets[0][1], other[1]):
+            assert abs(c0 - c1) <= 1e-6 * abs(c0)        # cost: rider vs stand-alone reduction order
+            np.testing.assert_array_equal(l0, l1)
+        for la, lb in zip(nets[0][0].tr_layers, other[0].tr_layers):
+            for wa, wb in zip(la.get_wts(), lb.get_wts()):
+                np.testing.assert_array_equal(wa, wb)
+
+
 def test_train_py_end_to_end(tmp_path):
     """The harness runs, prints the reference's table, learns, and writes a loadable pickle."""
     import subprocess

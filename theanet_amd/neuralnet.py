@@ -396,7 +396,9 @@ class NeuralNet():
         # first (weight costs) or it has to travel through the all-reduce (data-parallel ranks)
         has_wtcost = any(getattr(l, 'reg', None) and l.params and (l.reg['L1'] or l.reg['L2'])
                          for l in self.tr_layers)
-        self._cost_rider = (not has_wtcost) and self.world.size == 1 and \
+        # data-parallel step (TN_DP_FORCE=1: exercise it with a 1-rank communicator)
+        self._dp = self.world.size > 1 or os.environ.get("TN_DP_FORCE") == "1"
+        self._cost_rider = (not has_wtcost) and not self._dp and \
             os.environ.get("TN_COST_RIDER", "1") != "0"
         self._max_seg = max([sg[3] for sg in segs] or [0])
         if segs:
@@ -408,8 +410,25 @@ class NeuralNet():
         for lyr in self.tr_layers:
             self._need_gin.append(seen)
             seen = seen or lyr.has_updates()
-        if self.world.size > 1:
+        if self._dp:
             self._group()
+        # Optional overlap of the gradient all-reduce with the backward pass (TN_DP_OVERLAP=1): the
+        # fully-connected layers sit on top of the net and hold almost all parameters; their gradients
+        # (the tail of the flat buffer, cost included) are reduced on the second stream while the conv
+        # blocks below are still in their backward kernels.  _dp_split = first layer of that top group.
+        # Off by default: on one GPU the second flush, the stream joins and the second collective cost
+        # 18 us per step, about what a 1.5 MB all-reduce costs in the first place; the remaining
+        # small all-reduce is latency-bound either way.
+        self._dp_split, self._dp_off = None, 0
+        if self._dp and os.environ.get("TN_DP_OVERLAP", "0") == "1":
+            j = len(self.tr_layers)
+            while j > 0 and isinstance(self.tr_layers[j - 1], HiddenLayer):
+                j -= 1
+            top = [l for l in self.tr_layers[j:] if l.params]
+            if 0 < j < len(self.tr_layers) and top and any(l.has_updates() for l in self.tr_layers[:j]):
+                first_p = top[0].grads[0]
+                self._dp_split = j
+                self._dp_off = (first_p.ptr - self.flat_grads.ptr) // 4
         self._grads_ready = True
 
     def _train_step(self, y, y_row0, d_row0=None):
@@ -480,11 +499,22 @@ class NeuralNet():
                 ctx.call("tn_rider_elastic_field", first.draws.ptr, first.seed, 1, self.d_step.ptr,
                          *field_args)
         tail = False
+        dp_async = False
         try:
             for idx in range(len(self.tr_layers) - 1, -1, -1):
                 lyr = self.tr_layers[idx]
                 below = self.tr_layers[idx - 1] if idx > 0 else None
                 g = lyr.backward(g, self._need_gin[idx], below)
+                if idx == self._dp_split and g is not None:
+                    # the top (fully-connected) group is done: finish its slab sums and send its
+                    # gradients through the all-reduce on the second stream, under the conv backward
+                    ctx.call("tn_defer_reductions", 0)
+                    ctx.call("tn_defer_reductions", 1)
+                    ctx.call("tn_stream_wait", 1, 0)
+                    ctx.call("tn_stream_select", 1)
+                    self._group().allreduce_sum(self.flat_grads.view(self._dp_off, (self.n_flat - self._dp_off,)))
+                    ctx.call("tn_stream_select", 0)
+                    dp_async = True
                 if g is None:
                     break
         finally:
@@ -499,8 +529,13 @@ class NeuralNet():
                 ctx.call("tn_defer_flush_step", self.d_step.ptr)      # the counter advances here
             else:
                 ctx.call("tn_defer_reductions", 0)
-        if self.world.size > 1:
-            self._group().allreduce_sum(self.flat_grads, self.n_flat)
+        if self._dp:
+            if dp_async:
+                if self._dp_off:
+                    self._group().allreduce_sum(self.flat_grads, self._dp_off)     # the conv head
+                ctx.call("tn_stream_wait", 0, 1)                                  # join the tail
+            else:
+                self._group().allreduce_sum(self.flat_grads, self.n_flat)
         for lyr in self.tr_layers:
             lyr.get_wtcost(self.d_cost)
         if tail:
