@@ -500,7 +500,7 @@ int tn_convpool_bwd_mask(tn_ctx* ctx, const float* x, const float* g, const floa
     switch (C) {
         case 1: CP_BWDM(1, 4);
         case 2: CP_BWDM(2, 4);
-        case 3: CP_BWDM(3, 2);
+        case 3: CP_BWDM(3, 4);
         default: CP_BWDM(4, 2);
     }
 #undef CP_BWDM
