@@ -293,6 +293,15 @@ int tn_sgd_update_multi_cost(tn_ctx* ctx, const tn_sgd_seg* d_segs, int nseg, si
                              const float* d_lr, float gscale, uint32_t* d_step_inc,
                              const float* rowloss, int nrow, float cost_scale, float* d_cost);
 
+/* tn_sgd_update_multi_cost that also ENDS a tn_defer_reductions window: a segment whose gradient is
+ * still a stack of deferred partial slabs sums them on the fly (same order as the reduction launch:
+ * bit-identical), stores the gradient and applies the update -- one launch less per step.  h_segs is
+ * the host copy of d_segs (used to match pending sums to segments); pending sums that belong to no
+ * segment are finished by the ordinary reduction launch first.  nseg <= 16.                   */
+int tn_sgd_update_multi_lazy(tn_ctx* ctx, const tn_sgd_seg* d_segs, const tn_sgd_seg* h_segs, int nseg,
+                             size_t max_n, const float* d_lr, float gscale, uint32_t* d_step_inc,
+                             const float* rowloss, int nrow, float cost_scale, float* d_cost);
+
 /* ---- elastic input stage (replaces ElasticLayer's graph; inlayers.py:63-144) ----
  * draws layout (float32, device): [0:2] translation u(-1,1) ; [2:4] origin u(.25,.75) ;
  * [4:6] zoom u(-1,1) ; [6] theta u(-1,1) ; [7] pad ; [8 : 8+2hw] N(0,1) noise planes.

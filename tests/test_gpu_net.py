@@ -379,6 +379,32 @@ def test_step_tail_equals_separate_launches(monkeypatch):
                 np.testing.assert_array_equal(wa, wb)
 
 
+@pytest.mark.parametrize("name,img,ch,B", [("mnist.prms", 28, 1, 64), ("cifar_like.prms", 32, 3, 16)])
+def test_lazy_update_equals_reduce_then_update(monkeypatch, name, img, ch, B):
+    """Summing the weight-gradient slabs inside the update launch (tn_sgd_update_multi_lazy) keeps the
+    summation order of the reduction launch: costs, gradients and weights match bit for bit."""
+    from theanet_amd import NeuralNet
+    import copy
+    prms = load_prms(name, img, batch=B)
+    rng = np.random.RandomState(5)
+    x = rng.rand(4 * B, ch, img, img).astype(np.float32)
+    y = rng.randint(0, 10, 4 * B).astype(np.int32)
+    nets = []
+    for lazy in ("1", "0"):
+        monkeypatch.setenv("TN_LAZY_UPDATE", lazy)
+        net = NeuralNet(copy.deepcopy(prms["layers"]), dict(prms["training_params"]))
+        fn = net.get_trin_model(x, y)
+        outs = [fn(s % 4) for s in range(5)]
+        nets.append((net, outs))
+    for (c0, _, l0), (c1, _, l1) in zip(nets[0][1], nets[1][1]):
+        assert c0 == c1
+        np.testing.assert_array_equal(l0, l1)
+    np.testing.assert_array_equal(nets[0][0].flat_grads.get_value(), nets[1][0].flat_grads.get_value())
+    for la, lb in zip(nets[0][0].tr_layers, nets[1][0].tr_layers):
+        for wa, wb in zip(la.get_wts(), lb.get_wts()):
+            np.testing.assert_array_equal(wa, wb)
+
+
 @pytest.mark.parametrize("name,img,B", [("cifar_like.prms", 32, 16), ("wide6.prms", 16, 4)])
 def test_baseline_config_nets_match_oracle(name, img, B):
     """BASELINE.json configs 4 and 5 (MFMA conv path, dropout + maxnorm): two training steps at

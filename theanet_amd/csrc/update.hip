@@ -34,6 +34,113 @@ __global__ __launch_bounds__(256) void sgd_update_multi_kernel(const tn_sgd_seg*
                            blockIdx.x, blockIdx.y, gridDim.x, red);
 }
 
+// The same launch with LAZY gradients: segments whose weight gradient is still a stack of partial
+// slabs (the deferred finishing sums of reduce.hip) add the slabs up on the fly -- in exactly the
+// order slab_sum_multi_kernel uses, so the result is bit-identical -- write the gradient out and
+// apply the update, which saves the reduction launch and one round trip of the gradient through HBM.
+struct LazyBatch {
+    int8_t rec_of_seg[16];             // record index of segment s, -1: the gradient is already final
+    tn_red_rec r[TN_RED_MAX];
+};
+
+__device__ __forceinline__ void sgd_apply(float& pv, float& vv, float gg, float gscale, float m, float step,
+                                          float L1, float L2) {
+    gg *= gscale;
+    if (L1 != 0.f) gg += L1 * ((pv > 0.f) - (pv < 0.f));
+    if (L2 != 0.f) gg += 2.f * L2 * pv;
+    const float vo = vv;
+    vv = m * vo + (1.f - m) * gg;
+    pv = pv - step * vo;
+}
+
+__global__ __launch_bounds__(256) void sgd_update_lazy_kernel(const tn_sgd_seg* __restrict__ segs, int nseg,
+                                                             const float* __restrict__ d_lr, float gscale,
+                                                             uint32_t* d_step_inc,
+                                                             const float* __restrict__ rowloss, int nrow,
+                                                             float cost_scale, float* __restrict__ d_cost,
+                                                             LazyBatch lb) {
+    __shared__ float red[16][17];
+    const int bx = blockIdx.x, by = blockIdx.y, nbx = gridDim.x;
+    const int ri = by < nseg ? lb.rec_of_seg[by] : -1;
+    if (ri < 0) {
+        sgd_update_multi_block(segs, nseg, d_lr, gscale, d_step_inc, rowloss, nrow, cost_scale, d_cost, bx, by,
+                               nbx, &red[0][0]);
+        return;
+    }
+    if (d_step_inc && bx == 0 && by == 0 && threadIdx.x == 0) *d_step_inc += 1;
+    const tn_red_rec rec = lb.r[ri];
+    const tn_sgd_seg sg = segs[by];
+    const float step = sg.rate * d_lr[0], m = sg.momentum, L1 = sg.L1, L2 = sg.L2;
+    float* __restrict__ p = sg.p;
+    float* __restrict__ v = sg.v;
+    float* __restrict__ g = const_cast<float*>(sg.g);
+    const float* __restrict__ src = rec.src;
+    const uint32_t n = rec.n, S = rec.S, stride = rec.stride;
+    if (S <= 32) {
+        const bool vec = rec.flip == 0 && (n & 3) == 0 && (stride & 3) == 0 &&
+                         (((uintptr_t)src | (uintptr_t)g | (uintptr_t)p | (uintptr_t)v) & 15) == 0;
+        if (vec) {
+            for (uint32_t i4 = (bx * 256u + threadIdx.x) * 4u; i4 < n; i4 += nbx * 1024u) {
+                float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
+                for (uint32_t z = 0; z < S; ++z) {
+                    const float4 t = *reinterpret_cast<const float4*>(src + (size_t)z * stride + i4);
+                    s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+                }
+                float4 pv = *reinterpret_cast<const float4*>(p + i4), vv = *reinterpret_cast<const float4*>(v + i4);
+                sgd_apply(pv.x, vv.x, s.x, gscale, m, step, L1, L2);
+                sgd_apply(pv.y, vv.y, s.y, gscale, m, step, L1, L2);
+                sgd_apply(pv.z, vv.z, s.z, gscale, m, step, L1, L2);
+                sgd_apply(pv.w, vv.w, s.w, gscale, m, step, L1, L2);
+                *reinterpret_cast<float4*>(g + i4) = s;
+                *reinterpret_cast<float4*>(v + i4) = vv;
+                *reinterpret_cast<float4*>(p + i4) = pv;
+            }
+        } else {
+            for (uint32_t i = bx * 256u + threadIdx.x; i < n; i += nbx * 256u) {
+                uint32_t j = i;
+                if (rec.flip) {
+                    const uint32_t kc = i / rec.flip, uv = i - kc * rec.flip;
+                    j = kc * rec.flip + (rec.flip - 1 - uv);
+                }
+                float s = 0.f;
+#pragma unroll 8
+                for (uint32_t z = 0; z < S; ++z) s += src[(size_t)z * stride + j];
+                float pv = p[i], vv = v[i];
+                sgd_apply(pv, vv, s, gscale, m, step, L1, L2);
+                g[i] = s; v[i] = vv; p[i] = pv;
+            }
+        }
+        return;
+    }
+    // tall: 16 outputs x 16 slab lanes per trip, lane sums added in lane order (as in reduce.hip)
+    const uint32_t ol = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    for (uint32_t o0 = bx * 16u; o0 < n; o0 += nbx * 16u) {
+        const uint32_t i = o0 + ol;
+        float s = 0.f;
+        if (i < n) {
+            uint32_t j = i;
+            if (rec.flip) {
+                const uint32_t kc = i / rec.flip, uv = i - kc * rec.flip;
+                j = kc * rec.flip + (rec.flip - 1 - uv);
+            }
+#pragma unroll 4
+            for (uint32_t z = sl; z < S; z += 16) s += src[(size_t)z * stride + j];
+        }
+        red[sl][ol] = s;
+        __syncthreads();
+        if (sl == 0 && i < n) {
+            float t = red[0][ol];
+#pragma unroll
+            for (int l = 1; l < 16; ++l) t += red[l][ol];
+            float pv = p[i], vv = v[i];
+            sgd_apply(pv, vv, t, gscale, m, step, L1, L2);
+            g[i] = t; v[i] = vv; p[i] = pv;
+        }
+        __syncthreads();
+    }
+}
+
 __global__ __launch_bounds__(256) void clip_kernel(float* __restrict__ p, size_t n, float mx) {
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n) p[i] = fminf(fmaxf(p[i], -mx), mx);
@@ -113,6 +220,45 @@ int tn_sgd_update_multi_cost(tn_ctx* ctx, const tn_sgd_seg* d_segs, int nseg, si
     if (bx < 1) bx = 1;
     sgd_update_multi_kernel<<<dim3(bx, nseg + (rider ? 1 : 0)), 256, 0, ctx->stream>>>(
         d_segs, nseg, d_lr, gscale, d_step_inc, rowloss, nrow, cost_scale, d_cost);
+    TN_LAUNCH_CHECK();
+    return TN_OK;
+}
+
+int tn_sgd_update_multi_lazy(tn_ctx* ctx, const tn_sgd_seg* d_segs, const tn_sgd_seg* h_segs, int nseg,
+                             size_t max_n, const float* d_lr, float gscale, uint32_t* d_step_inc,
+                             const float* rowloss, int nrow, float cost_scale, float* d_cost) {
+    TN_REQUIRE(nseg > 0 && nseg <= 16 && d_segs && h_segs && d_lr, "tn_sgd_update_multi_lazy: bad arguments");
+    const bool rider = rowloss != nullptr;
+    TN_REQUIRE(!rider || (d_cost != nullptr && nrow > 0), "tn_sgd_update_multi_lazy: bad cost arguments");
+    // pending slab sums whose output is the gradient of one of the segments are folded into the update;
+    // the others (and everything when deferral is off) are finished by the ordinary reduction launch
+    LazyBatch lb;
+    for (int s = 0; s < 16; ++s) lb.rec_of_seg[s] = -1;
+    int nlazy = 0, keep = 0;
+    for (int i = 0; i < ctx->npend; ++i) {
+        int seg = -1;
+        for (int s = 0; s < nseg; ++s)
+            if (h_segs[s].g == ctx->pend[i].out && h_segs[s].n == ctx->pend[i].n && lb.rec_of_seg[s] < 0) seg = s;
+        if (seg >= 0) {
+            lb.r[nlazy] = ctx->pend[i];
+            lb.rec_of_seg[seg] = (int8_t)nlazy++;
+        } else {
+            ctx->pend[keep++] = ctx->pend[i];
+        }
+    }
+    ctx->npend = keep;
+    ctx->defer = false;
+    int rc = tn_red_flush(ctx);             // leftovers (also resets the scratch bump pointer)
+    if (rc) return rc;
+    ctx->scratch_off = 0;
+    if (nlazy == 0)
+        return tn_sgd_update_multi_cost(ctx, d_segs, nseg, max_n, d_lr, gscale, d_step_inc, rowloss, nrow,
+                                        cost_scale, d_cost);
+    int bx = cdiv(max_n, 1024);
+    if (bx > 256) bx = 256;
+    if (bx < 1) bx = 1;
+    sgd_update_lazy_kernel<<<dim3(bx, nseg + (rider ? 1 : 0)), 256, 0, ctx->stream>>>(
+        d_segs, nseg, d_lr, gscale, d_step_inc, rowloss, nrow, cost_scale, d_cost, lb);
     TN_LAUNCH_CHECK();
     return TN_OK;
 }

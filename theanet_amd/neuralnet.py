@@ -404,6 +404,7 @@ class NeuralNet():
         if segs:
             host = np.array(segs, dtype=seg_dt)
             self._d_segs = self.ctx.array(host.view(np.uint8))
+            self._h_segs = host                       # kept alive: tn_sgd_update_multi_lazy reads it
         # which layers must propagate a gradient to their input
         self._need_gin = []
         seen = False
@@ -500,6 +501,8 @@ class NeuralNet():
                          *field_args)
         tail = False
         dp_async = False
+        # single-GPU steps leave the finishing slab sums to the update launch (tn_sgd_update_multi_lazy)
+        lazy = False
         try:
             for idx in range(len(self.tr_layers) - 1, -1, -1):
                 lyr = self.tr_layers[idx]
@@ -517,6 +520,8 @@ class NeuralNet():
                     dp_async = True
                 if g is None:
                     break
+            lazy = (not self._dp and 0 < self._n_segs <= 16 and
+                    os.environ.get("TN_LAZY_UPDATE", "1") != "0")
         finally:
             if self.side_stream:
                 ctx.call("tn_stream_wait", 0, 1)  # join the side stream (leaf weight gradients)
@@ -525,9 +530,10 @@ class NeuralNet():
                 ctx.call("tn_rider_cancel")       # nobody carried it: it joins the update launch
             rode = ahead and not waiting and os.environ.get("TN_FIELD_RIDER", "1") != "0"
             tail = ahead and not rode
+            lazy = lazy and not tail
             if tail:
                 ctx.call("tn_defer_flush_step", self.d_step.ptr)      # the counter advances here
-            else:
+            elif not lazy:
                 ctx.call("tn_defer_reductions", 0)
         if self._dp:
             if dp_async:
@@ -544,6 +550,11 @@ class NeuralNet():
                      out.rowloss.ptr if rider else None, self.local_bsz, 1.0 / self.batch_sz,
                      self.d_cost.ptr if rider else None, first.draws.ptr, first.seed, self.d_step.ptr,
                      *field_args)
+        elif lazy:
+            ctx.call("tn_sgd_update_multi_lazy", self._d_segs.ptr, self._h_segs.ctypes.data, self._n_segs,
+                     self._max_seg, self.cur_learn_rate.ptr, 1.0, self.d_step.ptr,
+                     out.rowloss.ptr if rider else None, self.local_bsz, 1.0 / self.batch_sz,
+                     self.d_cost.ptr if rider else None)
         elif self._n_segs or rider:               # also advances the RNG step counter
             ctx.call("tn_sgd_update_multi_cost", self._d_segs.ptr if self._n_segs else None,
                      self._n_segs, self._max_seg, self.cur_learn_rate.ptr, 1.0, self.d_step.ptr,
