@@ -30,6 +30,14 @@ CONV_CASES = [
     (1, 8, 14, 16, 5, 1, "same", "relu05"),
     (5, 64, 8, 96, 3, 1, "same", "relu10"),
     (2, 24, 7, 40, 2, 1, "valid", "linear"),
+    # LDS-resident-tile MFMA path (3x3, row length % 4 == 0): whole small images per block, row
+    # tiles of larger ones, ragged filter / channel counts, partial image groups and lane tiles
+    (2, 8, 16, 48, 3, 1, "valid", "relu10"),        # forward on the tile path
+    (2, 8, 18, 32, 3, 1, "valid", "relu10"),        # dgrad on the tile path (padding 2)
+    (3, 20, 32, 64, 3, 1, "same", "relu10"),
+    (2, 16, 64, 64, 3, 1, "same", "tanh"),
+    (1, 40, 36, 24, 3, 1, "same", "relu05"),
+    (9, 10, 4, 33, 3, 1, "same", "sigmoid"),
 ]
 
 

@@ -366,6 +366,13 @@ __global__ __launch_bounds__(256) void conv_mfma_wgrad_reduce(const float* __res
     }
 }
 
+// conv_tile.hip: the LDS-resident-tile kernels for 3x3 windows
+int tn_conv_tile_ok(const float* x, int N, int C, int H, int Wd, int K, int f, int pad, int Ho, int Wo);
+int tn_conv_tile_fwd(tn_ctx* ctx, const float* x, const float* W, const float* b, float* a, int N, int C,
+                     int H, int Wd, int K, int pad, int Ho, int Wo, int act, float prm);
+int tn_conv_tile_dgrad(tn_ctx* ctx, const float* dz, const float* W, float* dx, int N, int C, int H,
+                       int Wd, int K, int pad, int Ho, int Wo, const float* prev_a, int act, float prm);
+
 static int vecA(const void* p, int kd) { return ((reinterpret_cast<uintptr_t>(p) & 15) == 0) && (kd % 4 == 0) && kd >= 4; }
 
 // 1 if the MFMA path applies (stride 1, deep enough reduction, enough filters)
@@ -375,6 +382,8 @@ extern "C" int tn_conv_mfma_supported(int C, int K, int f, int stride) {
 
 int tn_conv_mfma_fwd(tn_ctx* ctx, const float* x, const float* W, const float* b, float* a, int N,
                      int C, int H, int Wd, int K, int f, int pad, int Ho, int Wo, int act, float prm) {
+    if (tn_conv_tile_ok(x, N, C, H, Wd, K, f, pad, Ho, Wo))
+        return tn_conv_tile_fwd(ctx, x, W, b, a, N, C, H, Wd, K, pad, Ho, Wo, act, prm);
     ConvMG g{};
     g.x = x; g.W = W; g.out = a; g.bias = b;
     g.N = N; g.C = C; g.H = H; g.Wd = Wd; g.K = K; g.f = f; g.pad = pad; g.Ho = Ho; g.Wo = Wo;
@@ -395,6 +404,8 @@ int tn_conv_mfma_dgrad(tn_ctx* ctx, const float* dz, const float* W, float* dx, 
                        int Wd, int K, int f, int pad, int Ho, int Wo, const float* prev_a, int act,
                        float prm) {
     // dx = conv_fwd(dz, Wt) with padding f-1-pad: gathered tensor = dz (N,K,Ho,Wo), rows = C maps
+    if (tn_conv_tile_ok(dz, N, K, Ho, Wo, C, f, f - 1 - pad, H, Wd))
+        return tn_conv_tile_dgrad(ctx, dz, W, dx, N, C, H, Wd, K, pad, Ho, Wo, prev_a, act, prm);
     const size_t wt_bytes = (size_t)K * C * f * f * sizeof(float);
     float* Wt;
     int rc = tn_scratch_get(ctx, wt_bytes, &Wt);

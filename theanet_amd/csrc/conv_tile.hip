@@ -1,0 +1,410 @@
+// 3x3 stride-1 convolution on the fp32 matrix cores with the input tile RESIDENT IN LDS
+// (the wide layers of cifar_like / wide6; theanet/layer/convpool.py:54-72).
+//
+// conv_mfma.hip builds the im2col operand element by element (one clamped gather + a select per
+// value, integer divisions per K-tile); here the im2col never exists, not even as a gather:
+//   * a block owns 256 output pixels (TH full rows of one image, or NI whole small images) and
+//     32*FT filters; per chunk of 8 input channels it copies the (TH+2) x (W+2) halo tile into LDS
+//     with 16-byte coalesced loads (zero padding = cells that are cleared once and never written);
+//   * the reduction runs tap-major: for a fixed tap (u,v) one v_mfma_f32_32x32x2_f32 consumes two
+//     channels, A = W[filter][c+hi][tap] (pre-arranged by a tiny kernel so a chunk's weights are one
+//     straight copy into LDS), B = tile[c+hi][row+u][col+v] -- a plain ds_read_b32 of 32
+//     consecutive pixels at (lane base + constant): the "im2col" is an LDS address offset;
+//   * a wave keeps FT x 2 accumulators (two pixel tiles share every A value, the FT filter tiles
+//     share every B value), so 4 MFMAs are fed by 2 + FT ds_read_b32.
+// dgrad is the same kernel on dz with W[k][c][u][v] read as (filter = c, channel = k, no flip) and
+// padding 2 - pad, with act'(prev_a) of the layer below in the epilogue.
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+#define CT_CH 8           // input channels per chunk
+#define CT_SX 4           // 16-byte staging slots per thread for the input tile
+
+struct ConvTG {
+    const float* x;       // gathered tensor (N, C, H, Wd)
+    const float* wt;      // arranged weights [KT][nchunk][4][9][2][32*FT]
+    float* out;           // (N, K, Ho, Wo)
+    const float* bias;
+    const float* prev_a;
+    int N, C, H, Wd, K, pad, Ho, Wo, act;
+    float prm;
+    int KT, MT, RT, NI, TH, THi, RS, LP, plane, nchunk, TP, q4, nx4, vec_out;
+    unsigned long long* dbg;   // TN_CT_DBG=1: per block {start, prologue done, loop done, end} (s_memtime) + wall clock
+};
+
+// wt[kt][chunk][cp][tap][hi][j]: filter kt*KBF + j, channel chunk*8 + 2*cp + hi, correlation tap (u,v)
+__global__ __launch_bounds__(256) void conv_tile_wt_kernel(const float* __restrict__ W, float* __restrict__ wt,
+                                                          int K, int C, int KBF, int nchunk, int total,
+                                                          int dgrad) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    int r = idx;
+    const int j = r % KBF; r /= KBF;
+    const int hi = r & 1; r >>= 1;
+    const int tap = r % 9; r /= 9;
+    const int cp = r & 3; r >>= 2;
+    const int chunk = r % nchunk;
+    const int kt = r / nchunk;
+    const int filt = kt * KBF + j, ch = chunk * CT_CH + 2 * cp + hi;
+    float v = 0.f;
+    if (filt < K && ch < C)
+        v = dgrad ? W[((size_t)ch * K + filt) * 9 + tap]          // W[k = ch][c = filt][u][v]
+                  : W[((size_t)filt * C + ch) * 9 + (8 - tap)];   // true convolution: flipped taps
+    wt[idx] = v;
+}
+
+struct CtSlot { int g, l, c; bool ok; };
+// input staging slot s of thread t: (channel-in-chunk, image, tile row, 16-byte column group)
+__device__ __forceinline__ CtSlot ct_slot(const ConvTG& g, int t, int s, int n0, int r0) {
+    CtSlot o;
+    const int e = t + 256 * s;
+    bool ok = e < g.nx4;
+    int rr = min(e, g.nx4 - 1);
+    const int q = rr % g.q4; rr /= g.q4;
+    const int r = rr % g.THi; rr /= g.THi;
+    const int ni = rr % g.NI;
+    o.c = rr / g.NI;
+    const int in_row = r0 - g.pad + r, n = n0 + ni;
+    o.ok = ok && (unsigned)in_row < (unsigned)g.H && n < g.N;
+    o.g = (min(n, g.N - 1) * g.C * g.H + min(max(in_row, 0), g.H - 1)) * g.Wd + 4 * q;
+    o.l = o.c * g.plane + (ni * g.THi + r) * g.RS + g.pad + g.LP + 4 * q;
+    return o;
+}
+
+template <int FT, bool DGRAD>
+__global__ __launch_bounds__(256) void conv_tile_kernel(ConvTG g) {
+    extern __shared__ __attribute__((aligned(16))) float ct_smem[];
+    constexpr int KBF = 32 * FT;
+    constexpr int WSZ = 4 * 9 * 2 * KBF;              // floats of one weight chunk
+    constexpr int WS4 = (WSZ / 4 + 255) / 256;        // 16-byte staging slots per thread (3 or 5)
+    const int XSZ = CT_CH * g.plane;
+    float* Xs = ct_smem;                              // [2][XSZ]
+    float* Ws = ct_smem + 2 * XSZ;                    // [2][WSZ]
+    // XCD-aware decode: the filter tiles of one pixel tile share an L2
+    const int bid = blockIdx.x, xcd = bid & 7, idx = bid >> 3;
+    const int mt = (idx / g.KT) * 8 + xcd, kt = idx % g.KT;
+    if (mt >= g.MT) return;
+    const int grp = mt / g.RT, rt = mt - grp * g.RT;
+    const int n0 = grp * g.NI, r0 = rt * g.TH;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, hi = lane >> 5;
+    const int HW = g.H * g.Wd;
+    unsigned long long* dbg = (g.dbg && t == 0) ? g.dbg + 8 * (size_t)bid : nullptr;
+    if (dbg) { dbg[0] = __builtin_readcyclecounter(); dbg[4] = wall_clock64(); }
+
+    for (int i = t * 4; i < 2 * XSZ; i += 1024) *reinterpret_cast<float4*>(Xs + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    // staging slots live in named registers (arrays of float4 ended up in scratch memory)
+    const CtSlot s0 = ct_slot(g, t, 0, n0, r0), s1 = ct_slot(g, t, 1, n0, r0), s2 = ct_slot(g, t, 2, n0, r0),
+                 s3 = ct_slot(g, t, 3, n0, r0);
+    const float* wsrc = g.wt + (size_t)kt * g.nchunk * WSZ + 4 * t;
+    const int wo3 = min(3072, WSZ - 4 - 4 * t), wo4 = min(4096, WSZ - 4 - 4 * t), wo2 = min(2048, WSZ - 4 - 4 * t);
+
+    // this lane's two pixels (B operand)
+    int pixb[2];
+#pragma unroll
+    for (int pt = 0; pt < 2; ++pt) {
+        const int p = wave * 64 + pt * 32 + l31;
+        const int pp = p < g.TP ? p : 0;
+        const int per = g.TH * g.Wo;
+        const int ni = pp / per, rem = pp - ni * per;
+        const int r = rem / g.Wo, col = rem - r * g.Wo;
+        pixb[pt] = hi * g.plane + (ni * g.THi + r) * g.RS + col + g.LP;
+    }
+
+    f32x16 acc[FT][2];
+#pragma unroll
+    for (int a = 0; a < FT; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    float4 xr0, xr1, xr2, xr3, wr0, wr1, wr2, wr3, wr4;
+#define CT_XL(S, R) R = *reinterpret_cast<const float4*>(g.x + S.g + min(ch_ * CT_CH + S.c, g.C - 1) * HW)
+#define CT_GLOAD(CHUNK)                                                                          \
+    {                                                                                            \
+        const int ch_ = min((CHUNK), g.nchunk - 1);                                              \
+        CT_XL(s0, xr0); CT_XL(s1, xr1); CT_XL(s2, xr2); CT_XL(s3, xr3);                          \
+        const float* w_ = wsrc + (size_t)ch_ * WSZ;                                              \
+        wr0 = *reinterpret_cast<const float4*>(w_);                                              \
+        wr1 = *reinterpret_cast<const float4*>(w_ + 1024);                                       \
+        wr2 = *reinterpret_cast<const float4*>(w_ + wo2);                                        \
+        if (WS4 > 3) {                                                                           \
+            wr3 = *reinterpret_cast<const float4*>(w_ + wo3);                                    \
+            wr4 = *reinterpret_cast<const float4*>(w_ + wo4);                                    \
+        }                                                                                        \
+    }
+#define CT_XS(S, R) if (S.ok) *reinterpret_cast<float4*>(xb_ + S.l) = R
+#define CT_LSTORE(BUF)                                                                           \
+    {                                                                                            \
+        float* xb_ = Xs + (BUF) * XSZ;                                                           \
+        float* wb_ = Ws + (BUF) * WSZ + 4 * t;                                                   \
+        CT_XS(s0, xr0); CT_XS(s1, xr1); CT_XS(s2, xr2); CT_XS(s3, xr3);                          \
+        *reinterpret_cast<float4*>(wb_) = wr0;                                                   \
+        *reinterpret_cast<float4*>(wb_ + 1024) = wr1;                                            \
+        if (4 * t + 2048 < WSZ) *reinterpret_cast<float4*>(wb_ + 2048) = wr2;                    \
+        if (WS4 > 3) {                                                                           \
+            *reinterpret_cast<float4*>(wb_ + 3072) = wr3;                                        \
+            if (4 * t + 4096 < WSZ) *reinterpret_cast<float4*>(wb_ + 4096) = wr4;                \
+        }                                                                                        \
+    }
+    CT_GLOAD(0);
+    __syncthreads();                 // the clearing is done
+    CT_LSTORE(0);
+    __syncthreads();
+    if (dbg) dbg[1] = __builtin_readcyclecounter();
+    const int RS = g.RS, plane2 = 2 * g.plane;
+    for (int chunk = 0; chunk < g.nchunk; ++chunk) {
+        CT_GLOAD(chunk + 1);
+        const float* x0 = Xs + (chunk & 1) * XSZ + pixb[0];
+        const float* x1 = Xs + (chunk & 1) * XSZ + pixb[1];
+        const float* Wb = Ws + (chunk & 1) * WSZ + hi * KBF + l31;
+        // 12 steps (channel pair, tap row): the LDS operands of step s+1 (3 taps: 3 A pairs, 2 x 3 B
+        // values) are requested before the 6*FT MFMAs of step s are issued
+        float a[2][3][FT], b[2][3][2];
+#pragma unroll
+        for (int v = 0; v < 3; ++v) {
+#pragma unroll
+            for (int f = 0; f < FT; ++f) a[0][v][f] = Wb[(v * 2) * KBF + 32 * f];
+            b[0][v][0] = x0[v]; b[0][v][1] = x1[v];
+        }
+        __builtin_amdgcn_sched_group_barrier(0x100, 7, 0);            // step 0's operands
+#pragma unroll
+        for (int st = 0; st < 12; ++st) {
+            const int cur = st & 1, nx = cur ^ 1;
+            if (st + 1 < 12) {
+                const int cp = (st + 1) / 3, u = (st + 1) % 3;
+#pragma unroll
+                for (int v = 0; v < 3; ++v) {
+#pragma unroll
+                    for (int f = 0; f < FT; ++f) a[nx][v][f] = Wb[((cp * 9 + u * 3 + v) * 2) * KBF + 32 * f];
+                    b[nx][v][0] = x0[cp * plane2 + u * RS + v];
+                    b[nx][v][1] = x1[cp * plane2 + u * RS + v];
+                }
+            }
+#pragma unroll
+            for (int v = 0; v < 3; ++v)
+#pragma unroll
+                for (int f = 0; f < FT; ++f) {
+                    acc[f][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][v][f], b[cur][v][0], acc[f][0], 0, 0, 0);
+                    acc[f][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][v][f], b[cur][v][1], acc[f][1], 0, 0, 0);
+                }
+            __builtin_amdgcn_sched_group_barrier(0x100, 7, 0);        // DS reads of the next step
+            __builtin_amdgcn_sched_group_barrier(0x008, 6 * FT, 0);   // then this step's MFMAs
+        }
+        if (chunk + 1 < g.nchunk) CT_LSTORE((chunk + 1) & 1);
+        __syncthreads();
+    }
+#undef CT_GLOAD
+#undef CT_LSTORE
+#undef CT_XL
+#undef CT_XS
+    if (dbg) dbg[2] = __builtin_readcyclecounter();
+
+    const int HoWo = g.Ho * g.Wo;
+    if (g.vec_out) {
+        // ---- epilogue through LDS: the block's (32*FT filters) x (256 pixels) tile is laid out
+        // [filter][pixel]; a wave then owns whole filter rows: one 16-byte access per lane, 1 KB bursts
+        float* Os = ct_smem;
+#pragma unroll
+        for (int f = 0; f < FT; ++f)
+#pragma unroll
+            for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    Os[(f * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi) * 256 + wave * 64 + pt * 32 + l31] = acc[f][pt][r];
+        __syncthreads();
+        const int p = 4 * lane;                         // this thread's 4 pixels (same for all its filters)
+        const int per = g.TH * g.Wo;
+        const int pp = p < g.TP ? p : 0;
+        const int ni = pp / per, rem = pp - ni * per;
+        const int r = rem / g.Wo, col = rem - r * g.Wo;
+        const bool ok = p < g.TP && n0 + ni < g.N && r0 + r < g.Ho;
+        const size_t pbase = (size_t)(n0 + ni) * g.K * HoWo + (r0 + r) * g.Wo + col;
+        if (ok) {
+#pragma unroll 4
+            for (int i = 0; i < KBF / 4; ++i) {
+                const int kl = wave + 4 * i, k = kt * KBF + kl;
+                if (k >= g.K) break;
+                float4 v = *reinterpret_cast<const float4*>(Os + kl * 256 + p);
+                if (DGRAD) {
+                    if (g.prev_a) {
+                        const float4 pa = *reinterpret_cast<const float4*>(g.prev_a + pbase + (size_t)k * HoWo);
+                        v.x *= tn_act_grad_from_out(pa.x, g.act, g.prm);
+                        v.y *= tn_act_grad_from_out(pa.y, g.act, g.prm);
+                        v.z *= tn_act_grad_from_out(pa.z, g.act, g.prm);
+                        v.w *= tn_act_grad_from_out(pa.w, g.act, g.prm);
+                    }
+                } else {
+                    const float bk = g.bias[k];
+                    v.x = tn_act_fwd(v.x + bk, g.act, g.prm);
+                    v.y = tn_act_fwd(v.y + bk, g.act, g.prm);
+                    v.z = tn_act_fwd(v.z + bk, g.act, g.prm);
+                    v.w = tn_act_fwd(v.w + bk, g.act, g.prm);
+                }
+                *reinterpret_cast<float4*>(g.out + pbase + (size_t)k * HoWo) = v;
+            }
+        }
+    } else {
+        // ---- scalar epilogue: lane <-> pixel (32 consecutive pixels of a map per store)
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt) {
+            const int p = wave * 64 + pt * 32 + l31;
+            const int per = g.TH * g.Wo;
+            const int pp = p < g.TP ? p : 0;
+            const int ni = pp / per, rem = pp - ni * per;
+            const int r = rem / g.Wo, col = rem - r * g.Wo;
+            if (!(p < g.TP && n0 + ni < g.N && r0 + r < g.Ho)) continue;
+            const size_t pbase = (size_t)(n0 + ni) * g.K * HoWo + (r0 + r) * g.Wo + col;
+#pragma unroll
+            for (int f = 0; f < FT; ++f) {
+                float pa[16];
+                if (DGRAD && g.prev_a) {
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        const int k = min(kt * KBF + f * 32 + (q & 3) + 8 * (q >> 2) + 4 * hi, g.K - 1);
+                        pa[q] = g.prev_a[pbase + (size_t)k * HoWo];
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const int k = kt * KBF + f * 32 + (q & 3) + 8 * (q >> 2) + 4 * hi;
+                    if (k < g.K) {
+                        float v = acc[f][pt][q];
+                        if (DGRAD) {
+                            if (g.prev_a) v *= tn_act_grad_from_out(pa[q], g.act, g.prm);
+                        } else {
+                            v = tn_act_fwd(v + g.bias[k], g.act, g.prm);
+                        }
+                        g.out[pbase + (size_t)k * HoWo] = v;
+                    }
+                }
+            }
+        }
+    }
+    if (dbg) { dbg[3] = __builtin_readcyclecounter(); dbg[5] = wall_clock64(); }
+}
+
+// geometry of the pixel tiling; returns 0 when the shape is outside the kernel's limits
+static int ct_geometry(ConvTG& g, int FT) {
+    if (g.Wo > 256 || (g.Wd & 3)) return 0;
+    int TH = 256 / g.Wo;
+    if (TH >= g.Ho) {
+        g.TH = g.Ho; g.RT = 1;
+        g.NI = 256 / (g.Ho * g.Wo);
+        if (g.NI < 1) g.NI = 1;
+        if (g.NI > g.N) g.NI = g.N;
+    } else {
+        g.RT = cdiv(g.Ho, TH);
+        g.TH = cdiv(g.Ho, g.RT);
+        g.NI = 1;
+    }
+    g.TP = g.NI * g.TH * g.Wo;
+    g.THi = g.TH + 2;
+    g.LP = (4 - (g.pad & 3)) & 3;
+    g.RS = (g.LP + g.Wo + 2 + 3) & ~3;
+    if (g.RS < g.pad + g.LP + g.Wd) g.RS = (g.pad + g.LP + g.Wd + 3) & ~3;
+    g.plane = g.NI * g.THi * g.RS;
+    g.q4 = g.Wd / 4;
+    g.nx4 = CT_CH * g.NI * g.THi * g.q4;
+    if (g.nx4 > CT_SX * 256) return 0;
+    g.nchunk = cdiv(g.C, CT_CH);
+    g.KT = cdiv(g.K, 32 * FT);
+    g.MT = cdiv(g.N, g.NI) * g.RT;
+    return 1;
+}
+
+static size_t ct_lds_bytes(const ConvTG& g, int FT) {
+    const size_t loop = (size_t)(2 * CT_CH * g.plane + 2 * 4 * 9 * 2 * 32 * FT) * sizeof(float);
+    const size_t epi = (size_t)32 * FT * 256 * sizeof(float);        // the transposed output tile
+    return loop > epi ? loop : epi;
+}
+
+static int ct_pick_ft(int K) { return K > 32 ? 2 : 1; }
+
+static bool ct_enabled() {
+    static int on = -1;
+    if (on < 0) {
+        const char* e = getenv("TN_CONV_TILE");
+        on = (e && e[0] == '0') ? 0 : 1;
+    }
+    return on != 0;
+}
+
+// 1 if conv_tile_kernel handles the (gathered tensor N,C,H,Wd; K filters; pad; output Ho,Wo) problem
+int tn_conv_tile_ok(const float* x, int N, int C, int H, int Wd, int K, int f, int pad, int Ho, int Wo) {
+    if (!ct_enabled() || f != 3 || pad < 0 || pad > 2) return 0;
+    if (reinterpret_cast<uintptr_t>(x) & 15) return 0;
+    ConvTG g{};
+    g.N = N; g.C = C; g.H = H; g.Wd = Wd; g.K = K; g.pad = pad; g.Ho = Ho; g.Wo = Wo;
+    const int FT = ct_pick_ft(K);
+    if (!ct_geometry(g, FT)) return 0;
+    return ct_lds_bytes(g, FT) <= 150 * 1024;
+}
+
+static unsigned long long* ct_dbg_buf = nullptr;
+// debugging aid (not part of the C-ABI): copies the cycle stamps of the last stamped launch
+extern "C" int tn_conv_tile_dbg_read(tn_ctx* ctx, unsigned long long* host, int nblocks) {
+    if (!ct_dbg_buf) return -1;
+    hipStreamSynchronize(ctx->stream);
+    return hipMemcpy(host, ct_dbg_buf, (size_t)nblocks * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+}
+
+template <int FT, bool DGRAD>
+static int ct_launch(tn_ctx* ctx, ConvTG& g) {
+    static bool attr_set = false;
+    size_t lds = ct_lds_bytes(g, FT);
+    if (const char* e = getenv("TN_CT_LDS")) lds = (size_t)atoi(e) > lds ? (size_t)atoi(e) : lds;
+    if (!attr_set) {
+        TN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_tile_kernel<FT, DGRAD>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    const int grid = 8 * cdiv(g.MT, 8) * g.KT;
+    static unsigned long long* dbgbuf = nullptr;
+    if (getenv("TN_CT_DBG")) {
+        if (!dbgbuf) TN_HIP(hipMalloc(&dbgbuf, 8 * sizeof(unsigned long long) * 65536));
+        ct_dbg_buf = dbgbuf;
+        g.dbg = grid <= 65536 ? dbgbuf : nullptr;
+    }
+    conv_tile_kernel<FT, DGRAD><<<grid, 256, lds, ctx->stream>>>(g);
+    TN_LAUNCH_CHECK();
+    return TN_OK;
+}
+
+static int ct_run(tn_ctx* ctx, ConvTG& g, const float* W, bool dgrad) {
+    const int FT = ct_pick_ft(g.K);
+    TN_REQUIRE(ct_geometry(g, FT), "conv_tile: unsupported shape");
+    TN_REQUIRE((long long)g.N * g.C * g.H * g.Wd < (1ll << 31) && (long long)g.N * g.K * g.Ho * g.Wo < (1ll << 31),
+               "conv_tile: tensor too large for 32-bit offsets");
+    const int KBF = 32 * FT, total = g.KT * g.nchunk * 4 * 9 * 2 * KBF;
+    float* wt;
+    int rc = tn_scratch_get(ctx, (size_t)total * sizeof(float), &wt);
+    if (rc) return rc;
+    conv_tile_wt_kernel<<<cdiv(total, 256), 256, 0, ctx->stream>>>(W, wt, g.K, g.C, KBF, g.nchunk, total,
+                                                                  dgrad ? 1 : 0);
+    TN_LAUNCH_CHECK();
+    g.wt = wt;
+    g.vec_out = (g.Wo % 4 == 0) && ((reinterpret_cast<uintptr_t>(g.out) | reinterpret_cast<uintptr_t>(g.prev_a)) & 15) == 0;
+    if (dgrad) return FT == 2 ? ct_launch<2, true>(ctx, g) : ct_launch<1, true>(ctx, g);
+    return FT == 2 ? ct_launch<2, false>(ctx, g) : ct_launch<1, false>(ctx, g);
+}
+
+int tn_conv_tile_fwd(tn_ctx* ctx, const float* x, const float* W, const float* b, float* a, int N, int C,
+                     int H, int Wd, int K, int pad, int Ho, int Wo, int act, float prm) {
+    ConvTG g{};
+    g.x = x; g.out = a; g.bias = b;
+    g.N = N; g.C = C; g.H = H; g.Wd = Wd; g.K = K; g.pad = pad; g.Ho = Ho; g.Wo = Wo;
+    g.act = act; g.prm = prm;
+    return ct_run(ctx, g, W, false);
+}
+
+// dx (N,C,H,Wd) from dz (N,K,Ho,Wo): the forward kernel with (channels, filters) = (K, C), padding 2 - pad
+int tn_conv_tile_dgrad(tn_ctx* ctx, const float* dz, const float* W, float* dx, int N, int C, int H,
+                       int Wd, int K, int pad, int Ho, int Wo, const float* prev_a, int act, float prm) {
+    ConvTG g{};
+    g.x = dz; g.out = dx; g.prev_a = prev_a;
+    g.N = N; g.C = K; g.H = Ho; g.Wd = Wo; g.K = C; g.pad = 2 - pad; g.Ho = H; g.Wo = Wd;
+    g.act = act; g.prm = prm;
+    return ct_run(ctx, g, W, true);
+}

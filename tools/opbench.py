@@ -192,27 +192,31 @@ def _():
 
 # ---- a wide6-like layer: 64 -> 64 maps, 3x3 same, 64x64 images, 128 images/GPU ------------
 WB = int(os.environ.get("OPBENCH_WB", 128))
-wx = dev((WB, 64, 64, 64)); wW, wb_ = dev((64, 64, 3, 3)), dev((64,))
-wa = dev((WB, 64, 64, 64)); wdz = dev((WB, 64, 64, 64)); wdx = dev((WB, 64, 64, 64))
-wdW, wdb = dev((64, 64, 3, 3)), dev((64,))
-cw = (WB, 64, 64, 64, 64, 3)
-WFL = 2 * WB * 64 * 64 * 64 * 64 * 9
-WBY = 4 * (2 * WB * 64 * 64 * 64 + 64 * 64 * 9)
+WC = int(os.environ.get("OPBENCH_WC", 64))      # input maps
+WK = int(os.environ.get("OPBENCH_WK", 64))      # filters
+WH = int(os.environ.get("OPBENCH_WH", 64))      # image side
+wx = dev((WB, WC, WH, WH)); wW, wb_ = dev((WK, WC, 3, 3)), dev((WK,))
+wa = dev((WB, WK, WH, WH)); wdz = dev((WB, WK, WH, WH)); wdx = dev((WB, WC, WH, WH))
+wpa = dev((WB, WC, WH, WH))
+wdW, wdb = dev((WK, WC, 3, 3)), dev((WK,))
+cw = (WB, WC, WH, WH, WK, 3)
+WFL = 2 * WB * WH * WH * WK * WC * 9
+WBY = 4 * (WB * WH * WH * (WC + WK) + WK * WC * 9)
 
 
 @op("wide_conv_fwd", WFL, WBY)
 def _():
-    ctx.call("tn_conv2d_fwd", wx.ptr, wW.ptr, wb_.ptr, wa.ptr, *cw, 1, 1, 64, 64, LEAKY, .1)
+    ctx.call("tn_conv2d_fwd", wx.ptr, wW.ptr, wb_.ptr, wa.ptr, *cw, 1, 1, WH, WH, LEAKY, .1)
 
 
 @op("wide_conv_dgrad", WFL, WBY)
 def _():
-    ctx.call("tn_conv2d_dgrad", wdz.ptr, wW.ptr, wdx.ptr, *cw, 1, 1, 64, 64, wa.ptr, LEAKY, .1)
+    ctx.call("tn_conv2d_dgrad", wdz.ptr, wW.ptr, wdx.ptr, *cw, 1, 1, WH, WH, wpa.ptr, LEAKY, .1)
 
 
 @op("wide_conv_wgrad", WFL, WBY)
 def _():
-    ctx.call("tn_conv2d_wgrad", wx.ptr, wdz.ptr, wdW.ptr, wdb.ptr, *cw, 1, 1, 64, 64)
+    ctx.call("tn_conv2d_wgrad", wx.ptr, wdz.ptr, wdW.ptr, wdb.ptr, *cw, 1, 1, WH, WH)
 
 
 # ---- calibration: launch boundary and GEMM fixed cost ------------------------------------------
