@@ -74,8 +74,10 @@ def test_conv_wgrad_dgrad(case):
     dW, db, dx = empty(W.shape), empty((K,)), empty(x.shape)
     dxd, dzd, Wd = dev(x), dev(dz), dev(W)
     call("tn_conv2d_wgrad", dxd.ptr, dzd.ptr, dW.ptr, db.ptr, N, C, H, H, K, f, s, pad_lo, out, out)
-    assert_close(dW.get_value(), dW_w, atol=1e-4, what="conv dW %s" % (case,))
-    assert_close(db.get_value(), db_w, atol=1e-4, what="conv db %s" % (case,))
+    # entries near zero are sums of N*Ho*Wo products that cancel: the absolute floor follows the
+    # largest entry (fp32 accumulation), never below 1e-4
+    assert_close(dW.get_value(), dW_w, atol=max(1e-4, 2e-6 * np.abs(dW_w).max()), what="conv dW %s" % (case,))
+    assert_close(db.get_value(), db_w, atol=max(1e-4, 2e-6 * np.abs(db_w).max()), what="conv db %s" % (case,))
     call("tn_conv2d_dgrad", dzd.ptr, Wd.ptr, dx.ptr, N, C, H, H, K, f, s, pad_lo, out, out,
          None, 0, 0.0)
     assert_close(dx.get_value(), dx_w, atol=1e-4, what="conv dx %s" % (case,))

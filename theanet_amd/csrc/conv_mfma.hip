@@ -373,6 +373,11 @@ int tn_conv_tile_fwd(tn_ctx* ctx, const float* x, const float* W, const float* b
 int tn_conv_tile_dgrad(tn_ctx* ctx, const float* dz, const float* W, float* dx, int N, int C, int H,
                        int Wd, int K, int pad, int Ho, int Wo, const float* prev_a, int act, float prm);
 
+int tn_conv_tile_wgrad_ok(tn_ctx* ctx, const float* x, const float* dz, int N, int C, int H, int Wd, int K,
+                          int f, int pad, int Ho, int Wo);
+int tn_conv_tile_wgrad(tn_ctx* ctx, const float* x, const float* dz, float* dW, float* db, int N, int C,
+                       int H, int Wd, int K);
+
 static int vecA(const void* p, int kd) { return ((reinterpret_cast<uintptr_t>(p) & 15) == 0) && (kd % 4 == 0) && kd >= 4; }
 
 // 1 if the MFMA path applies (stride 1, deep enough reduction, enough filters)
@@ -427,6 +432,8 @@ int tn_conv_mfma_dgrad(tn_ctx* ctx, const float* dz, const float* W, float* dx, 
 
 int tn_conv_mfma_wgrad(tn_ctx* ctx, const float* x, const float* dz, float* dW, float* db, int N,
                        int C, int H, int Wd, int K, int f, int pad, int Ho, int Wo) {
+    if (tn_conv_tile_wgrad_ok(ctx, x, dz, N, C, H, Wd, K, f, pad, Ho, Wo))
+        return tn_conv_tile_wgrad(ctx, x, dz, dW, db, N, C, H, Wd, K);
     ConvMG g{};
     g.x = x; g.W = dz;
     g.N = N; g.C = C; g.H = H; g.Wd = Wd; g.K = K; g.f = f; g.pad = pad; g.Ho = Ho; g.Wo = Wo;

@@ -408,3 +408,289 @@ int tn_conv_tile_dgrad(tn_ctx* ctx, const float* dz, const float* W, float* dx, 
     g.act = act; g.prm = prm;
     return ct_run(ctx, g, W, true);
 }
+
+// =================================================================================================
+// Weight gradient of a 3x3 'same' convolution (CorrMM_gradWeights of convpool.py:54-56) with both
+// operands resident in LDS:  dW[k][c][2-u][2-v] = sum_{n,i,j} dz[n,k,i,j] * x[n,c,i-1+u,j-1+v].
+//   * GEMM rows = 32 filters, columns = 32 input channels at a FIXED tap, reduction = pixels: one
+//     v_mfma_f32_32x32x2_f32 reduces two pixels, A = dz[filter][pixel], B = x[channel][pixel + tap].
+//     A wave owns one (filter tile, channel tile) pair and keeps all nine taps: 9 accumulators.
+//   * per step of 8 pixels a lane reads ONE 16-byte dz vector and, per tap row, 6 consecutive x
+//     values (4-byte + 16-byte + 4-byte, all aligned): 10 LDS reads feed 36 MFMAs, the nine taps
+//     are register selections of those 6 values.  Channel planes / dz rows are 4*odd floats apart:
+//     conflict-free 16-byte reads.
+//   * a block = 32*NFT filters x 32 channels x one slab of images, ONE wave per SIMD (LDS holds two
+//     128-pixel tiles of both operands); the 4/NFT waves that share a filter tile take alternate
+//     8-pixel steps and write separate slabs.  The next tile is copied global -> registers -> LDS
+//     two steps behind its loads, in between the MFMAs; one barrier per tile.
+// =================================================================================================
+#define CW_DZS 132
+
+struct ConvWG {
+    const float* x;        // (N, C, H, Wd)
+    const float* dz;       // (N, K, H, Wd)
+    float* ws;             // [S * PS][K*C*9] partial weight gradients, dW layout
+    float* dbws;           // [S][K] partial bias gradients
+    int N, C, H, Wd, K;
+    int KG, CG, S, ipb;    // filter groups, channel groups, image slabs, images per slab
+    int NI, TH, THi, RT, NT;
+    int RS, plane, q4, nx4, lgW, lgP;
+};
+
+// v where ok, +0 elsewhere -- as bit masks, so that the compiler cannot turn it into a branch
+__device__ __forceinline__ float4 cw_mask4(float4 v, bool ok) {
+    const int m = ok ? -1 : 0;
+    return make_float4(__int_as_float(__float_as_int(v.x) & m), __int_as_float(__float_as_int(v.y) & m),
+                       __int_as_float(__float_as_int(v.z) & m), __int_as_float(__float_as_int(v.w) & m));
+}
+__device__ __forceinline__ const float4* cw_f4(const float* p) {
+    return reinterpret_cast<const float4*>(__builtin_assume_aligned(p, 16));
+}
+
+template <int NFT>
+__global__ __launch_bounds__(256) void conv_tile_wgrad_kernel(ConvWG g) {
+    extern __shared__ __attribute__((aligned(16))) float ct_smem[];
+    constexpr int KBF = 32 * NFT, PS = 4 / NFT, SPW = 16 / PS;
+    constexpr int NDZ = NFT * 4, NSL = NDZ + 8, SPS = (NSL + SPW - 1) / SPW;
+    constexpr int DZSZ = KBF * CW_DZS;
+    const int XSZ = 32 * g.plane, BUFSZ = DZSZ + XSZ;
+    const int bid = blockIdx.x, per = g.KG * g.CG;
+    const int z = ((bid >> 3) / per) * 8 + (bid & 7), rem = (bid >> 3) % per;
+    if (z >= g.S) return;
+    const int kg = rem / g.CG, cg = rem - kg * g.CG;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, hi = lane >> 5;
+    const int ft = wave % NFT, ps = wave / NFT;
+    const int n_beg = z * g.ipb, n_end = min(g.N, n_beg + g.ipb);
+    const int HW = g.H * g.Wd, Wm = g.Wd - 1, THm = g.TH - 1;
+
+    for (int i = t * 4; i < 2 * BUFSZ; i += 1024) *reinterpret_cast<float4*>(ct_smem + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    float dbacc[NDZ];
+#pragma unroll
+    for (int s = 0; s < NDZ; ++s) dbacc[s] = 0.f;
+
+    // staging slot SL of the tile (first image n0, first row r0): issue the 16-byte load, keep the
+    // value and its LDS offset (-1: nothing to write) for the store a couple of steps later
+    float4 sv[NSL];
+    int so[NSL];
+#define CW_SLOAD(SL, N0, R0)                                                                     \
+    {                                                                                            \
+        if ((SL) < NDZ) {                                                                        \
+            const int e_ = t + 256 * (SL);                                                       \
+            const int q_ = e_ & 31, f_ = e_ >> 5, p_ = 4 * q_;                                   \
+            const int n_ = (N0) + (p_ >> g.lgP), row_ = (R0) + ((p_ >> g.lgW) & THm), k_ = kg * KBF + f_; \
+            const bool ok_ = n_ < n_end && k_ < g.K;                                             \
+            const int go_ = ((min(n_, g.N - 1) * g.K + min(k_, g.K - 1)) * g.H + row_) * g.Wd + (p_ & Wm); \
+            sv[SL] = cw_mask4(*reinterpret_cast<const float4*>(g.dz + go_), ok_);                \
+            so[SL] = f_ * CW_DZS + p_;                                                           \
+        } else {                                                                                 \
+            const int e_ = t + 256 * ((SL) - NDZ);                                               \
+            int rr_ = min(e_, g.nx4 - 1);                                                        \
+            const int q_ = rr_ % g.q4; rr_ /= g.q4;                                              \
+            const int r_ = rr_ % g.THi; rr_ /= g.THi;                                            \
+            const int ni_ = rr_ % g.NI, c_ = rr_ / g.NI;                                         \
+            const int n_ = (N0) + ni_, row_ = (R0) - 1 + r_, cc_ = cg * 32 + c_;                 \
+            const bool ok_ = n_ < n_end && (unsigned)row_ < (unsigned)g.H && cc_ < g.C;          \
+            const int go_ = ((min(n_, g.N - 1) * g.C + min(cc_, g.C - 1)) * g.H + min(max(row_, 0), g.H - 1)) * g.Wd + 4 * q_; \
+            sv[SL] = cw_mask4(*reinterpret_cast<const float4*>(g.x + go_), ok_);                 \
+            so[SL] = e_ < g.nx4 ? DZSZ + c_ * g.plane + (ni_ * g.THi + r_) * g.RS + 4 + 4 * q_ : -1; \
+        }                                                                                        \
+    }
+#define CW_SSTORE(SL, BUF)                                                                       \
+    {                                                                                            \
+        if (so[SL] >= 0)                                                                         \
+            *reinterpret_cast<float4*>(__builtin_assume_aligned(ct_smem + (BUF) * BUFSZ + so[SL], 16)) = sv[SL]; \
+        if ((SL) < NDZ) dbacc[(SL) < NDZ ? (SL) : 0] += dbw_ * ((sv[SL].x + sv[SL].y) + (sv[SL].z + sv[SL].w)); \
+    }
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int a = 0; a < 9; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+
+    // tile 0
+    float dbw_ = 1.f;
+#pragma unroll
+    for (int s = 0; s < NSL; ++s) CW_SLOAD(s, n_beg, 0);
+    __syncthreads();                 // the clearing is done
+#pragma unroll
+    for (int s = 0; s < NSL; ++s) CW_SSTORE(s, 0);
+    __syncthreads();
+
+    int gi = 0, rt = 0;              // tile = (image group, row tile) inside the slab
+    for (int tl = 0; tl < g.NT; ++tl) {
+        const int cur = tl & 1;
+        int rt1 = rt + 1, gi1 = gi;
+        if (rt1 == g.RT) { rt1 = 0; ++gi1; }
+        // the last tile re-stages itself into the idle buffer (keeps the loop body branch-free)
+        const bool hasnext = tl + 1 < g.NT;
+        if (!hasnext) { rt1 = rt; gi1 = gi; }
+        dbw_ = hasnext ? 1.f : 0.f;
+        const int n1 = n_beg + gi1 * g.NI, r1 = rt1 * g.TH;
+        const float* dzb = ct_smem + cur * BUFSZ + (ft * 32 + l31) * CW_DZS + 4 * hi;
+        const float* xb = ct_smem + cur * BUFSZ + DZSZ + l31 * g.plane + 3;
+        float4 av[2], xm[2][3];
+        float xl[2][3], xr[2][3];
+#define CW_OPS(SLOT, SG)                                                                         \
+        {                                                                                        \
+            const int p_ = 8 * (SG) + 4 * hi;                                                    \
+            av[SLOT] = *cw_f4(dzb + 8 * (SG));                                                   \
+            const float* xp_ = xb + ((p_ >> g.lgP) * g.THi + ((p_ >> g.lgW) & THm)) * g.RS + (p_ & Wm); \
+            _Pragma("unroll") for (int u = 0; u < 3; ++u) {                                      \
+                xl[SLOT][u] = xp_[u * g.RS];                                                     \
+                xm[SLOT][u] = *cw_f4(xp_ + u * g.RS + 1);                                        \
+                xr[SLOT][u] = xp_[u * g.RS + 5];                                                 \
+            }                                                                                    \
+        }
+        CW_OPS(0, ps);
+        __builtin_amdgcn_sched_group_barrier(0x100, 10, 0);
+#pragma unroll
+        for (int i = 0; i < SPW; ++i) {
+            const int c_ = i & 1, nx_ = c_ ^ 1;
+            if (i >= 2) {
+#pragma unroll
+                for (int s = (i - 2) * SPS; s < (i - 1) * SPS && s < NSL; ++s) CW_SSTORE(s, cur ^ 1);
+            }
+#pragma unroll
+            for (int s = i * SPS; s < (i + 1) * SPS && s < NSL; ++s) CW_SLOAD(s, n1, r1);
+            if (i + 1 < SPW) CW_OPS(nx_, ps + PS * (i + 1));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float a_ = j == 0 ? av[c_].x : j == 1 ? av[c_].y : j == 2 ? av[c_].z : av[c_].w;
+#pragma unroll
+                for (int u = 0; u < 3; ++u) {
+                    const float x6[6] = {xl[c_][u], xm[c_][u].x, xm[c_][u].y, xm[c_][u].z, xm[c_][u].w, xr[c_][u]};
+#pragma unroll
+                    for (int v = 0; v < 3; ++v)
+                        acc[u * 3 + v] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_, x6[j + v], acc[u * 3 + v], 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_sched_group_barrier(0x100, 10, 0);       // LDS operands of the next step
+            __builtin_amdgcn_sched_group_barrier(0x008, 36, 0);       // then this step's MFMAs
+        }
+#pragma unroll
+        for (int s = (SPW - 2) * SPS; s < NSL; ++s) CW_SSTORE(s, cur ^ 1);
+        __syncthreads();
+        rt = rt1; gi = gi1;
+    }
+#undef CW_OPS
+#undef CW_SLOAD
+#undef CW_SSTORE
+
+    // bias gradient partial of the slab: per-filter sums of the dz this block staged
+    if (cg == 0) {
+#pragma unroll
+        for (int s = 0; s < NDZ; ++s) {
+            float v = dbacc[s];
+            v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 4, 64);
+            v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 1, 64);
+            const int k = kg * KBF + (t >> 5) + 8 * s;
+            if (l31 == 0 && k < g.K) g.dbws[(size_t)z * g.K + k] = v;
+        }
+    }
+    // slab (z, ps): dW layout, tap (u,v) of the correlation is element (2-u, 2-v)
+    const int c = cg * 32 + l31;
+    if (c < g.C) {
+        float* wz = g.ws + (size_t)(z * PS + ps) * g.K * g.C * 9;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int k = kg * KBF + ft * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            if (k < g.K) {
+#pragma unroll
+                for (int a = 0; a < 9; ++a) wz[((size_t)k * g.C + c) * 9 + 8 - a] = acc[a][r];
+            }
+        }
+    }
+}
+
+static int cw_log2(int v) { int l = 0; while ((1 << l) < v) ++l; return (1 << l) == v ? l : -1; }
+
+static int cw_geometry(ConvWG& g, int num_cus) {
+    const int lgW = cw_log2(g.Wd);
+    if (lgW < 3 || lgW > 6) return 0;                  // rows of 8..64 pixels
+    int TH = 128 / g.Wd;
+    g.NI = 1;
+    if (TH > g.H) {
+        if (TH % g.H) return 0;
+        g.NI = TH / g.H;
+        TH = g.H;
+    } else if (g.H % TH) {
+        return 0;
+    }
+    if (cw_log2(TH) < 0) return 0;
+    g.TH = TH; g.THi = TH + 2; g.RT = g.H / TH;
+    g.lgW = lgW; g.lgP = cw_log2(TH * g.Wd);
+    g.RS = g.Wd + 8;
+    g.plane = g.NI * g.THi * g.RS;
+    if (((g.plane >> 2) & 1) == 0) g.plane += 4;       // 4 * odd: conflict-free 16-byte column reads
+    g.q4 = g.Wd / 4;
+    g.nx4 = 32 * g.NI * g.THi * g.q4;
+    if (g.nx4 > 8 * 256) return 0;
+    const int NFT = g.K > 32 ? 2 : 1;
+    g.KG = cdiv(g.K, 32 * NFT);
+    g.CG = cdiv(g.C, 32);
+    int S = num_cus / (g.KG * g.CG);
+    const int groups = cdiv(g.N, g.NI);
+    if (S > groups) S = groups;
+    if (S < 1) S = 1;
+    g.ipb = cdiv(groups, S) * g.NI;
+    g.S = cdiv(g.N, g.ipb);
+    g.NT = (g.ipb / g.NI) * g.RT;
+    return 1;
+}
+
+static size_t cw_lds_bytes(const ConvWG& g) {
+    const int NFT = g.K > 32 ? 2 : 1;
+    return (size_t)2 * (32 * NFT * CW_DZS + 32 * g.plane) * sizeof(float);
+}
+
+int tn_conv_tile_wgrad_ok(tn_ctx* ctx, const float* x, const float* dz, int N, int C, int H, int Wd, int K,
+                          int f, int pad, int Ho, int Wo) {
+    if (!ct_enabled() || f != 3 || pad != 1 || Ho != H || Wo != Wd) return 0;
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dz)) & 15) return 0;
+    if (const char* e = getenv("TN_CONV_TILE_WGRAD")) if (e[0] == '0') return 0;
+    ConvWG g{};
+    g.N = N; g.C = C; g.H = H; g.Wd = Wd; g.K = K;
+    if (!cw_geometry(g, ctx->num_cus)) return 0;
+    return cw_lds_bytes(g) <= 160 * 1024;
+}
+
+template <int NFT>
+static int cw_launch(tn_ctx* ctx, ConvWG& g) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        TN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_tile_wgrad_kernel<NFT>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    const int grid = 8 * cdiv(g.S, 8) * g.KG * g.CG;
+    conv_tile_wgrad_kernel<NFT><<<grid, 256, cw_lds_bytes(g), ctx->stream>>>(g);
+    TN_LAUNCH_CHECK();
+    return TN_OK;
+}
+
+int tn_red_push(tn_ctx* ctx, const float* src, float* out, uint32_t n, uint32_t S, uint32_t stride, uint32_t flip);
+int tn_red_commit(tn_ctx* ctx);
+
+int tn_conv_tile_wgrad(tn_ctx* ctx, const float* x, const float* dz, float* dW, float* db, int N, int C,
+                       int H, int Wd, int K) {
+    ConvWG g{};
+    g.x = x; g.dz = dz;
+    g.N = N; g.C = C; g.H = H; g.Wd = Wd; g.K = K;
+    TN_REQUIRE(cw_geometry(g, ctx->num_cus), "conv_tile_wgrad: unsupported shape");
+    TN_REQUIRE((long long)N * C * H * Wd < (1ll << 31) && (long long)N * K * H * Wd < (1ll << 31),
+               "conv_tile_wgrad: tensor too large for 32-bit offsets");
+    const int NFT = K > 32 ? 2 : 1, PS = 4 / NFT;
+    const size_t n = (size_t)K * C * 9;
+    int rc = tn_scratch_get(ctx, ((size_t)g.S * PS * n + (size_t)g.S * K) * sizeof(float), &g.ws);
+    if (rc) return rc;
+    g.dbws = g.ws + (size_t)g.S * PS * n;
+    rc = NFT == 2 ? cw_launch<2>(ctx, g) : cw_launch<1>(ctx, g);
+    if (rc) return rc;
+    rc = tn_red_push(ctx, g.ws, dW, (uint32_t)n, (uint32_t)(g.S * PS), (uint32_t)n, 0);
+    if (rc) return rc;
+    rc = tn_red_push(ctx, g.dbws, db, (uint32_t)K, (uint32_t)g.S, (uint32_t)K, 0);
+    if (rc) return rc;
+    return tn_red_commit(ctx);
+}
