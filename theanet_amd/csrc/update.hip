@@ -166,25 +166,36 @@ __global__ __launch_bounds__(256) void maxnorm_rows_kernel(float* __restrict__ p
     for (int i = threadIdx.x; i < rest; i += 256) row[i] *= sc;
 }
 
-// ndim 2 (rows x cols, row-major): per-COLUMN norm.  Block = 64 columns x 4 row-lanes.
-__global__ __launch_bounds__(256) void maxnorm_cols_kernel(float* __restrict__ p, int rows, int cols,
-                                                          float mx) {
+// ndim 2 (rows x cols, row-major): per-COLUMN norm, two passes over row slabs so that a tall matrix
+// (wide6's 16384 x 1024 FC weight) fills the chip: partial[slab][col] = sum of squares, then every
+// block adds the slabs of its 64 columns in slab order (deterministic) and rescales its rows.
+__global__ __launch_bounds__(256) void maxnorm_cols_partial(const float* __restrict__ p, int rows, int cols,
+                                                           int rchunk, float* __restrict__ partial) {
     __shared__ float red[4][64];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int r0 = threadIdx.x >> 6;
+    const int cl = threadIdx.x & 63, c = blockIdx.x * 64 + cl, r0 = threadIdx.x >> 6;
+    const int rb = blockIdx.y * rchunk, re = min(rows, rb + rchunk);
     float s = 0.f;
     if (c < cols)
-        for (int r = r0; r < rows; r += 4) {
+        for (int r = rb + r0; r < re; r += 4) {
             const float v = p[(size_t)r * cols + c];
             s += v * v;
         }
-    red[r0][threadIdx.x & 63] = s;
+    red[r0][cl] = s;
     __syncthreads();
-    const int cl = threadIdx.x & 63;
-    const float nrm = sqrtf(red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl]);
+    if (r0 == 0 && c < cols)
+        partial[(size_t)blockIdx.y * cols + c] = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+}
+
+__global__ __launch_bounds__(256) void maxnorm_cols_scale(float* __restrict__ p, int rows, int cols, int rchunk,
+                                                         const float* __restrict__ partial, int R, float mx) {
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), r0 = threadIdx.x >> 6;
+    if (c >= cols) return;
+    float s = 0.f;
+    for (int z = 0; z < R; ++z) s += partial[(size_t)z * cols + c];
+    const float nrm = sqrtf(s);
     const float sc = (1e-7f + fminf(fmaxf(nrm, 0.f), mx)) / (1e-7f + nrm);
-    if (c < cols)
-        for (int r = r0; r < rows; r += 4) p[(size_t)r * cols + c] *= sc;
+    const int rb = blockIdx.y * rchunk, re = min(rows, rb + rchunk);
+    for (int r = rb + r0; r < re; r += 4) p[(size_t)r * cols + c] *= sc;
 }
 
 extern "C" {
@@ -268,7 +279,18 @@ int tn_maxnorm(tn_ctx* ctx, float* p, int ndim, int d0, int rest, float maxnorm)
     if (ndim == 1) {
         clip_kernel<<<cdiv(d0, 256), 256, 0, ctx->stream>>>(p, (size_t)d0, maxnorm);
     } else if (ndim == 2) {
-        maxnorm_cols_kernel<<<cdiv(rest, 64), 256, 0, ctx->stream>>>(p, d0, rest, maxnorm);
+        const int ct = cdiv(rest, 64);
+        int R = cdiv(4 * ctx->num_cus, ct);
+        if (R > cdiv(d0, 16)) R = cdiv(d0, 16);
+        if (R < 1) R = 1;
+        const int rchunk = cdiv(d0, R);
+        R = cdiv(d0, rchunk);
+        float* partial;
+        int rc = tn_scratch_get(ctx, (size_t)R * rest * sizeof(float), &partial);
+        if (rc) return rc;
+        maxnorm_cols_partial<<<dim3(ct, R), 256, 0, ctx->stream>>>(p, d0, rest, rchunk, partial);
+        TN_LAUNCH_CHECK();
+        maxnorm_cols_scale<<<dim3(ct, R), 256, 0, ctx->stream>>>(p, d0, rest, rchunk, partial, R, maxnorm);
     } else if (ndim == 4) {
         maxnorm_rows_kernel<<<d0, 256, 0, ctx->stream>>>(p, rest, maxnorm);
     } else {
