@@ -880,6 +880,50 @@ int tn_fc_softmax_nll(tn_ctx* ctx, const float* x, const float* W, const float* 
                           inv_batch);
 }
 
+// ---- short-and-deep forward products (wide6's 128 x 16384 x 1024): too few output tiles to fill
+// the chip, so the reduction is split into S slabs (plain partial products) and a finishing kernel
+// adds the slabs in order and applies bias + activation (+ dropout mask).
+__global__ __launch_bounds__(256) void fc_fwd_finish_kernel(const float* __restrict__ ws, int S, size_t MN,
+                                                           int n_out, const float* __restrict__ bias,
+                                                           const uint8_t* __restrict__ mask,
+                                                           float* __restrict__ out, int act, float prm) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= MN) return;
+    float v = 0.f;
+    for (int z = 0; z < S; ++z) v += ws[(size_t)z * MN + i];
+    v = tn_act_fwd(v + bias[i % n_out], act, prm);
+    if (mask) v = mask[i] ? v : 0.f;
+    out[i] = v;
+}
+
+static int fc_fwd_splits(tn_ctx* ctx, int B, int n_in, int n_out) {
+    const long long tiles = (long long)cdiv(B, 64) * cdiv(n_out, 64);
+    if (tiles * 4 > ctx->num_cus || n_in < 64 * BK) return 1;
+    int S = (int)(2 * ctx->num_cus / tiles);
+    if (S > n_in / (8 * BK)) S = n_in / (8 * BK);
+    if (S >= 8) S &= ~7;
+    return S < 2 ? 1 : S;
+}
+
+// g: the forward GemmArgs (EPI_FWD); runs it as S partial products + the finishing kernel
+static int fc_fwd_splitk(tn_ctx* ctx, GemmArgs g, int S, const uint8_t* mask) {
+    const size_t MN = (size_t)g.M * g.N;
+    float* out = g.C;
+    g.kchunk = cdiv(cdiv(g.K, S), BK) * BK;
+    const int Sx = cdiv(g.K, g.kchunk);
+    float* ws;
+    int rc = tn_scratch_get(ctx, (size_t)Sx * MN * sizeof(float), &ws);
+    if (rc) return rc;
+    g.C = ws; g.epi = EPI_PLAIN; g.mask = nullptr; g.drop_out = nullptr;
+    const float* bias = g.bias;
+    g.bias = nullptr;
+    launch_gemm<true, false, false>(ctx, g, Sx);
+    TN_LAUNCH_CHECK();
+    fc_fwd_finish_kernel<<<cdiv(MN, 256), 256, 0, ctx->stream>>>(ws, Sx, MN, g.N, bias, mask, out, g.act, g.act_prm);
+    TN_LAUNCH_CHECK();
+    return TN_OK;
+}
+
 int tn_fc_fwd(tn_ctx* ctx, const float* x, const float* W, const float* b, float* a, int B, int n_in,
               int n_out, int act, float act_param, const uint8_t* mask) {
     TN_REQUIRE(B > 0 && n_in > 0 && n_out > 0, "tn_fc_fwd: bad shape");
@@ -899,6 +943,8 @@ int tn_fc_fwd(tn_ctx* ctx, const float* x, const float* W, const float* b, float
     g.kchunk = cdiv(n_in, BK) * BK;
     g.epi = EPI_FWD; g.bias = b; g.mask = mask; g.act = act; g.act_prm = act_param;
     g.a_vec = vec_ok(x, n_in); g.b_vec = vec_ok(W, n_out);
+    const int S = fc_fwd_splits(ctx, B, n_in, n_out);
+    if (S > 1) return fc_fwd_splitk(ctx, g, S, mask);
     launch_gemm<true, false, false>(ctx, g, 1);
     TN_LAUNCH_CHECK();
     return TN_OK;
@@ -917,7 +963,8 @@ int tn_fc_fwd_dropout(tn_ctx* ctx, const float* x, const float* W, const float* 
     g.a_vec = vec_ok(x, n_in); g.b_vec = vec_ok(W, n_out);
     g.drop_out = mask_out; g.pdrop = pdrop; g.dk0 = (uint32_t)seed; g.dk1 = (uint32_t)(seed >> 32);
     g.dstep = step; g.d_step = d_step; g.elem0 = elem0;
-    if (n_out > SK_MAX && gemm_fast_ok<true, false>(g) && gemm_cvec_ok(g)) {
+    if (n_out > SK_MAX && fc_fwd_splits(ctx, B, n_in, n_out) == 1 && gemm_fast_ok<true, false>(g) &&
+        gemm_cvec_ok(g)) {
         launch_gemm<true, false, false>(ctx, g, 1);      // mask drawn in the epilogue
         TN_LAUNCH_CHECK();
         return TN_OK;
