@@ -172,6 +172,41 @@ def main():
             except (OSError, KeyError, ValueError):
                 pass
 
+    else:
+        # conv nets on the matrix-core path (cifar_like, wide6): the three conv products of every
+        # unfused conv layer, each as the sum over its launches in a step -> "fraction of the conv
+        # roofline" (conv-layer FLOPs / conv-kernel time / MFMA fp32 peak)
+        from theanet_amd.layer import ConvLayer
+        convs = [l for l in net.tr_layers if isinstance(l, ConvLayer) and l.fused_pool is None]
+        first_param = next(l for l in net.tr_layers if getattr(l, "params", None))
+        fl_of = lambda l: 2 * l.batch_sz * l.out_sz ** 2 * l.num_maps * l.num_prev_maps * l.filter_sz ** 2
+        fl_all = sum(fl_of(l) for l in convs)
+        fl_dgrad = sum(fl_of(l) for l in convs if l is not first_param)
+        for op, label, fl in (("tn_conv2d_fwd", "conv forward (all unfused conv layers)", fl_all),
+                              ("tn_conv2d_wgrad", "conv weight gradient (all unfused conv layers)", fl_all),
+                              ("tn_conv2d_dgrad", "conv input gradient (all unfused conv layers)", fl_dgrad)):
+            if not convs or not fl:
+                continue
+            nsteps = min(args.steps, 10)
+            ctx.time_calls(op, 0)
+            for i in range(nsteps):
+                ctx.new_step()
+                fn.enqueue(i % n_batches)
+            ctx.sync()
+            times = ctx.collect_times_ms()
+            if not times:
+                continue
+            ms = float(np.sum(times)) / nsteps          # time in this op per step
+            ach = fl / (ms * 1e-3) / 1e12
+            others.append({"kernel": label, "bound": "mfma", "achieved": ach,
+                           "peak": roofline.MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                           "frac": ach / roofline.MFMA_F32_PEAK_TFLOPS, "traffic": None,
+                           "ms_per_step": ms, "launches_per_step": len(times) // nsteps,
+                           "flops_per_step": fl})
+        if others:
+            others.sort(key=lambda r: -r["ms_per_step"])
+            roof, others = others[0], others[1:]
+
     if world.rank != 0:
         return
     value = tr["BATCH_SZ"] * args.steps / dt

@@ -40,7 +40,7 @@ class Context:
         hook = self.ev_hook
         if hook is not None and hook[0] == name:
             self._ev_seen += 1
-            if self._ev_seen == hook[1]:
+            if self._ev_seen == hook[1] or hook[1] == 0:         # nth 0: every call
                 return self._timed_call(name, args)
         rc = getattr(self.lib, name)(self.h, *args)
         if rc != 0:
