@@ -295,6 +295,44 @@ def test_dp_overlap_schedule_equals_plain(monkeypatch):
                 np.testing.assert_array_equal(wa, wb)
 
 
+def test_dp_schedule_autotune(monkeypatch):
+    """TN_DP_OVERLAP=auto (the default with more than one rank), exercised with a 1-rank RCCL
+    communicator: a few steps of each schedule are timed, the ranks agree on one through an
+    all-reduce(max), and training is unaffected (both schedules are pure re-orderings)."""
+    from theanet_amd import NeuralNet
+    import copy
+    prms = load_prms("mnist.prms", 28, batch=64)
+    rng = np.random.RandomState(6)
+    x = rng.rand(4 * 64, 1, 28, 28).astype(np.float32)
+    y = rng.randint(0, 10, 4 * 64).astype(np.int32)
+    nets = []
+    nsteps = 2 * NeuralNet._DP_TUNE_WARM + 2 * NeuralNet._DP_TUNE_STEPS + 4
+    for overlap in ("auto", "0"):
+        monkeypatch.setenv("TN_DP_FORCE", "1")
+        monkeypatch.setenv("TN_DP_OVERLAP", overlap)
+        net = NeuralNet(copy.deepcopy(prms["layers"]), dict(prms["training_params"]))
+        fn = net.get_trin_model(x, y)
+        if overlap == "auto":
+            assert net._dp_tune is not None and net._dp_split is None
+        for s in range(nsteps):
+            fn.enqueue(s % 4)
+            if overlap == "auto" and s == NeuralNet._DP_TUNE_WARM + NeuralNet._DP_TUNE_STEPS:
+                assert net._dp_split is not None          # second leg: overlapped schedule
+        outs = fn.fetch()
+        if overlap == "auto":
+            assert net._dp_tune is None and net.dp_schedule in ("plain", "overlap")
+            assert (net._dp_split is not None) == (net.dp_schedule == "overlap")
+            plain_ms, overlap_ms = net.dp_tuned_ms
+            assert 0 < plain_ms < 5 and 0 < overlap_ms < 5
+        nets.append((net, outs))
+        net.ctx.call("tn_comm_destroy")
+        net._dev_group = None
+    np.testing.assert_array_equal(nets[0][1][1], nets[1][1][1])
+    for la, lb in zip(nets[0][0].tr_layers, nets[1][0].tr_layers):
+        for wa, wb in zip(la.get_wts(), lb.get_wts()):
+            np.testing.assert_array_equal(wa, wb)
+
+
 def test_train_py_end_to_end(tmp_path):
     """The harness runs, prints the reference's table, learns, and writes a loadable pickle."""
     import subprocess

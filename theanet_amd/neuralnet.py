@@ -12,6 +12,7 @@ rank r works on rows [i*B + r*B/R, i*B + (r+1)*B/R) of minibatch i and the flat
 gradient buffer (+ the scalar cost) is sum-all-reduced once per step over RCCL.
 """
 import os
+import sys
 from functools import reduce
 from operator import mul
 
@@ -421,16 +422,76 @@ class NeuralNet():
         # 18 us per step, about what a 1.5 MB all-reduce costs in the first place; the remaining
         # small all-reduce is latency-bound either way.
         self._dp_split, self._dp_off = None, 0
-        if self._dp and os.environ.get("TN_DP_OVERLAP", "0") == "1":
+        self._dp_cand, self._dp_tune, self.dp_schedule = None, None, "plain"
+        if self._dp:
             j = len(self.tr_layers)
             while j > 0 and isinstance(self.tr_layers[j - 1], HiddenLayer):
                 j -= 1
             top = [l for l in self.tr_layers[j:] if l.params]
             if 0 < j < len(self.tr_layers) and top and any(l.has_updates() for l in self.tr_layers[:j]):
-                first_p = top[0].grads[0]
-                self._dp_split = j
-                self._dp_off = (first_p.ptr - self.flat_grads.ptr) // 4
+                self._dp_cand = (j, (top[0].grads[0].ptr - self.flat_grads.ptr) // 4)
+            # Which schedule is faster depends on what the all-reduce costs on this node (RCCL latency
+            # over xGMI vs. the 18 us of extra launches and stream joins): with more than one rank it is
+            # MEASURED -- TN_DP_OVERLAP=auto times a few steps of each schedule on the first calls,
+            # the ranks agree on the result through an all-reduce(max) and keep the faster one.
+            mode = os.environ.get("TN_DP_OVERLAP", "auto" if self.world.size > 1 else "0")
+            if self._dp_cand and mode == "1":
+                self._dp_split, self._dp_off = self._dp_cand
+                self.dp_schedule = "overlap"
+            elif self._dp_cand and mode == "auto":
+                self._dp_tune = {"k": 0, "ev": {}}
         self._grads_ready = True
+
+    _DP_TUNE_WARM, _DP_TUNE_STEPS = 8, 24
+
+    def _dp_tune_tick(self):
+        """TN_DP_OVERLAP=auto: steps [W, W+M) run the plain schedule under a pair of HIP events, steps
+        [2W+M, 2W+2M) the overlapped one; then every rank takes the max over ranks of both times and
+        keeps the faster schedule.  All ranks switch at the same step index (the schedules issue
+        different collectives).  The steps are ordinary training steps: nothing is thrown away."""
+        import ctypes
+        ctx, T = self.ctx, self._dp_tune
+        W, M = self._DP_TUNE_WARM, self._DP_TUNE_STEPS
+        k = T["k"]
+        T["k"] = k + 1
+
+        def mark(name):
+            e = ctypes.c_void_p()
+            ctx.call("tn_event_create", ctypes.byref(e))
+            ctx.call("tn_event_record", e)
+            T["ev"][name] = e
+
+        if k == W:
+            mark("a0")
+        elif k == W + M:
+            mark("a1")
+            self._dp_split, self._dp_off = self._dp_cand
+        elif k == 2 * W + M:
+            mark("b0")
+        elif k == 2 * W + 2 * M:
+            mark("b1")
+            ctx.sync()
+            ms = []
+            for a, b in (("a0", "a1"), ("b0", "b1")):
+                v = ctypes.c_float()
+                ctx.call("tn_event_elapsed_ms", T["ev"][a], T["ev"][b], ctypes.byref(v))
+                ms.append(v.value)
+            for e in T["ev"].values():
+                ctx.lib.tn_event_destroy(ctx.h, e)
+            t = ctx.array(np.asarray(ms, np.float32))
+            self._group().allreduce_max(t)
+            plain, overlap = (float(v) for v in t.get_value())
+            self.dp_tuned_ms = (plain / M, overlap / M)
+            if overlap < plain:
+                self.dp_schedule = "overlap"
+            else:
+                self.dp_schedule = "plain"
+                self._dp_split, self._dp_off = None, 0
+            self._dp_tune = None
+            if self.world.rank == 0:
+                sys.stderr.write("theanet_amd: data-parallel schedule '%s' (plain %.1f us/step, overlapped "
+                                 "all-reduce %.1f us/step)\n" % (self.dp_schedule, 1e3 * plain / M,
+                                                                 1e3 * overlap / M))
 
     def _train_step(self, y, y_row0, d_row0=None):
         """forward + backward + all-reduce + update for the minibatch the input slot
@@ -438,6 +499,8 @@ class NeuralNet():
         ctx = self.ctx
         out = self.tr_layers[-1]
         first = self.tr_layers[0]
+        if self._dp_tune is not None and not self.use_graph:
+            self._dp_tune_tick()
         if isinstance(first, ElasticLayer):
             first.precompute = self.side_stream and not self.use_graph and self.elastic_ahead
         # Random inputs that depend only on the step counter are produced on the side stream,
