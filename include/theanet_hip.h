@@ -150,6 +150,21 @@ int tn_convblock_supported(int C, int K, int f, int stride, int p, int Ho, int W
 int tn_convblock_bwd(tn_ctx* ctx, const float* x, const float* W, const float* b, const float* g,
                      float* dx, float* dW, float* db, int N, int C, int H, int Wd, int K, int f,
                      int pad_lo, int Ho, int Wo, int p, int Hp, int Wp, int act, float act_param);
+/* Wide conv + act + 2x2 max-pool blocks (3x3 'same', C*9 >= 32, K >= 16, even maps, rows % 4 == 0)
+ * on the LDS-tile matrix-core kernels: tn_convpool_fwd_mask pools in the conv kernel's epilogue (the
+ * conv activation never reaches HBM) and tn_convpool_bwd_mask_dx forms dz = mask bit ? g*act'(y) : 0
+ * while it stages the operands of the weight- and input-gradient products -- MaxPoolGrad, the
+ * activation gradient, CorrMM_gradWeights and CorrMM_gradInputs (convpool.py:54-72,106 under
+ * theano.grad, layer.py:83) without dz ever existing.  prev_a / prev_act: output and activation of
+ * the layer below, whose gradient is applied to dx in the epilogue (NULL: none); dx NULL: weight
+ * gradients only.                                                                               */
+int tn_convpool_tile_supported(int N, int C, int H, int Wd, int K, int f, int stride, int pad_lo, int Ho,
+                               int Wo, int p, int Hp, int Wp);
+int tn_convpool_bwd_mask_dx(tn_ctx* ctx, const float* x, const float* W, const float* g, const float* y,
+                            const uint8_t* mask, float* dx, float* dW, float* db, int N, int C, int H,
+                            int Wd, int K, int f, int pad_lo, int Ho, int Wo, int p, int Hp, int Wp, int act,
+                            float act_param, const float* prev_a, int prev_act, float prev_act_param);
+
 /* The same backward driven by the forward's record instead of a conv recompute: y and mask are
  * tn_convpool_fwd_mask's outputs, so dz = mask bit ? g * act'(y) : 0.  One wave per image on
  * the fp32 matrix cores (wgrad and dgrad products), dz lives in LDS only.  dx may be NULL;

@@ -228,6 +228,68 @@ def test_convblock_mask_backward(case):
 
 
 @pytest.mark.parametrize("case", [
+    (3, 16, 16, 32, "relu10"),          # whole 16x16 images per block, 32 filters (one filter tile)
+    (2, 32, 32, 64, "tanh"),            # 8-row tiles; activation gradient from the pooled output
+    (5, 64, 8, 96, "relu05"),           # 8x8 maps: 4 images per forward tile, 2 per wgrad tile; ragged K
+    (2, 20, 64, 40, "relu10"),          # 64-wide rows, ragged channel / filter counts
+])
+def test_convpool_tile_block(case):
+    """Wide conv + act + 2x2 max-pool block on the LDS-tile matrix-core kernels: the forward pools in
+    its epilogue (tn_convpool_fwd_mask), the backward forms dz from the pooling mask while staging
+    (tn_convpool_bwd_mask_dx), with the activation gradient of the layer below on dx."""
+    N, C, H, K, act = case
+    Hp = H // 2
+    geom_i = (N, C, H, H, K, 3, 1, 1, H, H, 2, Hp, Hp)
+    assert ctx().lib.tn_convpool_tile_supported(*geom_i)
+    rng = np.random.RandomState(N * 13 + K)
+    x = rng.randn(N, C, H, H).astype(np.float32)
+    W = (rng.randn(K, C, 3, 3) / np.sqrt(C * 9)).astype(np.float32)
+    b = rng.randn(K).astype(np.float32)
+    fa, dfa = O.activation(act)
+    x64, W64, b64 = x.astype(np.float64), W.astype(np.float64), b.astype(np.float64)
+    z = O.conv2d_fwd(x64, W64, b64, 1, "same")
+    a = fa(z)
+    want_y = O.pool_fwd(a, 2, False)
+    g = rng.randn(N, K, Hp, Hp).astype(np.float32)
+    dz_w = O.pool_bwd(a, g.astype(np.float64), 2, False) * dfa(z)
+    dx_w, dW_w, db_w = O.conv2d_bwd(x64, W64, dz_w, 1, "same")
+    kind, prm = act_code(act)
+    xd, Wd, bd, gd = dev(x), dev(W), dev(b), dev(g)
+    y, mask = empty((N, K, Hp, Hp)), empty((N, K, Hp, Hp), np.uint8)
+    geom = (N, C, H, H, K, 3, 1, H, H, 2, Hp, Hp, kind, prm)
+    call("tn_convpool_fwd_mask", xd.ptr, Wd.ptr, bd.ptr, y.ptr, mask.ptr, *geom)
+    assert_close(y.get_value(), want_y, what="tile convpool fwd %s" % (case,))
+    m = mask.get_value()
+    for r in range(4):
+        sub = a[:, :, (r >> 1)::2, (r & 1)::2]
+        bit = (m >> r) & 1
+        clear = np.abs(sub - want_y) > 1e-5
+        assert np.all(bit[clear] == 0), "mask bit %d set off the maximum" % r
+    assert np.all((m & 15) > 0) and np.all(m < 64)
+    # without a mask (test graphs) the pooled output is the same
+    y2 = empty((N, K, Hp, Hp))
+    call("tn_convpool_fwd_mask", xd.ptr, Wd.ptr, bd.ptr, y2.ptr, None, *geom)
+    np.testing.assert_array_equal(y2.get_value(), y.get_value())
+    dx, dW, db = empty(x.shape), empty(W.shape), empty((K,))
+    call("tn_convpool_bwd_mask_dx", xd.ptr, Wd.ptr, gd.ptr, y.ptr, mask.ptr, dx.ptr, dW.ptr, db.ptr, *geom,
+         None, 0, 0.0)
+    tolW = max(2e-4, 2e-6 * np.abs(dW_w).max())
+    assert_close(dx.get_value(), dx_w, atol=1e-4, what="tile block dx %s" % (case,))
+    assert_close(dW.get_value(), dW_w, atol=tolW, what="tile block dW %s" % (case,))
+    assert_close(db.get_value(), db_w, atol=max(2e-4, 2e-6 * np.abs(db_w).max()), what="tile block db %s" % (case,))
+    # activation gradient of the layer below in the epilogue; weight gradients only
+    prev_a = rng.randn(*x.shape).astype(np.float32)
+    pk, pp = act_code("relu10")
+    call("tn_convpool_bwd_mask_dx", xd.ptr, Wd.ptr, gd.ptr, y.ptr, mask.ptr, dx.ptr, None, None, *geom,
+         dev(prev_a).ptr, pk, pp)
+    assert_close(dx.get_value(), dx_w * np.where(prev_a > 0, 1.0, .1), atol=1e-4, what="tile block dx*act' %s" % (case,))
+    dW.fill_bytes(0)
+    call("tn_convpool_bwd_mask_dx", xd.ptr, Wd.ptr, gd.ptr, y.ptr, mask.ptr, None, dW.ptr, db.ptr, *geom,
+         None, 0, 0.0)
+    assert_close(dW.get_value(), dW_w, atol=tolW, what="tile block dW (no dx) %s" % (case,))
+
+
+@pytest.mark.parametrize("case", [
     (7, 1, 28, 4, "valid", "relu10", False),        # mnist.prms conv1
     (3, 1, 15, 5, "valid", "relu05", True),         # ignore_border: last row/col in no window
     (4, 3, 16, 6, "same", "tanh", False),

@@ -99,6 +99,9 @@ SIGNATURES = {
     "tn_convpool_fwd_mask": (c_int, [CTX, P, P, P, P, P] + [c_int] * 12 + [c_int, c_float]),
     "tn_convpool_bwd_mask": (c_int, [CTX, P, P, P, P, P, P, P] + [c_int] * 12 + [c_int, c_float]),
     "tn_convblock_mask_supported": (c_int, [c_int] * 12),
+    "tn_convpool_tile_supported": (c_int, [c_int] * 13),
+    "tn_convpool_bwd_mask_dx": (c_int, [CTX, P, P, P, P, P, P, P, P] + [c_int] * 12 + [c_int, c_float,
+                                                                                     P, c_int, c_float]),
     "tn_convblock_bwd_mask": (c_int, [CTX, P, P, P, P, P, P, P, P] + [c_int] * 12 + [c_int, c_float]),
     "tn_convblock_supported": (c_int, [c_int] * 7),
     "tn_convblock_bwd": (c_int, [CTX, P, P, P, P, P, P, P] + [c_int] * 12 + [c_int, c_float]),

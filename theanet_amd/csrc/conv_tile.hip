@@ -20,6 +20,40 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define CT_CH 8           // input channels per chunk
 #define CT_SX 4           // 16-byte staging slots per thread for the input tile
 
+// dz of a conv + act + 2x2 max-pool block, formed on the fly from what the fused forward left behind:
+// the pooled gradient g, the pooling mask (bit 2*di+dj: that window element attained the maximum,
+// bits 4 / 5: pooled value > 0 / < 0) and, for activations other than leaky-ReLU, the pooled output y.
+struct PoolSrc {
+    const float* g;
+    const float* y;
+    const uint8_t* mask;
+    int Hp, Wp, act;
+    float prm;
+};
+// dz[plane][row][col4 .. col4+3] (col4 % 4 == 0, pooled width even: the two window columns are one
+// 8-byte g load and one 2-byte mask load)
+__device__ __forceinline__ float4 pool_expand4(const PoolSrc& s, int plane, int row, int col4) {
+    const int idx = (plane * s.Hp + (row >> 1)) * s.Wp + (col4 >> 1);
+    const float2 g2 = *reinterpret_cast<const float2*>(s.g + idx);
+    const unsigned m2 = *reinterpret_cast<const unsigned short*>(s.mask + idx);
+    const unsigned m0 = m2 & 0xffu, m1 = m2 >> 8;
+    float ga0, ga1;
+    if (s.act == TN_ACT_LEAKY) {
+        const float tie = 1.f + s.prm;
+        float p0 = (m0 & 32u) ? s.prm : tie, p1 = (m1 & 32u) ? s.prm : tie;
+        p0 = (m0 & 16u) ? 1.f : p0;
+        p1 = (m1 & 16u) ? 1.f : p1;
+        ga0 = g2.x * p0; ga1 = g2.y * p1;
+    } else {
+        const float2 y2 = *reinterpret_cast<const float2*>(s.y + idx);
+        ga0 = g2.x * tn_act_grad_from_out(y2.x, s.act, s.prm);
+        ga1 = g2.y * tn_act_grad_from_out(y2.y, s.act, s.prm);
+    }
+    const int sh = (row & 1) * 2;
+    return make_float4((m0 >> sh) & 1u ? ga0 : 0.f, (m0 >> (sh + 1)) & 1u ? ga0 : 0.f,
+                       (m1 >> sh) & 1u ? ga1 : 0.f, (m1 >> (sh + 1)) & 1u ? ga1 : 0.f);
+}
+
 struct ConvTG {
     const float* x;       // gathered tensor (N, C, H, Wd)
     const float* wt;      // arranged weights [KT][nchunk][4][9][2][32*FT]
@@ -29,6 +63,8 @@ struct ConvTG {
     int N, C, H, Wd, K, pad, Ho, Wo, act;
     float prm;
     int KT, MT, RT, NI, TH, THi, RS, LP, plane, nchunk, TP, q4, nx4, vec_out;
+    PoolSrc ps;                // POOL dgrad: the gathered tensor is formed from (g, mask, y)
+    uint8_t* mask_out;         // POOL forward: pooling mask (may be NULL)
     unsigned long long* dbg;   // TN_CT_DBG=1: per block {start, prologue done, loop done, end} (s_memtime) + wall clock
 };
 
@@ -53,7 +89,7 @@ __global__ __launch_bounds__(256) void conv_tile_wt_kernel(const float* __restri
     wt[idx] = v;
 }
 
-struct CtSlot { int g, l, c; bool ok; };
+struct CtSlot { int g, l, c, n, row, col; bool ok; };
 // input staging slot s of thread t: (channel-in-chunk, image, tile row, 16-byte column group)
 __device__ __forceinline__ CtSlot ct_slot(const ConvTG& g, int t, int s, int n0, int r0) {
     CtSlot o;
@@ -66,12 +102,15 @@ __device__ __forceinline__ CtSlot ct_slot(const ConvTG& g, int t, int s, int n0,
     o.c = rr / g.NI;
     const int in_row = r0 - g.pad + r, n = n0 + ni;
     o.ok = ok && (unsigned)in_row < (unsigned)g.H && n < g.N;
-    o.g = (min(n, g.N - 1) * g.C * g.H + min(max(in_row, 0), g.H - 1)) * g.Wd + 4 * q;
+    o.n = min(n, g.N - 1); o.row = min(max(in_row, 0), g.H - 1); o.col = 4 * q;
+    o.g = (o.n * g.C * g.H + o.row) * g.Wd + 4 * q;
     o.l = o.c * g.plane + (ni * g.THi + r) * g.RS + g.pad + g.LP + 4 * q;
     return o;
 }
 
-template <int FT, bool DGRAD>
+// POOL: forward -> bias + act + 2x2 max-pool + pooling mask in the epilogue (the conv activation never
+// reaches HBM); dgrad -> the gathered tensor dz is expanded from the pooled gradient while it is staged.
+template <int FT, bool DGRAD, bool POOL>
 __global__ __launch_bounds__(256) void conv_tile_kernel(ConvTG g) {
     extern __shared__ __attribute__((aligned(16))) float ct_smem[];
     constexpr int KBF = 32 * FT;
@@ -120,7 +159,12 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(ConvTG g) {
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
     float4 xr0, xr1, xr2, xr3, wr0, wr1, wr2, wr3, wr4;
-#define CT_XL(S, R) R = *reinterpret_cast<const float4*>(g.x + S.g + min(ch_ * CT_CH + S.c, g.C - 1) * HW)
+#define CT_XL(S, R)                                                                              \
+    {                                                                                            \
+        const int cc_ = min(ch_ * CT_CH + S.c, g.C - 1);                                         \
+        if (DGRAD && POOL) R = pool_expand4(g.ps, S.n * g.C + cc_, S.row, S.col);                \
+        else R = *reinterpret_cast<const float4*>(g.x + S.g + cc_ * HW);                         \
+    }
 #define CT_GLOAD(CHUNK)                                                                          \
     {                                                                                            \
         const int ch_ = min((CHUNK), g.nchunk - 1);                                              \
@@ -202,7 +246,45 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(ConvTG g) {
     if (dbg) dbg[2] = __builtin_readcyclecounter();
 
     const int HoWo = g.Ho * g.Wo;
-    if (g.vec_out) {
+    if (!DGRAD && POOL) {
+        // ---- pooled epilogue: tile -> LDS [filter][pixel]; lane = one pooled pixel, wave = one filter
+        float* Os = ct_smem;
+#pragma unroll
+        for (int f = 0; f < FT; ++f)
+#pragma unroll
+            for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    Os[(f * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi) * 256 + wave * 64 + pt * 32 + l31] = acc[f][pt][r];
+        __syncthreads();
+        const int Wp = g.Wo >> 1, Hp = g.Ho >> 1, THp = g.TH >> 1, perp = THp * Wp;
+        const int pp = lane < (g.TP >> 2) ? lane : 0;
+        const int ni = pp / perp, rem = pp - ni * perp;
+        const int pr = rem / Wp, pc = rem - pr * Wp;
+        const int p00 = ni * g.TH * g.Wo + 2 * pr * g.Wo + 2 * pc;
+        const bool ok = lane < (g.TP >> 2) && n0 + ni < g.N && r0 + 2 * pr < g.Ho;
+        const size_t obase = ((size_t)(n0 + ni) * g.K * Hp + (r0 >> 1) + pr) * Wp + pc;
+        if (ok) {
+#pragma unroll 2
+            for (int i = 0; i < KBF / 4; ++i) {
+                const int kl = wave + 4 * i, k = kt * KBF + kl;
+                if (k >= g.K) break;
+                const float2 t0 = *reinterpret_cast<const float2*>(Os + kl * 256 + p00);
+                const float2 t1 = *reinterpret_cast<const float2*>(Os + kl * 256 + p00 + g.Wo);
+                const float bk = g.bias[k];
+                const float a00 = tn_act_fwd(t0.x + bk, g.act, g.prm), a01 = tn_act_fwd(t0.y + bk, g.act, g.prm);
+                const float a10 = tn_act_fwd(t1.x + bk, g.act, g.prm), a11 = tn_act_fwd(t1.y + bk, g.act, g.prm);
+                const float m = fmaxf(fmaxf(a00, a01), fmaxf(a10, a11));
+                const size_t o = obase + (size_t)k * Hp * Wp;
+                g.out[o] = m;
+                if (g.mask_out) {
+                    unsigned bits = (a00 == m ? 1u : 0u) | (a01 == m ? 2u : 0u) | (a10 == m ? 4u : 0u) | (a11 == m ? 8u : 0u);
+                    bits |= (m > 0.f ? 16u : 0u) | (m < 0.f ? 32u : 0u);
+                    g.mask_out[o] = (uint8_t)bits;
+                }
+            }
+        }
+    } else if (g.vec_out) {
         // ---- epilogue through LDS: the block's (32*FT filters) x (256 pixels) tile is laid out
         // [filter][pixel]; a wave then owns whole filter rows: one 16-byte access per lane, 1 KB bursts
         float* Os = ct_smem;
@@ -350,13 +432,13 @@ extern "C" int tn_conv_tile_dbg_read(tn_ctx* ctx, unsigned long long* host, int 
     return hipMemcpy(host, ct_dbg_buf, (size_t)nblocks * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
 }
 
-template <int FT, bool DGRAD>
+template <int FT, bool DGRAD, bool POOL>
 static int ct_launch(tn_ctx* ctx, ConvTG& g) {
     static bool attr_set = false;
     size_t lds = ct_lds_bytes(g, FT);
     if (const char* e = getenv("TN_CT_LDS")) lds = (size_t)atoi(e) > lds ? (size_t)atoi(e) : lds;
     if (!attr_set) {
-        TN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_tile_kernel<FT, DGRAD>),
+        TN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_tile_kernel<FT, DGRAD, POOL>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
@@ -367,12 +449,12 @@ static int ct_launch(tn_ctx* ctx, ConvTG& g) {
         ct_dbg_buf = dbgbuf;
         g.dbg = grid <= 65536 ? dbgbuf : nullptr;
     }
-    conv_tile_kernel<FT, DGRAD><<<grid, 256, lds, ctx->stream>>>(g);
+    conv_tile_kernel<FT, DGRAD, POOL><<<grid, 256, lds, ctx->stream>>>(g);
     TN_LAUNCH_CHECK();
     return TN_OK;
 }
 
-static int ct_run(tn_ctx* ctx, ConvTG& g, const float* W, bool dgrad) {
+static int ct_run(tn_ctx* ctx, ConvTG& g, const float* W, bool dgrad, bool pool = false) {
     const int FT = ct_pick_ft(g.K);
     TN_REQUIRE(ct_geometry(g, FT), "conv_tile: unsupported shape");
     TN_REQUIRE((long long)g.N * g.C * g.H * g.Wd < (1ll << 31) && (long long)g.N * g.K * g.Ho * g.Wo < (1ll << 31),
@@ -386,8 +468,12 @@ static int ct_run(tn_ctx* ctx, ConvTG& g, const float* W, bool dgrad) {
     TN_LAUNCH_CHECK();
     g.wt = wt;
     g.vec_out = (g.Wo % 4 == 0) && ((reinterpret_cast<uintptr_t>(g.out) | reinterpret_cast<uintptr_t>(g.prev_a)) & 15) == 0;
-    if (dgrad) return FT == 2 ? ct_launch<2, true>(ctx, g) : ct_launch<1, true>(ctx, g);
-    return FT == 2 ? ct_launch<2, false>(ctx, g) : ct_launch<1, false>(ctx, g);
+    if (pool) {
+        if (dgrad) return FT == 2 ? ct_launch<2, true, true>(ctx, g) : ct_launch<1, true, true>(ctx, g);
+        return FT == 2 ? ct_launch<2, false, true>(ctx, g) : ct_launch<1, false, true>(ctx, g);
+    }
+    if (dgrad) return FT == 2 ? ct_launch<2, true, false>(ctx, g) : ct_launch<1, true, false>(ctx, g);
+    return FT == 2 ? ct_launch<2, false, false>(ctx, g) : ct_launch<1, false, false>(ctx, g);
 }
 
 int tn_conv_tile_fwd(tn_ctx* ctx, const float* x, const float* W, const float* b, float* a, int N, int C,
@@ -435,6 +521,7 @@ struct ConvWG {
     int KG, CG, S, ipb;    // filter groups, channel groups, image slabs, images per slab
     int NI, TH, THi, RT, NT;
     int RS, plane, q4, nx4, lgW, lgP;
+    PoolSrc ps;            // POOL: dz is formed from (g, mask, y) while it is staged
 };
 
 // v where ok, +0 elsewhere -- as bit masks, so that the compiler cannot turn it into a branch
@@ -447,7 +534,7 @@ __device__ __forceinline__ const float4* cw_f4(const float* p) {
     return reinterpret_cast<const float4*>(__builtin_assume_aligned(p, 16));
 }
 
-template <int NFT>
+template <int NFT, bool POOL>
 __global__ __launch_bounds__(256) void conv_tile_wgrad_kernel(ConvWG g) {
     extern __shared__ __attribute__((aligned(16))) float ct_smem[];
     constexpr int KBF = 32 * NFT, PS = 4 / NFT, SPW = 16 / PS;
@@ -481,7 +568,10 @@ __global__ __launch_bounds__(256) void conv_tile_wgrad_kernel(ConvWG g) {
             const int n_ = (N0) + (p_ >> g.lgP), row_ = (R0) + ((p_ >> g.lgW) & THm), k_ = kg * KBF + f_; \
             const bool ok_ = n_ < n_end && k_ < g.K;                                             \
             const int go_ = ((min(n_, g.N - 1) * g.K + min(k_, g.K - 1)) * g.H + row_) * g.Wd + (p_ & Wm); \
-            sv[SL] = cw_mask4(*reinterpret_cast<const float4*>(g.dz + go_), ok_);                \
+            if (POOL)                                                                            \
+                sv[SL] = cw_mask4(pool_expand4(g.ps, min(n_, g.N - 1) * g.K + min(k_, g.K - 1), row_, p_ & Wm), ok_); \
+            else                                                                                 \
+                sv[SL] = cw_mask4(*reinterpret_cast<const float4*>(g.dz + go_), ok_);            \
             so[SL] = f_ * CW_DZS + p_;                                                           \
         } else {                                                                                 \
             const int e_ = t + 256 * ((SL) - NDZ);                                               \
@@ -656,16 +746,16 @@ int tn_conv_tile_wgrad_ok(tn_ctx* ctx, const float* x, const float* dz, int N, i
     return cw_lds_bytes(g) <= 160 * 1024;
 }
 
-template <int NFT>
+template <int NFT, bool POOL>
 static int cw_launch(tn_ctx* ctx, ConvWG& g) {
     static bool attr_set = false;
     if (!attr_set) {
-        TN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_tile_wgrad_kernel<NFT>),
+        TN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_tile_wgrad_kernel<NFT, POOL>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
     const int grid = 8 * cdiv(g.S, 8) * g.KG * g.CG;
-    conv_tile_wgrad_kernel<NFT><<<grid, 256, cw_lds_bytes(g), ctx->stream>>>(g);
+    conv_tile_wgrad_kernel<NFT, POOL><<<grid, 256, cw_lds_bytes(g), ctx->stream>>>(g);
     TN_LAUNCH_CHECK();
     return TN_OK;
 }
@@ -673,24 +763,91 @@ static int cw_launch(tn_ctx* ctx, ConvWG& g) {
 int tn_red_push(tn_ctx* ctx, const float* src, float* out, uint32_t n, uint32_t S, uint32_t stride, uint32_t flip);
 int tn_red_commit(tn_ctx* ctx);
 
+static int cw_run(tn_ctx* ctx, ConvWG& g, float* dW, float* db, bool pool) {
+    TN_REQUIRE(cw_geometry(g, ctx->num_cus), "conv_tile_wgrad: unsupported shape");
+    TN_REQUIRE((long long)g.N * g.C * g.H * g.Wd < (1ll << 31) && (long long)g.N * g.K * g.H * g.Wd < (1ll << 31),
+               "conv_tile_wgrad: tensor too large for 32-bit offsets");
+    const int NFT = g.K > 32 ? 2 : 1, PS = 4 / NFT;
+    const size_t n = (size_t)g.K * g.C * 9;
+    int rc = tn_scratch_get(ctx, ((size_t)g.S * PS * n + (size_t)g.S * g.K) * sizeof(float), &g.ws);
+    if (rc) return rc;
+    g.dbws = g.ws + (size_t)g.S * PS * n;
+    if (pool) rc = NFT == 2 ? cw_launch<2, true>(ctx, g) : cw_launch<1, true>(ctx, g);
+    else rc = NFT == 2 ? cw_launch<2, false>(ctx, g) : cw_launch<1, false>(ctx, g);
+    if (rc) return rc;
+    rc = tn_red_push(ctx, g.ws, dW, (uint32_t)n, (uint32_t)(g.S * PS), (uint32_t)n, 0);
+    if (rc) return rc;
+    rc = tn_red_push(ctx, g.dbws, db, (uint32_t)g.K, (uint32_t)g.S, (uint32_t)g.K, 0);
+    if (rc) return rc;
+    return tn_red_commit(ctx);
+}
+
 int tn_conv_tile_wgrad(tn_ctx* ctx, const float* x, const float* dz, float* dW, float* db, int N, int C,
                        int H, int Wd, int K) {
     ConvWG g{};
     g.x = x; g.dz = dz;
     g.N = N; g.C = C; g.H = H; g.Wd = Wd; g.K = K;
-    TN_REQUIRE(cw_geometry(g, ctx->num_cus), "conv_tile_wgrad: unsupported shape");
-    TN_REQUIRE((long long)N * C * H * Wd < (1ll << 31) && (long long)N * K * H * Wd < (1ll << 31),
-               "conv_tile_wgrad: tensor too large for 32-bit offsets");
-    const int NFT = K > 32 ? 2 : 1, PS = 4 / NFT;
-    const size_t n = (size_t)K * C * 9;
-    int rc = tn_scratch_get(ctx, ((size_t)g.S * PS * n + (size_t)g.S * K) * sizeof(float), &g.ws);
-    if (rc) return rc;
-    g.dbws = g.ws + (size_t)g.S * PS * n;
-    rc = NFT == 2 ? cw_launch<2>(ctx, g) : cw_launch<1>(ctx, g);
-    if (rc) return rc;
-    rc = tn_red_push(ctx, g.ws, dW, (uint32_t)n, (uint32_t)(g.S * PS), (uint32_t)n, 0);
-    if (rc) return rc;
-    rc = tn_red_push(ctx, g.dbws, db, (uint32_t)K, (uint32_t)g.S, (uint32_t)K, 0);
-    if (rc) return rc;
-    return tn_red_commit(ctx);
+    return cw_run(ctx, g, dW, db, false);
+}
+
+// ---- conv + act + 2x2 max-pool blocks on the tile kernels (3x3 'same', even maps) ------------------
+extern "C" {
+
+// 1 if the block (N,C,H,Wd) -> K maps (Ho,Wo) -> pooled (Hp,Wp) runs fused on the tile kernels: the
+// forward pools in its epilogue and records the pooling mask, the backward forms dz from that mask.
+int tn_convpool_tile_supported(int N, int C, int H, int Wd, int K, int f, int stride, int pad, int Ho, int Wo,
+                               int p, int Hp, int Wp) {
+    if (!ct_enabled() || f != 3 || stride != 1 || p != 2 || pad != 1 || Ho != H || Wo != Wd) return 0;
+    if ((Ho & 1) || (Wo & 3) || Hp * 2 != Ho || Wp * 2 != Wo) return 0;
+    if (C * 9 < 32 || K < 16) return 0;
+    if (const char* e = getenv("TN_CONV_TILE_POOL")) if (e[0] == '0') return 0;
+    ConvTG a{};                                   // forward
+    a.N = N; a.C = C; a.H = H; a.Wd = Wd; a.K = K; a.pad = 1; a.Ho = Ho; a.Wo = Wo;
+    if (!ct_geometry(a, ct_pick_ft(K)) || (a.TH & 1) || ct_lds_bytes(a, ct_pick_ft(K)) > 150 * 1024) return 0;
+    ConvTG d{};                                   // input gradient: gathers dz (N,K,Ho,Wo)
+    d.N = N; d.C = K; d.H = Ho; d.Wd = Wo; d.K = C; d.pad = 1; d.Ho = H; d.Wo = Wd;
+    if (C < 16 || !ct_geometry(d, ct_pick_ft(C)) || ct_lds_bytes(d, ct_pick_ft(C)) > 150 * 1024) return 0;
+    ConvWG w{};                                   // weight gradient
+    w.N = N; w.C = C; w.H = H; w.Wd = Wd; w.K = K;
+    if (!cw_geometry(w, 256) || cw_lds_bytes(w) > 160 * 1024) return 0;
+    return 1;
+}
+
+}  // extern "C"
+
+int tn_conv_tile_pool_fwd(tn_ctx* ctx, const float* x, const float* W, const float* b, float* y,
+                          uint8_t* mask, int N, int C, int H, int Wd, int K, int act, float prm) {
+    TN_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0, "conv_tile_pool_fwd: x must be 16-byte aligned");
+    ConvTG g{};
+    g.x = x; g.out = y; g.bias = b; g.mask_out = mask;
+    g.N = N; g.C = C; g.H = H; g.Wd = Wd; g.K = K; g.pad = 1; g.Ho = H; g.Wo = Wd;
+    g.act = act; g.prm = prm;
+    return ct_run(ctx, g, W, false, true);
+}
+
+// dW, db and (dx != NULL) the input gradient of the fused block from the pooled gradient g, the pooled
+// output y and the pooling mask; prev_a: output of the layer below, whose activation gradient is
+// applied to dx in the epilogue (NULL: none).
+int tn_conv_tile_pool_bwd(tn_ctx* ctx, const float* x, const float* W, const float* g_, const float* y,
+                          const uint8_t* mask, float* dx, float* dW, float* db, int N, int C, int H, int Wd,
+                          int K, int act, float prm, const float* prev_a, int prev_act, float prev_prm) {
+    PoolSrc ps{};
+    ps.g = g_; ps.y = y; ps.mask = mask; ps.Hp = H / 2; ps.Wp = Wd / 2; ps.act = act; ps.prm = prm;
+    TN_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(g_) | reinterpret_cast<uintptr_t>(y)) & 15) == 0 &&
+               (reinterpret_cast<uintptr_t>(mask) & 3) == 0, "conv_tile_pool_bwd: misaligned operand");
+    if (dW) {
+        ConvWG w{};
+        w.x = x; w.ps = ps;
+        w.N = N; w.C = C; w.H = H; w.Wd = Wd; w.K = K;
+        int rc = cw_run(ctx, w, dW, db, true);
+        if (rc) return rc;
+    }
+    if (dx) {
+        ConvTG d{};
+        d.out = dx; d.prev_a = prev_a; d.ps = ps;
+        d.N = N; d.C = K; d.H = H; d.Wd = Wd; d.K = C; d.pad = 1; d.Ho = H; d.Wo = Wd;
+        d.act = prev_act; d.prm = prev_prm;
+        return ct_run(ctx, d, W, true, true);
+    }
+    return TN_OK;
 }

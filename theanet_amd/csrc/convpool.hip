@@ -19,6 +19,15 @@
 
 #include "common.h"
 
+// conv_tile.hip: the matrix-core kernels for wide 3x3 'same' blocks
+extern "C" int tn_convpool_tile_supported(int N, int C, int H, int Wd, int K, int f, int stride, int pad, int Ho,
+                                          int Wo, int p, int Hp, int Wp);
+int tn_conv_tile_pool_fwd(tn_ctx* ctx, const float* x, const float* W, const float* b, float* y,
+                          uint8_t* mask, int N, int C, int H, int Wd, int K, int act, float prm);
+int tn_conv_tile_pool_bwd(tn_ctx* ctx, const float* x, const float* W, const float* g_, const float* y,
+                          const uint8_t* mask, float* dx, float* dW, float* db, int N, int C, int H, int Wd,
+                          int K, int act, float prm, const float* prev_a, int prev_act, float prev_prm);
+
 template <int ACT>
 __device__ __forceinline__ float act_fwd_t(float z, int act, float prm) {
     if (ACT == TN_ACT_LEAKY) return fmaxf(0.f, z) + fminf(0.f, z) * prm;
@@ -523,6 +532,9 @@ int tn_convpool_fwd(tn_ctx* ctx, const float* x, const float* W, const float* b,
 int tn_convpool_fwd_mask(tn_ctx* ctx, const float* x, const float* W, const float* b, float* y,
                          uint8_t* mask, int N, int C, int H, int Wd, int K, int f, int pad_lo, int Ho,
                          int Wo, int p, int Hp, int Wp, int act, float act_param) {
+    if (!tn_convpool_supported(C, f, 1, p) &&
+        tn_convpool_tile_supported(N, C, H, Wd, K, f, 1, pad_lo, Ho, Wo, p, Hp, Wp))
+        return tn_conv_tile_pool_fwd(ctx, x, W, b, y, mask, N, C, H, Wd, K, act, act_param);   // wide layers
     TN_REQUIRE(tn_convpool_supported(C, f, 1, p), "tn_convpool_fwd: unsupported C=%d f=%d p=%d", C, f, p);
 #define CP_FWD(F_, C_)                                                                            \
     return launch_fwd<F_, 2, C_>(ctx, x, W, b, y, mask, N, H, Wd, K, pad_lo, Ho, Wo, Hp, Wp, act,  \
@@ -539,6 +551,17 @@ int tn_convpool_fwd_mask(tn_ctx* ctx, const float* x, const float* W, const floa
         CP_FWD(5, 2);
     }
 #undef CP_FWD
+}
+
+int tn_convpool_bwd_mask_dx(tn_ctx* ctx, const float* x, const float* W, const float* g, const float* y,
+                            const uint8_t* mask, float* dx, float* dW, float* db, int N, int C, int H,
+                            int Wd, int K, int f, int pad_lo, int Ho, int Wo, int p, int Hp, int Wp, int act,
+                            float act_param, const float* prev_a, int prev_act, float prev_act_param) {
+    TN_REQUIRE(x && W && g && y && mask, "tn_convpool_bwd_mask_dx: null argument");
+    TN_REQUIRE(tn_convpool_tile_supported(N, C, H, Wd, K, f, 1, pad_lo, Ho, Wo, p, Hp, Wp),
+               "tn_convpool_bwd_mask_dx: unsupported block (C=%d K=%d %dx%d f=%d p=%d)", C, K, H, Wd, f, p);
+    return tn_conv_tile_pool_bwd(ctx, x, W, g, y, mask, dx, dW, db, N, C, H, Wd, K, act, act_param, prev_a,
+                                 prev_act, prev_act_param);
 }
 
 int tn_convpool_bwd(tn_ctx* ctx, const float* x, const float* W, const float* b, const float* g,

@@ -54,6 +54,7 @@ class ConvLayer(Layer):
         self.output = self.ctx.empty((batch_sz, num_maps, self.out_sz, self.out_sz))
         self.gin = None
         self.fused_pool = None     # set by NeuralNet: conv+act+pool run as ONE kernel
+        self._tile_pool = False    # ... on the LDS-tile matrix-core kernels (wide layers)
         self._mask_block = None
         self.dz = None
 
@@ -88,8 +89,15 @@ class ConvLayer(Layer):
     def can_fuse_with(self, pool):
         """conv -> act -> 2x2 max-pool on small channel counts runs as one fused kernel pair
         (tn_convpool_fwd / tn_convpool_bwd): the conv activation never reaches HBM."""
-        return bool(self.stride == 1 and self.ctx.lib.tn_convpool_supported(
-            self.num_prev_maps, self.filter_sz, self.stride, pool.pool_sz))
+        if self.stride == 1 and self.ctx.lib.tn_convpool_supported(
+                self.num_prev_maps, self.filter_sz, self.stride, pool.pool_sz):
+            return True
+        # wide 3x3 'same' layers: the LDS-tile matrix-core kernels pool in their epilogue and run the
+        # backward from the pooling mask (tn_convpool_fwd_mask / tn_convpool_bwd_mask_dx)
+        self._tile_pool = bool(self.ctx.lib.tn_convpool_tile_supported(
+            self.batch_sz, self.num_prev_maps, self.in_sz, self.in_sz, self.num_maps, self.filter_sz,
+            self.stride, self.pad_lo, self.out_sz, self.out_sz, pool.pool_sz, pool.out_sz, pool.out_sz))
+        return self._tile_pool
 
     def mask_backward_supported(self, pool):
         """True if the fused block's whole backward (dW, db and the input gradient) can run as
@@ -118,6 +126,23 @@ class ConvLayer(Layer):
         gradient through max-pool and activation and reduces dW/db; dz is only materialised
         when the layer below needs a gradient."""
         pool = self.fused_pool
+        if self._tile_pool:
+            # wide block: dW, db and the input gradient straight from the pooled gradient + mask
+            assert pool.mask is not None
+            b_out, b_act, b_prm, b_mask = below.act_info() if (need_gin and below is not None) \
+                else (None, 0, 0., None)
+            assert b_mask is None
+            if need_gin and self.gin is None:
+                self.gin = self.ctx.empty(self.inpt.shape)
+            upd = self.has_updates()
+            self.ctx.call("tn_convpool_bwd_mask_dx", self.inpt.ptr, self.W.ptr, gpool.ptr, pool.output.ptr,
+                          pool.mask.ptr, self.gin.ptr if need_gin else None,
+                          self.grads[0].ptr if upd else None, self.grads[1].ptr if upd else None,
+                          *self._fused_geom(),
+                          b_out.ptr if b_out is not None and b_act != _lib.TN_ACT_LINEAR else None,
+                          b_act, b_prm)
+            self._gin_done = True
+            return self.gin if need_gin else None
         if pool.mask is not None:
             # the forward recorded where every pooled value came from: no conv recompute
             b_out, b_act, b_prm, b_mask = below.act_info() if below is not None else (None, 0, 0., None)
@@ -217,8 +242,8 @@ class PoolLayer(Layer):
     def forward(self, train=True):
         conv = self.fused_conv
         if conv is not None:
-            if train and self.mask is None and os.environ.get("TN_POOL_MASK", "1") != "0" and \
-                    conv.filter_sz == 3 and self.pool_sz == 2:
+            if train and self.mask is None and conv.filter_sz == 3 and self.pool_sz == 2 and \
+                    (conv._tile_pool or os.environ.get("TN_POOL_MASK", "1") != "0"):
                 self.mask = self.ctx.empty(self.output.shape, np.uint8)
             el = self.fused_elastic
             if el is not None and train and el._apply_args is not None:
