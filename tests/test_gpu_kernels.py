@@ -295,6 +295,12 @@ def test_convpool_tile_block(case):
     (4, 3, 16, 6, "same", "tanh", False),
     (2, 4, 11, 9, "same", "relu", False),
     (3, 2, 9, 3, "valid", "sigmoid", False),
+    # 'same' blocks with even power-of-two maps and >= 16 filters: without dz (first layer) the weight
+    # gradient runs on the matrix core with the (channel, tap) pairs as GEMM columns (conv_tile.hip)
+    (5, 3, 32, 32, "same", "relu10", False),        # cifar_like conv1
+    (3, 2, 16, 40, "same", "tanh", False),          # two filter groups, the second ragged
+    (7, 1, 8, 16, "same", "relu05", False),         # 8x8 maps: two images per tile, odd image count
+    (2, 3, 64, 20, "same", "sigmoid", False),
 ])
 def test_convpool_mask_backward(case):
     """tn_convpool_bwd_mask (window-per-thread backward from the pooling mask) vs the oracle."""
@@ -325,12 +331,15 @@ def test_convpool_mask_backward(case):
     dz, dW, db = empty((N, K, Ho, Ho)), empty(W.shape), empty((K,))
     dz.fill_bytes(0xff)
     call("tn_convpool_bwd_mask", xd.ptr, gd.ptr, y.ptr, mask.ptr, dz.ptr, dW.ptr, db.ptr, *geom)
+    tolW, tolb = max(2e-4, 2e-6 * np.abs(dW_w).max()), max(2e-4, 2e-6 * np.abs(db_w).max())
     assert_close(dz.get_value(), dz_w, atol=1e-5, what="convpool(mask) dz %s" % (case,))
-    assert_close(dW.get_value(), dW_w, atol=2e-4, what="convpool(mask) dW %s" % (case,))
-    assert_close(db.get_value(), db_w, atol=2e-4, what="convpool(mask) db %s" % (case,))
+    assert_close(dW.get_value(), dW_w, atol=tolW, what="convpool(mask) dW %s" % (case,))
+    assert_close(db.get_value(), db_w, atol=tolb, what="convpool(mask) db %s" % (case,))
     dW.fill_bytes(0)
+    db.fill_bytes(0)
     call("tn_convpool_bwd_mask", xd.ptr, gd.ptr, y.ptr, mask.ptr, None, dW.ptr, db.ptr, *geom)
-    assert_close(dW.get_value(), dW_w, atol=2e-4, what="convpool(mask) dW (no dz) %s" % (case,))
+    assert_close(dW.get_value(), dW_w, atol=tolW, what="convpool(mask) dW (no dz) %s" % (case,))
+    assert_close(db.get_value(), db_w, atol=tolb, what="convpool(mask) db (no dz) %s" % (case,))
 
 
 def test_convpool_tie_rule():

@@ -851,3 +851,193 @@ int tn_conv_tile_pool_bwd(tn_ctx* ctx, const float* x, const float* W, const flo
     }
     return TN_OK;
 }
+
+// =================================================================================================
+// Weight gradient of a fused 3x3 'same' conv + act + 2x2 max-pool block with FEW input channels
+// (C*9 <= 32: the first layer of cifar_like, C = 3), from the pooling mask.  The channel tile of the
+// kernel above would be 3/32 full; here the 32 GEMM columns are the (channel, tap) pairs themselves:
+//   dWf[k][(c,u,v)] = sum_pix dz[k][pix] * x[c][pix + (u-1, v-1)],
+// lane n = (c,u,v) reads its own shifted x value (4 consecutive pixels = two ds_read2_b32 at a
+// per-lane constant offset), A = one 16-byte dz vector as above, one accumulator per wave.  The four
+// waves of a block take every fourth 8-pixel step of a 128-pixel tile; tiles are double-buffered in
+// LDS (20 KB per buffer, several blocks per CU).  dz = mask bit ? g*act'(y) : 0 is formed while staging.
+// =================================================================================================
+struct ConvSG {
+    const float* x;
+    float* ws;             // [S*4][K*C*9]
+    float* dbws;           // [S][K]
+    int N, C, H, Wd, K;
+    int KG, S, ipb;
+    int NI, TH, THi, RT, NT;
+    int RS, plane, q4, nx4, lgW, lgP;
+    PoolSrc ps;
+};
+
+__global__ __launch_bounds__(256) void conv_tile_wgrad_smallc_kernel(ConvSG g) {
+    extern __shared__ __attribute__((aligned(16))) float ct_smem[];
+    constexpr int DZSZ = 32 * CW_DZS;
+    const int XSZ = (g.C * g.plane + 3) & ~3, BUFSZ = DZSZ + XSZ;      // + one zero cell region below
+    const int bid = blockIdx.x;
+    const int z = ((bid >> 3) / g.KG) * 8 + (bid & 7), kg = (bid >> 3) % g.KG;
+    if (z >= g.S) return;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, hi = lane >> 5;
+    const int n_beg = z * g.ipb, n_end = min(g.N, n_beg + g.ipb);
+    const int Wm = g.Wd - 1, THm = g.TH - 1, CT = g.C * 9;
+
+    for (int i = t * 4; i < 2 * BUFSZ + 16; i += 1024) *reinterpret_cast<float4*>(ct_smem + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    // this lane's GEMM column (c,u,v): offset of its shifted pixel inside an x tile; columns beyond
+    // C*9 read a spare cell that stays zero
+    const bool colok = l31 < CT;
+    const int cc = colok ? l31 / 9 : 0, tap = colok ? l31 - cc * 9 : 0, tu = tap / 3, tv = tap - tu * 3;
+    const int lanex = cc * g.plane + tu * g.RS + tv + 3;
+
+    float dbacc[4] = {0.f, 0.f, 0.f, 0.f};
+    float4 sv[5];
+    int so[5];
+#define CS_SLOAD(SL, N0, R0)                                                                     \
+    {                                                                                            \
+        if ((SL) < 4) {                                                                          \
+            const int e_ = t + 256 * (SL);                                                       \
+            const int q_ = e_ & 31, f_ = e_ >> 5, p_ = 4 * q_;                                   \
+            const int n_ = (N0) + (p_ >> g.lgP), row_ = (R0) + ((p_ >> g.lgW) & THm), k_ = kg * 32 + f_; \
+            const bool ok_ = n_ < n_end && k_ < g.K;                                             \
+            sv[SL] = cw_mask4(pool_expand4(g.ps, min(n_, g.N - 1) * g.K + min(k_, g.K - 1), row_, p_ & Wm), ok_); \
+            so[SL] = f_ * CW_DZS + p_;                                                           \
+        } else {                                                                                 \
+            const int e_ = t;                                                                    \
+            int rr_ = min(e_, g.nx4 - 1);                                                        \
+            const int q_ = rr_ % g.q4; rr_ /= g.q4;                                              \
+            const int r_ = rr_ % g.THi; rr_ /= g.THi;                                            \
+            const int ni_ = rr_ % g.NI, c_ = rr_ / g.NI;                                         \
+            const int n_ = (N0) + ni_, row_ = (R0) - 1 + r_;                                     \
+            const bool ok_ = n_ < n_end && (unsigned)row_ < (unsigned)g.H;                       \
+            const int go_ = ((min(n_, g.N - 1) * g.C + c_) * g.H + min(max(row_, 0), g.H - 1)) * g.Wd + 4 * q_; \
+            sv[SL] = cw_mask4(*reinterpret_cast<const float4*>(g.x + go_), ok_);                 \
+            so[SL] = e_ < g.nx4 ? DZSZ + c_ * g.plane + (ni_ * g.THi + r_) * g.RS + 4 + 4 * q_ : -1; \
+        }                                                                                        \
+    }
+#define CS_SSTORE(SL, BUF)                                                                       \
+    {                                                                                            \
+        *reinterpret_cast<float4*>(__builtin_assume_aligned(                                     \
+            ct_smem + (so[SL] >= 0 ? (BUF) * BUFSZ + so[SL] : 2 * BUFSZ + 8), 16)) = sv[SL];     \
+        if ((SL) < 4) dbacc[(SL) < 4 ? (SL) : 0] += dbw_ * ((sv[SL].x + sv[SL].y) + (sv[SL].z + sv[SL].w)); \
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+    float dbw_ = 1.f;
+#pragma unroll
+    for (int s = 0; s < 5; ++s) CS_SLOAD(s, n_beg, 0);
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < 5; ++s) CS_SSTORE(s, 0);
+    __syncthreads();
+    // the spare zero region [2*BUFSZ, 2*BUFSZ + 8) serves the columns beyond C*9; the dummy store
+    // target of absent slots is 2*BUFSZ + 8
+    int gi = 0, rt = 0;
+    for (int tl = 0; tl < g.NT; ++tl) {
+        const int cur = tl & 1;
+        int rt1 = rt + 1, gi1 = gi;
+        if (rt1 == g.RT) { rt1 = 0; ++gi1; }
+        const bool hasnext = tl + 1 < g.NT;
+        if (!hasnext) { rt1 = rt; gi1 = gi; }
+        dbw_ = hasnext ? 1.f : 0.f;
+        const int n1 = n_beg + gi1 * g.NI, r1 = rt1 * g.TH;
+#pragma unroll
+        for (int s = 0; s < 5; ++s) CS_SLOAD(s, n1, r1);
+        const float* dzb = ct_smem + cur * BUFSZ + l31 * CW_DZS + 4 * hi;
+        const float* xb = colok ? ct_smem + cur * BUFSZ + DZSZ + lanex : ct_smem + 2 * BUFSZ;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int sg = wave + 4 * i, p_ = 8 * sg + 4 * hi;
+            const float4 a = *cw_f4(dzb + 8 * sg);
+            const float* xp = colok ? xb + ((p_ >> g.lgP) * g.THi + ((p_ >> g.lgW) & THm)) * g.RS + (p_ & Wm) : xb;
+            const float x0 = xp[0], x1 = xp[1], x2 = xp[2], x3 = xp[3];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, x0, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, x1, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, x2, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, x3, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int s = 0; s < 5; ++s) CS_SSTORE(s, cur ^ 1);
+        __syncthreads();
+        rt = rt1; gi = gi1;
+    }
+#undef CS_SLOAD
+#undef CS_SSTORE
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        float v = dbacc[s];
+        v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 4, 64);
+        v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 1, 64);
+        const int k = kg * 32 + (t >> 5) + 8 * s;
+        if (l31 == 0 && k < g.K) g.dbws[(size_t)z * g.K + k] = v;
+    }
+    if (colok) {
+        float* wz = g.ws + (size_t)(z * 4 + wave) * g.K * CT;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int k = kg * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            if (k < g.K) wz[(size_t)k * CT + cc * 9 + 8 - tap] = acc[r];
+        }
+    }
+}
+
+static int cs_geometry(ConvSG& g, int num_cus) {
+    ConvWG w{};
+    w.N = g.N; w.C = 32; w.H = g.H; w.Wd = g.Wd; w.K = 32;
+    if (!cw_geometry(w, num_cus)) return 0;
+    g.NI = w.NI; g.TH = w.TH; g.THi = w.THi; g.RT = w.RT; g.lgW = w.lgW; g.lgP = w.lgP; g.RS = w.RS;
+    g.plane = g.NI * g.THi * g.RS;
+    if ((g.plane & 15) == 0) g.plane += 4;          // keep the channel planes off one bank
+    g.q4 = g.Wd / 4;
+    g.nx4 = g.C * g.NI * g.THi * g.q4;
+    if (g.nx4 > 256) return 0;
+    g.KG = cdiv(g.K, 32);
+    const int groups = cdiv(g.N, g.NI);
+    int S = 4 * num_cus / g.KG;
+    if (S > groups) S = groups;
+    if (S < 1) S = 1;
+    g.ipb = cdiv(groups, S) * g.NI;
+    g.S = cdiv(g.N, g.ipb);
+    g.NT = (g.ipb / g.NI) * g.RT;
+    return 1;
+}
+
+extern "C" int tn_convpool_smallc_supported(int N, int C, int H, int Wd, int K, int f, int pad, int Ho,
+                                            int Wo, int p, int Hp, int Wp) {
+    if (!ct_enabled() || f != 3 || p != 2 || pad != 1 || Ho != H || Wo != Wd || C * 9 > 32 || K < 16) return 0;
+    if ((Ho & 1) || (Wo & 3) || Hp * 2 != Ho || Wp * 2 != Wo) return 0;
+    if (const char* e = getenv("TN_CONV_TILE_SMALLC")) if (e[0] == '0') return 0;
+    ConvSG g{};
+    g.N = N; g.C = C; g.H = H; g.Wd = Wd; g.K = K;
+    return cs_geometry(g, 256);
+}
+
+int tn_conv_tile_smallc_bwd(tn_ctx* ctx, const float* x, const float* g_, const float* y, const uint8_t* mask,
+                            float* dW, float* db, int N, int C, int H, int Wd, int K, int act, float prm) {
+    ConvSG g{};
+    g.x = x;
+    g.N = N; g.C = C; g.H = H; g.Wd = Wd; g.K = K;
+    g.ps.g = g_; g.ps.y = y; g.ps.mask = mask; g.ps.Hp = H / 2; g.ps.Wp = Wd / 2; g.ps.act = act; g.ps.prm = prm;
+    TN_REQUIRE(cs_geometry(g, ctx->num_cus), "conv_tile_smallc_bwd: unsupported shape");
+    TN_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(g_) | reinterpret_cast<uintptr_t>(y)) & 15) == 0 &&
+               (reinterpret_cast<uintptr_t>(mask) & 3) == 0, "conv_tile_smallc_bwd: misaligned operand");
+    TN_REQUIRE((long long)N * K * H * Wd < (1ll << 31), "conv_tile_smallc_bwd: tensor too large for 32-bit offsets");
+    const size_t n = (size_t)K * C * 9;
+    int rc = tn_scratch_get(ctx, ((size_t)g.S * 4 * n + (size_t)g.S * K) * sizeof(float), &g.ws);
+    if (rc) return rc;
+    g.dbws = g.ws + (size_t)g.S * 4 * n;
+    const int XSZ = (C * g.plane + 3) & ~3;
+    const size_t lds = (size_t)(2 * (32 * CW_DZS + XSZ) + 16) * sizeof(float);
+    const int grid = 8 * cdiv(g.S, 8) * g.KG;
+    conv_tile_wgrad_smallc_kernel<<<grid, 256, lds, ctx->stream>>>(g);
+    TN_LAUNCH_CHECK();
+    rc = tn_red_push(ctx, g.ws, dW, (uint32_t)n, (uint32_t)(g.S * 4), (uint32_t)n, 0);
+    if (rc) return rc;
+    rc = tn_red_push(ctx, g.dbws, db, (uint32_t)K, (uint32_t)g.S, (uint32_t)K, 0);
+    if (rc) return rc;
+    return tn_red_commit(ctx);
+}

@@ -22,6 +22,10 @@
 // conv_tile.hip: the matrix-core kernels for wide 3x3 'same' blocks
 extern "C" int tn_convpool_tile_supported(int N, int C, int H, int Wd, int K, int f, int stride, int pad, int Ho,
                                           int Wo, int p, int Hp, int Wp);
+extern "C" int tn_convpool_smallc_supported(int N, int C, int H, int Wd, int K, int f, int pad, int Ho,
+                                            int Wo, int p, int Hp, int Wp);
+int tn_conv_tile_smallc_bwd(tn_ctx* ctx, const float* x, const float* g_, const float* y, const uint8_t* mask,
+                            float* dW, float* db, int N, int C, int H, int Wd, int K, int act, float prm);
 int tn_conv_tile_pool_fwd(tn_ctx* ctx, const float* x, const float* W, const float* b, float* y,
                           uint8_t* mask, int N, int C, int H, int Wd, int K, int act, float prm);
 int tn_conv_tile_pool_bwd(tn_ctx* ctx, const float* x, const float* W, const float* g_, const float* y,
@@ -501,6 +505,9 @@ int tn_convpool_bwd_mask(tn_ctx* ctx, const float* x, const float* g, const floa
                          int act, float act_param) {
     TN_REQUIRE(f == 3 && p == 2 && C >= 1 && C <= 4, "tn_convpool_bwd_mask: unsupported C=%d f=%d p=%d", C, f, p);
     TN_REQUIRE(x && g && y && mask && dW && db, "tn_convpool_bwd_mask: null argument");
+    // weight gradients only (first layer), 'same' block with even maps: matrix-core kernel of conv_tile.hip
+    if (!dz && tn_convpool_smallc_supported(N, C, H, Wd, K, f, pad_lo, Ho, Wo, p, Hp, Wp))
+        return tn_conv_tile_smallc_bwd(ctx, x, g, y, mask, dW, db, N, C, H, Wd, K, act, act_param);
     if (dz && (Hp * p < Ho || Wp * p < Wo))   // rows/cols outside every window (ignore_border)
         TN_HIP(hipMemsetAsync(dz, 0, (size_t)N * K * Ho * Wo * sizeof(float), ctx->stream));
 #define CP_BWDM(C_, KT_)                                                                          \
