@@ -173,36 +173,40 @@ def main():
                 pass
 
     else:
-        # conv nets on the matrix-core path (cifar_like, wide6): the three conv products of every
-        # unfused conv layer, each as the sum over its launches in a step -> "fraction of the conv
-        # roofline" (conv-layer FLOPs / conv-kernel time / MFMA fp32 peak)
+        # conv nets (cifar_like, wide6): every conv product of the step, grouped into forward and
+        # backward, each as the sum over its launches -> "fraction of the conv roofline" (SURVEY.md 8d:
+        # conv-layer FLOPs / conv-kernel time / MFMA fp32 peak).  Fused conv+act+pool blocks count
+        # with their conv FLOPs only (pooling, masks and activations ride along).
         from theanet_amd.layer import ConvLayer
-        convs = [l for l in net.tr_layers if isinstance(l, ConvLayer) and l.fused_pool is None]
+        convs = [l for l in net.tr_layers if isinstance(l, ConvLayer)]
         first_param = next(l for l in net.tr_layers if getattr(l, "params", None))
         fl_of = lambda l: 2 * l.batch_sz * l.out_sz ** 2 * l.num_maps * l.num_prev_maps * l.filter_sz ** 2
-        fl_all = sum(fl_of(l) for l in convs)
-        fl_dgrad = sum(fl_of(l) for l in convs if l is not first_param)
-        for op, label, fl in (("tn_conv2d_fwd", "conv forward (all unfused conv layers)", fl_all),
-                              ("tn_conv2d_wgrad", "conv weight gradient (all unfused conv layers)", fl_all),
-                              ("tn_conv2d_dgrad", "conv input gradient (all unfused conv layers)", fl_dgrad)):
-            if not convs or not fl:
+        groups = (("conv forward, all conv layers (conv_tile / convpool kernels)",
+                   ("tn_conv2d_fwd", "tn_convpool_fwd_mask", "tn_elastic_convpool_fwd_mask"),
+                   sum(fl_of(l) for l in convs)),
+                  ("conv backward, all conv layers (weight + input gradients)",
+                   ("tn_conv2d_wgrad", "tn_conv2d_dgrad", "tn_convpool_bwd_mask_dx", "tn_convpool_bwd_mask",
+                    "tn_convblock_bwd_mask", "tn_convblock_bwd", "tn_convpool_bwd"),
+                   sum(fl_of(l) * (1 if l is first_param else 2) for l in convs)))
+        nsteps = min(args.steps, 10)
+        for label, ops, fl in groups:
+            ms, launches = 0.0, 0
+            for op in ops:
+                ctx.time_calls(op, 0)
+                for i in range(nsteps):
+                    ctx.new_step()
+                    fn.enqueue(i % n_batches)
+                ctx.sync()
+                times = ctx.collect_times_ms()
+                ms += float(np.sum(times)) / nsteps
+                launches += len(times) // nsteps
+            if not launches or not fl:
                 continue
-            nsteps = min(args.steps, 10)
-            ctx.time_calls(op, 0)
-            for i in range(nsteps):
-                ctx.new_step()
-                fn.enqueue(i % n_batches)
-            ctx.sync()
-            times = ctx.collect_times_ms()
-            if not times:
-                continue
-            ms = float(np.sum(times)) / nsteps          # time in this op per step
             ach = fl / (ms * 1e-3) / 1e12
             others.append({"kernel": label, "bound": "mfma", "achieved": ach,
                            "peak": roofline.MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                            "frac": ach / roofline.MFMA_F32_PEAK_TFLOPS, "traffic": None,
-                           "ms_per_step": ms, "launches_per_step": len(times) // nsteps,
-                           "flops_per_step": fl})
+                           "ms_per_step": ms, "launches_per_step": launches, "flops_per_step": fl})
         if others:
             others.sort(key=lambda r: -r["ms_per_step"])
             roof, others = others[0], others[1:]

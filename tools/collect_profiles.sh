@@ -14,4 +14,9 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -o p
     python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -o p -- \
     python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/write.log 2>&1
+# the two wider configurations (BASELINE.json configs 4 and 5): kernel-trace stats only
+for c in cifar_like wide6; do
+    rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$c -o $c -- \
+        python $GRAFT_REPO_ROOT/bench.py --prms $c.prms --steps 10 --warmup 3 --no-cpu-baseline > $OUT/stats_$c.log 2>&1
+done
 tail -1 $OUT/stats.log | cut -c1-200

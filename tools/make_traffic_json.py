@@ -66,3 +66,15 @@ with open(os.path.join(ROOT, "profiles", "%s_mnist_bs4096_summary.md" % tag), "w
                                                      r["Percentage"], "%.2f MB" % (hb / 1e6) if hb else "-"))
     md.write("\nbench line of the same run:\n\n```\n%s\n```\n" % line[:1500])
 print("wrote", dst)
+for cfg in ("cifar_like", "wide6"):
+    found = glob.glob(os.path.join(src, "stats_%s" % cfg, "*kernel_stats.csv"))
+    if not found:
+        continue
+    dst2 = os.path.join(ROOT, "profiles", "%s_%s_kernel_stats.csv" % (tag, cfg))
+    with open(found[0]) as fh, open(dst2, "w") as out:
+        out.write(fh.read())
+    lines = [l for l in open(os.path.join(src, "stats_%s.log" % cfg)).read().splitlines() if l.startswith("{")]
+    if lines:
+        with open(os.path.join(ROOT, "profiles", "%s_%s_bench.json" % (tag, cfg)), "w") as out:
+            out.write(lines[-1] + "\n")
+    print("wrote", dst2)
