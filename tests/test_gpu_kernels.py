@@ -38,6 +38,11 @@ CONV_CASES = [
     (2, 16, 64, 64, 3, 1, "same", "tanh"),
     (1, 40, 36, 24, 3, 1, "same", "relu05"),
     (9, 10, 4, 33, 3, 1, "same", "sigmoid"),
+    # first layers (C <= 4, >= 16 filters): forward on the tile kernel with two channel pairs, weight
+    # gradient with the (channel, tap) pairs as GEMM columns
+    (3, 3, 16, 32, 3, 1, "same", "relu10"),
+    (2, 1, 32, 16, 3, 1, "same", "tanh"),
+    (5, 2, 8, 40, 3, 1, "same", "relu05"),
 ]
 
 

@@ -369,6 +369,13 @@ int tn_conv_mfma_dgrad(tn_ctx* ctx, const float* dz, const float* W, float* dx, 
 int tn_conv_mfma_wgrad(tn_ctx* ctx, const float* x, const float* dz, float* dW, float* db, int N,
                        int C, int H, int Wd, int K, int f, int pad, int Ho, int Wo);
 extern "C" int tn_conv_mfma_supported(int C, int K, int f, int stride);
+int tn_conv_tile_smallc_ok(const float* x, const float* dz, int N, int C, int H, int Wd, int K, int f, int pad,
+                           int Ho, int Wo);
+int tn_conv_tile_smallc_wgrad(tn_ctx* ctx, const float* x, const float* dz, float* dW, float* db, int N, int C,
+                              int H, int Wd, int K);
+int tn_conv_tile_ok(const float* x, int N, int C, int H, int Wd, int K, int f, int pad, int Ho, int Wo);
+int tn_conv_tile_fwd(tn_ctx* ctx, const float* x, const float* W, const float* b, float* a, int N, int C,
+                     int H, int Wd, int K, int pad, int Ho, int Wo, int act, float prm);
 
 int tn_conv_wgrad_finish(tn_ctx* ctx, const float* partial, const float* dbpartial, float* dW,
                          float* db, int nblk, int K, int C, int f) {
@@ -390,6 +397,9 @@ int tn_conv2d_fwd(tn_ctx* ctx, const float* x, const float* W, const float* b, f
                "tn_conv2d_fwd: bad shape");
     if (tn_conv_mfma_supported(C, K, f, stride))
         return tn_conv_mfma_fwd(ctx, x, W, b, a, N, C, H, Wd, K, f, pad_lo, Ho, Wo, act, act_param);
+    // few input channels (first layers): still worth the matrix core when the LDS-tile kernel applies
+    if (stride == 1 && K >= 16 && tn_conv_tile_ok(x, N, C, H, Wd, K, f, pad_lo, Ho, Wo))
+        return tn_conv_tile_fwd(ctx, x, W, b, a, N, C, H, Wd, K, pad_lo, Ho, Wo, act, act_param);
     const long long M = (long long)N * Ho * Wo;
     const int gx = cdiv(M, 256);
 #define LAUNCH_FWD(F_, KT_)                                                                     \
@@ -413,6 +423,8 @@ int tn_conv2d_wgrad(tn_ctx* ctx, const float* x, const float* dz, float* dW, flo
     TN_REQUIRE(N > 0 && C > 0 && K > 0 && f > 0 && stride > 0, "tn_conv2d_wgrad: bad shape");
     if (tn_conv_mfma_supported(C, K, f, stride))
         return tn_conv_mfma_wgrad(ctx, x, dz, dW, db, N, C, H, Wd, K, f, pad_lo, Ho, Wo);
+    if (stride == 1 && tn_conv_tile_smallc_ok(x, dz, N, C, H, Wd, K, f, pad_lo, Ho, Wo))   // first layers
+        return tn_conv_tile_smallc_wgrad(ctx, x, dz, dW, db, N, C, H, Wd, K);
     const long long M = (long long)N * Ho * Wo;
     if (f == 3 || f == 5 || f == 1 || f == 2) {
         int nblk = cdiv(M, 256 * 16);

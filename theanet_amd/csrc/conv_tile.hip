@@ -110,7 +110,9 @@ __device__ __forceinline__ CtSlot ct_slot(const ConvTG& g, int t, int s, int n0,
 
 // POOL: forward -> bias + act + 2x2 max-pool + pooling mask in the epilogue (the conv activation never
 // reaches HBM); dgrad -> the gathered tensor dz is expanded from the pooled gradient while it is staged.
-template <int FT, bool DGRAD, bool POOL>
+// NCP: channel pairs of a chunk that can be non-zero (4; 2 for nets' first layers with C <= 4, which
+// fit one chunk: the steps of the all-zero pairs are not issued).
+template <int FT, bool DGRAD, bool POOL, int NCP = 4>
 __global__ __launch_bounds__(256) void conv_tile_kernel(ConvTG g) {
     extern __shared__ __attribute__((aligned(16))) float ct_smem[];
     constexpr int KBF = 32 * FT;
@@ -214,9 +216,9 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(ConvTG g) {
         }
         __builtin_amdgcn_sched_group_barrier(0x100, 7, 0);            // step 0's operands
 #pragma unroll
-        for (int st = 0; st < 12; ++st) {
+        for (int st = 0; st < 3 * NCP; ++st) {
             const int cur = st & 1, nx = cur ^ 1;
-            if (st + 1 < 12) {
+            if (st + 1 < 3 * NCP) {
                 const int cp = (st + 1) / 3, u = (st + 1) % 3;
 #pragma unroll
                 for (int v = 0; v < 3; ++v) {
@@ -432,13 +434,13 @@ extern "C" int tn_conv_tile_dbg_read(tn_ctx* ctx, unsigned long long* host, int 
     return hipMemcpy(host, ct_dbg_buf, (size_t)nblocks * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
 }
 
-template <int FT, bool DGRAD, bool POOL>
+template <int FT, bool DGRAD, bool POOL, int NCP = 4>
 static int ct_launch(tn_ctx* ctx, ConvTG& g) {
     static bool attr_set = false;
     size_t lds = ct_lds_bytes(g, FT);
     if (const char* e = getenv("TN_CT_LDS")) lds = (size_t)atoi(e) > lds ? (size_t)atoi(e) : lds;
     if (!attr_set) {
-        TN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_tile_kernel<FT, DGRAD, POOL>),
+        TN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_tile_kernel<FT, DGRAD, POOL, NCP>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
@@ -449,7 +451,7 @@ static int ct_launch(tn_ctx* ctx, ConvTG& g) {
         ct_dbg_buf = dbgbuf;
         g.dbg = grid <= 65536 ? dbgbuf : nullptr;
     }
-    conv_tile_kernel<FT, DGRAD, POOL><<<grid, 256, lds, ctx->stream>>>(g);
+    conv_tile_kernel<FT, DGRAD, POOL, NCP><<<grid, 256, lds, ctx->stream>>>(g);
     TN_LAUNCH_CHECK();
     return TN_OK;
 }
@@ -468,6 +470,10 @@ static int ct_run(tn_ctx* ctx, ConvTG& g, const float* W, bool dgrad, bool pool 
     TN_LAUNCH_CHECK();
     g.wt = wt;
     g.vec_out = (g.Wo % 4 == 0) && ((reinterpret_cast<uintptr_t>(g.out) | reinterpret_cast<uintptr_t>(g.prev_a)) & 15) == 0;
+    if (!dgrad && g.C <= 4) {        // first layers: one chunk, two channel pairs
+        if (pool) return FT == 2 ? ct_launch<2, false, true, 2>(ctx, g) : ct_launch<1, false, true, 2>(ctx, g);
+        return FT == 2 ? ct_launch<2, false, false, 2>(ctx, g) : ct_launch<1, false, false, 2>(ctx, g);
+    }
     if (pool) {
         if (dgrad) return FT == 2 ? ct_launch<2, true, true>(ctx, g) : ct_launch<1, true, true>(ctx, g);
         return FT == 2 ? ct_launch<2, false, true>(ctx, g) : ct_launch<1, false, true>(ctx, g);
@@ -864,6 +870,7 @@ int tn_conv_tile_pool_bwd(tn_ctx* ctx, const float* x, const float* W, const flo
 // =================================================================================================
 struct ConvSG {
     const float* x;
+    const float* dz;       // POOL == false: the plain dz tensor (N, K, H, Wd)
     float* ws;             // [S*4][K*C*9]
     float* dbws;           // [S][K]
     int N, C, H, Wd, K;
@@ -873,6 +880,7 @@ struct ConvSG {
     PoolSrc ps;
 };
 
+template <bool POOL>
 __global__ __launch_bounds__(256) void conv_tile_wgrad_smallc_kernel(ConvSG g) {
     extern __shared__ __attribute__((aligned(16))) float ct_smem[];
     constexpr int DZSZ = 32 * CW_DZS;
@@ -902,7 +910,9 @@ __global__ __launch_bounds__(256) void conv_tile_wgrad_smallc_kernel(ConvSG g) {
             const int q_ = e_ & 31, f_ = e_ >> 5, p_ = 4 * q_;                                   \
             const int n_ = (N0) + (p_ >> g.lgP), row_ = (R0) + ((p_ >> g.lgW) & THm), k_ = kg * 32 + f_; \
             const bool ok_ = n_ < n_end && k_ < g.K;                                             \
-            sv[SL] = cw_mask4(pool_expand4(g.ps, min(n_, g.N - 1) * g.K + min(k_, g.K - 1), row_, p_ & Wm), ok_); \
+            const int pl_ = min(n_, g.N - 1) * g.K + min(k_, g.K - 1);                            \
+            if (POOL) sv[SL] = cw_mask4(pool_expand4(g.ps, pl_, row_, p_ & Wm), ok_);            \
+            else sv[SL] = cw_mask4(*reinterpret_cast<const float4*>(g.dz + ((size_t)pl_ * g.H + row_) * g.Wd + (p_ & Wm)), ok_); \
             so[SL] = f_ * CW_DZS + p_;                                                           \
         } else {                                                                                 \
             const int e_ = t;                                                                    \
@@ -1016,28 +1026,52 @@ extern "C" int tn_convpool_smallc_supported(int N, int C, int H, int Wd, int K, 
     return cs_geometry(g, 256);
 }
 
+static int cs_run(tn_ctx* ctx, ConvSG& g, float* dW, float* db, bool pool) {
+    TN_REQUIRE(cs_geometry(g, ctx->num_cus), "conv_tile_smallc: unsupported shape");
+    TN_REQUIRE((long long)g.N * g.K * g.H * g.Wd < (1ll << 31), "conv_tile_smallc: tensor too large for 32-bit offsets");
+    const size_t n = (size_t)g.K * g.C * 9;
+    int rc = tn_scratch_get(ctx, ((size_t)g.S * 4 * n + (size_t)g.S * g.K) * sizeof(float), &g.ws);
+    if (rc) return rc;
+    g.dbws = g.ws + (size_t)g.S * 4 * n;
+    const int XSZ = (g.C * g.plane + 3) & ~3;
+    const size_t lds = (size_t)(2 * (32 * CW_DZS + XSZ) + 16) * sizeof(float);
+    const int grid = 8 * cdiv(g.S, 8) * g.KG;
+    if (pool) conv_tile_wgrad_smallc_kernel<true><<<grid, 256, lds, ctx->stream>>>(g);
+    else conv_tile_wgrad_smallc_kernel<false><<<grid, 256, lds, ctx->stream>>>(g);
+    TN_LAUNCH_CHECK();
+    rc = tn_red_push(ctx, g.ws, dW, (uint32_t)n, (uint32_t)(g.S * 4), (uint32_t)n, 0);
+    if (rc) return rc;
+    rc = tn_red_push(ctx, g.dbws, db, (uint32_t)g.K, (uint32_t)g.S, (uint32_t)g.K, 0);
+    if (rc) return rc;
+    return tn_red_commit(ctx);
+}
+
 int tn_conv_tile_smallc_bwd(tn_ctx* ctx, const float* x, const float* g_, const float* y, const uint8_t* mask,
                             float* dW, float* db, int N, int C, int H, int Wd, int K, int act, float prm) {
     ConvSG g{};
     g.x = x;
     g.N = N; g.C = C; g.H = H; g.Wd = Wd; g.K = K;
     g.ps.g = g_; g.ps.y = y; g.ps.mask = mask; g.ps.Hp = H / 2; g.ps.Wp = Wd / 2; g.ps.act = act; g.ps.prm = prm;
-    TN_REQUIRE(cs_geometry(g, ctx->num_cus), "conv_tile_smallc_bwd: unsupported shape");
     TN_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(g_) | reinterpret_cast<uintptr_t>(y)) & 15) == 0 &&
                (reinterpret_cast<uintptr_t>(mask) & 3) == 0, "conv_tile_smallc_bwd: misaligned operand");
-    TN_REQUIRE((long long)N * K * H * Wd < (1ll << 31), "conv_tile_smallc_bwd: tensor too large for 32-bit offsets");
-    const size_t n = (size_t)K * C * 9;
-    int rc = tn_scratch_get(ctx, ((size_t)g.S * 4 * n + (size_t)g.S * K) * sizeof(float), &g.ws);
-    if (rc) return rc;
-    g.dbws = g.ws + (size_t)g.S * 4 * n;
-    const int XSZ = (C * g.plane + 3) & ~3;
-    const size_t lds = (size_t)(2 * (32 * CW_DZS + XSZ) + 16) * sizeof(float);
-    const int grid = 8 * cdiv(g.S, 8) * g.KG;
-    conv_tile_wgrad_smallc_kernel<<<grid, 256, lds, ctx->stream>>>(g);
-    TN_LAUNCH_CHECK();
-    rc = tn_red_push(ctx, g.ws, dW, (uint32_t)n, (uint32_t)(g.S * 4), (uint32_t)n, 0);
-    if (rc) return rc;
-    rc = tn_red_push(ctx, g.dbws, db, (uint32_t)K, (uint32_t)g.S, (uint32_t)K, 0);
-    if (rc) return rc;
-    return tn_red_commit(ctx);
+    return cs_run(ctx, g, dW, db, true);
+}
+
+// unfused first layers: dW, db from the plain dz tensor
+int tn_conv_tile_smallc_ok(const float* x, const float* dz, int N, int C, int H, int Wd, int K, int f, int pad,
+                           int Ho, int Wo) {
+    if (!ct_enabled() || f != 3 || pad != 1 || Ho != H || Wo != Wd || C * 9 > 32 || K < 16) return 0;
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dz)) & 15) return 0;
+    if (const char* e = getenv("TN_CONV_TILE_SMALLC")) if (e[0] == '0') return 0;
+    ConvSG g{};
+    g.N = N; g.C = C; g.H = H; g.Wd = Wd; g.K = K;
+    return cs_geometry(g, 256);
+}
+
+int tn_conv_tile_smallc_wgrad(tn_ctx* ctx, const float* x, const float* dz, float* dW, float* db, int N, int C,
+                              int H, int Wd, int K) {
+    ConvSG g{};
+    g.x = x; g.dz = dz;
+    g.N = N; g.C = C; g.H = H; g.Wd = Wd; g.K = K;
+    return cs_run(ctx, g, dW, db, false);
 }
