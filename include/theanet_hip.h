@@ -308,6 +308,15 @@ int tn_sgd_update_multi_cost(tn_ctx* ctx, const tn_sgd_seg* d_segs, int nseg, si
                              const float* d_lr, float gscale, uint32_t* d_step_inc,
                              const float* rowloss, int nrow, float cost_scale, float* d_cost);
 
+/* Update for the data-parallel "delayed" schedule.  layer.py:82-86 applies the OLD velocity
+ * (p' = p - rate*lr*v, v' = m v + (1-m) g), so the weights of step t+1 do not depend on the gradient
+ * of step t and its all-reduce may overlap the whole next step.  seg.g points at the REDUCED gradient
+ * of the PREVIOUS step; mode 1: v = m v + (1-m) g, then p -= rate*lr*v (steady state); mode 2: p only
+ * (first delayed step); mode 3: v only (leaving the schedule).  No L1/L2 terms (they need the weights
+ * the gradient was taken at).  Same weight trajectory as tn_sgd_update_multi, bit for bit.        */
+int tn_sgd_update_multi_delayed(tn_ctx* ctx, const tn_sgd_seg* d_segs, int nseg, size_t max_n,
+                                const float* d_lr, float gscale, uint32_t* d_step_inc, int mode);
+
 /* tn_sgd_update_multi_cost that also ENDS a tn_defer_reductions window: a segment whose gradient is
  * still a stack of deferred partial slabs sums them on the fly (same order as the reduction launch:
  * bit-identical), stores the gradient and applies the update -- one launch less per step.  h_segs is

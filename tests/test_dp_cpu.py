@@ -70,3 +70,37 @@ def test_world_size_2_gradient_allreduce_equals_full_batch(tmp_path):
     r = np.load(out)
     assert r["err"] < 1e-12
     np.testing.assert_allclose(r["cost"], r["cost_full"], rtol=1e-12)
+
+
+def test_delayed_update_recurrence_is_the_reference_recurrence():
+    """The data-parallel 'delayed' schedule (NeuralNet._train_step, tn_sgd_update_multi_delayed): the
+    reference's update applies the OLD velocity (layer.py:82-86), so p_{t+1} only needs the gradient of
+    step t-1.  Updating at the end of step t with the reduced gradient of step t-1 (mode 2 on the first
+    step, mode 1 afterwards, mode 3 when leaving) must reproduce the reference weights exactly."""
+    rng = np.random.RandomState(0)
+    A, p0 = rng.randn(6, 6), rng.randn(6)
+    grad = lambda p: A @ p + np.sin(p)          # any function of the CURRENT weights
+    m, s = 0.95, 0.1
+
+    p, v = p0.copy(), np.zeros(6)
+    ref_p, ref_v = [], []
+    for t in range(8):                           # layer.py:82-86, simultaneous updates
+        g = grad(p)
+        p, v = p - s * v, m * v + (1 - m) * g
+        ref_p.append(p.copy())
+        ref_v.append(v.copy())
+
+    p, v, pending = p0.copy(), np.zeros(6), None
+    got = []
+    for t in range(8):
+        g = grad(p)                              # its all-reduce starts here, lands during step t+1
+        if pending is None:
+            p = p - s * v                        # mode 2: v is v_t already
+        else:
+            v = m * v + (1 - m) * pending        # mode 1: v_t from the gradient of step t-1
+            p = p - s * v
+        pending = g
+        got.append(p.copy())
+    np.testing.assert_array_equal(np.array(got), np.array(ref_p))
+    v = m * v + (1 - m) * pending                # mode 3: leaving the schedule catches v up
+    np.testing.assert_array_equal(v, ref_v[-1])

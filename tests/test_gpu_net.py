@@ -297,8 +297,9 @@ def test_dp_overlap_schedule_equals_plain(monkeypatch):
 
 def test_dp_schedule_autotune(monkeypatch):
     """TN_DP_OVERLAP=auto (the default with more than one rank), exercised with a 1-rank RCCL
-    communicator: a few steps of each schedule are timed, the ranks agree on one through an
-    all-reduce(max), and training is unaffected (both schedules are pure re-orderings)."""
+    communicator: a few steps of each schedule (plain, overlapped, delayed all-reduce) are timed, the
+    ranks agree on one through an all-reduce(max), and training is unaffected (the schedules are pure
+    re-orderings; switching in and out of the delayed one catches the velocity up)."""
     from theanet_amd import NeuralNet
     import copy
     prms = load_prms("mnist.prms", 28, batch=64)
@@ -306,28 +307,68 @@ def test_dp_schedule_autotune(monkeypatch):
     x = rng.rand(4 * 64, 1, 28, 28).astype(np.float32)
     y = rng.randint(0, 10, 4 * 64).astype(np.int32)
     nets = []
-    nsteps = 2 * NeuralNet._DP_TUNE_WARM + 2 * NeuralNet._DP_TUNE_STEPS + 4
+    leg = NeuralNet._DP_TUNE_WARM + NeuralNet._DP_TUNE_STEPS
+    nsteps = 3 * leg + 5
     for overlap in ("auto", "0"):
         monkeypatch.setenv("TN_DP_FORCE", "1")
         monkeypatch.setenv("TN_DP_OVERLAP", overlap)
         net = NeuralNet(copy.deepcopy(prms["layers"]), dict(prms["training_params"]))
         fn = net.get_trin_model(x, y)
         if overlap == "auto":
-            assert net._dp_tune is not None and net._dp_split is None
+            assert net._dp_tune is not None and net._dp_tune["cands"] == ["plain", "overlap", "delayed"]
         for s in range(nsteps):
             fn.enqueue(s % 4)
-            if overlap == "auto" and s == NeuralNet._DP_TUNE_WARM + NeuralNet._DP_TUNE_STEPS:
-                assert net._dp_split is not None          # second leg: overlapped schedule
+            if overlap == "auto" and s == leg + 1:
+                assert net._dp_split is not None and not net._dp_delayed     # second leg: overlapped
+            if overlap == "auto" and s == 2 * leg + 1:
+                assert net._dp_delayed and net._dp_pending                   # third leg: delayed
         outs = fn.fetch()
         if overlap == "auto":
-            assert net._dp_tune is None and net.dp_schedule in ("plain", "overlap")
+            assert net._dp_tune is None and net.dp_schedule in ("plain", "overlap", "delayed")
             assert (net._dp_split is not None) == (net.dp_schedule == "overlap")
-            plain_ms, overlap_ms = net.dp_tuned_ms
-            assert 0 < plain_ms < 5 and 0 < overlap_ms < 5
+            assert net._dp_delayed == (net.dp_schedule == "delayed")
+            assert set(net.dp_tuned_ms) == {"plain", "overlap", "delayed"}
+            assert all(0 < v < 5 for v in net.dp_tuned_ms.values())
         nets.append((net, outs))
         net.ctx.call("tn_comm_destroy")
         net._dev_group = None
+    assert nets[0][1][0] == nets[1][1][0]
     np.testing.assert_array_equal(nets[0][1][1], nets[1][1][1])
+    for la, lb in zip(nets[0][0].tr_layers, nets[1][0].tr_layers):
+        for wa, wb in zip(la.get_wts(), lb.get_wts()):
+            np.testing.assert_array_equal(wa, wb)
+
+
+@pytest.mark.parametrize("name,img,ch,B", [("mnist.prms", 28, 1, 64), ("cifar_like.prms", 32, 3, 16)])
+def test_dp_delayed_allreduce_equals_plain(monkeypatch, name, img, ch, B):
+    """Delayed schedule (TN_DP_OVERLAP=2): step t updates with the reduced gradient of step t-1 -- the
+    reference applies the old velocity, so this is the same weight trajectory -- and the all-reduce of
+    step t runs under step t+1.  Costs, log-probabilities and weights must match the plain schedule
+    bit for bit at every step."""
+    from theanet_amd import NeuralNet
+    import copy
+    prms = load_prms(name, img, batch=B)
+    rng = np.random.RandomState(8)
+    x = rng.rand(4 * B, ch, img, img).astype(np.float32)
+    y = rng.randint(0, 10, 4 * B).astype(np.int32)
+    nets = []
+    for mode in ("2", "0"):
+        monkeypatch.setenv("TN_DP_FORCE", "1")
+        monkeypatch.setenv("TN_DP_OVERLAP", mode)
+        net = NeuralNet(copy.deepcopy(prms["layers"]), dict(prms["training_params"]))
+        fn = net.get_trin_model(x, y)
+        assert net._dp_delayed == (mode == "2")
+        outs = []
+        for s in range(7):
+            if s == 4:
+                net.inc_epoch_set_rate()
+            outs.append(fn(s % 4))
+        nets.append((net, outs))
+        net.ctx.call("tn_comm_destroy")
+        net._dev_group = None
+    for (c0, _, l0), (c1, _, l1) in zip(nets[0][1], nets[1][1]):
+        assert c0 == c1
+        np.testing.assert_array_equal(l0, l1)
     for la, lb in zip(nets[0][0].tr_layers, nets[1][0].tr_layers):
         for wa, wb in zip(la.get_wts(), lb.get_wts()):
             np.testing.assert_array_equal(wa, wb)

@@ -88,6 +88,7 @@ SIGNATURES = {
                              P, c_uint64, P, c_int, c_int, c_double, c_double, c_double, c_int, c_double,
                              c_int, P, P, P, P]),
     "tn_sgd_update_multi": (c_int, [CTX, P, c_int, c_size_t, P, c_float, P]),
+    "tn_sgd_update_multi_delayed": (c_int, [CTX, P, c_int, c_size_t, P, c_float, P, c_int]),
     "tn_sgd_update_multi_lazy": (c_int, [CTX, P, P, c_int, c_size_t, P, c_float, P, P, c_int, c_float, P]),
     "tn_sgd_update_multi_cost": (c_int, [CTX, P, c_int, c_size_t, P, c_float, P, P, c_int, c_float, P]),
     "tn_softmax_cost_ws_bytes": (c_size_t, [c_int]),

@@ -34,6 +34,40 @@ __global__ __launch_bounds__(256) void sgd_update_multi_kernel(const tn_sgd_seg*
                            blockIdx.x, blockIdx.y, gridDim.x, red);
 }
 
+// Data-parallel "delayed" schedule (see NeuralNet._train_step): the reference applies the OLD velocity
+// (layer.py:82-86: v' = m v + (1-m) g ; p' = p - rate*lr*v), so the weights of step t+1 do not depend
+// on the gradient of step t -- the all-reduce of g_t may take the whole of step t+1.  At the end of
+// step t the stored velocity is still v_{t-1} and seg.g points at the REDUCED gradient of step t-1:
+//   mode 1: v = m v + (1-m) G_{t-1} (= v_t) ; p = p - step * v      -- the steady state
+//   mode 2: p = p - step * v                                        -- first delayed step (v is v_t already)
+//   mode 3: v = m v + (1-m) G_{t-1}                                 -- leaving the schedule: catch v up
+// Same expressions as sgd_update_multi_block, so the weight trajectory is bit-identical.
+__global__ __launch_bounds__(256) void sgd_update_delayed_kernel(const tn_sgd_seg* __restrict__ segs, int nseg,
+                                                                const float* __restrict__ d_lr, float gscale,
+                                                                uint32_t* d_step_inc, int mode) {
+    const int bx = blockIdx.x, by = blockIdx.y, nbx = gridDim.x;
+    if (d_step_inc && bx == 0 && by == 0 && threadIdx.x == 0) *d_step_inc += 1;
+    const tn_sgd_seg sg = segs[by];
+    const float step = sg.rate * d_lr[0];
+    float* __restrict__ p = sg.p;
+    float* __restrict__ v = sg.v;
+    const float* __restrict__ g = sg.g;
+    const size_t n = sg.n;
+    const float m = sg.momentum;
+    for (size_t i = (size_t)bx * 256 + threadIdx.x; i < n; i += (size_t)nbx * 256) {
+        float vv = v[i];
+        if (mode != 2) {
+            const float gg = g[i] * gscale;
+            vv = m * vv + (1.f - m) * gg;
+            v[i] = vv;
+        }
+        if (mode != 3) {
+            const float pv = p[i];
+            p[i] = pv - step * vv;
+        }
+    }
+}
+
 // The same launch with LAZY gradients: segments whose weight gradient is still a stack of partial
 // slabs (the deferred finishing sums of reduce.hip) add the slabs up on the fly -- in exactly the
 // order slab_sum_multi_kernel uses, so the result is bit-identical -- write the gradient out and
@@ -231,6 +265,17 @@ int tn_sgd_update_multi_cost(tn_ctx* ctx, const tn_sgd_seg* d_segs, int nseg, si
     if (bx < 1) bx = 1;
     sgd_update_multi_kernel<<<dim3(bx, nseg + (rider ? 1 : 0)), 256, 0, ctx->stream>>>(
         d_segs, nseg, d_lr, gscale, d_step_inc, rowloss, nrow, cost_scale, d_cost);
+    TN_LAUNCH_CHECK();
+    return TN_OK;
+}
+
+int tn_sgd_update_multi_delayed(tn_ctx* ctx, const tn_sgd_seg* d_segs, int nseg, size_t max_n,
+                                const float* d_lr, float gscale, uint32_t* d_step_inc, int mode) {
+    TN_REQUIRE(nseg > 0 && d_segs && d_lr && mode >= 1 && mode <= 3, "tn_sgd_update_multi_delayed: bad arguments");
+    int bx = cdiv(max_n, 1024);
+    if (bx > 256) bx = 256;
+    if (bx < 1) bx = 1;
+    sgd_update_delayed_kernel<<<dim3(bx, nseg), 256, 0, ctx->stream>>>(d_segs, nseg, d_lr, gscale, d_step_inc, mode);
     TN_LAUNCH_CHECK();
     return TN_OK;
 }

@@ -143,6 +143,8 @@ class _TrainFn:
     def fetch(self):
         net = self.net
         out = net.tr_layers[-1]
+        if getattr(net, "_dp_pending", False):
+            net.ctx.sync()                        # the cost travels with the all-reduce on the second stream
         cost = net.d_cost.get_value()[0]
         logprob = out.logprob.get_value()
         return [cost, logprob, logprob]      # features IS logprob for Softmax (outlayers.py:92-93)
@@ -423,6 +425,8 @@ class NeuralNet():
         # small all-reduce is latency-bound either way.
         self._dp_split, self._dp_off = None, 0
         self._dp_cand, self._dp_tune, self.dp_schedule = None, None, "plain"
+        self._dp_delayed, self._dp_pending, self._dp_cur, self._dp_can_delay = False, False, 0, False
+        self._dp_bound = 0
         if self._dp:
             j = len(self.tr_layers)
             while j > 0 and isinstance(self.tr_layers[j - 1], HiddenLayer):
@@ -430,30 +434,79 @@ class NeuralNet():
             top = [l for l in self.tr_layers[j:] if l.params]
             if 0 < j < len(self.tr_layers) and top and any(l.has_updates() for l in self.tr_layers[:j]):
                 self._dp_cand = (j, (top[0].grads[0].ptr - self.flat_grads.ptr) // 4)
-            # Which schedule is faster depends on what the all-reduce costs on this node (RCCL latency
-            # over xGMI vs. the 18 us of extra launches and stream joins): with more than one rank it is
+            # "delayed" schedule: the all-reduce of step t runs under the whole of step t+1 (exact, see
+            # _train_step).  It needs a second flat gradient buffer (g_{t+1} is produced while G_t is
+            # in flight) and gradients that do not depend on the weights they are applied to (no L1/L2).
+            self._dp_can_delay = bool(segs) and not has_wtcost
+            if self._dp_can_delay:
+                self._flat_ab = [self.flat_grads, self.ctx.zeros((total + _GRAD_ALIGN,))]
+                self._grads_ab, self._segs_ab = [], [self._d_segs]
+                for buf in self._flat_ab:
+                    self._grads_ab.append({id(lyr): [buf.view(off, p.shape) for l2, p, off in slots if l2 is lyr]
+                                           for lyr in self.tr_layers if lyr.params})
+                host_b = host.copy()
+                host_b['g'] = host['g'] - self.flat_grads.ptr + self._flat_ab[1].ptr
+                self._segs_ab.append(self.ctx.array(host_b.view(np.uint8)))
+            # Which schedule is fastest depends on what the all-reduce costs on this node (RCCL latency
+            # over xGMI vs. the extra launches and stream joins): with more than one rank it is
             # MEASURED -- TN_DP_OVERLAP=auto times a few steps of each schedule on the first calls,
-            # the ranks agree on the result through an all-reduce(max) and keep the faster one.
+            # the ranks agree on the result through an all-reduce(max) and keep the fastest one.
             mode = os.environ.get("TN_DP_OVERLAP", "auto" if self.world.size > 1 else "0")
             if self._dp_cand and mode == "1":
                 self._dp_split, self._dp_off = self._dp_cand
                 self.dp_schedule = "overlap"
-            elif self._dp_cand and mode == "auto":
-                self._dp_tune = {"k": 0, "ev": {}}
+            elif self._dp_can_delay and mode == "2":
+                self._dp_delayed, self.dp_schedule = True, "delayed"
+            elif mode == "auto":
+                cands = ["plain"] + (["overlap"] if self._dp_cand else []) + \
+                    (["delayed"] if self._dp_can_delay else [])
+                if len(cands) > 1:
+                    self._dp_tune = {"k": 0, "ev": {}, "cands": cands, "ms": []}
         self._grads_ready = True
 
     _DP_TUNE_WARM, _DP_TUNE_STEPS = 8, 24
 
+    def _dp_bind(self, cur):
+        """Point every layer's gradient views, the cost slot and the update's segment table at flat
+        gradient buffer ``cur`` (the delayed schedule alternates between two)."""
+        if not self._dp_can_delay or self._dp_bound == cur:
+            return
+        self._dp_bound = cur
+        self.flat_grads = self._flat_ab[cur]
+        for lyr in self.tr_layers:
+            if lyr.params:
+                lyr.grads = self._grads_ab[cur][id(lyr)]
+        self.d_cost = self.flat_grads.view(self.n_flat - 1, (1,))
+        self.tr_layers[-1].d_cost = self.d_cost
+        self._d_segs = self._segs_ab[cur]
+
+    def _dp_set_schedule(self, name):
+        """Switch the data-parallel schedule between steps (all ranks at the same step index)."""
+        if self._dp_delayed and name != "delayed" and self._dp_pending:
+            # leaving the delayed schedule: the velocity is one gradient behind -- catch it up
+            prev = 1 - self._dp_cur
+            self.ctx.call("tn_stream_wait", 0, 1)
+            self.ctx.call("tn_sgd_update_multi_delayed", self._segs_ab[prev].ptr, self._n_segs, self._max_seg,
+                          self.cur_learn_rate.ptr, 1.0, None, 3)
+            self._dp_pending = False
+        if name != "delayed":
+            self._dp_cur = 0
+        self._dp_delayed = name == "delayed"
+        self._dp_split, self._dp_off = self._dp_cand if name == "overlap" else (None, 0)
+        self.dp_schedule = name
+
     def _dp_tune_tick(self):
-        """TN_DP_OVERLAP=auto: steps [W, W+M) run the plain schedule under a pair of HIP events, steps
-        [2W+M, 2W+2M) the overlapped one; then every rank takes the max over ranks of both times and
-        keeps the faster schedule.  All ranks switch at the same step index (the schedules issue
-        different collectives).  The steps are ordinary training steps: nothing is thrown away."""
+        """TN_DP_OVERLAP=auto: every candidate schedule (plain / overlapped all-reduce / delayed
+        all-reduce) runs W warm-up + M timed steps under a pair of HIP events; then every rank takes
+        the max over ranks of the times and keeps the fastest schedule.  All ranks switch at the same
+        step index (the schedules issue different collectives).  The steps are ordinary training
+        steps: nothing is thrown away, the weight trajectory is the same under every schedule."""
         import ctypes
         ctx, T = self.ctx, self._dp_tune
         W, M = self._DP_TUNE_WARM, self._DP_TUNE_STEPS
-        k = T["k"]
+        k, cands = T["k"], T["cands"]
         T["k"] = k + 1
+        leg, pos = divmod(k, W + M)
 
         def mark(name):
             e = ctypes.c_void_p()
@@ -461,37 +514,31 @@ class NeuralNet():
             ctx.call("tn_event_record", e)
             T["ev"][name] = e
 
-        if k == W:
-            mark("a0")
-        elif k == W + M:
-            mark("a1")
-            self._dp_split, self._dp_off = self._dp_cand
-        elif k == 2 * W + M:
-            mark("b0")
-        elif k == 2 * W + 2 * M:
-            mark("b1")
+        if pos == 0:
+            if leg > 0:
+                mark("e%d" % (leg - 1))
+            if leg < len(cands):
+                self._dp_set_schedule(cands[leg])
+        if pos == W and leg < len(cands):
+            mark("s%d" % leg)
+        if leg == len(cands) and pos == 0:
             ctx.sync()
             ms = []
-            for a, b in (("a0", "a1"), ("b0", "b1")):
+            for q in range(len(cands)):
                 v = ctypes.c_float()
-                ctx.call("tn_event_elapsed_ms", T["ev"][a], T["ev"][b], ctypes.byref(v))
+                ctx.call("tn_event_elapsed_ms", T["ev"]["s%d" % q], T["ev"]["e%d" % q], ctypes.byref(v))
                 ms.append(v.value)
             for e in T["ev"].values():
                 ctx.lib.tn_event_destroy(ctx.h, e)
             t = ctx.array(np.asarray(ms, np.float32))
             self._group().allreduce_max(t)
-            plain, overlap = (float(v) for v in t.get_value())
-            self.dp_tuned_ms = (plain / M, overlap / M)
-            if overlap < plain:
-                self.dp_schedule = "overlap"
-            else:
-                self.dp_schedule = "plain"
-                self._dp_split, self._dp_off = None, 0
+            ms = [float(v) / M for v in t.get_value()]
+            self.dp_tuned_ms = dict(zip(cands, ms))
             self._dp_tune = None
+            self._dp_set_schedule(cands[int(np.argmin(ms))])
             if self.world.rank == 0:
-                sys.stderr.write("theanet_amd: data-parallel schedule '%s' (plain %.1f us/step, overlapped "
-                                 "all-reduce %.1f us/step)\n" % (self.dp_schedule, 1e3 * plain / M,
-                                                                 1e3 * overlap / M))
+                sys.stderr.write("theanet_amd: data-parallel schedule '%s' (%s)\n" % (
+                    self.dp_schedule, ", ".join("%s %.1f us/step" % (c, 1e3 * m) for c, m in zip(cands, ms))))
 
     def _train_step(self, y, y_row0, d_row0=None):
         """forward + backward + all-reduce + update for the minibatch the input slot
@@ -501,6 +548,8 @@ class NeuralNet():
         first = self.tr_layers[0]
         if self._dp_tune is not None and not self.use_graph:
             self._dp_tune_tick()
+        if self._dp_can_delay:
+            self._dp_bind(self._dp_cur if self._dp_delayed else 0)
         if isinstance(first, ElasticLayer):
             first.precompute = self.side_stream and not self.use_graph and self.elastic_ahead
         # Random inputs that depend only on the step counter are produced on the side stream,
@@ -598,7 +647,29 @@ class NeuralNet():
                 ctx.call("tn_defer_flush_step", self.d_step.ptr)      # the counter advances here
             elif not lazy:
                 ctx.call("tn_defer_reductions", 0)
-        if self._dp:
+        delayed = self._dp_delayed
+        if delayed and (tail or self.use_graph):
+            self._dp_set_schedule("plain")        # (configuration-determined: the same on every rank)
+            delayed = False
+        if delayed:
+            # Delayed schedule.  layer.py:82-86 applies the OLD velocity, so p_{t+1} = p_t - s*v_t needs
+            # the gradient of step t-1, not of this step: update with the REDUCED gradient of the
+            # previous step (its all-reduce had this whole step to finish), then start this step's
+            # all-reduce on the second stream, where it runs under the next step.  Bit-identical weights.
+            cur = self._dp_cur
+            if self._dp_pending:
+                ctx.call("tn_stream_wait", 0, 1)
+                ctx.call("tn_sgd_update_multi_delayed", self._segs_ab[1 - cur].ptr, self._n_segs,
+                         self._max_seg, self.cur_learn_rate.ptr, 1.0, self.d_step.ptr, 1)
+            else:
+                ctx.call("tn_sgd_update_multi_delayed", self._segs_ab[cur].ptr, self._n_segs,
+                         self._max_seg, self.cur_learn_rate.ptr, 1.0, self.d_step.ptr, 2)
+            ctx.call("tn_stream_wait", 1, 0)
+            ctx.call("tn_stream_select", 1)
+            self._group().allreduce_sum(self._flat_ab[cur], self.n_flat)
+            ctx.call("tn_stream_select", 0)
+            self._dp_pending, self._dp_cur = True, 1 - cur
+        elif self._dp:
             if dp_async:
                 if self._dp_off:
                     self._group().allreduce_sum(self.flat_grads, self._dp_off)     # the conv head
@@ -607,7 +678,9 @@ class NeuralNet():
                 self._group().allreduce_sum(self.flat_grads, self.n_flat)
         for lyr in self.tr_layers:
             lyr.get_wtcost(self.d_cost)
-        if tail:
+        if delayed:
+            pass
+        elif tail:
             ctx.call("tn_step_tail", self._d_segs.ptr if self._n_segs else None, self._n_segs,
                      self._max_seg, self.cur_learn_rate.ptr, 1.0,
                      out.rowloss.ptr if rider else None, self.local_bsz, 1.0 / self.batch_sz,
