@@ -104,6 +104,12 @@ def main():
         if group is not None:
             group.barrier()
 
+    # data-parallel runs first let the schedule autotune finish (untimed set-up steps: it times a few
+    # steps of each all-reduce schedule and every rank adopts the fastest, NeuralNet._dp_tune_tick)
+    tune_steps = 0
+    while getattr(net, "_dp_tune", None) is not None and tune_steps < 1000:
+        fn.enqueue(tune_steps % n_batches)
+        tune_steps += 1
     for i in range(args.warmup):
         fn.enqueue(i % n_batches)
     barrier()
@@ -223,6 +229,9 @@ def main():
         "config": {"workload": "params/%s %dx%dx%d synthetic, %d images/GPU/step, elastic stage on"
                                % (args.prms, img, img, C, per_gpu),
                    "global_batch": tr["BATCH_SZ"], "parallelism": "dp%d" % world.size,
+                   "dp_schedule": getattr(net, "dp_schedule", None) if world.size > 1 else None,
+                   "dp_schedule_us_per_step": {k: 1e3 * v for k, v in getattr(net, "dp_tuned_ms", {}).items()}
+                   if world.size > 1 and isinstance(getattr(net, "dp_tuned_ms", None), dict) else None,
                    "step_gflop_algorithmic": step_flops / 1e9,
                    "step_tflops_algorithmic": step_flops / (dt / args.steps) / 1e12},
         "roofline": roof,

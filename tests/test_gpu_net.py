@@ -307,8 +307,8 @@ def test_dp_schedule_autotune(monkeypatch):
     x = rng.rand(4 * 64, 1, 28, 28).astype(np.float32)
     y = rng.randint(0, 10, 4 * 64).astype(np.int32)
     nets = []
-    leg = NeuralNet._DP_TUNE_WARM + NeuralNet._DP_TUNE_STEPS
-    nsteps = 3 * leg + 5
+    leg, pre = NeuralNet._DP_TUNE_WARM + NeuralNet._DP_TUNE_STEPS, NeuralNet._DP_TUNE_PRE
+    nsteps = pre + 3 * leg + 5
     for overlap in ("auto", "0"):
         monkeypatch.setenv("TN_DP_FORCE", "1")
         monkeypatch.setenv("TN_DP_OVERLAP", overlap)
@@ -318,9 +318,9 @@ def test_dp_schedule_autotune(monkeypatch):
             assert net._dp_tune is not None and net._dp_tune["cands"] == ["plain", "overlap", "delayed"]
         for s in range(nsteps):
             fn.enqueue(s % 4)
-            if overlap == "auto" and s == leg + 1:
+            if overlap == "auto" and s == pre + leg + 1:
                 assert net._dp_split is not None and not net._dp_delayed     # second leg: overlapped
-            if overlap == "auto" and s == 2 * leg + 1:
+            if overlap == "auto" and s == pre + 2 * leg + 1:
                 assert net._dp_delayed and net._dp_pending                   # third leg: delayed
         outs = fn.fetch()
         if overlap == "auto":

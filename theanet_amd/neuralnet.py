@@ -464,7 +464,7 @@ class NeuralNet():
                     self._dp_tune = {"k": 0, "ev": {}, "cands": cands, "ms": []}
         self._grads_ready = True
 
-    _DP_TUNE_WARM, _DP_TUNE_STEPS = 8, 24
+    _DP_TUNE_PRE, _DP_TUNE_WARM, _DP_TUNE_STEPS = 32, 8, 24      # settle-in steps, per-leg warm-up, timed
 
     def _dp_bind(self, cur):
         """Point every layer's gradient views, the cost slot and the update's segment table at flat
@@ -504,8 +504,10 @@ class NeuralNet():
         import ctypes
         ctx, T = self.ctx, self._dp_tune
         W, M = self._DP_TUNE_WARM, self._DP_TUNE_STEPS
-        k, cands = T["k"], T["cands"]
-        T["k"] = k + 1
+        k, cands = T["k"] - self._DP_TUNE_PRE, T["cands"]
+        T["k"] += 1
+        if k < 0:                                 # the first steps of a run are not representative
+            return
         leg, pos = divmod(k, W + M)
 
         def mark(name):
