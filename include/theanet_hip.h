@@ -86,6 +86,7 @@ int tn_graph_destroy(tn_ctx* ctx, void* graph_exec);
 /* ---- timing with HIP events on the ctx stream (bench.py roofline leg) ---- */
 int tn_event_create(tn_ctx* ctx, void** ev);
 int tn_event_record(tn_ctx* ctx, void* ev);
+int tn_event_wait(tn_ctx* ctx, void* ev);            /* the current stream waits for the event */
 int tn_event_elapsed_ms(tn_ctx* ctx, void* ev_start, void* ev_stop, float* ms); /* syncs on stop */
 int tn_event_destroy(tn_ctx* ctx, void* ev);
 
@@ -316,6 +317,23 @@ int tn_sgd_update_multi_cost(tn_ctx* ctx, const tn_sgd_seg* d_segs, int nseg, si
  * the gradient was taken at).  Same weight trajectory as tn_sgd_update_multi, bit for bit.        */
 int tn_sgd_update_multi_delayed(tn_ctx* ctx, const tn_sgd_seg* d_segs, int nseg, size_t max_n,
                                 const float* d_lr, float gscale, uint32_t* d_step_inc, int mode);
+
+/* Update of the PIPELINED single-GPU schedule: two training steps are in flight on the context's two
+ * streams, each with its own weights / activations / gradients.  layer.py:82-86 applies the old
+ * velocity, so the weights of step t are p_{t-1} - rate*lr*v_{t-1} with v_{t-1} built from the gradient
+ * of step t-2: p = the stepping stream's own copy, psrc = the other stream's copy (p_{t-1}, read-only
+ * there), g = the stepping stream's gradient of two steps ago, v shared.  update_v = 0 for the first
+ * two steps (no gradient yet).  *d_step += step_inc (the stream's RNG step counter).          */
+typedef struct tn_pipe_seg {
+    float* p;
+    const float* psrc;
+    float* v;
+    const float* g;
+    uint64_t n;
+    float momentum, rate;
+} tn_pipe_seg;
+int tn_sgd_update_multi_pipe(tn_ctx* ctx, const tn_pipe_seg* d_segs, int nseg, size_t max_n, const float* d_lr,
+                             uint32_t* d_step, uint32_t step_inc, int update_v);
 
 /* tn_sgd_update_multi_cost that also ENDS a tn_defer_reductions window: a segment whose gradient is
  * still a stack of deferred partial slabs sums them on the fly (same order as the reduction launch:

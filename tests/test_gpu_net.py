@@ -441,6 +441,7 @@ def test_step_tail_equals_separate_launches(monkeypatch):
     y = rng.randint(0, 10, 4 * 64).astype(np.int32)
     nets = []
     # rider in the paired GEMM launch / beside the update (tn_step_tail) / a launch of its own
+    monkeypatch.setenv("TN_PIPELINE", "0")        # this test is about the sequential step's launches
     for tail, rider in (("1", "1"), ("1", "0"), ("0", "0")):
         monkeypatch.setenv("TN_STEP_TAIL", tail)
         monkeypatch.setenv("TN_FIELD_RIDER", rider)
@@ -458,6 +459,55 @@ def test_step_tail_equals_separate_launches(monkeypatch):
                 np.testing.assert_array_equal(wa, wb)
 
 
+@pytest.mark.parametrize("name,img,ch,B", [("mnist.prms", 28, 1, 64), ("cifar_like.prms", 32, 3, 16),
+                                           ("wide6.prms", 16, 3, 4)])
+def test_pipelined_steps_equal_sequential(monkeypatch, name, img, ch, B):
+    """Two steps in flight (_PipeTrainFn: the default single-GPU schedule) against the sequential
+    schedule: costs and log-probabilities of every step, test-function results in the middle of
+    training, and the final weights must match bit for bit -- with device RNG (dropout, elastic field),
+    max-norm, a learning-rate change between steps, and both ways of driving the function (fn(i) every
+    step / enqueue-only with one fetch at the end)."""
+    from theanet_amd import NeuralNet
+    from theanet_amd.neuralnet import _PipeTrainFn, _TrainFn
+    import copy
+    prms = load_prms(name, img, batch=B)
+    rng = np.random.RandomState(9)
+    x = rng.rand(4 * B, ch, img, img).astype(np.float32)
+    y = rng.randint(0, 10, 4 * B).astype(np.int32)
+    runs = []
+    for pipe, every in (("1", True), ("0", True), ("1", False), ("0", False)):
+        monkeypatch.setenv("TN_PIPELINE", pipe)
+        net = NeuralNet(copy.deepcopy(prms["layers"]), dict(prms["training_params"]))
+        fn = net.get_trin_model(x, y)
+        assert isinstance(fn, _PipeTrainFn if pipe == "1" else _TrainFn)
+        te = net.get_test_model(x, y)
+        outs, mids = [], []
+        for s in range(9):
+            if s == 5:
+                net.inc_epoch_set_rate()
+            if every:
+                outs.append(fn(s % 4))
+            else:
+                fn.enqueue(s % 4)
+            if s in (2, 5):                       # reading weights / testing mid-training
+                mids.append((te(1), [w.copy() for l in net.tr_layers for w in l.get_wts()]))
+        outs.append(fn.fetch())
+        if pipe == "1":
+            assert fn._seq is None and fn.t == 9
+        runs.append((net, outs, mids))
+    for a, b in ((0, 1), (2, 3)):
+        for (c0, _, l0), (c1, _, l1) in zip(runs[a][1], runs[b][1]):
+            assert c0 == c1
+            np.testing.assert_array_equal(l0, l1)
+        for (t0, w0), (t1, w1) in zip(runs[a][2], runs[b][2]):
+            assert t0 == t1
+            for u, v in zip(w0, w1):
+                np.testing.assert_array_equal(u, v)
+        for la, lb in zip(runs[a][0].tr_layers, runs[b][0].tr_layers):
+            for wa, wb in zip(la.get_wts(), lb.get_wts()):
+                np.testing.assert_array_equal(wa, wb)
+
+
 @pytest.mark.parametrize("name,img,ch,B", [("mnist.prms", 28, 1, 64), ("cifar_like.prms", 32, 3, 16)])
 def test_lazy_update_equals_reduce_then_update(monkeypatch, name, img, ch, B):
     """Summing the weight-gradient slabs inside the update launch (tn_sgd_update_multi_lazy) keeps the
@@ -469,6 +519,7 @@ def test_lazy_update_equals_reduce_then_update(monkeypatch, name, img, ch, B):
     x = rng.rand(4 * B, ch, img, img).astype(np.float32)
     y = rng.randint(0, 10, 4 * B).astype(np.int32)
     nets = []
+    monkeypatch.setenv("TN_PIPELINE", "0")        # this test is about the sequential step's launches
     for lazy in ("1", "0"):
         monkeypatch.setenv("TN_LAZY_UPDATE", lazy)
         net = NeuralNet(copy.deepcopy(prms["layers"]), dict(prms["training_params"]))

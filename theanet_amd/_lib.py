@@ -45,6 +45,7 @@ SIGNATURES = {
     "tn_graph_destroy": (c_int, [CTX, P]),
     "tn_event_create": (c_int, [CTX, POINTER(c_void_p)]),
     "tn_event_record": (c_int, [CTX, P]),
+    "tn_event_wait": (c_int, [CTX, P]),
     "tn_event_elapsed_ms": (c_int, [CTX, P, P, POINTER(c_float)]),
     "tn_event_destroy": (c_int, [CTX, P]),
     "tn_conv2d_fwd": (c_int, [CTX, P, P, P, P] + [c_int] * 10 + [c_int, c_float]),
@@ -89,6 +90,7 @@ SIGNATURES = {
                              c_int, P, P, P, P]),
     "tn_sgd_update_multi": (c_int, [CTX, P, c_int, c_size_t, P, c_float, P]),
     "tn_sgd_update_multi_delayed": (c_int, [CTX, P, c_int, c_size_t, P, c_float, P, c_int]),
+    "tn_sgd_update_multi_pipe": (c_int, [CTX, P, c_int, c_size_t, P, P, c_uint32, c_int]),
     "tn_sgd_update_multi_lazy": (c_int, [CTX, P, P, c_int, c_size_t, P, c_float, P, P, c_int, c_float, P]),
     "tn_sgd_update_multi_cost": (c_int, [CTX, P, c_int, c_size_t, P, c_float, P, P, c_int, c_float, P]),
     "tn_softmax_cost_ws_bytes": (c_size_t, [c_int]),

@@ -47,8 +47,10 @@ struct tn_ctx {
     void* comm = nullptr;
     int rank = 0, world = 1;
     // small persistent scratch (reductions)
-    float* scratch = nullptr;
+    float* scratch = nullptr;              // scratch of the stream ops are currently issued on
     size_t scratch_bytes = 0;
+    float* scratch_slot[2] = {nullptr, nullptr};   // parked scratch of the other stream (tn_stream_select):
+    size_t scratch_slot_bytes[2] = {0, 0};         // two pipelined steps never share slab memory
     // deferred finishing reductions (reduce.hip)
     bool defer = false;
     size_t scratch_off = 0;

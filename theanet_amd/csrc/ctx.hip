@@ -53,6 +53,8 @@ int tn_ctx_destroy(tn_ctx* ctx) {
     hipStreamSynchronize(ctx->streams[0]);
     hipStreamSynchronize(ctx->streams[1]);
     if (ctx->scratch) hipFree(ctx->scratch);
+    for (int i = 0; i < 2; ++i)
+        if (ctx->scratch_slot[i]) hipFree(ctx->scratch_slot[i]);
     hipEventDestroy(ctx->sync_ev[0]);
     hipEventDestroy(ctx->sync_ev[1]);
     hipStreamDestroy(ctx->streams[0]);
@@ -71,6 +73,15 @@ int tn_sync(tn_ctx* ctx) {
 
 int tn_stream_select(tn_ctx* ctx, int idx) {
     TN_REQUIRE(idx == 0 || idx == 1, "tn_stream_select: idx %d", idx);
+    const int cur = ctx->stream == ctx->streams[1] ? 1 : 0;
+    if (idx != cur) {       // every stream has its own scratch (slabs of two steps in flight must not alias)
+        ctx->scratch_slot[cur] = ctx->scratch;
+        ctx->scratch_slot_bytes[cur] = ctx->scratch_bytes;
+        ctx->scratch = ctx->scratch_slot[idx];
+        ctx->scratch_bytes = ctx->scratch_slot_bytes[idx];
+        ctx->scratch_slot[idx] = nullptr;
+        ctx->scratch_slot_bytes[idx] = 0;
+    }
     ctx->stream = ctx->streams[idx];
     return TN_OK;
 }
@@ -207,6 +218,10 @@ int tn_event_create(tn_ctx* ctx, void** ev) {
 }
 int tn_event_record(tn_ctx* ctx, void* ev) {
     TN_HIP(hipEventRecord((hipEvent_t)ev, ctx->stream));
+    return TN_OK;
+}
+int tn_event_wait(tn_ctx* ctx, void* ev) {
+    TN_HIP(hipStreamWaitEvent(ctx->stream, (hipEvent_t)ev, 0));
     return TN_OK;
 }
 int tn_event_elapsed_ms(tn_ctx* ctx, void* a, void* b, float* ms) {

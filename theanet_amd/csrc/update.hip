@@ -68,6 +68,38 @@ __global__ __launch_bounds__(256) void sgd_update_delayed_kernel(const tn_sgd_se
     }
 }
 
+// Update of the PIPELINED single-GPU schedule (two steps in flight on two streams, each with its own
+// weights, activations and gradients; NeuralNet / _PipeTrainFn).  Because the reference applies the old
+// velocity, p_t = p_{t-1} - s*v_{t-1} with v_{t-1} = m v_{t-2} + (1-m) g_{t-2}: the weights of step t
+// need the gradient of step t-2 -- which the same stream produced two steps ago -- and the weights
+// p_{t-1} the OTHER stream is using right now (read-only there).  One launch at the start of step t:
+//   v = m v + (1-m) g   (update_v; v is shared by both streams)   ;   p = psrc - rate*lr*v
+// Same expressions as sgd_update_multi_block: the weight trajectory is bit-identical.
+__global__ __launch_bounds__(256) void sgd_update_pipe_kernel(const tn_pipe_seg* __restrict__ segs, int nseg,
+                                                             const float* __restrict__ d_lr,
+                                                             uint32_t* d_step, uint32_t step_inc, int update_v) {
+    const int bx = blockIdx.x, by = blockIdx.y, nbx = gridDim.x;
+    if (d_step && step_inc && bx == 0 && by == 0 && threadIdx.x == 0) *d_step += step_inc;
+    const tn_pipe_seg sg = segs[by];
+    const float step = sg.rate * d_lr[0];
+    float* __restrict__ p = sg.p;
+    const float* __restrict__ ps = sg.psrc;
+    float* __restrict__ v = sg.v;
+    const float* __restrict__ g = sg.g;
+    const size_t n = sg.n;
+    const float m = sg.momentum;
+    for (size_t i = (size_t)bx * 256 + threadIdx.x; i < n; i += (size_t)nbx * 256) {
+        float vv = v[i];
+        if (update_v) {
+            const float gg = g[i] * 1.f;
+            vv = m * vv + (1.f - m) * gg;
+            v[i] = vv;
+        }
+        const float pv = ps[i];
+        p[i] = pv - step * vv;
+    }
+}
+
 // The same launch with LAZY gradients: segments whose weight gradient is still a stack of partial
 // slabs (the deferred finishing sums of reduce.hip) add the slabs up on the fly -- in exactly the
 // order slab_sum_multi_kernel uses, so the result is bit-identical -- write the gradient out and
@@ -276,6 +308,17 @@ int tn_sgd_update_multi_delayed(tn_ctx* ctx, const tn_sgd_seg* d_segs, int nseg,
     if (bx > 256) bx = 256;
     if (bx < 1) bx = 1;
     sgd_update_delayed_kernel<<<dim3(bx, nseg), 256, 0, ctx->stream>>>(d_segs, nseg, d_lr, gscale, d_step_inc, mode);
+    TN_LAUNCH_CHECK();
+    return TN_OK;
+}
+
+int tn_sgd_update_multi_pipe(tn_ctx* ctx, const tn_pipe_seg* d_segs, int nseg, size_t max_n, const float* d_lr,
+                             uint32_t* d_step, uint32_t step_inc, int update_v) {
+    TN_REQUIRE(nseg > 0 && d_segs && d_lr, "tn_sgd_update_multi_pipe: bad arguments");
+    int bx = cdiv(max_n, 1024);
+    if (bx > 256) bx = 256;
+    if (bx < 1) bx = 1;
+    sgd_update_pipe_kernel<<<dim3(bx, nseg), 256, 0, ctx->stream>>>(d_segs, nseg, d_lr, d_step, step_inc, update_v);
     TN_LAUNCH_CHECK();
     return TN_OK;
 }

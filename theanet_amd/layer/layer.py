@@ -57,7 +57,11 @@ class Layer:
     def __str__(self):
         return self.representation
 
+    _wts_hook = None           # set by NeuralNet: brings the weights up to date before they are read
+
     def get_wts(self):
+        if self._wts_hook is not None:
+            self._wts_hook()
         return [borrow(p) for p in self.params]
 
     # -- how the layer ABOVE must turn d(cost)/d(output) into d(cost)/d(z) -----------

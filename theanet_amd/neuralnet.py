@@ -154,6 +154,183 @@ class _TrainFn:
         return self.fetch()
 
 
+class _PipeTrainFn:
+    """``get_trin_model``'s function for single-GPU training with TWO STEPS IN FLIGHT.
+
+    The reference's update applies the OLD velocity (layer.py:82-86: ``v' = m v + (1-m) g``,
+    ``p' = p - rate*lr*v``), so the weights of step t are ``p_{t-1} - s*v_{t-1}`` with ``v_{t-1}`` built
+    from the gradient of step t-2: step t does not depend on the backward pass of step t-1.  Even steps
+    run on the context's first stream with the net itself, odd steps on the second stream with a twin
+    (own weights copy, activations and gradients; the velocities are shared).  Step t starts by waiting
+    for the other stream's update, then ``v <- m v + (1-m) g_{t-2}`` (its own gradient of two steps ago)
+    and ``p_own <- p_other - s*v`` in one launch (tn_sgd_update_multi_pipe), then runs its forward and
+    backward passes while the other stream is still busy with step t-1 -- the two fill each other's
+    launch gaps and lock-step phases (-18 % per step on mnist.prms).  Same weights, costs and outputs as
+    the sequential schedule, bit for bit (tests/test_gpu_net.py::test_pipelined_steps_equal_sequential);
+    reading weights (get_wts, test functions, checkpoints) first brings the net up to date."""
+
+    def __init__(self, net, x_data, y_data):
+        import ctypes
+        self.net, self.x_data, self.y_data = net, x_data, y_data
+        self.take_index_list = False
+        self.t = 0                   # steps enqueued so far
+        self._updated = False        # the update for step self.t has already been applied (weights were read)
+        self._seq = None             # sequential fallback (_TrainFn) once something rules pipelining out
+        self._twin = None
+        self._last = net
+        net._pipe_fn = self
+        self._ctypes = ctypes
+
+    # -- set-up of the twin on first use ---------------------------------------------------------
+    def _build(self):
+        net, ctx = self.net, self.net.ctx
+        import copy
+        twin = NeuralNet.__new__(NeuralNet)
+        twin._is_twin = True
+        twin.__init__(copy.deepcopy(net.layers), dict(net.tr_prms))
+        twin._prepare_training()
+        for a, b in zip(net.tr_layers, twin.tr_layers):
+            if hasattr(a, "seed"):
+                b.seed = a.seed
+            if getattr(a, "drop", None) is not None:
+                b.drop.seed = a.drop.seed
+            for pa, pb in zip(a.params, b.params):
+                ctx.call("tn_d2d", pb.ptr, pa.ptr, pa.size * 4)
+            if a.params:
+                b.accumulated_updates = a.accumulated_updates        # ONE velocity per tensor
+        self._twin = twin
+        self.nets = (net, twin)
+        seg_dt = np.dtype([('p', 'u8'), ('psrc', 'u8'), ('v', 'u8'), ('g', 'u8'), ('n', 'u8'),
+                           ('momentum', 'f4'), ('rate', 'f4')])
+        self._segs, self._lr, self._lr_set = [], [], [None, None]
+        for X, Y in ((net, twin), (twin, net)):
+            rows = []
+            for lx, ly in zip(X.tr_layers, Y.tr_layers):
+                if lx.has_updates():
+                    for p, ps, v, g in zip(lx.params, ly.params, lx.accumulated_updates, lx.grads):
+                        rows.append((p.ptr, ps.ptr, v.ptr, g.ptr, p.size, lx.reg['momentum'], lx.reg['rate']))
+            self._segs.append(ctx.array(np.array(rows, dtype=seg_dt).view(np.uint8)))
+            self._lr.append(ctx.zeros((1,)))
+            X._cost_rider = False
+        self._nseg, self._max_seg = net._n_segs, net._max_seg
+        self._ev = []
+        for _ in range(2):
+            e = self._ctypes.c_void_p()
+            ctx.call("tn_event_create", self._ctypes.byref(e))
+            self._ev.append(e)
+        ctx.call("tn_set_u32", twin.d_step.ptr, 1)       # the twin takes the odd steps
+        self._lr_prev = None
+
+    def _lr_now(self):
+        tp = self.net.tr_prms
+        return float(np.float32(tp['INIT_LEARNING_RATE'] / (1 + tp['CUR_EPOCH'] / tp['EPOCHS_TO_HALF_RATE'])))
+
+    def _blocked(self):
+        net = self.net
+        for lyr in net.tr_layers:
+            drop = getattr(lyr, "drop", None)
+            if (drop is not None and drop.injected) or getattr(lyr, "_inj_draws", False) or \
+                    getattr(lyr, "_inj_flip", None) is not None:
+                return True
+        return net.use_graph or net.side_stream or net.ctx.ev_hook is not None
+
+    # -- the start-of-step update -----------------------------------------------------------------
+    def _update_for(self, t):
+        """weights (and velocity) for step t on the stream that will run it"""
+        ctx, k = self.net.ctx, t & 1
+        X = self.nets[k]
+        ctx.call("tn_stream_select", k)
+        ctx.call("tn_event_wait", self._ev[1 - k])
+        if self._lr_set[k] != self._lr_prev:              # the rate step t-1 was enqueued under
+            ctx.call("tn_set_f32", self._lr[k].ptr, self._lr_prev)
+            self._lr_set[k] = self._lr_prev
+        ctx.call("tn_sgd_update_multi_pipe", self._segs[k].ptr, self._nseg, self._max_seg, self._lr[k].ptr,
+                 X.d_step.ptr, 2 if t >= 2 else 0, 1 if t >= 2 else 0)
+        for lyr in X.tr_layers:
+            lyr.apply_maxnorm()
+        ctx.call("tn_event_record", self._ev[k])
+
+    def sync_weights(self):
+        """Bring the net's own weights up to date (p_t after t steps) before anything reads them."""
+        if self._seq is not None or self._twin is None or self.t == 0:
+            return
+        ctx, t = self.net.ctx, self.t
+        if not self._updated:
+            self._update_for(t)
+            self._updated = True
+        if t & 1:                                         # the twin holds p_t: copy into the net
+            ctx.call("tn_stream_select", 0)
+            ctx.call("tn_event_wait", self._ev[1])
+            for a, b in zip(self.net.tr_layers, self._twin.tr_layers):
+                for pa, pb in zip(a.params, b.params):
+                    ctx.call("tn_d2d", pa.ptr, pb.ptr, pa.size * 4)
+        ctx.call("tn_stream_select", 0)
+        ctx.sync()
+
+    def _fall_back(self):
+        """Leave the pipelined schedule for good: bring weights AND velocity to the sequential state."""
+        net, ctx = self.net, self.net.ctx
+        if self._twin is not None and self.t > 0:
+            self.sync_weights()
+            # the velocity is one gradient behind (that of step t-1, held by the stream that ran it)
+            Y = self.nets[(self.t - 1) & 1]
+            ctx.call("tn_stream_select", 0)
+            ctx.call("tn_sgd_update_multi_delayed", Y._d_segs.ptr, Y._n_segs, Y._max_seg,
+                     net.cur_learn_rate.ptr, 1.0, None, 3)
+            ctx.call("tn_set_u32", net.d_step.ptr, self.t)
+            ctx.sync()
+        has_wtcost = any(getattr(l, 'reg', None) and l.params and (l.reg['L1'] or l.reg['L2'])
+                         for l in net.tr_layers)
+        net._cost_rider = (not has_wtcost) and os.environ.get("TN_COST_RIDER", "1") != "0"
+        net._pipe_fn = None
+        self._seq = _TrainFn(net, self.x_data, self.y_data, False)
+
+    # -- the step ---------------------------------------------------------------------------------
+    def enqueue(self, i):
+        if self._seq is None and self._blocked():
+            self._fall_back()
+        if self._seq is not None:
+            return self._seq.enqueue(i)
+        if self._twin is None:
+            self._build()
+        net, ctx, t = self.net, self.net.ctx, self.t
+        k = t & 1
+        X = self.nets[k]
+        if t >= 1 and not self._updated:
+            self._update_for(t)
+        elif t == 0:
+            ctx.call("tn_stream_select", 0)
+            ctx.call("tn_event_record", self._ev[0])
+        else:
+            ctx.call("tn_stream_select", k)
+        self._updated = False
+        self._lr_prev = self._lr_now()
+        slot = X.x
+        slot.d_row0 = None
+        slot.bind(self.x_data)
+        slot.row0 = int(i) * net.batch_sz + net.shard_lo
+        slot.row_global0 = net.shard_lo
+        try:
+            X._train_step(self.y_data, slot.row0, pipe_stride=2)
+        finally:
+            ctx.call("tn_stream_select", 0)
+        self._last = X
+        self.t = t + 1
+
+    def fetch(self):
+        if self._seq is not None:
+            return self._seq.fetch()
+        X = self._last
+        X.ctx.sync()
+        cost = X.d_cost.get_value()[0]
+        logprob = X.tr_layers[-1].logprob.get_value()
+        return [cost, logprob, logprob]
+
+    def __call__(self, i):
+        self.enqueue(i)
+        return self.fetch()
+
+
 class _TestFn:
     """``get_test_model``'s function: ``fn(i) -> [sym_err, P(MLE)](, features, y_preds)``."""
 
@@ -162,6 +339,7 @@ class _TestFn:
 
     def __call__(self, i):
         net, ctx = self.net, self.net.ctx
+        net._sync_weights()
         slot = net.test_x
         slot.bind(self.x_data)
         slot.row0 = int(i) * net.batch_sz + net.shard_lo
@@ -340,6 +518,8 @@ class NeuralNet():
 
         self.tr_layers.append(curr_layer)
         self.te_layers.append(curr_layer.TestVersion(te_inpt))
+        if not getattr(self, "_is_twin", False):
+            curr_layer._wts_hook = self.te_layers[-1]._wts_hook = self._sync_weights
         self.num_layers += 1
 
     @staticmethod
@@ -542,7 +722,7 @@ class NeuralNet():
                 sys.stderr.write("theanet_amd: data-parallel schedule '%s' (%s)\n" % (
                     self.dp_schedule, ", ".join("%s %.1f us/step" % (c, 1e3 * m) for c, m in zip(cands, ms))))
 
-    def _train_step(self, y, y_row0, d_row0=None):
+    def _train_step(self, y, y_row0, d_row0=None, pipe_stride=0):
         """forward + backward + all-reduce + update for the minibatch the input slot
         currently points at.  Everything is enqueued; nothing is read back."""
         ctx = self.ctx
@@ -585,7 +765,7 @@ class NeuralNet():
         # cost = -mean logprob[n, y_n] (this rank's share of the global mean).  Without weight
         # costs it rides in the update launch at the end of the step (tn_sgd_update_multi_cost);
         # with them it must exist before tn_wtcost accumulates onto it: a leaf reduction here.
-        rider = self._cost_rider
+        rider = self._cost_rider and not pipe_stride
         if not rider:
             if self.side_stream:
                 ctx.call("tn_stream_wait", 1, 0)
@@ -611,8 +791,8 @@ class NeuralNet():
                           int(first.sigma), float(first.angle), int(first.nearest), m[0].ptr, m[1].ptr,
                           m[2].ptr, m[3].ptr)
             if os.environ.get("TN_FIELD_RIDER", "1") != "0":
-                ctx.call("tn_rider_elastic_field", first.draws.ptr, first.seed, 1, self.d_step.ptr,
-                         *field_args)
+                ctx.call("tn_rider_elastic_field", first.draws.ptr, first.seed, pipe_stride or 1,
+                         self.d_step.ptr, *field_args)
         tail = False
         dp_async = False
         # single-GPU steps leave the finishing slab sums to the update launch (tn_sgd_update_multi_lazy)
@@ -644,11 +824,18 @@ class NeuralNet():
                 ctx.call("tn_rider_cancel")       # nobody carried it: it joins the update launch
             rode = ahead and not waiting and os.environ.get("TN_FIELD_RIDER", "1") != "0"
             tail = ahead and not rode
+            if pipe_stride:                       # pipelined schedule: the update is not part of the step
+                ahead, tail, lazy = rode, False, False
             lazy = lazy and not tail
             if tail:
                 ctx.call("tn_defer_flush_step", self.d_step.ptr)      # the counter advances here
             elif not lazy:
                 ctx.call("tn_defer_reductions", 0)
+        if pipe_stride:
+            # two steps in flight (_PipeTrainFn): this stream's next step starts with the update
+            if ahead:
+                first._cur, first._pre_valid = nxt, True
+            return
         delayed = self._dp_delayed
         if delayed and (tail or self.use_graph):
             self._dp_set_schedule("plain")        # (configuration-determined: the same on every rank)
@@ -712,7 +899,26 @@ class NeuralNet():
         self.tr_layers[-1].cost(None)            # validates the loss name (outlayers.py:12-36)
         assert aux_data is None, "auxiliary inputs are outside the accelerated path"
         self._prepare_training()
+        if self._pipe_ok(take_index_list):
+            return _PipeTrainFn(self, share(x_data), share(y_data, np.int32))
         return _TrainFn(self, share(x_data), share(y_data, np.int32), take_index_list)
+
+    def _sync_weights(self):
+        """With two steps in flight (_PipeTrainFn) the net's own weight buffers lag behind: catch up."""
+        fn = getattr(self, "_pipe_fn", None)
+        if fn is not None:
+            fn.sync_weights()
+
+    def _pipe_ok(self, take_index_list):
+        """Two-steps-in-flight schedule (_PipeTrainFn): single GPU, plain momentum-SGD nets."""
+        if getattr(self, "_is_twin", False) or os.environ.get("TN_PIPELINE", "1") == "0":
+            return False
+        has_wtcost = any(getattr(l, 'reg', None) and l.params and (l.reg['L1'] or l.reg['L2'])
+                         for l in self.tr_layers)
+        inject = any((getattr(l, "drop", None) is not None and l.drop.injected) or getattr(l, "_inj_draws", False)
+                     or getattr(l, "_inj_flip", None) is not None for l in self.tr_layers)
+        return (not self._dp and not take_index_list and not self.use_graph and not self.side_stream and
+                self._n_segs > 0 and not has_wtcost and not inject)
 
     def reset_accumulated_gradients(self):
         self._prepare_training()
@@ -742,6 +948,7 @@ class NeuralNet():
                 lyr.fused_pool.fused_conv, lyr.fused_pool = None, None
 
         def fn(x):
+            self._sync_weights()
             x = np.ascontiguousarray(x, np.float32).reshape(stage.shape)
             stage.set_value(x)
             slot = self.test_x
