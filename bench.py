@@ -69,6 +69,9 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: 4096 for mnist)")
     ap.add_argument("--img", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true", help="skip the per-kernel roofline leg")
+    ap.add_argument("--sequential", action="store_true",
+                    help="one step at a time (TN_PIPELINE=0) instead of two steps in flight")
     ap.add_argument("--time-op", default="", help="C-ABI function to bracket with HIP events, "
                     "e.g. tn_fc_wgrad:1 (nth call inside a step)")
     args = ap.parse_args()
@@ -76,6 +79,8 @@ def main():
     from theanet_amd import NeuralNet, comm, roofline
     from theanet_amd.device import get_context
 
+    if args.sequential:
+        os.environ["TN_PIPELINE"] = "0"
     world = comm.get_world()
     assert world.size == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
     prms = load_prms(args.prms)
@@ -127,7 +132,9 @@ def main():
     # heavy kernels of the SAME workload; the dominant one (largest share of the step) is
     # reported as `roofline`, the rest as `roofline_others`.
     roof, others = None, []
-    if args.prms == "mnist.prms":
+    if args.no_roofline:
+        pass
+    elif args.prms == "mnist.prms":
         conv2, fc1 = net.tr_layers[3], net.tr_layers[5]
         B_ = per_gpu
         # algorithmic FLOPs / bytes per launch
@@ -165,6 +172,9 @@ def main():
         if others:
             others.sort(key=lambda r: -r["avg_launch_ms"])
             roof, others = others[0], others[1:]
+            # the per-kernel leg always runs one step at a time: with two steps in flight the launches
+            # of the two streams share the GPU and a kernel's own duration cannot be separated
+            roof["measured_in"] = "one-step-at-a-time schedule (bench.py --sequential)"
             # HBM traffic of the dominant kernel: measured offline with rocprofv3 --pmc (separate
             # FETCH_SIZE / WRITE_SIZE passes, gfx950 correction) by tools/collect_profiles.sh
             try:
@@ -229,6 +239,8 @@ def main():
         "config": {"workload": "params/%s %dx%dx%d synthetic, %d images/GPU/step, elastic stage on"
                                % (args.prms, img, img, C, per_gpu),
                    "global_batch": tr["BATCH_SZ"], "parallelism": "dp%d" % world.size,
+                   "schedule": "two steps in flight (exact: the update applies the old velocity)"
+                   if type(fn).__name__ == "_PipeTrainFn" and fn._twin is not None else "one step at a time",
                    "dp_schedule": getattr(net, "dp_schedule", None) if world.size > 1 else None,
                    "dp_schedule_us_per_step": {k: 1e3 * v for k, v in getattr(net, "dp_tuned_ms", {}).items()}
                    if world.size > 1 and isinstance(getattr(net, "dp_tuned_ms", None), dict) else None,

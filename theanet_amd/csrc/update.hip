@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void sgd_update_pipe_kernel(const tn_pipe_seg*
     for (size_t i = (size_t)bx * 256 + threadIdx.x; i < n; i += (size_t)nbx * 256) {
         float vv = v[i];
         if (update_v) {
-            const float gg = g[i] * 1.f;
+            const float gg = g[i];
             vv = m * vv + (1.f - m) * gg;
             v[i] = vv;
         }

@@ -54,7 +54,7 @@ with open(stats) as fh, open(dst, "w") as out:
     out.write(fh.read())
 line = [l for l in open(os.path.join(src, "stats.log")).read().splitlines() if l.startswith("{")][-1]
 with open(os.path.join(ROOT, "profiles", "%s_mnist_bs4096_summary.md" % tag), "w") as md:
-    md.write("# %s: rocprofv3 --kernel-trace --stats, `python bench.py --steps 50 --warmup 5`\n\n" % tag)
+    md.write("# %s: rocprofv3 --kernel-trace --stats, `python bench.py --sequential --steps 50 --warmup 5`\n\n" % tag)
     md.write("mnist.prms, 4096 images/step, 1 MI355X.  Kernel durations are averages over all launches of\n"
              "the run (timed steps, warm-up and the roofline leg).  HBM bytes: separate `--pmc FETCH_SIZE` /\n"
              "`--pmc WRITE_SIZE` passes, corrected as in MI355X_MICROARCH.md (see r01_traffic.json).\n\n")
@@ -66,6 +66,16 @@ with open(os.path.join(ROOT, "profiles", "%s_mnist_bs4096_summary.md" % tag), "w
                                                      r["Percentage"], "%.2f MB" % (hb / 1e6) if hb else "-"))
     md.write("\nbench line of the same run:\n\n```\n%s\n```\n" % line[:1500])
 print("wrote", dst)
+pipe = glob.glob(os.path.join(src, "stats_pipe", "*kernel_stats.csv"))
+if pipe:
+    dstp = os.path.join(ROOT, "profiles", "%s_mnist_bs4096_pipelined_kernel_stats.csv" % tag)
+    with open(pipe[0]) as fh, open(dstp, "w") as out:
+        out.write(fh.read())
+    lines = [l for l in open(os.path.join(src, "stats_pipe.log")).read().splitlines() if l.startswith("{")]
+    if lines:
+        with open(os.path.join(ROOT, "profiles", "%s_mnist_bs4096_pipelined_bench.json" % tag), "w") as out:
+            out.write(lines[-1] + "\n")
+    print("wrote", dstp)
 for cfg in ("cifar_like", "wide6"):
     found = glob.glob(os.path.join(src, "stats_%s" % cfg, "*kernel_stats.csv"))
     if not found:
