@@ -275,6 +275,7 @@ def test_dp_overlap_schedule_equals_plain(monkeypatch):
     x = rng.rand(4 * 64, 1, 28, 28).astype(np.float32)
     y = rng.randint(0, 10, 4 * 64).astype(np.int32)
     nets = []
+    monkeypatch.setenv("TN_PIPELINE", "0")        # the one-step-at-a-time schedules
     for force, overlap in (("0", "1"), ("1", "1"), ("1", "0")):
         monkeypatch.setenv("TN_DP_FORCE", force)
         monkeypatch.setenv("TN_DP_OVERLAP", overlap)
@@ -307,6 +308,7 @@ def test_dp_schedule_autotune(monkeypatch):
     x = rng.rand(4 * 64, 1, 28, 28).astype(np.float32)
     y = rng.randint(0, 10, 4 * 64).astype(np.int32)
     nets = []
+    monkeypatch.setenv("TN_PIPELINE", "0")        # the tuner chooses among the one-step-at-a-time schedules
     leg, pre = NeuralNet._DP_TUNE_WARM + NeuralNet._DP_TUNE_STEPS, NeuralNet._DP_TUNE_PRE
     nsteps = pre + 3 * leg + 5
     for overlap in ("auto", "0"):
@@ -352,6 +354,7 @@ def test_dp_delayed_allreduce_equals_plain(monkeypatch, name, img, ch, B):
     x = rng.rand(4 * B, ch, img, img).astype(np.float32)
     y = rng.randint(0, 10, 4 * B).astype(np.int32)
     nets = []
+    monkeypatch.setenv("TN_PIPELINE", "0")
     for mode in ("2", "0"):
         monkeypatch.setenv("TN_DP_FORCE", "1")
         monkeypatch.setenv("TN_DP_OVERLAP", mode)
@@ -372,6 +375,43 @@ def test_dp_delayed_allreduce_equals_plain(monkeypatch, name, img, ch, B):
     for la, lb in zip(nets[0][0].tr_layers, nets[1][0].tr_layers):
         for wa, wb in zip(la.get_wts(), lb.get_wts()):
             np.testing.assert_array_equal(wa, wb)
+
+
+def test_dp_pipelined_equals_sequential(monkeypatch):
+    """Data-parallel step (1-rank RCCL communicator) with two steps in flight: the all-reduce follows the
+    backward pass on the step's own stream, the update that consumes it opens that stream's next step.
+    Same costs, outputs and weights as one step at a time with the plain all-reduce schedule."""
+    from theanet_amd import NeuralNet
+    from theanet_amd.neuralnet import _PipeTrainFn
+    import copy
+    prms = load_prms("mnist.prms", 28, batch=64)
+    rng = np.random.RandomState(10)
+    x = rng.rand(4 * 64, 1, 28, 28).astype(np.float32)
+    y = rng.randint(0, 10, 4 * 64).astype(np.int32)
+    runs = []
+    for pipe in ("1", "0"):
+        monkeypatch.setenv("TN_DP_FORCE", "1")
+        monkeypatch.setenv("TN_DP_PIPELINE", pipe)
+        monkeypatch.setenv("TN_PIPELINE", pipe)
+        monkeypatch.setenv("TN_DP_OVERLAP", "0")
+        net = NeuralNet(copy.deepcopy(prms["layers"]), dict(prms["training_params"]))
+        fn = net.get_trin_model(x, y)
+        assert isinstance(fn, _PipeTrainFn) == (pipe == "1")
+        outs = []
+        for s in range(8):
+            fn.enqueue(s % 4)
+            if s in (3, 7):
+                outs.append(fn.fetch())
+        if pipe == "1":
+            assert fn._seq is None and net.dp_schedule == "pipelined"
+        runs.append((net, outs, [w.copy() for l in net.tr_layers for w in l.get_wts()]))
+        net.ctx.call("tn_comm_destroy")
+        net._dev_group = None
+    for (c0, _, l0), (c1, _, l1) in zip(runs[0][1], runs[1][1]):
+        assert c0 == c1
+        np.testing.assert_array_equal(l0, l1)
+    for wa, wb in zip(runs[0][2], runs[1][2]):
+        np.testing.assert_array_equal(wa, wb)
 
 
 def test_train_py_end_to_end(tmp_path):

@@ -188,7 +188,13 @@ class _PipeTrainFn:
         twin = NeuralNet.__new__(NeuralNet)
         twin._is_twin = True
         twin.__init__(copy.deepcopy(net.layers), dict(net.tr_prms))
+        if net._dp:
+            twin._dev_group = net._group()                 # ONE communicator; the streams alternate on it
         twin._prepare_training()
+        if net._dp:
+            net._dp_set_schedule("plain")
+            net._dp_tune = twin._dp_tune = None              # nothing to tune: the all-reduce rides in-stream
+            net.dp_schedule = twin.dp_schedule = "pipelined"
         for a, b in zip(net.tr_layers, twin.tr_layers):
             if hasattr(a, "seed"):
                 b.seed = a.seed
@@ -281,7 +287,7 @@ class _PipeTrainFn:
             ctx.sync()
         has_wtcost = any(getattr(l, 'reg', None) and l.params and (l.reg['L1'] or l.reg['L2'])
                          for l in net.tr_layers)
-        net._cost_rider = (not has_wtcost) and os.environ.get("TN_COST_RIDER", "1") != "0"
+        net._cost_rider = (not has_wtcost) and not net._dp and os.environ.get("TN_COST_RIDER", "1") != "0"
         net._pipe_fn = None
         self._seq = _TrainFn(net, self.x_data, self.y_data, False)
 
@@ -728,7 +734,7 @@ class NeuralNet():
         ctx = self.ctx
         out = self.tr_layers[-1]
         first = self.tr_layers[0]
-        if self._dp_tune is not None and not self.use_graph:
+        if self._dp_tune is not None and not self.use_graph and not pipe_stride:
             self._dp_tune_tick()
         if self._dp_can_delay:
             self._dp_bind(self._dp_cur if self._dp_delayed else 0)
@@ -832,7 +838,11 @@ class NeuralNet():
             elif not lazy:
                 ctx.call("tn_defer_reductions", 0)
         if pipe_stride:
-            # two steps in flight (_PipeTrainFn): this stream's next step starts with the update
+            # two steps in flight (_PipeTrainFn): this stream's next step starts with the update.
+            # Data-parallel: the all-reduce simply follows on this stream -- its latency is covered by
+            # the other stream's step, and the update that needs it is a whole step away.
+            if self._dp:
+                self._group().allreduce_sum(self.flat_grads, self.n_flat)
             if ahead:
                 first._cur, first._pre_valid = nxt, True
             return
@@ -917,7 +927,9 @@ class NeuralNet():
                          for l in self.tr_layers)
         inject = any((getattr(l, "drop", None) is not None and l.drop.injected) or getattr(l, "_inj_draws", False)
                      or getattr(l, "_inj_flip", None) is not None for l in self.tr_layers)
-        return (not self._dp and not take_index_list and not self.use_graph and not self.side_stream and
+        if self._dp and os.environ.get("TN_DP_PIPELINE", "1") == "0":
+            return False
+        return (not take_index_list and not self.use_graph and not self.side_stream and
                 self._n_segs > 0 and not has_wtcost and not inject)
 
     def reset_accumulated_gradients(self):
