@@ -548,6 +548,33 @@ def test_pipelined_steps_equal_sequential(monkeypatch, name, img, ch, B):
                 np.testing.assert_array_equal(wa, wb)
 
 
+def test_pipelined_function_handover(monkeypatch):
+    """A second get_trin_model on a net whose first training function had steps in flight, and a
+    training function that is driven after a test function was compiled: the weights stay exact."""
+    from theanet_amd import NeuralNet
+    import copy
+    prms = load_prms("mnist.prms", 28, batch=64)
+    rng = np.random.RandomState(11)
+    x = rng.rand(4 * 64, 1, 28, 28).astype(np.float32)
+    y = rng.randint(0, 10, 4 * 64).astype(np.int32)
+    res = []
+    for pipe in ("1", "0"):
+        monkeypatch.setenv("TN_PIPELINE", pipe)
+        net = NeuralNet(copy.deepcopy(prms["layers"]), dict(prms["training_params"]))
+        f1 = net.get_trin_model(x, y)
+        for s in range(3):
+            f1.enqueue(s % 4)
+        f2 = net.get_trin_model(x, y)
+        for s in range(3, 7):
+            f2.enqueue(s % 4)
+        out = f2.fetch()
+        res.append((out, [w.copy() for l in net.tr_layers for w in l.get_wts()]))
+    assert res[0][0][0] == res[1][0][0]
+    np.testing.assert_array_equal(res[0][0][1], res[1][0][1])
+    for wa, wb in zip(res[0][1], res[1][1]):
+        np.testing.assert_array_equal(wa, wb)
+
+
 @pytest.mark.parametrize("name,img,ch,B", [("mnist.prms", 28, 1, 64), ("cifar_like.prms", 32, 3, 16)])
 def test_lazy_update_equals_reduce_then_update(monkeypatch, name, img, ch, B):
     """Summing the weight-gradient slabs inside the update launch (tn_sgd_update_multi_lazy) keeps the

@@ -224,7 +224,8 @@ class _PipeTrainFn:
             e = self._ctypes.c_void_p()
             ctx.call("tn_event_create", self._ctypes.byref(e))
             self._ev.append(e)
-        ctx.call("tn_set_u32", twin.d_step.ptr, 1)       # the twin takes the odd steps
+        base = int(net.d_step.get_value()[0])            # steps already taken (an earlier training function)
+        ctx.call("tn_set_u32", twin.d_step.ptr, base + 1)    # the twin takes every second step
         self._lr_prev = None
 
     def _lr_now(self):
@@ -289,6 +290,9 @@ class _PipeTrainFn:
                          for l in net.tr_layers)
         net._cost_rider = (not has_wtcost) and not net._dp and os.environ.get("TN_COST_RIDER", "1") != "0"
         net._pipe_fn = None
+        first = net.tr_layers[0]
+        if isinstance(first, ElasticLayer):
+            first._pre_valid = False              # a field built ahead was for this stream's step t+2
         self._seq = _TrainFn(net, self.x_data, self.y_data, False)
 
     # -- the step ---------------------------------------------------------------------------------
@@ -909,6 +913,8 @@ class NeuralNet():
         self.tr_layers[-1].cost(None)            # validates the loss name (outlayers.py:12-36)
         assert aux_data is None, "auxiliary inputs are outside the accelerated path"
         self._prepare_training()
+        if getattr(self, "_pipe_fn", None) is not None:
+            self._pipe_fn._fall_back()           # an earlier training function: bring the net up to date
         if self._pipe_ok(take_index_list):
             return _PipeTrainFn(self, share(x_data), share(y_data, np.int32))
         return _TrainFn(self, share(x_data), share(y_data, np.int32), take_index_list)
