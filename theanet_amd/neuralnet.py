@@ -593,6 +593,7 @@ class NeuralNet():
         self._dp = self.world.size > 1 or os.environ.get("TN_DP_FORCE") == "1"
         self._cost_rider = (not has_wtcost) and not self._dp and \
             os.environ.get("TN_COST_RIDER", "1") != "0"
+        self._cost_rider_ok = self._cost_rider
         self._max_seg = max([sg[3] for sg in segs] or [0])
         if segs:
             host = np.array(segs, dtype=seg_dt)
@@ -780,8 +781,14 @@ class NeuralNet():
             if self.side_stream:
                 ctx.call("tn_stream_wait", 1, 0)
                 ctx.call("tn_stream_select", 1)
-            ctx.call("tn_reduce_sum", out.rowloss.ptr, self.local_bsz, 1.0 / self.batch_sz,
-                     self.d_cost.ptr, 0)
+            if pipe_stride and self._cost_rider_ok:
+                # the cost block of the update launch on its own: the same summation order as the
+                # one-step-at-a-time schedule, so the reported cost is bit-identical too
+                ctx.call("tn_sgd_update_multi_cost", None, 0, 0, self.cur_learn_rate.ptr, 1.0, None,
+                         out.rowloss.ptr, self.local_bsz, 1.0 / self.batch_sz, self.d_cost.ptr)
+            else:
+                ctx.call("tn_reduce_sum", out.rowloss.ptr, self.local_bsz, 1.0 / self.batch_sz,
+                         self.d_cost.ptr, 0)
             if self.side_stream:
                 ctx.call("tn_stream_select", 0)
         g = out.dlogits
