@@ -548,6 +548,30 @@ def test_pipelined_steps_equal_sequential(monkeypatch, name, img, ch, B):
                 np.testing.assert_array_equal(wa, wb)
 
 
+def test_pipelined_equals_sequential_at_full_batch(monkeypatch):
+    """BASELINE config 2 (mnist.prms, 4096 images per step): five steps with two steps in flight give
+    the same cost (to the bit: same summation order) and the same weights as one step at a time."""
+    from theanet_amd import NeuralNet
+    import copy
+    prms = load_prms("mnist.prms", 28, batch=4096)
+    rng = np.random.RandomState(12)
+    x = rng.rand(2 * 4096, 1, 28, 28).astype(np.float32)
+    y = rng.randint(0, 10, 2 * 4096).astype(np.int32)
+    res = []
+    for pipe in ("1", "0"):
+        monkeypatch.setenv("TN_PIPELINE", pipe)
+        net = NeuralNet(copy.deepcopy(prms["layers"]), dict(prms["training_params"]))
+        fn = net.get_trin_model(x, y)
+        for s in range(5):
+            fn.enqueue(s % 2)
+        out = fn.fetch()
+        res.append((out, [w.copy() for l in net.tr_layers for w in l.get_wts()]))
+    assert res[0][0][0] == res[1][0][0]
+    np.testing.assert_array_equal(res[0][0][1], res[1][0][1])
+    for wa, wb in zip(res[0][1], res[1][1]):
+        np.testing.assert_array_equal(wa, wb)
+
+
 def test_pipelined_function_handover(monkeypatch):
     """A second get_trin_model on a net whose first training function had steps in flight, and a
     training function that is driven after a test function was compiled: the weights stay exact."""
