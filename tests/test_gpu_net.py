@@ -377,17 +377,18 @@ def test_dp_delayed_allreduce_equals_plain(monkeypatch, name, img, ch, B):
             np.testing.assert_array_equal(wa, wb)
 
 
-def test_dp_pipelined_equals_sequential(monkeypatch):
+@pytest.mark.parametrize("name,img,ch,B", [("mnist.prms", 28, 1, 64), ("cifar_like.prms", 32, 3, 16)])
+def test_dp_pipelined_equals_sequential(monkeypatch, name, img, ch, B):
     """Data-parallel step (1-rank RCCL communicator) with two steps in flight: the all-reduce follows the
     backward pass on the step's own stream, the update that consumes it opens that stream's next step.
     Same costs, outputs and weights as one step at a time with the plain all-reduce schedule."""
     from theanet_amd import NeuralNet
     from theanet_amd.neuralnet import _PipeTrainFn
     import copy
-    prms = load_prms("mnist.prms", 28, batch=64)
+    prms = load_prms(name, img, batch=B)
     rng = np.random.RandomState(10)
-    x = rng.rand(4 * 64, 1, 28, 28).astype(np.float32)
-    y = rng.randint(0, 10, 4 * 64).astype(np.int32)
+    x = rng.rand(4 * B, ch, img, img).astype(np.float32)
+    y = rng.randint(0, 10, 4 * B).astype(np.int32)
     runs = []
     for pipe in ("1", "0"):
         monkeypatch.setenv("TN_DP_FORCE", "1")
