@@ -947,6 +947,8 @@ class NeuralNet():
 
     def reset_accumulated_gradients(self):
         self._prepare_training()
+        if getattr(self, "_pipe_fn", None) is not None:
+            self._pipe_fn._fall_back()           # steps in flight: apply their gradients first
         for lyr in self.tr_layers:
             for au in (lyr.accumulated_updates or ()):
                 au.fill_bytes(0)
