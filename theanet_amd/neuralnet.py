@@ -219,11 +219,14 @@ class _PipeTrainFn:
             self._lr.append(ctx.zeros((1,)))
             X._cost_rider = False
         self._nseg, self._max_seg = net._n_segs, net._max_seg
-        self._ev = []
+        self._ev, arev = [], []
         for _ in range(2):
-            e = self._ctypes.c_void_p()
-            ctx.call("tn_event_create", self._ctypes.byref(e))
-            self._ev.append(e)
+            for lst in (self._ev, arev):
+                e = self._ctypes.c_void_p()
+                ctx.call("tn_event_create", self._ctypes.byref(e))
+                lst.append(e)
+        for k, X in enumerate(self.nets):                  # all-reduce k waits for all-reduce k-1
+            X._ar_done_ev, X._ar_wait_ev = arev[k], arev[1 - k]
         base = int(net.d_step.get_value()[0])            # steps already taken (an earlier training function)
         ctx.call("tn_set_u32", twin.d_step.ptr, base + 1)    # the twin takes every second step
         self._lr_prev = None
@@ -853,7 +856,13 @@ class NeuralNet():
             # Data-parallel: the all-reduce simply follows on this stream -- its latency is covered by
             # the other stream's step, and the update that needs it is a whole step away.
             if self._dp:
+                # consecutive collectives of the one communicator alternate between the two streams:
+                # keep them strictly ordered on the device whatever the library does by itself
+                if getattr(self, "_ar_wait_ev", None) is not None:
+                    ctx.call("tn_event_wait", self._ar_wait_ev)
                 self._group().allreduce_sum(self.flat_grads, self.n_flat)
+                if getattr(self, "_ar_done_ev", None) is not None:
+                    ctx.call("tn_event_record", self._ar_done_ev)
             if ahead:
                 first._cur, first._pre_valid = nxt, True
             return
