@@ -111,6 +111,22 @@ int tn_conv2d_dgrad(tn_ctx* ctx, const float* dz, const float* W, float* dx,
                     int N, int C, int H, int Wd, int K, int f, int stride, int pad_lo,
                     int Ho, int Wo, const float* prev_a, int prev_act, float prev_act_param);
 
+/* ---- fp16-operand / fp32-accumulate products for the 3x3 stride-1 conv layers (BASELINE configs[4];
+ * the reference is float32-only, weights.py:8 `floatX`: this is an opt-in DTYPE, default off) ----
+ * dtype 0: fp32 operands (reference arithmetic).  dtype 1: tn_conv2d_fwd / _wgrad / _dgrad and the
+ * fused conv+pool blocks round BOTH operands of every product to fp16 (round-to-nearest-even) while
+ * staging them and accumulate in fp32 on v_mfma_f32_32x32x16_f16; tensors stay fp32 in HBM (fp32
+ * master weights).  grad_scale (a power of two, e.g. 4096): products that have dz as an operand round
+ * grad_scale*dz and multiply the fp32 result by 1/grad_scale, so small gradients do not fall into
+ * fp16's subnormal range.  In dtype 1 an unsupported conv shape is an ERROR (TN_E_ARG), never a silent
+ * fp32 run: tn_conv_f16_supported says beforehand (bit 0 forward, bit 1 dgrad, bit 2 wgrad).        */
+int tn_set_matmul_dtype(tn_ctx* ctx, int dtype, float grad_scale);
+int tn_get_matmul_dtype(tn_ctx* ctx);
+int tn_conv_f16_supported(int N, int C, int H, int Wd, int K, int f, int stride, int pad_lo, int Ho, int Wo);
+/* 1 if the conv + act + 2x2 max-pool block runs fused on the fp16-operand tile kernels */
+int tn_convpool_f16_supported(int N, int C, int H, int Wd, int K, int f, int stride, int pad_lo, int Ho, int Wo,
+                              int p, int Hp, int Wp);
+
 /* 1 if tn_conv2d_* run this shape on the implicit-im2col fp32-MFMA kernels (stride 1, reduction
  * C*f*f >= 32, >= 16 output maps); otherwise the direct VALU kernels are used.              */
 int tn_conv_mfma_supported(int C, int K, int f, int stride);

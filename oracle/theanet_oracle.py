@@ -149,27 +149,44 @@ def _windows(x, f, stride, pad_lo, pad_hi):
     return xp, win[:, :, ::stride, ::stride]
 
 
-def conv2d_fwd(x, W, b, stride=1, mode="valid"):
-    """z[n,k,i,j] = b[k] + sum_{c,u,v} xpad[n,c,i*s+u,j*s+v] * W[k,c,f-1-u,f-1-v]."""
+def r16(a, scale=1.0):
+    """fp16 operand rounding of the DTYPE='float16' mode (NOT in the reference, which is float32-only:
+    weights.py:8; BASELINE.json configs[4]): round-to-nearest-even to IEEE half (scale*a, a power-of-two
+    scale being exact), widened to float64 so that the products and sums that follow are exact /
+    float64 -- the device accumulates the same exact products in fp32."""
+    return (np.asarray(a, np.float64) * scale).astype(np.float16).astype(np.float64) / scale
+
+
+def conv2d_fwd(x, W, b, stride=1, mode="valid", f16=False):
+    """z[n,k,i,j] = b[k] + sum_{c,u,v} xpad[n,c,i*s+u,j*s+v] * W[k,c,f-1-u,f-1-v].
+    f16: both operands rounded to fp16 first, float64 accumulation (see r16)."""
     f = W.shape[2]
+    out_dtype = x.dtype
+    if f16:
+        x, W = r16(x), r16(W)
     pad_lo, pad_hi, _ = conv_geometry(x.shape[2], f, stride, mode)
     _, win = _windows(x, f, stride, pad_lo, pad_hi)
     Wf = W[:, :, ::-1, ::-1]
     z = np.tensordot(win, Wf, axes=([1, 4, 5], [1, 2, 3]))   # N,Ho,Wo,K
     z = np.ascontiguousarray(z.transpose(0, 3, 1, 2)) + b[None, :, None, None]
-    return z.astype(x.dtype)
+    return z.astype(out_dtype)
 
 
-def conv2d_bwd(x, W, dz, stride=1, mode="valid", need_dx=True):
-    """Returns (dx or None, dW, db) for z = conv2d_fwd(x, W, b)."""
+def conv2d_bwd(x, W, dz, stride=1, mode="valid", need_dx=True, f16=False, grad_scale=1.0):
+    """Returns (dx or None, dW, db) for z = conv2d_fwd(x, W, b).
+    f16: the operands of both gradient products are rounded to fp16 (dz as r16(grad_scale*dz)/grad_scale);
+    db sums the unrounded dz."""
     f = W.shape[2]
     H = x.shape[2]
+    out_dtype = x.dtype
+    db = dz.sum(axis=(0, 2, 3)).astype(out_dtype)
+    if f16:
+        x, W, dz = r16(x), r16(W), r16(dz, grad_scale)
     pad_lo, pad_hi, _ = conv_geometry(H, f, stride, mode)
     xp, win = _windows(x, f, stride, pad_lo, pad_hi)
     # dWf[k,c,u,v] = sum_{n,i,j} dz[n,k,i,j] * win[n,c,i,j,u,v]
     dWf = np.tensordot(dz, win, axes=([0, 2, 3], [0, 2, 3]))  # K,C,f,f
-    dW = np.ascontiguousarray(dWf[:, :, ::-1, ::-1]).astype(x.dtype)
-    db = dz.sum(axis=(0, 2, 3)).astype(x.dtype)
+    dW = np.ascontiguousarray(dWf[:, :, ::-1, ::-1]).astype(out_dtype)
     dx = None
     if need_dx:
         Wf = W[:, :, ::-1, ::-1]
@@ -182,7 +199,7 @@ def conv2d_bwd(x, W, dz, stride=1, mode="valid", need_dx=True):
                 dxp[:, :, u:u + stride * Ho:stride, v:v + stride * Wo:stride] += \
                     contrib.transpose(0, 3, 1, 2)
         dx = np.ascontiguousarray(
-            dxp[:, :, pad_lo:pad_lo + H, pad_lo:pad_lo + H]).astype(x.dtype)
+            dxp[:, :, pad_lo:pad_lo + H, pad_lo:pad_lo + H]).astype(out_dtype)
     return dx, dW, db
 
 
@@ -534,6 +551,10 @@ class OracleNet:
         self.batch_sz = training_params['BATCH_SZ']
         if 'CUR_EPOCH' not in training_params:
             training_params['CUR_EPOCH'] = 0                       # :108-109
+        # DTYPE='float16' (this build's extension; the reference is float32-only): conv products on
+        # fp16-rounded operands, dz scaled by GRAD_SCALE before rounding
+        self.f16 = training_params.get('DTYPE', 'float32') == 'float16'
+        self.grad_scale = float(training_params.get('GRAD_SCALE', 4096.))
         self.L = []
         for i, (ltype, largs) in enumerate(layers):
             wts = allwts[i] if allwts else None
@@ -641,7 +662,7 @@ class OracleNet:
             elif l.kind == "Elastic":
                 h, c["target"] = l.stage.forward(h, draws.get(i), train)
             elif l.kind == "Conv":
-                z = conv2d_fwd(h, l.params[0], l.params[1], l.stride, l.mode)
+                z = conv2d_fwd(h, l.params[0], l.params[1], l.stride, l.mode, f16=self.f16)
                 c["z"] = z
                 h = activation(l.actvn)[0](z)
             elif l.kind == "Pool":
@@ -712,7 +733,7 @@ class OracleNet:
             elif l.kind == "Conv":
                 dz = (g.reshape(c["z"].shape) * activation(l.actvn)[1](c["z"])).astype(self.dtype)
                 g, dW, db = conv2d_bwd(c["in"], l.params[0], dz, l.stride, l.mode,
-                                       need_dx=i > first_param)
+                                       need_dx=i > first_param, f16=self.f16, grad_scale=self.grad_scale)
                 grads[i] = [dW + wtcost_grad(l.params[0], l.reg),
                             db + wtcost_grad(l.params[1], l.reg)]
             elif l.kind in ("Input", "Elastic"):

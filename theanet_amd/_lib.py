@@ -51,6 +51,10 @@ SIGNATURES = {
     "tn_conv2d_fwd": (c_int, [CTX, P, P, P, P] + [c_int] * 10 + [c_int, c_float]),
     "tn_conv2d_wgrad": (c_int, [CTX, P, P, P, P] + [c_int] * 10),
     "tn_conv2d_dgrad": (c_int, [CTX, P, P, P] + [c_int] * 10 + [P, c_int, c_float]),
+    "tn_set_matmul_dtype": (c_int, [CTX, c_int, c_float]),
+    "tn_get_matmul_dtype": (c_int, [CTX]),
+    "tn_conv_f16_supported": (c_int, [c_int] * 10),
+    "tn_convpool_f16_supported": (c_int, [c_int] * 13),
     "tn_pool_fwd": (c_int, [CTX, P, P] + [c_int] * 6),
     "tn_pool_bwd": (c_int, [CTX, P, P, P, P] + [c_int] * 6 + [c_int, c_float]),
     "tn_mean_fwd": (c_int, [CTX, P, P, c_int, c_int]),

@@ -41,6 +41,10 @@ struct tn_ctx {
     hipStream_t streams[2] = {nullptr, nullptr};   // [0] main, [1] side (leaf work: weight gradients)
     hipEvent_t sync_ev[2] = {nullptr, nullptr};
     int num_cus = 256;
+    // matmul operand precision of the 3x3 conv products (tn_set_matmul_dtype): 0 fp32, 1 fp16 operands /
+    // fp32 accumulate; grad_scale: power of two applied to dz before it is rounded to fp16
+    int mm_f16 = 0;
+    float grad_scale = 1.f;
     char err[512] = {0};
     // RCCL (loaded lazily, comm.hip)
     void* rccl_lib = nullptr;

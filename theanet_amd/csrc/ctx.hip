@@ -1,6 +1,8 @@
 // Context lifecycle, memory, scalar stores, graph capture, events, small utilities.
 #include "common.h"
 
+#include <cmath>
+
 char g_tn_err[512] = {0};
 
 extern "C" {
@@ -62,6 +64,18 @@ int tn_ctx_destroy(tn_ctx* ctx) {
     delete ctx;
     return TN_OK;
 }
+
+int tn_set_matmul_dtype(tn_ctx* ctx, int dtype, float grad_scale) {
+    TN_REQUIRE(dtype == 0 || dtype == 1, "tn_set_matmul_dtype: dtype %d (0 fp32, 1 fp16 operands)", dtype);
+    int ex = 0;
+    const float m = frexpf(grad_scale, &ex);
+    TN_REQUIRE(grad_scale > 0.f && m == 0.5f, "tn_set_matmul_dtype: grad_scale %g is not a power of two", grad_scale);
+    ctx->mm_f16 = dtype;
+    ctx->grad_scale = dtype ? grad_scale : 1.f;
+    return TN_OK;
+}
+
+int tn_get_matmul_dtype(tn_ctx* ctx) { return ctx->mm_f16; }
 
 const char* tn_last_error(tn_ctx* ctx) { return ctx ? ctx->err : g_tn_err; }
 

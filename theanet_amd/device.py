@@ -32,6 +32,8 @@ class Context:
                 "There is no CPU fallback." % (device, msg.decode() if msg else "?"))
         self.h = h
         self.device = device
+        self.mm_dtype = "float32"  # operand precision of the conv products (NeuralNet's DTYPE training param)
+        self._mm_set = ("float32", 1.0)
         self.ev_hook = None       # (name, nth) -> HIP-event bracket around that C-ABI call
         self._ev_seen = 0
         self.ev_pairs = []
@@ -82,6 +84,15 @@ class Context:
 
     def sync(self):
         self.call("tn_sync")
+
+    def set_matmul_dtype(self, dtype, grad_scale=1.0):
+        """'float32' (the reference's floatX) or 'float16' = fp16 operands / fp32 accumulation for the
+        3x3 conv products (tn_set_matmul_dtype); a no-op when already in that mode."""
+        want = (dtype, float(grad_scale) if dtype == "float16" else 1.0)
+        if want != self._mm_set:
+            self.call("tn_set_matmul_dtype", 1 if dtype == "float16" else 0, want[1])
+            self._mm_set = want
+        self.mm_dtype = dtype
 
     def info(self):
         name = ctypes.create_string_buffer(128)

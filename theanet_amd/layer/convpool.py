@@ -48,6 +48,17 @@ class ConvLayer(Layer):
         self.act = activation_by_name(actvn)
         assert self.act.kind is not None, "softmax is not a conv activation"
         self.ctx = self.W.ctx
+        # DTYPE 'float16' (NeuralNet training param): fp16 operands / fp32 accumulation on the matrix
+        # cores.  Every conv product of the net runs that way or construction fails -- no silent fp32.
+        self.f16 = self.ctx.mm_dtype == "float16"
+        if self.f16:
+            bits = self.ctx.lib.tn_conv_f16_supported(batch_sz, num_prev_maps, in_sz, in_sz, num_maps, filter_sz,
+                                                      stride, self.pad_lo, self.out_sz, self.out_sz)
+            assert bits & 5 == 5, (
+                "DTYPE float16 needs 3x3 stride-1 'same' conv layers on power-of-two maps of 8..64 pixels "
+                "(got {}->{} maps, {}x{} {} filter {} stride {}: forward {}, weight gradient {})".format(
+                    num_prev_maps, num_maps, in_sz, in_sz, mode, filter_sz, stride, bool(bits & 1), bool(bits & 4)))
+            self._f16_dgrad = bool(bits & 2)
         self.inpt = inpt
         self.batch_sz, self.num_prev_maps, self.in_sz = batch_sz, num_prev_maps, in_sz
         self.filter_sz, self.stride = filter_sz, stride
@@ -89,6 +100,11 @@ class ConvLayer(Layer):
     def can_fuse_with(self, pool):
         """conv -> act -> 2x2 max-pool on small channel counts runs as one fused kernel pair
         (tn_convpool_fwd / tn_convpool_bwd): the conv activation never reaches HBM."""
+        if self.f16:
+            self._tile_pool = bool(self.ctx.lib.tn_convpool_f16_supported(
+                self.batch_sz, self.num_prev_maps, self.in_sz, self.in_sz, self.num_maps, self.filter_sz,
+                self.stride, self.pad_lo, self.out_sz, self.out_sz, pool.pool_sz, pool.out_sz, pool.out_sz))
+            return self._tile_pool
         if self.stride == 1 and self.ctx.lib.tn_convpool_supported(
                 self.num_prev_maps, self.filter_sz, self.stride, pool.pool_sz):
             return True

@@ -353,6 +353,7 @@ class _TestFn:
     def __call__(self, i):
         net, ctx = self.net, self.net.ctx
         net._sync_weights()
+        net._apply_dtype()
         slot = net.test_x
         slot.bind(self.x_data)
         slot.row0 = int(i) * net.batch_sz + net.shard_lo
@@ -389,6 +390,13 @@ class NeuralNet():
             self.rand_gen = None
 
         self.ctx = get_context()             # raises without libtheanet_hip.so / a GPU
+        # DTYPE: 'float32' (default = the reference's floatX, weights.py:8) or 'float16' = fp16 operands /
+        # fp32 accumulation for the conv products, fp32 master weights; GRAD_SCALE: power of two applied
+        # to dz before it is rounded to fp16 (results are scaled back: exact)
+        self.dtype = training_params.get('DTYPE', 'float32')
+        assert self.dtype in ('float32', 'float16'), "DTYPE must be 'float32' or 'float16'"
+        self.grad_scale = float(training_params.get('GRAD_SCALE', 4096.))
+        self._apply_dtype()
         self.world = comm.get_world()
         self._dev_group = None
 
@@ -546,13 +554,16 @@ class NeuralNet():
         # an active single-channel ElasticLayer feeding such a block: the block's forward resamples
         # the raw images itself (tn_elastic_convpool_fwd_mask)
         if len(lyrs) >= 3 and isinstance(lyrs[0], ElasticLayer) and lyrs[0].active and \
-                lyrs[0].num_maps == 1 and isinstance(lyrs[1], ConvLayer) and \
+                lyrs[0].num_maps == 1 and not getattr(lyrs[1], "f16", False) and isinstance(lyrs[1], ConvLayer) and \
                 lyrs[1].fused_pool is lyrs[2]:
             el, conv, pool = lyrs[0], lyrs[1], lyrs[2]
             if conv.ctx.lib.tn_elastic_convpool_supported(
                     el.img_sz, el.img_sz, conv.num_maps, conv.filter_sz, conv.pad_lo, conv.out_sz,
                     conv.out_sz, pool.pool_sz, pool.out_sz, pool.out_sz) and not pool.ignore_border:
                 el.fused_conv, pool.fused_elastic = conv, el
+
+    def _apply_dtype(self):
+        self.ctx.set_matmul_dtype(self.dtype, self.grad_scale)
 
     # ------------------------------------------------------------------------------
     def _group(self):
@@ -740,6 +751,7 @@ class NeuralNet():
         """forward + backward + all-reduce + update for the minibatch the input slot
         currently points at.  Everything is enqueued; nothing is read back."""
         ctx = self.ctx
+        self._apply_dtype()
         out = self.tr_layers[-1]
         first = self.tr_layers[0]
         if self._dp_tune is not None and not self.use_graph and not pipe_stride:
@@ -985,6 +997,7 @@ class NeuralNet():
 
         def fn(x):
             self._sync_weights()
+            self._apply_dtype()
             x = np.ascontiguousarray(x, np.float32).reshape(stage.shape)
             stage.set_value(x)
             slot = self.test_x
