@@ -7,8 +7,9 @@
 
 One process per GPU; RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* come from the launcher (torch itself
 is not imported: the hot path is libtheanet_hip.so + RCCL).  Rank 0 prints ONE JSON line.
-Weak scaling: every GPU trains on 4096 images per step (global batch 4096*N), one flat
-gradient all-reduce per step.
+N > 1 defaults to STRONG scaling as BASELINE.json configs[2] states it ("bs4096 sharded 8 ways"):
+the global batch stays 4096 and every rank trains on 4096/N rows, one flat gradient all-reduce per
+step.  --scaling weak keeps 4096 rows per GPU instead (global 4096*N).
 """
 import argparse
 import ast
@@ -35,17 +36,20 @@ def synthetic(rows, c, hw):
     return x, y
 
 
-def cpu_baseline(prms, hw, c, budget_s=12.0, batch=256):
+def cpu_baseline(prms, hw, c, batch, budget_s=15.0):
     """The numpy oracle (a CPU port of the reference path -- Theano itself cannot be
-    installed) timed on a bounded sample of the same workload, on this box's host cores."""
+    installed) timed on a bounded sample of the SAME workload (same net, same batch size), on this
+    box's host cores: whole training steps until ~budget_s is used (at least one)."""
     from oracle import theanet_oracle as O
     p = copy.deepcopy(prms)
     p["training_params"]["BATCH_SZ"] = batch
     net = O.OracleNet(p["layers"], p["training_params"])
     x, y = synthetic(batch * 2, c, hw)
-    net.train_step(x[:batch], y[:batch])            # warm-up
+    t0 = time.perf_counter()
+    net.train_step(x[:batch], y[:batch])            # warm-up (and the step-time estimate)
+    est = time.perf_counter() - t0
     t0, n = time.perf_counter(), 0
-    while time.perf_counter() - t0 < budget_s and n < 200:
+    while n == 0 or (time.perf_counter() - t0 + est < budget_s and n < 200):
         net.train_step(x[(n % 2) * batch:(n % 2 + 1) * batch], y[(n % 2) * batch:(n % 2 + 1) * batch])
         n += 1
     dt = time.perf_counter() - t0
@@ -54,10 +58,10 @@ def cpu_baseline(prms, hw, c, budget_s=12.0, batch=256):
         threads = max([i.get("num_threads", 1) for i in threadpool_info()] or [1])
     except Exception:
         threads = os.cpu_count()
-    return {"value": batch * n / dt, "unit": "images/sec", "cores": int(threads), "kind": "port",
-            "sample": "numpy oracle (oracle/theanet_oracle.py), %s fwd+bwd+update, %d steps of "
-                      "batch %d in %.1f s; host has %d cores" % (prms.get("_name", "net"), n, batch,
-                                                                dt, os.cpu_count())}
+    return {"value": batch * n / dt, "unit": "images/sec", "cores": int(threads), "threads": int(threads),
+            "nproc": os.cpu_count(), "kind": "port",
+            "sample": "numpy oracle (oracle/theanet_oracle.py; BLAS threads = cores), %s fwd+bwd+update, "
+                      "%d steps of batch %d in %.1f s" % (prms.get("_name", "net"), n, batch, dt)}
 
 
 def main():
@@ -66,7 +70,12 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--prms", default="mnist.prms")
-    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: 4096 for mnist)")
+    ap.add_argument("--batch", type=int, default=0, help="batch of the N=1 workload (default: 4096 for mnist)")
+    ap.add_argument("--scaling", choices=("strong", "weak"), default="strong",
+                    help="N > 1: strong = the global batch stays --batch, every rank takes batch/N rows "
+                         "(BASELINE configs[2]); weak = --batch rows per GPU")
+    ap.add_argument("--dtype", choices=("f32", "f16"), default="f32",
+                    help="f16: fp16 operands / fp32 accumulation for the conv products (DTYPE float16)")
     ap.add_argument("--img", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true", help="skip the per-kernel roofline leg")
@@ -88,13 +97,21 @@ def main():
     defaults = {"mnist.prms": (4096, 28, 1), "cifar_like.prms": (2048, 32, 3),
                 "wide6.prms": (128, 64, 3), "3flat.prms": (4096, 28, 1)}
     dB, dimg, C = defaults.get(args.prms, (4096, 28, 1))
-    per_gpu = args.batch or dB
+    base_batch = args.batch or dB
+    scaling = args.scaling if world.size > 1 else "weak"     # N = 1: the two coincide
+    if scaling == "strong":
+        assert base_batch % world.size == 0, "batch %d does not divide over %d GPUs" % (base_batch, world.size)
+        per_gpu = base_batch // world.size
+    else:
+        per_gpu = base_batch
     img = args.img or dimg
     C = prms["layers"][0][1].get("num_maps", C)
     prms["layers"][0][1]["img_sz"] = img
     tr = prms["training_params"]
     tr["SEED"] = 555555
     tr["BATCH_SZ"] = per_gpu * world.size
+    if args.dtype == "f16":
+        tr["DTYPE"] = "float16"
 
     ctx = get_context()
     net = NeuralNet(copy.deepcopy(prms["layers"]), dict(tr))
@@ -132,6 +149,34 @@ def main():
         dt = group.rdzv.gather_max(dt)
     cost = fn.fetch()[0]
     assert np.isfinite(cost), "training diverged"
+
+    # The driver's --steps can make the timed region a few milliseconds: a second, longer loop of the
+    # same enqueue-only steps (>= 0.5 s) is reported beside it as `sustained`.
+    sustained = None
+    if dt < 0.05:
+        n_sus = int(min(50000, max(args.steps, 0.6 / max(dt / args.steps, 1e-6))))
+        barrier()
+        t1 = time.perf_counter()
+        for i in range(n_sus):
+            fn.enqueue(i % n_batches)
+        barrier()
+        dt_sus = time.perf_counter() - t1
+        if group is not None:
+            dt_sus = group.rdzv.gather_max(dt_sus)
+        sustained = {"steps": n_sus, "seconds": dt_sus, "ms_per_step": 1e3 * dt_sus / n_sus,
+                     "value": tr["BATCH_SZ"] * n_sus / dt_sus}
+    # The drop-in call fn(i) of the reference's loop (train.py:211: cost, features, logprob come back
+    # every step, i.e. a device sync + a D2H of B x n_out floats per step) -- its throughput, untimed above.
+    n_sync = int(min(2000, max(20, 0.3 / max(dt / args.steps, 1e-6))))
+    barrier()
+    t1 = time.perf_counter()
+    for i in range(n_sync):
+        fn(i % n_batches)
+    barrier()
+    dt_sync = time.perf_counter() - t1
+    if group is not None:
+        dt_sync = group.rdzv.gather_max(dt_sync)
+    value_sync_api = tr["BATCH_SZ"] * n_sync / dt_sync
 
     # ---- per-kernel roofline leg: HIP events (on the stream the kernel runs on) around the
     # heavy kernels of the SAME workload; the dominant one (largest share of the step) is
@@ -236,14 +281,30 @@ def main():
         return
     value = tr["BATCH_SZ"] * args.steps / dt
     step_flops = roofline.net_step_flops(net) * world.size
+    first = net.tr_layers[0]
+    stage = "elastic stage on" if type(first).__name__ == "ElasticLayer" and first.active else \
+        "no input distortion (%s)" % type(first).__name__
+    f16 = args.dtype == "f16"
+    if f16:          # the conv legs are priced against the fp16 MFMA peak, the fp32 fraction beside it
+        for rec in ([roof] if roof else []) + others:
+            if rec.get("bound") == "mfma" and "conv" in rec["kernel"]:
+                rec["frac_of_fp32_peak"] = rec["frac"]
+                rec["peak"] = roofline.MFMA_F16_PEAK_TFLOPS
+                rec["frac"] = rec["achieved"] / roofline.MFMA_F16_PEAK_TFLOPS
     line = {
         "metric": "training images/sec (fwd+bwd+update) MNIST-CNN bs4096, 1/2/4/8 MI355X",
         "value": value, "unit": "images/sec", "n_gpus": world.size, "steps": args.steps,
         "warmup": args.warmup, "setup_steps": setup_steps, "ms_per_step": 1e3 * dt / args.steps,
         "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "params/%s %dx%dx%d synthetic, %d images/GPU/step, elastic stage on"
-                               % (args.prms, img, img, C, per_gpu),
+        "scaling": scaling, "vs_baseline": None,
+        "dtype": "f16/f32acc (fp16 conv operands, fp32 accumulate, fp32 master weights)" if f16 else "f32",
+        "data": "synthetic",
+        "value_sync_api": value_sync_api,
+        "sync_api": {"steps": n_sync, "ms_per_step": 1e3 * dt_sync / n_sync,
+                     "what": "fn(i) returning [cost, features, logprob] every step as train.py:211 does"},
+        "sustained": sustained,
+        "config": {"workload": "params/%s %dx%dx%d synthetic, global batch %d = %d images/GPU/step x %d, %s"
+                               % (args.prms, img, img, C, tr["BATCH_SZ"], per_gpu, world.size, stage),
                    "global_batch": tr["BATCH_SZ"], "parallelism": "dp%d" % world.size,
                    "schedule": "two steps in flight (exact: the update applies the old velocity)"
                    if type(fn).__name__ == "_PipeTrainFn" and fn._twin is not None else "one step at a time",
@@ -257,7 +318,7 @@ def main():
         "final_cost": float(cost),
     }
     if world.size == 1 and not args.no_cpu_baseline:
-        line["cpu_baseline"] = cpu_baseline(prms, img, C)
+        line["cpu_baseline"] = cpu_baseline(prms, img, C, tr["BATCH_SZ"])
     print(json.dumps(line))
 
 

@@ -7,6 +7,7 @@ written once, no im2col buffer, no re-reads.
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md: 6.3 TB/s achievable)
 MFMA_F32_PEAK_TFLOPS = 157.3  # v_mfma_f32_32x32x2_f32 dense peak
+MFMA_F16_PEAK_TFLOPS = 2500.0  # v_mfma_f32_32x32x16_f16 dense peak (MI355X_MICROARCH.md; not the 2:1-sparse figure)
 
 
 def conv_shapes(N, C, H, K, f, Ho):
