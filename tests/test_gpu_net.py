@@ -573,12 +573,18 @@ def test_pipelined_equals_sequential_at_full_batch(monkeypatch):
         np.testing.assert_array_equal(wa, wb)
 
 
-def test_pipelined_function_handover(monkeypatch):
+@pytest.mark.parametrize("n1,n2", [(3, 4), (4, 4), (2, 6), (6, 3)])
+def test_pipelined_function_handover(monkeypatch, n1, n2):
     """A second get_trin_model on a net whose first training function had steps in flight, and a
-    training function that is driven after a test function was compiled: the weights stay exact."""
+    training function that is driven after a test function was compiled: the weights stay exact.
+    Even step counts matter: then the TWIN ran the last step and the fall-back folds its gradient
+    through the twin's update table (which must name the shared velocity buffers); the second
+    function's fall-back must keep the RNG step counter of the first (dropout + elastic stay in step),
+    and reset_accumulated_gradients must leave zero velocities behind."""
     from theanet_amd import NeuralNet
     import copy
     prms = load_prms("mnist.prms", 28, batch=64)
+    prms["layers"][5][1]["reg"] = {"maxnorm": 1.5}
     rng = np.random.RandomState(11)
     x = rng.rand(4 * 64, 1, 28, 28).astype(np.float32)
     y = rng.randint(0, 10, 4 * 64).astype(np.int32)
@@ -587,13 +593,18 @@ def test_pipelined_function_handover(monkeypatch):
         monkeypatch.setenv("TN_PIPELINE", pipe)
         net = NeuralNet(copy.deepcopy(prms["layers"]), dict(prms["training_params"]))
         f1 = net.get_trin_model(x, y)
-        for s in range(3):
+        for s in range(n1):
             f1.enqueue(s % 4)
         f2 = net.get_trin_model(x, y)
-        for s in range(3, 7):
+        for s in range(n1, n1 + n2):
+            f2.enqueue(s % 4)
+        mid = [w.copy() for l in net.tr_layers for w in l.get_wts()]
+        net.reset_accumulated_gradients()            # falls back from the second function
+        assert all((v.get_value() == 0).all() for l in net.tr_layers for v in (l.accumulated_updates or ()))
+        for s in range(n1 + n2, n1 + n2 + 3):
             f2.enqueue(s % 4)
         out = f2.fetch()
-        res.append((out, [w.copy() for l in net.tr_layers for w in l.get_wts()]))
+        res.append((out, mid + [w.copy() for l in net.tr_layers for w in l.get_wts()]))
     assert res[0][0][0] == res[1][0][0]
     np.testing.assert_array_equal(res[0][0][1], res[1][0][1])
     for wa, wb in zip(res[0][1], res[1][1]):

@@ -187,7 +187,9 @@ class _PipeTrainFn:
         import copy
         twin = NeuralNet.__new__(NeuralNet)
         twin._is_twin = True
-        twin.__init__(copy.deepcopy(net.layers), dict(net.tr_prms))
+        tp = dict(net.tr_prms)
+        tp.setdefault('SEED', 0)      # (a net loaded from a checkpoint has none; weights and stream seeds are copied below)
+        twin.__init__(copy.deepcopy(net.layers), tp)
         if net._dp:
             twin._dev_group = net._group()                 # ONE communicator; the streams alternate on it
         twin._prepare_training()
@@ -204,6 +206,11 @@ class _PipeTrainFn:
                 ctx.call("tn_d2d", pb.ptr, pa.ptr, pa.size * 4)
             if a.params:
                 b.accumulated_updates = a.accumulated_updates        # ONE velocity per tensor
+        # the twin's own velocity buffers are gone with that: its update table must name the shared ones
+        # (it is what _fall_back folds the last gradient through when the twin ran the last step)
+        twin._build_seg_table()
+        if getattr(twin, "_dp_can_delay", False):
+            twin._segs_ab[0] = twin._d_segs
         self._twin = twin
         self.nets = (net, twin)
         seg_dt = np.dtype([('p', 'u8'), ('psrc', 'u8'), ('v', 'u8'), ('g', 'u8'), ('n', 'u8'),
@@ -228,6 +235,7 @@ class _PipeTrainFn:
         for k, X in enumerate(self.nets):                  # all-reduce k waits for all-reduce k-1
             X._ar_done_ev, X._ar_wait_ev = arev[k], arev[1 - k]
         base = int(net.d_step.get_value()[0])            # steps already taken (an earlier training function)
+        self._base = base
         ctx.call("tn_set_u32", twin.d_step.ptr, base + 1)    # the twin takes every second step
         self._lr_prev = None
 
@@ -287,7 +295,7 @@ class _PipeTrainFn:
             ctx.call("tn_stream_select", 0)
             ctx.call("tn_sgd_update_multi_delayed", Y._d_segs.ptr, Y._n_segs, Y._max_seg,
                      net.cur_learn_rate.ptr, 1.0, None, 3)
-            ctx.call("tn_set_u32", net.d_step.ptr, self.t)
+            ctx.call("tn_set_u32", net.d_step.ptr, self._base + self.t)
             ctx.sync()
         has_wtcost = any(getattr(l, 'reg', None) and l.params and (l.reg['L1'] or l.reg['L2'])
                          for l in net.tr_layers)
@@ -589,16 +597,7 @@ class NeuralNet():
             lyr.grads.append(self.flat_grads.view(off, p.shape))
             lyr.accumulated_updates.append(self.ctx.zeros(p.shape))
         self.tr_layers[-1].d_cost = self.d_cost
-        # one multi-tensor momentum-SGD launch for every parameter tensor (layer.py:70-107)
-        seg_dt = np.dtype([('p', 'u8'), ('v', 'u8'), ('g', 'u8'), ('n', 'u8'),
-                           ('momentum', 'f4'), ('rate', 'f4'), ('L1', 'f4'), ('L2', 'f4')])
-        segs = []
-        for lyr in self.tr_layers:
-            if lyr.has_updates():
-                for p, v, g in zip(lyr.params, lyr.accumulated_updates, lyr.grads):
-                    segs.append((p.ptr, v.ptr, g.ptr, p.size, lyr.reg['momentum'], lyr.reg['rate'],
-                                 lyr.reg['L1'], lyr.reg['L2']))
-        self._n_segs = len(segs)
+        segs = host = self._build_seg_table()
         # the minibatch cost can ride in the update launch unless something must be added to it
         # first (weight costs) or it has to travel through the all-reduce (data-parallel ranks)
         has_wtcost = any(getattr(l, 'reg', None) and l.params and (l.reg['L1'] or l.reg['L2'])
@@ -608,11 +607,6 @@ class NeuralNet():
         self._cost_rider = (not has_wtcost) and not self._dp and \
             os.environ.get("TN_COST_RIDER", "1") != "0"
         self._cost_rider_ok = self._cost_rider
-        self._max_seg = max([sg[3] for sg in segs] or [0])
-        if segs:
-            host = np.array(segs, dtype=seg_dt)
-            self._d_segs = self.ctx.array(host.view(np.uint8))
-            self._h_segs = host                       # kept alive: tn_sgd_update_multi_lazy reads it
         # which layers must propagate a gradient to their input
         self._need_gin = []
         seen = False
@@ -642,7 +636,7 @@ class NeuralNet():
             # "delayed" schedule: the all-reduce of step t runs under the whole of step t+1 (exact, see
             # _train_step).  It needs a second flat gradient buffer (g_{t+1} is produced while G_t is
             # in flight) and gradients that do not depend on the weights they are applied to (no L1/L2).
-            self._dp_can_delay = bool(segs) and not has_wtcost
+            self._dp_can_delay = len(segs) > 0 and not has_wtcost
             if self._dp_can_delay:
                 self._flat_ab = [self.flat_grads, self.ctx.zeros((total + _GRAD_ALIGN,))]
                 self._grads_ab, self._segs_ab = [], [self._d_segs]
@@ -668,6 +662,26 @@ class NeuralNet():
                 if len(cands) > 1:
                     self._dp_tune = {"k": 0, "ev": {}, "cands": cands, "ms": []}
         self._grads_ready = True
+
+    def _build_seg_table(self):
+        """One multi-tensor momentum-SGD launch for every parameter tensor (layer.py:70-107): the table
+        of (param, velocity, gradient, ...) segments, on the device and (for the lazy update) on the host.
+        Rebuilt whenever a layer's velocity buffers are re-pointed (the twin of the pipelined schedule)."""
+        seg_dt = np.dtype([('p', 'u8'), ('v', 'u8'), ('g', 'u8'), ('n', 'u8'),
+                           ('momentum', 'f4'), ('rate', 'f4'), ('L1', 'f4'), ('L2', 'f4')])
+        segs = []
+        for lyr in self.tr_layers:
+            if lyr.has_updates():
+                for p, v, g in zip(lyr.params, lyr.accumulated_updates, lyr.grads):
+                    segs.append((p.ptr, v.ptr, g.ptr, p.size, lyr.reg['momentum'], lyr.reg['rate'],
+                                 lyr.reg['L1'], lyr.reg['L2']))
+        self._n_segs = len(segs)
+        self._max_seg = max([sg[3] for sg in segs] or [0])
+        host = np.array(segs, dtype=seg_dt)
+        if segs:
+            self._d_segs = self.ctx.array(host.view(np.uint8))
+            self._h_segs = host                       # kept alive: tn_sgd_update_multi_lazy reads it
+        return host
 
     _DP_TUNE_PRE, _DP_TUNE_WARM, _DP_TUNE_STEPS = 32, 8, 24      # settle-in steps, per-leg warm-up, timed
 
@@ -970,6 +984,11 @@ class NeuralNet():
         self._prepare_training()
         if getattr(self, "_pipe_fn", None) is not None:
             self._pipe_fn._fall_back()           # steps in flight: apply their gradients first
+        if self._dp_delayed and self._dp_pending:
+            # delayed all-reduce schedule: the reduced gradient of the last step is still to be folded
+            # into the velocity -- the reference zeroes that contribution too: drop it
+            self.ctx.call("tn_stream_wait", 0, 1)
+            self._dp_pending = False
         for lyr in self.tr_layers:
             for au in (lyr.accumulated_updates or ()):
                 au.fill_bytes(0)
