@@ -17,3 +17,8 @@ def _release_device_temporaries():
     yield
     from tests import gpu_util
     gpu_util._KEEP.clear()
+    # the matmul operand dtype is context state (tn_set_matmul_dtype): a DTYPE='float16' net leaves it
+    # set; per-op tests that call the C-ABI directly expect the reference's float32
+    from theanet_amd import device
+    if device._context is not None:
+        device._context.set_matmul_dtype("float32")
