@@ -26,6 +26,17 @@ def main(out_path):
     assert got == bytes(range(128))
     assert rdzv.gather_max(float(world.rank)) == world.size - 1
     rdzv.barrier()
+    # 1b. what train.py / NeuralNet use to keep replicas identical: rank 0's SEED everywhere, and a
+    # loud failure on EVERY rank when replicas disagree (weights checksum, order of collectives)
+    comm._rdzv = rdzv
+    assert comm.broadcast_int(1234 if world.rank == 0 else 99) == 1234
+    comm.agree(3.25, "a value all ranks share")
+    try:
+        comm.agree(float(world.rank), "the rank")
+    except RuntimeError as e:
+        assert "disagree" in str(e)
+    else:
+        raise SystemExit("comm.agree did not notice that the ranks differ")
 
     # 2. equal shards of a global minibatch; per-rank oracle gradients; flat buffer; all-reduce
     with open(os.path.join(ROOT, "params", "mnist.prms")) as fh:

@@ -151,29 +151,80 @@ class Rendezvous:
         self.conns, self.sock = [], None
 
 
+_rdzv = None
+
+
+def get_rendezvous():
+    """The process-wide socket rendezvous of the launch (created on first use; every rank must reach
+    its first use -- train.py's seed broadcast or the RCCL bootstrap -- at the same point)."""
+    global _rdzv
+    if _rdzv is None:
+        _rdzv = Rendezvous(get_world())
+    return _rdzv
+
+
+def broadcast_int(value):
+    """Rank 0's integer on every rank (e.g. the SEED every replica must build its net from)."""
+    r = get_rendezvous()
+    return struct.unpack("<q", r.broadcast(struct.pack("<q", int(value)), 8))[0]
+
+
+def agree(value, what="value", rdzv=None):
+    """Raise unless ``value`` (a float) is identical on every rank -- replicas that disagree on their
+    weights would silently all-reduce gradients of different nets."""
+    r = rdzv if rdzv is not None else get_rendezvous()
+    hi, lo = r.gather_max(float(value)), -r.gather_max(-float(value))
+    if hi != lo:
+        raise RuntimeError("data-parallel ranks disagree on %s (min %r, max %r): every rank must build "
+                           "the net from the same SEED / weights" % (what, lo, hi))
+
+
 class DeviceGroup:
     """RCCL communicator bound to a theanet_amd Context (GPU path)."""
 
     def __init__(self, ctx, world, rdzv=None):
         import ctypes
         self.ctx, self.world = ctx, world
-        self.rdzv = rdzv if rdzv is not None else Rendezvous(world)
+        self.rdzv = rdzv if rdzv is not None else (get_rendezvous() if world is get_world() else Rendezvous(world))
         idbuf = ctypes.create_string_buffer(128)
         if world.rank == 0:
             ctx.call("tn_comm_unique_id", idbuf)
         blob = self.rdzv.broadcast(idbuf.raw, 128)
         idbuf = ctypes.create_string_buffer(blob, 128)
         ctx.call("tn_comm_init", idbuf, world.rank, world.size)
+        # every collective issued on this communicator, as a running hash of (sequence number, kind,
+        # element count): all ranks must issue the same sequence (the two streams of the pipelined
+        # schedule alternate on ONE communicator) -- verify_order() compares it across ranks
+        self.n_issued, self.order_hash = 0, 0
+        self.check_every_call = os.environ.get("TN_DP_CHECK_ORDER") == "1"
+
+    def _note(self, kind, count):
+        self.n_issued += 1
+        self.order_hash = (self.order_hash * 1000003 + hash((self.n_issued, kind, int(count)))) % (1 << 52)
+        if self.check_every_call:
+            self.verify_order()
+
+    def verify_order(self):
+        """Raise unless every rank has issued the same sequence of collectives so far (host-side
+        bookkeeping compared over the socket rendezvous; call at points where the host syncs anyway)."""
+        agree(float(self.order_hash), "the order of collectives issued so far (%d on this rank)" % self.n_issued,
+              self.rdzv)
 
     def allreduce_sum(self, darr, count=None):
-        self.ctx.call("tn_allreduce_sum", darr.ptr, darr.size if count is None else count)
+        n = darr.size if count is None else count
+        self._note("sum", n)
+        self.ctx.call("tn_allreduce_sum", darr.ptr, n)
 
     def allreduce_max(self, darr, count=None):
-        self.ctx.call("tn_allreduce_max", darr.ptr, darr.size if count is None else count)
+        n = darr.size if count is None else count
+        self._note("max", n)
+        self.ctx.call("tn_allreduce_max", darr.ptr, n)
 
     def barrier(self):
         self.ctx.sync()
         self.rdzv.barrier()
+        if self.world.size > 1:
+            self.verify_order()
 
 
 class HostGroup:

@@ -11,7 +11,6 @@ from .weights import init_wb
 
 
 class HiddenLayer(Layer):
-    side_stream = True        # overlap the weight-gradient GEMM with the backward chain
 
     def __init__(self, inpt, wts,
                  rand_gen=None,
@@ -90,7 +89,7 @@ class HiddenLayer(Layer):
 
     def backward(self, gout, need_gin, below):
         """gout = d cost / d z (activation gradient and dropout mask already applied)."""
-        if self.has_updates() and need_gin and not self.side_stream:
+        if self.has_updates() and need_gin:
             # weight gradient and input gradient only share dz: one op, one launch
             if self.wgrad_ws is None:
                 nbytes = self.ctx.lib.tn_fc_wgrad_ws_bytes(self.batch_sz, self.n_in, self.n_out)
@@ -108,17 +107,9 @@ class HiddenLayer(Layer):
             if self.wgrad_ws is None:
                 nbytes = self.ctx.lib.tn_fc_wgrad_ws_bytes(self.batch_sz, self.n_in, self.n_out)
                 self.wgrad_ws = self.ctx.empty((nbytes + 3) // 4)
-            # dW/db only feed the update: run them on the side stream, concurrently with the
-            # dgrad chain on the main stream (joined again before the all-reduce / update)
-            side = self.side_stream and need_gin
-            if side:
-                self.ctx.call("tn_stream_wait", 1, 0)
-                self.ctx.call("tn_stream_select", 1)
             self.ctx.call("tn_fc_wgrad", self.inpt.ptr, gout.ptr, self.grads[0].ptr,
                           self.grads[1].ptr, self.batch_sz, self.n_in, self.n_out,
                           self.wgrad_ws.ptr)
-            if side:
-                self.ctx.call("tn_stream_select", 0)
         if not need_gin:
             return None
         if self.gin is None:

@@ -115,12 +115,12 @@ class ElasticLayer(Layer):
         n_draws = ctx.lib.tn_elastic_draws_count(h, w)
         self.draws = ctx.zeros((n_draws,))
         # two sample maps: while the minibatch of step t is resampled through one, the field of
-        # step t+1 (it depends only on the step counter) is built into the other on the side stream
+        # step t+1 (it depends only on the step counter) is built into the other by a rider of the
+        # backward pass / the update launch (NeuralNet._train_step)
         self._maps = [(ctx.empty((h * w,), np.int32), ctx.empty((h * w,)), ctx.empty((h * w,)),
                        ctx.empty((2, h, w), np.float64)) for _ in range(2)]
         self._cur = 0
         self._pre_valid = False
-        self.precompute = False         # set by NeuralNet (needs the side stream, eager launches)
         self.map_idx, self.map_fy, self.map_fx, self.target = self._maps[0]
 
     def TestVersion(self, te_inpt):
@@ -172,13 +172,10 @@ class ElasticLayer(Layer):
                           None, None, None, 0.0, None, 0, 0, None, rg0)
             return
         d_step_ptr = self.d_step.ptr if self.d_step is not None else None
-        ahead = self.precompute and self.has_field and not self._inj_draws and self.d_step is not None
         if self.has_field:
             self.map_idx, self.map_fy, self.map_fx, self.target = self._maps[self._cur]
             if self._pre_valid and not self._inj_draws:
-                if ahead:
-                    self.ctx.call("tn_stream_wait", 0, 1)    # the side stream built this map
-                # else: built by the previous step's closing launch (NeuralNet._train_step)
+                pass                # built by the previous step's closing launch (NeuralNet._train_step)
             else:
                 if not self._inj_draws:      # draws generated inside the field launch
                     m = self._maps[self._cur]
@@ -200,16 +197,6 @@ class ElasticLayer(Layer):
         if self.fused_conv is not None and train:
             return                      # the conv block's forward resamples while it loads (PoolLayer)
         self.ctx.call("tn_elastic_apply", *self._apply_args)
-        if ahead:
-            # next step's field: draws keyed by (seed, *d_step + 1); the step counter only
-            # advances in the update, which the net issues after joining the side stream
-            nxt = 1 - self._cur
-            self.ctx.call("tn_stream_wait", 1, 0)
-            self.ctx.call("tn_stream_select", 1)
-            self.ctx.call("tn_elastic_draws", self.draws.ptr, h, w, self.seed, 1, d_step_ptr)
-            self._field(self._maps[nxt])
-            self.ctx.call("tn_stream_select", 0)
-            self._cur, self._pre_valid = nxt, True
 
     def _field(self, m):
         h = w = self.img_sz

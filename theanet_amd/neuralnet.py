@@ -69,7 +69,6 @@ class _TrainFn:
     def __init__(self, net, x_data, y_data, take_index_list):
         self.net, self.x_data, self.y_data = net, x_data, y_data
         self.take_index_list = take_index_list
-        self._graph, self._warm = None, False
         ctx = net.ctx
         if take_index_list:
             row = int(np.prod(x_data.shape[1:]))
@@ -78,51 +77,10 @@ class _TrainFn:
             self.idx_dev = ctx.empty((net.local_bsz,), np.int32)
             self.row_bytes = row * 4
 
-    # -- HIP-graph replay ---------------------------------------------------------------
-    def _graph_ok(self):
-        net = self.net
-        if not net.use_graph or self.take_index_list or net.ctx.ev_hook is not None:
-            return False
-        for lyr in net.tr_layers:               # injected draws change buffers: stay eager
-            drop = getattr(lyr, "drop", None)
-            if drop is not None and drop.injected:
-                return False
-            if getattr(lyr, "_inj_draws", False) or getattr(lyr, "_inj_flip", None) is not None:
-                return False
-        return True
-
-    def _enqueue_graph(self, i):
-        """Step = one tiny kernel that stores the minibatch's first row on the device + one
-        graph launch (the ~25 kernels of the step were captured once; every per-step value --
-        row offset, RNG step counter, learning rate -- is read from device memory)."""
-        net, ctx = self.net, self.net.ctx
-        slot = net.x
-        row0 = int(i) * net.batch_sz + net.shard_lo
-        if self._graph is None:
-            if not self._warm:                  # first call runs eagerly: sizes every lazy buffer
-                self._warm = True
-                return False
-            slot.bind(self.x_data)
-            slot.row0, slot.d_row0, slot.row_global0 = 0, net.d_row0, net.shard_lo
-            ctx.call("tn_graph_begin")
-            try:
-                net._train_step(self.y_data, 0, net.d_row0)
-            finally:
-                import ctypes
-                g = ctypes.c_void_p()
-                ctx.call("tn_graph_end", ctypes.byref(g))
-            slot.d_row0 = None
-            self._graph = g
-        ctx.call("tn_set_i64", net.d_row0.ptr, row0)
-        ctx.call("tn_graph_launch", self._graph)
-        return True
-
     def enqueue(self, i):
         net, ctx = self.net, self.net.ctx
         B, lo = net.batch_sz, net.shard_lo
         slot = net.x
-        if self._graph_ok() and self._enqueue_graph(i):
-            return
         slot.d_row0 = None
         if self.take_index_list:
             idx = np.ascontiguousarray(np.asarray(i, np.int32)[lo:lo + net.local_bsz])
@@ -250,7 +208,7 @@ class _PipeTrainFn:
             if (drop is not None and drop.injected) or getattr(lyr, "_inj_draws", False) or \
                     getattr(lyr, "_inj_flip", None) is not None:
                 return True
-        return net.use_graph or net.side_stream or net.ctx.ev_hook is not None
+        return net.ctx.ev_hook is not None
 
     # -- the start-of-step update -----------------------------------------------------------------
     def _update_for(self, t):
@@ -375,6 +333,8 @@ class _TestFn:
         if net.world.size > 1:
             net._group().allreduce_sum(out.d_stats)
         stats = out.d_stats.get_value() / net.world.size
+        if net.world.size > 1:
+            net._group().verify_order()      # the host has synchronised anyway: cheap point to compare
         res = [stats[0], stats[1]]
         if self.preds_feats:
             res += [out.features.get_value(), out.y_preds.get_value().astype(np.int64)]
@@ -431,16 +391,6 @@ class NeuralNet():
         self.d_step = self.ctx.zeros((1,), np.uint32)       # RNG step counter
         self.d_row0 = self.ctx.zeros((1,), np.int64)        # first dataset row of the minibatch
         self.cur_learn_rate = self.ctx.zeros((1,), np.float32)
-        import os
-        env = os.environ.get("TN_GRAPH")
-        # measured on MI355X: replaying the captured step is NOT faster than eager launches (the
-        # ~1.5-2 us kernel boundaries are GPU-side either way) and loses ~12 % with the
-        # two-stream backward, so capture is opt-in (TN_GRAPH=1)
-        self.use_graph = (env == "1")
-        self.side_stream = os.environ.get("TN_SIDE", "0") in ("1", "2")   # measured: contends with the matrix-core backward
-        self.elastic_ahead = os.environ.get("TN_ELASTIC_AHEAD", "0") == "1"   # measured: -2 %
-        HiddenLayer.side_stream = self.side_stream and os.environ.get("TN_SIDE") != "2"   # 2: light work only
-
         # Input Layer
         input_layer_type = getattr(layer, layers[0][0])
         assert input_layer_type in (InputLayer, ElasticLayer), \
@@ -467,7 +417,6 @@ class NeuralNet():
         for lyr in self.tr_layers:
             if isinstance(lyr, ElasticLayer):
                 lyr.d_step = self.d_step
-                lyr.precompute = self.side_stream and not self.use_graph
             drop = getattr(lyr, "drop", None)
             if drop is not None:
                 drop.d_step = self.d_step
@@ -615,6 +564,10 @@ class NeuralNet():
             seen = seen or lyr.has_updates()
         if self._dp:
             self._group()
+            if self.world.size > 1 and not getattr(self, "_is_twin", False):
+                # replicas must start from identical weights (same SEED or same checkpoint on every rank)
+                chk = float(sum(np.float64(w.astype(np.float64).sum()) for l in self.tr_layers for w in l.get_wts()))
+                comm.agree(chk, "the initial weights (checksum)")
         # Optional overlap of the gradient all-reduce with the backward pass (TN_DP_OVERLAP=1): the
         # fully-connected layers sit on top of the net and hold almost all parameters; their gradients
         # (the tail of the flat buffer, cost included) are reduced on the second stream while the conv
@@ -768,34 +721,16 @@ class NeuralNet():
         self._apply_dtype()
         out = self.tr_layers[-1]
         first = self.tr_layers[0]
-        if self._dp_tune is not None and not self.use_graph and not pipe_stride:
+        if self._dp_tune is not None and not pipe_stride:
             self._dp_tune_tick()
         if self._dp_can_delay:
             self._dp_bind(self._dp_cur if self._dp_delayed else 0)
-        if isinstance(first, ElasticLayer):
-            first.precompute = self.side_stream and not self.use_graph and self.elastic_ahead
-        # Random inputs that depend only on the step counter are produced on the side stream,
-        # off the critical path: dropout masks now, the NEXT step's elastic field later on.
-        pre = [l for l in self.tr_layers if getattr(l, "drop", None) is not None and not l.drop.injected] \
-            if self.side_stream else []
-        if pre:
-            ctx.call("tn_stream_wait", 1, 0)
-            ctx.call("tn_stream_select", 1)
-            for lyr in pre:
-                lyr.drop.generate()
-                lyr.drop.ready = True
-            ctx.call("tn_stream_select", 0)
-        joined = not pre
         for lyr in self.tr_layers[:-1]:
-            if not joined and getattr(lyr, "drop", None) is not None:
-                ctx.call("tn_stream_wait", 0, 1)
-                joined = True
             lyr.forward(True)
         # the weight-gradient ops only record their finishing slab sums; one launch does them all
         ctx.call("tn_defer_reductions", 1)
         n_lyr = len(self.tr_layers)
-        fuse_out = n_lyr >= 2 and self._need_gin[n_lyr - 1] and not self.side_stream and \
-            os.environ.get("TN_SOFTMAX_TRAIN", "1") != "0"
+        fuse_out = n_lyr >= 2 and self._need_gin[n_lyr - 1] and os.environ.get("TN_SOFTMAX_TRAIN", "1") != "0"
         try:
             out.forward(True, y=y, y_row0=y_row0, d_row0=d_row0,
                         below=self.tr_layers[-2] if fuse_out else None)
@@ -807,9 +742,6 @@ class NeuralNet():
         # with them it must exist before tn_wtcost accumulates onto it: a leaf reduction here.
         rider = self._cost_rider and not pipe_stride
         if not rider:
-            if self.side_stream:
-                ctx.call("tn_stream_wait", 1, 0)
-                ctx.call("tn_stream_select", 1)
             if pipe_stride and self._cost_rider_ok:
                 # the cost block of the update launch on its own: the same summation order as the
                 # one-step-at-a-time schedule, so the reported cost is bit-identical too
@@ -818,16 +750,13 @@ class NeuralNet():
             else:
                 ctx.call("tn_reduce_sum", out.rowloss.ptr, self.local_bsz, 1.0 / self.batch_sz,
                          self.d_cost.ptr, 0)
-            if self.side_stream:
-                ctx.call("tn_stream_select", 0)
         g = out.dlogits
         # The elastic field of the NEXT minibatch only depends on the step counter.  It is left with
         # the context as a rider (offset +1: the counter advances at the end of the step) and
         # travels as extra blocks of the backward pass's paired GEMM launch; nets without such a
         # launch build it beside the update instead (tn_step_tail).
         ahead = (isinstance(first, ElasticLayer) and first.active and first.has_field and
-                 not first._inj_draws and first.d_step is not None and not self.side_stream and
-                 not self.use_graph and (self._n_segs or rider) and
+                 not first._inj_draws and first.d_step is not None and (self._n_segs or rider) and
                  os.environ.get("TN_STEP_TAIL", "1") != "0")
         if ahead:
             nxt = 1 - first._cur
@@ -863,8 +792,6 @@ class NeuralNet():
             lazy = (not self._dp and 0 < self._n_segs <= 16 and
                     os.environ.get("TN_LAZY_UPDATE", "1") != "0")
         finally:
-            if self.side_stream:
-                ctx.call("tn_stream_wait", 0, 1)  # join the side stream (leaf weight gradients)
             waiting = bool(ctx.lib.tn_rider_pending(ctx.h))
             if waiting:
                 ctx.call("tn_rider_cancel")       # nobody carried it: it joins the update launch
@@ -893,7 +820,7 @@ class NeuralNet():
                 first._cur, first._pre_valid = nxt, True
             return
         delayed = self._dp_delayed
-        if delayed and (tail or self.use_graph):
+        if delayed and tail:
             self._dp_set_schedule("plain")        # (configuration-determined: the same on every rank)
             delayed = False
         if delayed:
@@ -977,8 +904,7 @@ class NeuralNet():
                      or getattr(l, "_inj_flip", None) is not None for l in self.tr_layers)
         if self._dp and os.environ.get("TN_DP_PIPELINE", "1") == "0":
             return False
-        return (not take_index_list and not self.use_graph and not self.side_stream and
-                self._n_segs > 0 and not has_wtcost and not inject)
+        return not take_index_list and self._n_segs > 0 and not has_wtcost and not inject
 
     def reset_accumulated_gradients(self):
         self._prepare_training()

@@ -3,13 +3,19 @@
 """Training harness: the counterpart of the reference's train.py for the MI355X backend.
 
     python3 train.py <dataset> <params_file(.prms|.pkl)> [1]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 train.py ...
 
-Same command line, same stdout table (Epoch Cost Tr_Error Tr_P(MLE) Te_Error Te_P(MLE)),
-same pickle checkpoints ({"layers","training_params","allwts"}; float32 ndarrays) so
-files move freely between the reference and this build.  The dataset, weights and all
-activations stay in HBM; per step only the minibatch index crosses to the device.
+Same command line, same stdout table (Epoch Cost Tr_Error Tr_P(MLE) Te_Error Te_P(MLE)) and the same
+pickle checkpoints ({"layers","training_params","allwts"}; float32 ndarrays) as the reference's
+train.py:58-245, so parameter files, logs and checkpoints move freely between the two.  The dataset,
+weights and all activations stay in HBM; per step only the minibatch index crosses to the device.
+
+Data-parallel launches (one process per GPU): rank 0 chooses the SEED and broadcasts it, so every
+replica builds the same net; rank 0 alone prints the table and writes / rotates checkpoints; every rank
+runs the training and test functions (they contain the collectives).
 """
 import ast
+import contextlib
 import importlib
 import os
 import pickle
@@ -21,46 +27,10 @@ from datetime import datetime
 import numpy as np
 
 import theanet_amd.neuralnet as nn
+from theanet_amd import comm
 from theanet_amd.device import get_context, share
 
-
-def fixdim(arr):
-    """2-D (N, side*side) / 3-D (N,H,W) / 4-D image arrays -> NCHW."""
-    if arr.ndim == 2:
-        side = int(arr.shape[-1] ** .5)
-        assert side ** 2 == arr.shape[-1], "Need a perfect square"
-        return arr.reshape((arr.shape[0], 1, side, side))
-    if arr.ndim == 3:
-        return np.expand_dims(arr, axis=1)
-    if arr.ndim == 4:
-        return arr
-    raise ValueError("Image data arrays must have 2,3 or 4 dimensions only")
-
-
-class WrapOut:
-    """stdout, optionally teed into <params>_<SEED>.txt (line buffered)."""
-
-    def __init__(self, use_file, name=''):
-        self.name, self.use_file = name, use_file
-        self.stream = open(name, 'w', 1) if use_file else sys.__stdout__
-
-    def write(self, data):
-        self.stream.write(data)
-
-    def forceflush(self):
-        if self.use_file:
-            self.stream.close()
-            self.stream = open(self.name, 'a', 1)
-        else:
-            self.stream.flush()
-
-    def __getattr__(self, attr):
-        return getattr(self.stream, attr)
-
-
-def main(argv):
-    if len(argv) < 3:
-        print('Usage:', argv[0], ''' <dataset> <params_file(s)> [redirect=0]
+USAGE = '''Usage: {} <dataset> <params_file(s)> [redirect=0]
     dataset:
         Name of a module in the data folder: "synthetic", "mnist", ...
     params_file(s) :
@@ -69,146 +39,198 @@ def main(argv):
         - name.pkl  : pickled file from a previous run (has wts too).
     redirect:
         1 - redirect stdout to a params_<SEED>.txt file
-    ''')
-        return 1
+'''
 
-    dataset_name, prms_file_name = argv[1], argv[2]
 
-    # ---------------------------------------------------------------- parameters
-    if prms_file_name.endswith('.pkl'):
-        with open(prms_file_name, 'rb') as f:
-            params = pickle.load(f)
-    else:
-        with open(prms_file_name, 'r') as f:
-            params = ast.literal_eval(f.read())
+def as_nchw(images):
+    """Dataset image arrays come flat (N, side*side), as (N, H, W) or already (N, C, H, W)."""
+    a = np.asarray(images)
+    if a.ndim == 4:
+        return a
+    if a.ndim == 3:
+        return a[:, None, :, :]
+    if a.ndim != 2:
+        raise ValueError("Image data arrays must have 2,3 or 4 dimensions only")
+    side = int(round(a.shape[1] ** .5))
+    assert side * side == a.shape[1], "Need a perfect square"
+    return a.reshape(a.shape[0], 1, side, side)
 
-    layers = params['layers']
-    tr_prms = params['training_params']
-    allwts = params.get('allwts')
 
-    if tr_prms.get('SEED') is None:
-        tr_prms['SEED'] = int(np.random.randint(0, 1e6))
+def load_params(path):
+    if path.endswith('.pkl'):
+        with open(path, 'rb') as fh:
+            return pickle.load(fh)
+    with open(path, 'r') as fh:
+        return ast.literal_eval(fh.read())
 
-    out_file_head = os.path.basename(prms_file_name).replace(
-        os.path.splitext(prms_file_name)[1], "_{:06d}".format(tr_prms['SEED']))
 
-    if argv[-1] == '1':
-        print("Printing output to {}.txt".format(out_file_head), file=sys.stderr)
-        sys.stdout = WrapOut(True, out_file_head + '.txt')
-    else:
-        sys.stdout = WrapOut(False)
+class Log:
+    """Where the report goes: the console, a line-buffered <params>_<SEED>.txt (redirect = 1), or
+    nowhere (data-parallel ranks other than 0)."""
 
-    # ---------------------------------------------------------------- banner
-    ctx = get_context()
-    dev_name, cus, mem = ctx.info()
-    print(' '.join(argv), file=sys.stderr)
-    print(' '.join(argv))
-    print('Time   :' + datetime.now().strftime('%Y-%m-%d %H:%M:%S'))
-    print('Device : {} ({} CUs, {:.0f} GB) (float32)'.format(dev_name, cus, mem / 2 ** 30))
-    print('Host   :', socket.gethostname())
-    print(nn.get_layers_info(layers))
-    print(nn.get_training_params_info(tr_prms))
+    def __init__(self, path=None, mute=False):
+        self.path, self.mute = path, mute
+        self.fh = open(os.devnull, 'w') if mute else (open(path, 'w', 1) if path else None)
 
-    # ---------------------------------------------------------------- data -> HBM
-    data = importlib.import_module("data." + dataset_name)
-    data.training_x = fixdim(np.asarray(data.training_x))
-    data.testing_x = fixdim(np.asarray(data.testing_x))
-    tr_corpus_sz, n_maps, _, layers[0][1]['img_sz'] = data.training_x.shape
-    te_corpus_sz = data.testing_x.shape[0]
-    if n_maps != 1:
-        layers[0][1].setdefault('num_maps', n_maps)
+    @contextlib.contextmanager
+    def capture(self):
+        if self.fh is None:
+            yield
+        else:
+            with contextlib.redirect_stdout(self.fh):
+                yield
 
-    trin_x = share(data.training_x)
-    test_x = share(data.testing_x)
-    trin_y = share(data.training_y, 'int32')
-    test_y = share(data.testing_y, 'int32')
+    def checkpoint(self):
+        """Make what was printed so far durable (the reference closes and re-opens its file)."""
+        if self.path and not self.mute:
+            self.fh.flush()
+            os.fsync(self.fh.fileno())
+        else:
+            sys.stdout.flush()
 
-    print("\nInitializing the net ... ")
-    net = nn.NeuralNet(layers, tr_prms, allwts)
-    print(net)
-    print(net.get_wts_info(detailed=True).replace("\n\t", ""))
 
-    print("\nCompiling ... ")
-    training_fn = net.get_trin_model(trin_x, trin_y)
-    test_fn_tr = net.get_test_model(trin_x, trin_y)
-    test_fn_te = net.get_test_model(test_x, test_y)
+class BatchWindows:
+    """Rolling windows of minibatch indices for the periodic tests: each call yields the next
+    TEST_SAMP_SZ / BATCH_SZ batches of a corpus, wrapping around (train.py:170-176)."""
 
-    batch_sz = tr_prms['BATCH_SZ']
-    n_epochs = tr_prms['NUM_EPOCHS']
-    n_tr_batches = tr_corpus_sz // batch_sz
-    n_te_batches = te_corpus_sz // batch_sz
+    def __init__(self, corpus_sz, batch_sz, samp_sz):
+        self.n_all = corpus_sz // batch_sz
+        self.n_each = max(1, samp_sz // batch_sz)
+        self.pos = 0
 
-    def test_wrapper(nylist):
-        sym_err, bit_err, n = 0., 0., 0
-        for symdiff, bitdiff in nylist:
-            sym_err += symdiff
-            bit_err += bitdiff
-            n += 1
-        return 100 * sym_err / n, 100 * bit_err / n
+    def next(self):
+        idx = [(self.pos + k) % self.n_all for k in range(self.n_each)]
+        self.pos = (self.pos + self.n_each) % self.n_all
+        return idx
 
-    aux_err_name = 'BitErr' if net.tr_layers[-1].kind == 'LOGIT' else 'P(MLE)'
 
-    def get_test_indices(tot_samps, bth_samps=tr_prms['TEST_SAMP_SZ']):
-        n_bths_each = max(1, int(bth_samps / batch_sz))
-        n_bths_all = int(tot_samps / batch_sz)
-        cur = 0
-        while True:
-            yield [i % n_bths_all for i in range(cur, cur + n_bths_each)]
-            cur = (cur + n_bths_each) % n_bths_all
+def error_rates(test_fn, batches):
+    """Mean symbol error and mean second statistic (P(MLE) / bit error) over ``batches``, in percent."""
+    stats = np.array([test_fn(i)[:2] for i in batches], dtype=np.float64)
+    return 100 * stats[:, 0].mean(), 100 * stats[:, 1].mean()
 
-    test_indices = get_test_indices(te_corpus_sz)
-    trin_indices = get_test_indices(tr_corpus_sz)
-    pickle_file_name = out_file_head + '_{:02.0f}.pkl'
-    saved = {"name": None}
 
-    def do_test():
-        test_err, aux_test_err = test_wrapper(test_fn_te(i) for i in next(test_indices))
-        trin_err, aux_trin_err = test_wrapper(test_fn_tr(i) for i in next(trin_indices))
-        print("{:5.2f}%  ({:5.2f}%)      {:5.2f}%  ({:5.2f}%)".format(
-            trin_err, aux_trin_err, test_err, aux_test_err))
-        sys.stdout.forceflush()
-        if os.environ.get("THEANET_NO_PICKLE"):
+class Checkpoints:
+    """<head>_<test error>.pkl after every test, the previous one removed (train.py:195-200)."""
+
+    def __init__(self, head, enabled):
+        self.head, self.enabled, self.last = head, enabled, None
+
+    def save(self, net, test_err):
+        if not self.enabled:
             return
-        if saved["name"]:
-            os.remove(saved["name"])
-        saved["name"] = pickle_file_name.format(test_err)
-        with open(saved["name"], 'wb') as pkl_file:
-            pickle.dump(net.get_init_params(), pkl_file, -1)
+        name = '{}_{:02.0f}.pkl'.format(self.head, test_err)
+        tmp = name + '.tmp'
+        with open(tmp, 'wb') as fh:
+            pickle.dump(net.get_init_params(), fh, -1)
+        os.replace(tmp, name)
+        if self.last and self.last != name and os.path.exists(self.last):
+            os.remove(self.last)
+        self.last = name
 
-    # ---------------------------------------------------------------- training loop
-    np.set_printoptions(precision=2)
-    print("Training ...")
-    print("Epoch   Cost  Tr_Error Tr_{0}    Te_Error Te_{0}".format(aux_err_name))
-    for epoch in range(n_epochs):
-        total_cost = 0
-        t0 = time.perf_counter()
-        for ibatch in range(n_tr_batches):
-            cost, features, logprobs = training_fn(ibatch)
-            total_cost += cost
-            if np.isnan(total_cost):
-                print("Epoch:{} Iteration:{}".format(epoch, ibatch))
-                print(net.get_wts_info(detailed=True))
-                raise ZeroDivisionError("Nan cost at Epoch:{} Iteration:{}"
-                                        "".format(epoch, ibatch))
-        dt = time.perf_counter() - t0
 
-        if epoch % tr_prms['EPOCHS_TO_TEST'] == 0:
-            print("{:3d} {:>8.2f}".format(net.get_epoch(), total_cost), end='    ')
-            do_test()
-            print("        [{:,.0f} images/sec]".format(n_tr_batches * batch_sz / dt),
-                  file=sys.stderr)
-            if total_cost > 1e6:
-                print(net.get_wts_info(detailed=True))
+def run(dataset_name, prms_file_name, redirect):
+    world = comm.get_world()
+    lead = world.rank == 0
+    params = load_params(prms_file_name)
+    layers, tr_prms, allwts = params['layers'], params['training_params'], params.get('allwts')
 
-        net.inc_epoch_set_rate()
+    # every replica must build the same net: the seed is rank 0's
+    seed = tr_prms.get('SEED')
+    if seed is None:
+        seed = int(np.random.randint(0, 1e6))
+    if world.size > 1:
+        seed = comm.broadcast_int(seed)
+    tr_prms['SEED'] = seed
 
-    # ---------------------------------------------------------------- final error rates
-    test_err, aux_test_err = test_wrapper(test_fn_te(i) for i in range(n_te_batches))
-    trin_err, aux_trin_err = test_wrapper(test_fn_tr(i) for i in range(n_tr_batches))
-    print("{:3d} {:>8.2f}".format(net.get_epoch(), 0), end='    ')
-    print("{:5.2f}%  ({:5.2f}%)      {:5.2f}%  ({:5.2f}%)".format(
-        trin_err, aux_trin_err, test_err, aux_test_err))
+    stem = os.path.splitext(os.path.basename(prms_file_name))[0]
+    head = '{}_{:06d}'.format(stem, seed)
+    if redirect and lead:
+        print("Printing output to {}.txt".format(head), file=sys.stderr)
+    log = Log(head + '.txt' if redirect else None, mute=not lead)
+
+    with log.capture():
+        ctx = get_context()
+        dev_name, cus, mem = ctx.info()
+        print(' '.join(sys.argv))
+        print('Time   :' + datetime.now().strftime('%Y-%m-%d %H:%M:%S'))
+        print('Device : {} ({} CUs, {:.0f} GB) ({}){}'.format(
+            dev_name, cus, mem / 2 ** 30, tr_prms.get('DTYPE', 'float32'),
+            ' x {} data-parallel ranks'.format(world.size) if world.size > 1 else ''))
+        print('Host   :', socket.gethostname())
+        print(nn.get_layers_info(layers))
+        print(nn.get_training_params_info(tr_prms))
+
+        # ------------------------------------------------------------ data -> HBM (once)
+        data = importlib.import_module("data." + dataset_name)
+        tr_x, te_x = as_nchw(data.training_x), as_nchw(data.testing_x)
+        n_maps, img_sz = tr_x.shape[1], tr_x.shape[2]
+        layers[0][1]['img_sz'] = img_sz
+        if n_maps != 1:
+            layers[0][1].setdefault('num_maps', n_maps)
+        trin_x, trin_y = share(tr_x), share(data.training_y, 'int32')
+        test_x, test_y = share(te_x), share(data.testing_y, 'int32')
+
+        print("\nInitializing the net ... ")
+        net = nn.NeuralNet(layers, tr_prms, allwts)
+        print(net)
+        print(net.get_wts_info(detailed=True).replace("\n\t", ""))
+
+        print("\nCompiling ... ")
+        training_fn = net.get_trin_model(trin_x, trin_y)
+        test_fn_tr = net.get_test_model(trin_x, trin_y)
+        test_fn_te = net.get_test_model(test_x, test_y)
+
+        batch_sz = tr_prms['BATCH_SZ']
+        n_tr_batches, n_te_batches = len(tr_x) // batch_sz, len(te_x) // batch_sz
+        te_windows = BatchWindows(len(te_x), batch_sz, tr_prms['TEST_SAMP_SZ'])
+        tr_windows = BatchWindows(len(tr_x), batch_sz, tr_prms['TEST_SAMP_SZ'])
+        ckpt = Checkpoints(head, lead and not os.environ.get("THEANET_NO_PICKLE"))
+        aux = 'BitErr' if net.tr_layers[-1].kind == 'LOGIT' else 'P(MLE)'
+        row = "{:5.2f}%  ({:5.2f}%)      {:5.2f}%  ({:5.2f}%)"
+
+        np.set_printoptions(precision=2)
+        print("Training ...")
+        print("Epoch   Cost  Tr_Error Tr_{0}    Te_Error Te_{0}".format(aux))
+        for epoch in range(tr_prms['NUM_EPOCHS']):
+            total_cost, t0 = 0, time.perf_counter()
+            for ibatch in range(n_tr_batches):
+                cost = training_fn(ibatch)[0]
+                total_cost += cost
+                if np.isnan(total_cost):
+                    print("Epoch:{} Iteration:{}".format(epoch, ibatch))
+                    print(net.get_wts_info(detailed=True))
+                    raise ZeroDivisionError("Nan cost at Epoch:{} Iteration:{}".format(epoch, ibatch))
+            rate = n_tr_batches * batch_sz / (time.perf_counter() - t0)
+
+            if epoch % tr_prms['EPOCHS_TO_TEST'] == 0:
+                te_err, te_aux = error_rates(test_fn_te, te_windows.next())
+                tr_err, tr_aux = error_rates(test_fn_tr, tr_windows.next())
+                print("{:3d} {:>8.2f}".format(net.get_epoch(), total_cost), end='    ')
+                print(row.format(tr_err, tr_aux, te_err, te_aux))
+                log.checkpoint()
+                ckpt.save(net, te_err)
+                if lead:
+                    print("        [{:,.0f} images/sec]".format(rate), file=sys.stderr)
+                if total_cost > 1e6:
+                    print(net.get_wts_info(detailed=True))
+
+            net.inc_epoch_set_rate()
+
+        # ------------------------------------------------------------ final error rates, whole corpora
+        te_err, te_aux = error_rates(test_fn_te, range(n_te_batches))
+        tr_err, tr_aux = error_rates(test_fn_tr, range(n_tr_batches))
+        print("{:3d} {:>8.2f}".format(net.get_epoch(), 0), end='    ')
+        print(row.format(tr_err, tr_aux, te_err, te_aux))
+        log.checkpoint()
     return 0
+
+
+def main(argv):
+    if len(argv) < 3:
+        print(USAGE.format(argv[0]))
+        return 1
+    return run(argv[1], argv[2], redirect=argv[-1] == '1' and len(argv) > 3)
 
 
 if __name__ == '__main__':
