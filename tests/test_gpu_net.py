@@ -714,3 +714,24 @@ def test_baseline_config_nets_match_oracle(name, img, B):
     for i, (lyr, ol) in enumerate(zip(net.tr_layers, ora.L)):
         for j, w in enumerate(lyr.get_wts()):
             assert_close(w, ol.params[j], 2e-4, 2e-6, what="%s w %d %d" % (name, i, j))
+
+
+def test_hip_trajectory_matches_the_torch_fixture():
+    """The HIP path against tests/golden/torch_xchk.npz -- an implementation that shares no arithmetic
+    with the oracle (torch CPU autograd, float64; tests/golden/make_torch_xchk.py): three training
+    steps of the mnist.prms net (injected dropout masks), logprob 1e-4 rel, argmax exact, weights after
+    the third step 1e-4."""
+    from theanet_amd import NeuralNet
+    from tests.test_oracle_kat import _xchk_net, xchk_compare
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "torch_xchk.npz"))
+    layers, tr = _xchk_net(np.float32)
+    net = NeuralNet(layers, tr)
+    fn = net.get_trin_model(gold["x"], gold["y"])
+    for s in range(3):
+        net.tr_layers[5].drop.inject(gold["masks"][s])
+        cost, _, lp = fn(s)
+        assert_close(lp, gold["logprob_%d" % s], 1e-4, 1e-5, what="logprob step %d vs torch" % s)
+        assert_close(cost, gold["cost_%d" % s], 1e-4, 1e-5, what="cost step %d vs torch" % s)
+        np.testing.assert_array_equal(lp.argmax(1), gold["logprob_%d" % s].argmax(1))
+    for i, w in enumerate([w for l in net.tr_layers for w in l.get_wts()]):
+        xchk_compare(gold, "w3_%d" % i, w, 1e-4, 1e-6)

@@ -215,3 +215,51 @@ def test_torch_cross_check_forward_backward():
     lp = O.log_softmax(z)
     np.testing.assert_allclose(O.nll(lp, y), lt.item(), rtol=1e-12)
     np.testing.assert_allclose(O.nll_dlogits(lp, y), zt.grad.numpy(), atol=1e-12)
+
+
+def _xchk_net(dtype):
+    import ast
+    with open(os.path.join(ROOT, "params", "mnist.prms")) as fh:
+        prms = ast.literal_eval(fh.read())
+    prms["layers"][0] = ("InputLayer", {"img_sz": 28})
+    tr = dict(prms["training_params"], SEED=555555, BATCH_SZ=8)
+    return prms["layers"], tr
+
+
+def xchk_compare(gold, name, arr, rtol, atol):
+    """Compare ``arr`` with fixture entry ``name`` (large tensors are stored as a fixed subsample plus
+    their sum and absolute sum, see tests/golden/make_torch_xchk.py::put)."""
+    arr = np.asarray(arr, np.float64)
+    if name in gold.files:
+        np.testing.assert_allclose(arr, gold[name], rtol=rtol, atol=atol, err_msg=name)
+        return
+    idx = np.random.RandomState(arr.size % (2 ** 31)).choice(arr.size, 4096, replace=False)
+    np.testing.assert_allclose(arr.reshape(-1)[idx], gold[name + "@sub"], rtol=rtol, atol=atol, err_msg=name)
+    scale = float(gold[name + "@abs"])
+    assert abs(arr.sum() - float(gold[name + "@sum"])) <= 10 * rtol * scale + atol, name
+    assert abs(np.abs(arr).sum() - scale) <= 10 * rtol * scale + atol, name
+
+
+def test_whole_net_trajectory_matches_the_torch_fixture():
+    """tests/golden/torch_xchk.npz (made by tests/golden/make_torch_xchk.py: torch CPU autograd,
+    float64, written from the reference's layer definitions without the oracle's arithmetic) pins the
+    oracle on a WHOLE training trajectory of the mnist.prms net: logprobs and cost of three steps,
+    every gradient of the first, the weights after the third (old-velocity update)."""
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "torch_xchk.npz"))
+    layers, tr = _xchk_net(np.float64)
+    net = O.OracleNet(layers, tr, dtype=np.float64)
+    for i, w in enumerate([w for l in net.L for w in l.params]):     # same seed chain -> same initial weights
+        xchk_compare(gold, "w0_%d" % i, w.astype(np.float32), 0, 0)
+    x, y, masks = gold["x"].astype(np.float64), gold["y"], gold["masks"].astype(np.float64)
+    B = 8
+    for s in range(3):
+        xs, ys = x[s * B:(s + 1) * B], y[s * B:(s + 1) * B]
+        if s == 0:
+            cost, lp, grads, _ = net.grads(xs, ys, {5: masks[0]})
+            for i, g in enumerate([g for gl in grads if gl is not None for g in gl]):
+                xchk_compare(gold, "grad0_%d" % i, g, 1e-9, 1e-13)
+        cost, lp, _ = net.train_step(xs, ys, {5: masks[s]})
+        np.testing.assert_allclose(lp, gold["logprob_%d" % s], rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(cost, gold["cost_%d" % s], rtol=1e-10)
+    for i, w in enumerate([w for l in net.L for w in l.params]):
+        xchk_compare(gold, "w3_%d" % i, w, 1e-9, 1e-13)
