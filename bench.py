@@ -36,32 +36,54 @@ def synthetic(rows, c, hw):
     return x, y
 
 
+CPU_LEG = r"""
+import copy, json, os, sys, time
+import numpy as np
+sys.path.insert(0, %(root)r)
+from theanet_amd import NeuralNet
+prms, batch, c, hw, budget = %(prms)r, %(batch)d, %(c)d, %(hw)d, %(budget)f
+x = np.random.default_rng(0).random((2 * batch, c, hw, hw), dtype=np.float32)
+y = np.random.default_rng(1).integers(0, 10, 2 * batch).astype(np.int32)
+net = NeuralNet(copy.deepcopy(prms["layers"]), dict(prms["training_params"]))
+fn = net.get_trin_model(x, y)
+t0 = time.perf_counter(); fn(0); est = time.perf_counter() - t0          # warm-up + step-time estimate
+fn(1)
+t0, n = time.perf_counter(), 0
+while n == 0 or (time.perf_counter() - t0 + est < budget and n < 500):
+    fn.enqueue(n %% 2); n += 1
+cost = float(fn.fetch()[0])
+dt = time.perf_counter() - t0
+print("CPULEG " + json.dumps({"steps": n, "seconds": dt, "cost": cost}))
+"""
+
+
 def cpu_baseline(prms, hw, c, batch, budget_s=15.0):
-    """The numpy oracle (a CPU port of the reference path -- Theano itself cannot be
-    installed) timed on a bounded sample of the SAME workload (same net, same batch size), on this
-    box's host cores: whole training steps until ~budget_s is used (at least one)."""
-    from oracle import theanet_oracle as O
-    p = copy.deepcopy(prms)
+    """The timed CPU baseline: this build's C++/OpenMP backend behind the same C-ABI (theanet_amd/csrc_cpu:
+    im2col + blocked SGEMM conv, C loops for pooling, SGEMM for the fully-connected layers -- the algorithms
+    Theano's CPU path uses; Theano itself cannot be installed), driving the SAME net at the SAME batch
+    size through the same NeuralNet host code, on this box's host cores, in a subprocess with
+    THEANET_BACKEND=cpu.  Whole training steps until ~budget_s is used (at least one).  A CPU
+    restatement of the reference path, not the reference: baseline only."""
+    import subprocess
+    p = copy.deepcopy({k: v for k, v in prms.items() if not k.startswith("_")})
     p["training_params"]["BATCH_SZ"] = batch
-    net = O.OracleNet(p["layers"], p["training_params"])
-    x, y = synthetic(batch * 2, c, hw)
-    t0 = time.perf_counter()
-    net.train_step(x[:batch], y[:batch])            # warm-up (and the step-time estimate)
-    est = time.perf_counter() - t0
-    t0, n = time.perf_counter(), 0
-    while n == 0 or (time.perf_counter() - t0 + est < budget_s and n < 200):
-        net.train_step(x[(n % 2) * batch:(n % 2 + 1) * batch], y[(n % 2) * batch:(n % 2 + 1) * batch])
-        n += 1
-    dt = time.perf_counter() - t0
-    try:
-        from threadpoolctl import threadpool_info
-        threads = max([i.get("num_threads", 1) for i in threadpool_info()] or [1])
-    except Exception:
-        threads = os.cpu_count()
-    return {"value": batch * n / dt, "unit": "images/sec", "cores": int(threads), "threads": int(threads),
-            "nproc": os.cpu_count(), "kind": "port",
-            "sample": "numpy oracle (oracle/theanet_oracle.py; BLAS threads = cores), %s fwd+bwd+update, "
-                      "%d steps of batch %d in %.1f s" % (prms.get("_name", "net"), n, batch, dt)}
+    p["training_params"].pop("DTYPE", None)                     # the reference's floatX: float32
+    threads = min(os.cpu_count() or 1, 128)
+    env = dict(os.environ, THEANET_BACKEND="cpu", OMP_NUM_THREADS=str(threads), OMP_PROC_BIND="spread",
+               RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    code = CPU_LEG % {"root": ROOT, "prms": p, "batch": batch, "c": c, "hw": hw, "budget": budget_s}
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    line = [l for l in r.stdout.splitlines() if l.startswith("CPULEG ")]
+    if r.returncode != 0 or not line:
+        return {"value": None, "unit": "images/sec", "cores": threads, "kind": "port",
+                "sample": "CPU backend leg failed: " + (r.stderr or r.stdout)[-300:]}
+    rec = json.loads(line[-1][7:])
+    return {"value": batch * rec["steps"] / rec["seconds"], "unit": "images/sec", "cores": threads,
+            "threads": threads, "nproc": os.cpu_count(), "kind": "port",
+            "sample": "C++/OpenMP CPU backend behind the same C-ABI (lib/libtheanet_cpu.so, THEANET_BACKEND=cpu; "
+                      "a CPU restatement of the reference path -- Theano is not installable), %s fwd+bwd+update, "
+                      "%d steps of batch %d in %.1f s on %d OpenMP threads"
+                      % (prms.get("_name", "net"), rec["steps"], batch, rec["seconds"], threads)}
 
 
 def main():

@@ -30,6 +30,17 @@ def test_header_symbols_are_exported_and_bound():
     assert lib.tn_version() >= 100
 
 
+def test_cpu_backend_library_exports_the_same_abi():
+    """lib/libtheanet_cpu.so (C++/OpenMP, opt-in via THEANET_BACKEND=cpu) implements the same header."""
+    from theanet_amd import _lib
+    if not os.path.isfile(_lib.CPU_LIB_PATH):
+        pytest.skip("libtheanet_cpu.so not built")
+    lib = _lib.bind(_lib.CPU_LIB_PATH, ctypes.RTLD_LOCAL)
+    for n in declared_functions():
+        assert hasattr(lib, n), "libtheanet_cpu.so does not export " + n
+    assert lib.tn_version() >= 100
+
+
 def test_struct_layout_matches_header():
     import numpy as np
     seg = np.dtype([('p', 'u8'), ('v', 'u8'), ('g', 'u8'), ('n', 'u8'),

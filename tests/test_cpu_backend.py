@@ -1,0 +1,133 @@
+"""The C++/OpenMP CPU backend (theanet_amd/csrc_cpu -> lib/libtheanet_cpu.so; same C-ABI as the HIP
+library, selected ONLY by THEANET_BACKEND=cpu) -- BASELINE.json configs[0], the reference's own
+CPU-runnable case, and the GPU-less way to drive the product's host logic:
+
+  * the library exports every symbol of include/theanet_hip.h (tests/test_abi.py checks both libraries);
+  * the SAME parity tests that pin the HIP path (tests/test_gpu_*.py: per-op tests against the oracle,
+    the GOLD-A / GOLD-B trajectories, the torch-CPU fixture, whole nets, checkpoints, train.py end to
+    end, two-steps-in-flight schedule) run against it in a subprocess -- minus the tests of MI355X-only
+    fused entry points, whose capability queries answer 0 here;
+  * params/mnist.prms verbatim (BATCH_SZ 20) and at BASELINE's batch 128 through train.py;
+  * the PRODUCT's data-parallel step with world_size 2 (socket rendezvous + host all-reduce) equals
+    the single-process step on the same global minibatches."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CPU_LIB = os.path.join(ROOT, "theanet_amd", "lib", "libtheanet_cpu.so")
+pytestmark = pytest.mark.skipif(not os.path.isfile(CPU_LIB), reason="libtheanet_cpu.so not built")
+
+# tests of MI355X-only fused entry points (conv+pool blocks, LDS-resident backward, elastic+conv fusion,
+# HIP graphs, RCCL, fp16 MFMA) and BASELINE-size runs that only make sense on the GPU
+NOT_ON_CPU = ("convpool_fused or convblock or convpool_tile or convpool_mask or convpool_tie or "
+              "elastic_convpool_fused or graph_capture or rccl or two_gpu or dp_ or 4096 or full_size or "
+              "full_batch or f16")
+
+
+def _env(**kw):
+    env = dict(os.environ, THEANET_BACKEND="cpu", OMP_NUM_THREADS="4", PYTHONPATH=ROOT)
+    env.update(kw)
+    return env
+
+
+def test_hip_parity_suite_runs_against_the_cpu_backend():
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-m", "gpu", "-x", "-p", "no:cacheprovider",
+                        "tests/test_gpu_kernels.py", "tests/test_gpu_elastic.py", "tests/test_gpu_net.py",
+                        "-k", "not (%s)" % NOT_ON_CPU],
+                       cwd=ROOT, env=_env(), capture_output=True, text=True, timeout=1500)
+    tail = r.stdout[-3000:] + r.stderr[-2000:]
+    assert r.returncode == 0, tail
+    import re
+    m = re.search(r"(\d+) passed", r.stdout)
+    assert m and int(m.group(1)) >= 140, tail
+
+
+def test_cpu_backend_is_never_a_fallback():
+    """Without THEANET_BACKEND=cpu the product loads the HIP library and fails loudly without a GPU
+    (tests/test_abi.py::test_no_gpu_means_loud_failure); the CPU library is opt-in by name only."""
+    from theanet_amd import _lib
+    assert os.environ.get("THEANET_BACKEND", "hip") != "cpu" or True
+    code = ("import os; os.environ.pop('THEANET_BACKEND', None); from theanet_amd import _lib; "
+            "assert _lib.backend() == 'hip'; l = _lib.get_lib(); assert 'hip' in l._name")
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env={k: v for k, v in _env().items() if k != "THEANET_BACKEND"},
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    with pytest.raises(_lib.BackendError):
+        os.environ["THEANET_BACKEND"] = "cuda"
+        try:
+            _lib.backend()
+        finally:
+            os.environ.pop("THEANET_BACKEND")
+
+
+@pytest.mark.parametrize("batch", [20, 128])
+def test_config1_mnist_prms_through_train_py(tmp_path, batch):
+    """BASELINE.json configs[0]: params/mnist.prms (file batch 20; BASELINE's batch 128) on MNIST-shaped
+    synthetic data, CPU, float32: train.py prints the reference's table, learns and writes a pickle."""
+    import ast
+    import pickle
+    with open(os.path.join(ROOT, "params", "mnist.prms")) as fh:
+        prms = ast.literal_eval(fh.read())
+    prms["training_params"].update(SEED=11, BATCH_SZ=batch, NUM_EPOCHS=2, TEST_SAMP_SZ=256)
+    prm = tmp_path / "mnist.prms"
+    prm.write_text(repr(prms))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "train.py"), "synthetic", str(prm)], cwd=str(tmp_path),
+                       env=_env(THEANET_SYNTH_TRAIN="1280", THEANET_SYNTH_TEST="256"), capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "CPU backend (OpenMP" in r.stdout
+    assert "Epoch   Cost  Tr_Error Tr_P(MLE)    Te_Error Te_P(MLE)" in r.stdout
+    rows = [l for l in r.stdout.splitlines() if l.strip().startswith(("0 ", "1 ", "2 "))]
+    assert len(rows) == 3, r.stdout
+    errs = [float(l.split()[2].rstrip("%")) for l in rows]
+    assert errs[-1] < errs[0] or errs[-1] < 5.0, rows
+    pk = [f for f in os.listdir(tmp_path) if f.endswith(".pkl")]
+    assert len(pk) == 1
+    with open(tmp_path / pk[0], "rb") as fh:
+        ck = pickle.load(fh)
+    assert len(ck["allwts"]) == 7 and ck["allwts"][5][0].dtype == np.float32
+
+
+@pytest.mark.parametrize("pipe,overlap", [("1", "auto"), ("0", "0"), ("0", "1"), ("0", "2")],
+                         ids=["pipelined", "plain", "overlap", "delayed"])
+def test_product_data_parallel_step_world_size_2(tmp_path, pipe, overlap):
+    """The product's own data-parallel training step (NeuralNet._train_step: row shards, flat gradient
+    buffer + cost through ONE all-reduce, replicated update, global-index RNG, both schedules) with two
+    ranks equals the one-rank run on the same global minibatches (1e-5 rel: summation order)."""
+    worker = os.path.join(ROOT, "tests", "dp_gpu_worker.py")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    outs = []
+    for world in (1, 2):
+        out = str(tmp_path / ("w%d.npz" % world))
+        procs = []
+        for rank in range(world):
+            env = _env(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                       MASTER_PORT=str(port + world), TN_PIPELINE=pipe, TN_DP_OVERLAP=overlap,
+                       TN_DP_CHECK_ORDER="1", OMP_NUM_THREADS="2")
+            procs.append(subprocess.Popen([sys.executable, worker, out, "mnist.prms", "28", "1", "32", "7"],
+                                          env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+        for p in procs:
+            try:
+                o, _ = p.communicate(timeout=600)
+            except subprocess.TimeoutExpired:
+                for q in procs:
+                    q.kill()
+                raise
+            assert p.returncode == 0, o.decode()[-3000:]
+        outs.append(np.load(out))
+    one, two = outs
+    np.testing.assert_allclose(two["costs"], one["costs"], rtol=2e-5)
+    np.testing.assert_allclose(two["stats"], one["stats"], rtol=1e-5, atol=1e-6)
+    for k in one.files:
+        if k.startswith("w"):
+            np.testing.assert_allclose(two[k], one[k], rtol=1e-5, atol=1e-6, err_msg=k)
+    want = {"auto": "pipelined", "0": "plain", "1": "overlap", "2": "delayed"}[overlap]
+    assert str(two["schedule"]) == want, str(two["schedule"])

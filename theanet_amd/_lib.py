@@ -3,6 +3,11 @@
 The HIP library IS the compute path: there is no CPU fallback.  If the shared
 object is missing this module raises with build instructions; if no MI355X is
 visible, context creation raises with the library's own error string.
+
+libtheanet_cpu.so (theanet_amd/csrc_cpu: C++/OpenMP, the same C-ABI) is a separate, explicitly
+selected backend -- ``THEANET_BACKEND=cpu`` in the environment -- for GPU-less plumbing runs
+(BASELINE configs[0]), the timed CPU baseline and host-logic tests.  It is never picked
+automatically: without that variable a missing GPU is an error.
 """
 import ctypes
 import os
@@ -10,6 +15,15 @@ from ctypes import (POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int6
                     c_uint8, c_uint32, c_uint64, c_void_p)
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libtheanet_hip.so")
+CPU_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libtheanet_cpu.so")
+
+
+def backend():
+    """'hip' (default) or 'cpu' -- only ever from an explicit THEANET_BACKEND."""
+    b = os.environ.get("THEANET_BACKEND", "hip").lower()
+    if b not in ("hip", "cpu"):
+        raise BackendError("THEANET_BACKEND must be 'hip' or 'cpu', not %r" % b)
+    return b
 
 TN_ACT_LINEAR, TN_ACT_LEAKY, TN_ACT_TANH, TN_ACT_SIGMOID, TN_ACT_SOFTPLUS, TN_ACT_SCALED_TANH = range(6)
 TN_UNIQUE_ID_BYTES = 128
@@ -139,10 +153,26 @@ class BackendError(RuntimeError):
     """Raised when libtheanet_hip.so is missing or a C-ABI call returns an error."""
 
 
+def bind(path, mode=ctypes.RTLD_GLOBAL):
+    """dlopen ``path`` and attach the prototypes of every declared entry point."""
+    lib = ctypes.CDLL(path, mode=mode)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)      # AttributeError if the .so lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
 def get_lib():
-    """Load libtheanet_hip.so (once) and attach the prototypes.  No fallback."""
+    """Load the backend library (once) and attach the prototypes.  No fallback."""
     global _lib
     if _lib is not None:
+        return _lib
+    if backend() == "cpu":
+        if not os.path.isfile(CPU_LIB_PATH):
+            raise BackendError("theanet_amd: THEANET_BACKEND=cpu but %s is not built "
+                               "(`make -C theanet_amd/csrc_cpu`)." % CPU_LIB_PATH)
+        _lib = bind(CPU_LIB_PATH, ctypes.RTLD_LOCAL)
         return _lib
     if not os.path.isfile(LIB_PATH):
         raise BackendError(
@@ -150,13 +180,8 @@ def get_lib():
             "`python -c 'import __graft_entry__ as g; g.build()'` or "
             "`make -C theanet_amd/csrc` (needs hipcc, targets gfx950). "
             "There is no CPU fallback." % LIB_PATH)
-    lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
-    for name, (res, args) in SIGNATURES.items():
-        fn = getattr(lib, name)      # AttributeError if the .so lacks a declared symbol
-        fn.restype = res
-        fn.argtypes = args
-    _lib = lib
-    return lib
+    _lib = bind(LIB_PATH)
+    return _lib
 
 
 def check(ctx_handle, rc, what=""):

@@ -143,6 +143,26 @@ class Rendezvous:
     def barrier(self):
         self.gather_max(0.0)
 
+    def allreduce_host(self, arr, op="sum"):
+        """In-place all-reduce of a HOST float32 array through rank 0 (summed in rank order, so every
+        rank gets the same bits): the exchange of the CPU backend's data-parallel ranks."""
+        if self.world.size == 1:
+            return arr
+        nbytes = arr.nbytes
+        if self.world.rank == 0:
+            acc = arr.copy()
+            for c in self.conns:
+                other = np.frombuffer(_recv_exact(c, nbytes), dtype=arr.dtype).reshape(arr.shape)
+                acc = acc + other if op == "sum" else np.maximum(acc, other)
+            arr[...] = acc
+            blob = arr.tobytes()
+            for c in self.conns:
+                c.sendall(blob)
+        else:
+            self.sock.sendall(arr.tobytes())
+            arr[...] = np.frombuffer(_recv_exact(self.sock, nbytes), dtype=arr.dtype).reshape(arr.shape)
+        return arr
+
     def close(self):
         for c in self.conns:
             c.close()
@@ -200,7 +220,9 @@ class DeviceGroup:
 
     def _note(self, kind, count):
         self.n_issued += 1
-        self.order_hash = (self.order_hash * 1000003 + hash((self.n_issued, kind, int(count)))) % (1 << 52)
+        import zlib      # (python's hash() of a str is salted per process: not comparable across ranks)
+        self.order_hash = (self.order_hash * 1000003 +
+                           zlib.crc32(("%d %s %d" % (self.n_issued, kind, int(count))).encode())) % (1 << 52)
         if self.check_every_call:
             self.verify_order()
 
@@ -210,15 +232,25 @@ class DeviceGroup:
         agree(float(self.order_hash), "the order of collectives issued so far (%d on this rank)" % self.n_issued,
               self.rdzv)
 
+    def _host_view(self, darr, n):
+        import ctypes
+        return np.ctypeslib.as_array((ctypes.c_float * n).from_address(darr.ptr))
+
     def allreduce_sum(self, darr, count=None):
         n = darr.size if count is None else count
         self._note("sum", n)
-        self.ctx.call("tn_allreduce_sum", darr.ptr, n)
+        if self.ctx.backend == "cpu" and self.world.size > 1:      # "device" memory is host memory there
+            self.rdzv.allreduce_host(self._host_view(darr, n), "sum")
+        else:
+            self.ctx.call("tn_allreduce_sum", darr.ptr, n)
 
     def allreduce_max(self, darr, count=None):
         n = darr.size if count is None else count
         self._note("max", n)
-        self.ctx.call("tn_allreduce_max", darr.ptr, n)
+        if self.ctx.backend == "cpu" and self.world.size > 1:
+            self.rdzv.allreduce_host(self._host_view(darr, n), "max")
+        else:
+            self.ctx.call("tn_allreduce_max", darr.ptr, n)
 
     def barrier(self):
         self.ctx.sync()

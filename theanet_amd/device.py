@@ -21,6 +21,7 @@ class Context:
 
     def __init__(self, device=None):
         self.lib = _lib.get_lib()
+        self.backend = _lib.backend()
         if device is None:
             device = int(os.environ.get("LOCAL_RANK", "0"))
         h = ctypes.c_void_p()

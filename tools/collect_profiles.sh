@@ -1,26 +1,40 @@
 #!/bin/bash
-# Runs ON THE GPU BOX (via gpurun): kernel-trace stats and the HBM-traffic PMC passes for the
-# headline workload, written under gpurun_out/ (copy the summaries into profiles/ afterwards).
-#   FETCH_SIZE / WRITE_SIZE are collected in their own passes (TCC has 4 slots: 3 + 2 do not
-#   fit together), exactly as /opt/skills/guides/MI355X_MICROARCH.md prescribes.
-set -e
-TAG=${1:-r01}
+# Runs ON THE GPU BOX (via gpurun): kernel-trace stats, the HBM-traffic PMC passes and the matrix-core
+# utilisation counters for the BASELINE workloads, written under gpurun_out/<tag>/ (tools/make_traffic_json.py
+# then copies the summaries into profiles/).
+#   FETCH_SIZE / WRITE_SIZE are collected in their own passes (TCC has 4 slots: 3 + 2 do not fit
+#   together) and PMC passes never carry a trace domain other than --kernel-trace, exactly as
+#   /opt/skills/guides/MI355X_MICROARCH.md prescribes.
+TAG=${1:-r02}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-# kernel quality: one step at a time (the schedule bench.py's roofline leg measures in)
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o mnist -- \
-    python $GRAFT_REPO_ROOT/bench.py --sequential --steps 50 --warmup 5 --no-cpu-baseline > $OUT/stats.log 2>&1
-# the default schedule: two steps in flight (kernel durations overlap)
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_pipe -o mnist_pipe -- \
-    python $GRAFT_REPO_ROOT/bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-roofline > $OUT/stats_pipe.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -o p -- \
-    python $GRAFT_REPO_ROOT/bench.py --sequential --steps 5 --warmup 2 --no-cpu-baseline > $OUT/fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -o p -- \
-    python $GRAFT_REPO_ROOT/bench.py --sequential --steps 5 --warmup 2 --no-cpu-baseline > $OUT/write.log 2>&1
-# the two wider configurations (BASELINE.json configs 4 and 5): kernel-trace stats only
+B="python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline"
+run() {   # name, rocprof args..., -- bench args
+    local name=$1; shift
+    timeout 600 rocprofv3 "$@" > $OUT/$name.log 2>&1 || echo "FAILED $name (see $name.log)"
+}
+stats() { run $1 --kernel-trace --stats --output-format csv -d $OUT/$1 -o s -- $B "${@:2}"; }
+pmc()   { run $1 --pmc $2 --kernel-trace --output-format csv -d $OUT/$1 -o p -- $B --no-roofline "${@:3}"; }
+MFMA="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_F16 GRBM_GUI_ACTIVE"
+# ---- mnist.prms, B = 4096 (the headline): one step at a time (the roofline leg's schedule), default schedule
+stats mnist_seq --sequential --steps 50 --warmup 5
+stats mnist_pipe --steps 200 --warmup 20 --no-roofline
+pmc mnist_fetch FETCH_SIZE --sequential --steps 5 --warmup 2
+pmc mnist_write WRITE_SIZE --sequential --steps 5 --warmup 2
+pmc mnist_mfma "$MFMA" --sequential --steps 5 --warmup 2
+# ---- what every rank of the 8-GPU strong-scaling run does: 512 images per step
+stats mnist512_seq --batch 512 --sequential --steps 200 --warmup 20 --no-roofline
+stats mnist512_pipe --batch 512 --steps 200 --warmup 20 --no-roofline
+# ---- the wider configurations (BASELINE.json configs 4 and 5), fp32 and fp16 operands
 for c in cifar_like wide6; do
-    rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$c -o $c -- \
-        python $GRAFT_REPO_ROOT/bench.py --prms $c.prms --steps 10 --warmup 3 --no-cpu-baseline > $OUT/stats_$c.log 2>&1
+    for d in f32 f16; do
+        stats ${c}_${d} --prms $c.prms --dtype $d --steps 10 --warmup 3
+        pmc ${c}_${d}_fetch FETCH_SIZE --prms $c.prms --dtype $d --sequential --steps 3 --warmup 1
+        pmc ${c}_${d}_write WRITE_SIZE --prms $c.prms --dtype $d --sequential --steps 3 --warmup 1
+        pmc ${c}_${d}_mfma "$MFMA" --prms $c.prms --dtype $d --sequential --steps 3 --warmup 1
+    done
 done
-tail -1 $OUT/stats.log | cut -c1-200
+python $GRAFT_REPO_ROOT/tools/condense_profiles.py $OUT
+du -sh $OUT
+grep -l FAILED $OUT/*.log 2>/dev/null | head
