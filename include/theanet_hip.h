@@ -348,8 +348,15 @@ typedef struct tn_pipe_seg {
     uint64_t n;
     float momentum, rate;
 } tn_pipe_seg;
-int tn_sgd_update_multi_pipe(tn_ctx* ctx, const tn_pipe_seg* d_segs, int nseg, size_t max_n, const float* d_lr,
-                             uint32_t* d_step, uint32_t step_inc, int update_v);
+int tn_sgd_update_multi_pipe(tn_ctx* ctx, const tn_pipe_seg* d_segs, const tn_pipe_seg* h_segs, int nseg, size_t max_n,
+                             const float* d_lr, uint32_t* d_step, uint32_t step_inc, int update_v,
+                             const float* rowloss, int nrow, float cost_scale, float* d_cost);
+/* ... which also CLOSES the stream's parked tn_defer_reductions window: a pipelined step leaves its weight-
+ * gradient slabs pending (no reduction launch at its end); this launch, which opens the same stream's next
+ * step, adds them up on the fly (same order as the reduction launch: bit-identical), stores the gradient and
+ * applies the update.  h_segs = host copy of d_segs (matches pending sums to segments; NULL: no folding).
+ * rowloss != NULL: one more block row computes *d_cost = cost_scale * sum(rowloss[0:nrow]) -- the cost of the
+ * stream's PREVIOUS step (outlayers.py:50-51), in the fixed order of tn_sgd_update_multi_cost's rider.     */
 
 /* tn_sgd_update_multi_cost that also ENDS a tn_defer_reductions window: a segment whose gradient is
  * still a stack of deferred partial slabs sums them on the fly (same order as the reduction launch:

@@ -108,7 +108,7 @@ SIGNATURES = {
                              c_int, P, P, P, P]),
     "tn_sgd_update_multi": (c_int, [CTX, P, c_int, c_size_t, P, c_float, P]),
     "tn_sgd_update_multi_delayed": (c_int, [CTX, P, c_int, c_size_t, P, c_float, P, c_int]),
-    "tn_sgd_update_multi_pipe": (c_int, [CTX, P, c_int, c_size_t, P, P, c_uint32, c_int]),
+    "tn_sgd_update_multi_pipe": (c_int, [CTX, P, P, c_int, c_size_t, P, P, c_uint32, c_int, P, c_int, c_float, P]),
     "tn_sgd_update_multi_lazy": (c_int, [CTX, P, P, c_int, c_size_t, P, c_float, P, P, c_int, c_float, P]),
     "tn_sgd_update_multi_cost": (c_int, [CTX, P, c_int, c_size_t, P, c_float, P, P, c_int, c_float, P]),
     "tn_softmax_cost_ws_bytes": (c_size_t, [c_int]),

@@ -55,6 +55,12 @@ struct tn_ctx {
     size_t scratch_bytes = 0;
     float* scratch_slot[2] = {nullptr, nullptr};   // parked scratch of the other stream (tn_stream_select):
     size_t scratch_slot_bytes[2] = {0, 0};         // two pipelined steps never share slab memory
+    // ... and its parked deferral window: a pipelined step leaves its slab sums pending, the update that
+    // opens the stream's NEXT step folds them in (tn_sgd_update_multi_pipe)
+    bool defer_slot[2] = {false, false};
+    size_t scratch_off_slot[2] = {0, 0};
+    int npend_slot[2] = {0, 0};
+    tn_red_rec pend_slot[2][TN_RED_MAX];
     // deferred finishing reductions (reduce.hip)
     bool defer = false;
     size_t scratch_off = 0;

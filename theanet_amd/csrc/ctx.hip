@@ -95,6 +95,12 @@ int tn_stream_select(tn_ctx* ctx, int idx) {
         ctx->scratch_bytes = ctx->scratch_slot_bytes[idx];
         ctx->scratch_slot[idx] = nullptr;
         ctx->scratch_slot_bytes[idx] = 0;
+        // the deferral window travels with its stream
+        ctx->defer_slot[cur] = ctx->defer; ctx->scratch_off_slot[cur] = ctx->scratch_off; ctx->npend_slot[cur] = ctx->npend;
+        for (int i = 0; i < ctx->npend; ++i) ctx->pend_slot[cur][i] = ctx->pend[i];
+        ctx->defer = ctx->defer_slot[idx]; ctx->scratch_off = ctx->scratch_off_slot[idx]; ctx->npend = ctx->npend_slot[idx];
+        for (int i = 0; i < ctx->npend; ++i) ctx->pend[i] = ctx->pend_slot[idx][i];
+        ctx->defer_slot[idx] = false; ctx->scratch_off_slot[idx] = 0; ctx->npend_slot[idx] = 0;
     }
     ctx->stream = ctx->streams[idx];
     return TN_OK;

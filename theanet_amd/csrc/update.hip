@@ -207,6 +207,116 @@ __global__ __launch_bounds__(256) void sgd_update_lazy_kernel(const tn_sgd_seg* 
     }
 }
 
+// The pipelined update with LAZY gradients and the cost rider: the stream's previous step left its
+// weight-gradient slabs pending (and its per-row losses unsummed); the launch that opens the stream's
+// next step adds the slabs up on the fly (order of slab_sum_multi_kernel: bit-identical), stores the
+// gradient, applies v = m v + (1-m) g ; p = psrc - rate*lr*v, and one extra block row (by == nseg) sums
+// the previous step's cost in the fixed order of sgd_update_multi_block's rider.
+__global__ __launch_bounds__(256) void sgd_update_pipe_lazy_kernel(const tn_pipe_seg* __restrict__ segs, int nseg,
+                                                                  const float* __restrict__ d_lr, uint32_t* d_step,
+                                                                  uint32_t step_inc, int update_v,
+                                                                  const float* __restrict__ rowloss, int nrow,
+                                                                  float cost_scale, float* __restrict__ d_cost,
+                                                                  LazyBatch lb) {
+    __shared__ float red[16][17];
+    const int bx = blockIdx.x, by = blockIdx.y, nbx = gridDim.x;
+    if (d_step && step_inc && bx == 0 && by == 0 && threadIdx.x == 0) *d_step += step_inc;
+    if (by == nseg) {
+        if (bx != 0) return;
+        float s = 0.f;
+        for (int i = threadIdx.x; i < nrow; i += 256) s += rowloss[i];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        float* r4 = &red[0][0];
+        if ((threadIdx.x & 63) == 0) r4[threadIdx.x >> 6] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) d_cost[0] = cost_scale * ((r4[0] + r4[1]) + (r4[2] + r4[3]));
+        return;
+    }
+    const tn_pipe_seg sg = segs[by];
+    const float step = sg.rate * d_lr[0], m = sg.momentum;
+    float* __restrict__ p = sg.p;
+    const float* __restrict__ ps = sg.psrc;
+    float* __restrict__ v = sg.v;
+    float* __restrict__ g = const_cast<float*>(sg.g);
+    const int ri = lb.rec_of_seg[by];
+    if (ri < 0 || !update_v) {
+        const size_t n = sg.n;
+        for (size_t i = (size_t)bx * 256 + threadIdx.x; i < n; i += (size_t)nbx * 256) {
+            float vv = v[i];
+            if (update_v) {
+                vv = m * vv + (1.f - m) * g[i];
+                v[i] = vv;
+            }
+            p[i] = ps[i] - step * vv;
+        }
+        return;
+    }
+    const tn_red_rec rec = lb.r[ri];
+    const float* __restrict__ src = rec.src;
+    const uint32_t n = rec.n, S = rec.S, stride = rec.stride;
+    if (S <= 32) {
+        const bool vec = rec.flip == 0 && (n & 3) == 0 && (stride & 3) == 0 &&
+                         (((uintptr_t)src | (uintptr_t)g | (uintptr_t)p | (uintptr_t)ps | (uintptr_t)v) & 15) == 0;
+        if (vec) {
+            for (uint32_t i4 = (bx * 256u + threadIdx.x) * 4u; i4 < n; i4 += nbx * 1024u) {
+                float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
+                for (uint32_t z = 0; z < S; ++z) {
+                    const float4 t = *reinterpret_cast<const float4*>(src + (size_t)z * stride + i4);
+                    s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+                }
+                float4 vv = *reinterpret_cast<const float4*>(v + i4);
+                const float4 pv = *reinterpret_cast<const float4*>(ps + i4);
+                vv.x = m * vv.x + (1.f - m) * s.x; vv.y = m * vv.y + (1.f - m) * s.y;
+                vv.z = m * vv.z + (1.f - m) * s.z; vv.w = m * vv.w + (1.f - m) * s.w;
+                *reinterpret_cast<float4*>(g + i4) = s;
+                *reinterpret_cast<float4*>(v + i4) = vv;
+                *reinterpret_cast<float4*>(p + i4) = make_float4(pv.x - step * vv.x, pv.y - step * vv.y,
+                                                                 pv.z - step * vv.z, pv.w - step * vv.w);
+            }
+        } else {
+            for (uint32_t i = bx * 256u + threadIdx.x; i < n; i += nbx * 256u) {
+                uint32_t j = i;
+                if (rec.flip) {
+                    const uint32_t kc = i / rec.flip, uv = i - kc * rec.flip;
+                    j = kc * rec.flip + (rec.flip - 1 - uv);
+                }
+                float s = 0.f;
+#pragma unroll 8
+                for (uint32_t z = 0; z < S; ++z) s += src[(size_t)z * stride + j];
+                const float vv = m * v[i] + (1.f - m) * s;
+                g[i] = s; v[i] = vv; p[i] = ps[i] - step * vv;
+            }
+        }
+        return;
+    }
+    const uint32_t ol = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    for (uint32_t o0 = bx * 16u; o0 < n; o0 += nbx * 16u) {
+        const uint32_t i = o0 + ol;
+        float s = 0.f;
+        if (i < n) {
+            uint32_t j = i;
+            if (rec.flip) {
+                const uint32_t kc = i / rec.flip, uv = i - kc * rec.flip;
+                j = kc * rec.flip + (rec.flip - 1 - uv);
+            }
+#pragma unroll 4
+            for (uint32_t z = sl; z < S; z += 16) s += src[(size_t)z * stride + j];
+        }
+        red[sl][ol] = s;
+        __syncthreads();
+        if (sl == 0 && i < n) {
+            float t = red[0][ol];
+#pragma unroll
+            for (int l = 1; l < 16; ++l) t += red[l][ol];
+            const float vv = m * v[i] + (1.f - m) * t;
+            g[i] = t; v[i] = vv; p[i] = ps[i] - step * vv;
+        }
+        __syncthreads();
+    }
+}
+
 __global__ __launch_bounds__(256) void clip_kernel(float* __restrict__ p, size_t n, float mx) {
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n) p[i] = fminf(fmaxf(p[i], -mx), mx);
@@ -312,13 +422,44 @@ int tn_sgd_update_multi_delayed(tn_ctx* ctx, const tn_sgd_seg* d_segs, int nseg,
     return TN_OK;
 }
 
-int tn_sgd_update_multi_pipe(tn_ctx* ctx, const tn_pipe_seg* d_segs, int nseg, size_t max_n, const float* d_lr,
-                             uint32_t* d_step, uint32_t step_inc, int update_v) {
+int tn_sgd_update_multi_pipe(tn_ctx* ctx, const tn_pipe_seg* d_segs, const tn_pipe_seg* h_segs, int nseg, size_t max_n,
+                             const float* d_lr, uint32_t* d_step, uint32_t step_inc, int update_v,
+                             const float* rowloss, int nrow, float cost_scale, float* d_cost) {
     TN_REQUIRE(nseg > 0 && d_segs && d_lr, "tn_sgd_update_multi_pipe: bad arguments");
+    const bool rider = rowloss != nullptr;
+    TN_REQUIRE(!rider || (d_cost != nullptr && nrow > 0), "tn_sgd_update_multi_pipe: bad cost arguments");
     int bx = cdiv(max_n, 1024);
     if (bx > 256) bx = 256;
     if (bx < 1) bx = 1;
-    sgd_update_pipe_kernel<<<dim3(bx, nseg), 256, 0, ctx->stream>>>(d_segs, nseg, d_lr, d_step, step_inc, update_v);
+    // this stream's pending slab sums whose output is the gradient of one of the segments are folded into
+    // the update; the others are finished by the ordinary reduction launch first
+    LazyBatch lb;
+    for (int s = 0; s < 16; ++s) lb.rec_of_seg[s] = -1;
+    int nlazy = 0, keep = 0;
+    const bool can = h_segs != nullptr && nseg <= 16 && update_v;
+    for (int i = 0; i < ctx->npend; ++i) {
+        int seg = -1;
+        if (can)
+            for (int s = 0; s < nseg; ++s)
+                if (h_segs[s].g == ctx->pend[i].out && h_segs[s].n == ctx->pend[i].n && lb.rec_of_seg[s] < 0) seg = s;
+        if (seg >= 0) {
+            lb.r[nlazy] = ctx->pend[i];
+            lb.rec_of_seg[seg] = (int8_t)nlazy++;
+        } else {
+            ctx->pend[keep++] = ctx->pend[i];
+        }
+    }
+    ctx->npend = keep;
+    ctx->defer = false;
+    int rc = tn_red_flush(ctx);             // leftovers (also resets the scratch bump pointer)
+    if (rc) return rc;
+    ctx->scratch_off = 0;
+    if (nlazy == 0 && !rider) {
+        sgd_update_pipe_kernel<<<dim3(bx, nseg), 256, 0, ctx->stream>>>(d_segs, nseg, d_lr, d_step, step_inc, update_v);
+    } else {
+        sgd_update_pipe_lazy_kernel<<<dim3(bx, nseg + (rider ? 1 : 0)), 256, 0, ctx->stream>>>(
+            d_segs, nseg, d_lr, d_step, step_inc, update_v, rowloss, nrow, cost_scale, d_cost, lb);
+    }
     TN_LAUNCH_CHECK();
     return TN_OK;
 }

@@ -652,9 +652,11 @@ int tn_sgd_update_multi_delayed(tn_ctx* ctx, const tn_sgd_seg* segs, int nseg, s
     if (d_step_inc) *d_step_inc += 1;
     return TN_OK;
 }
-int tn_sgd_update_multi_pipe(tn_ctx* ctx, const tn_pipe_seg* segs, int nseg, size_t, const float* d_lr, uint32_t* d_step,
-                             uint32_t step_inc, int update_v) {
+int tn_sgd_update_multi_pipe(tn_ctx* ctx, const tn_pipe_seg* segs, const tn_pipe_seg*, int nseg, size_t, const float* d_lr,
+                             uint32_t* d_step, uint32_t step_inc, int update_v, const float* rowloss, int nrow,
+                             float cost_scale, float* d_cost) {
     REQUIRE(nseg > 0 && segs && d_lr, "tn_sgd_update_multi_pipe: bad arguments");
+    if (rowloss) tn_reduce_sum(ctx, rowloss, nrow, cost_scale, d_cost, 0);      // the previous step's cost
     for (int s = 0; s < nseg; ++s) {
         const tn_pipe_seg& sg = segs[s];
         const float step = sg.rate * d_lr[0], m = sg.momentum;

@@ -173,14 +173,20 @@ class _PipeTrainFn:
         self.nets = (net, twin)
         seg_dt = np.dtype([('p', 'u8'), ('psrc', 'u8'), ('v', 'u8'), ('g', 'u8'), ('n', 'u8'),
                            ('momentum', 'f4'), ('rate', 'f4')])
-        self._segs, self._lr, self._lr_set = [], [], [None, None]
+        self._segs, self._hsegs, self._lr, self._lr_set = [], [], [], [None, None]
         for X, Y in ((net, twin), (twin, net)):
             rows = []
             for lx, ly in zip(X.tr_layers, Y.tr_layers):
                 if lx.has_updates():
                     for p, ps, v, g in zip(lx.params, ly.params, lx.accumulated_updates, lx.grads):
                         rows.append((p.ptr, ps.ptr, v.ptr, g.ptr, p.size, lx.reg['momentum'], lx.reg['rate']))
-            self._segs.append(ctx.array(np.array(rows, dtype=seg_dt).view(np.uint8)))
+            host = np.array(rows, dtype=seg_dt)
+            self._hsegs.append(host)             # kept alive: the update matches pending slab sums against it
+            self._segs.append(ctx.array(host.view(np.uint8)))
+            X._cost_pending = False
+            # single-GPU runs leave a step's slab sums and cost to the update that opens the stream's next
+            # step (one launch instead of three); data-parallel steps need both before their all-reduce
+            X._pipe_lazy = not net._dp and os.environ.get("TN_PIPE_LAZY", "1") != "0"
             self._lr.append(ctx.zeros((1,)))
             X._cost_rider = False
         self._nseg, self._max_seg = net._n_segs, net._max_seg
@@ -220,8 +226,13 @@ class _PipeTrainFn:
         if self._lr_set[k] != self._lr_prev:              # the rate step t-1 was enqueued under
             ctx.call("tn_set_f32", self._lr[k].ptr, self._lr_prev)
             self._lr_set[k] = self._lr_prev
-        ctx.call("tn_sgd_update_multi_pipe", self._segs[k].ptr, self._nseg, self._max_seg, self._lr[k].ptr,
-                 X.d_step.ptr, 2 if t >= 2 else 0, 1 if t >= 2 else 0)
+        out = X.tr_layers[-1]
+        rider = X._cost_pending
+        ctx.call("tn_sgd_update_multi_pipe", self._segs[k].ptr, self._hsegs[k].ctypes.data, self._nseg,
+                 self._max_seg, self._lr[k].ptr, X.d_step.ptr, 2 if t >= 2 else 0, 1 if t >= 2 else 0,
+                 out.rowloss.ptr if rider else None, X.local_bsz, 1.0 / X.batch_sz,
+                 X.d_cost.ptr if rider else None)
+        X._cost_pending = False
         for lyr in X.tr_layers:
             lyr.apply_maxnorm()
         ctx.call("tn_event_record", self._ev[k])
@@ -246,6 +257,12 @@ class _PipeTrainFn:
     def _fall_back(self):
         """Leave the pipelined schedule for good: bring weights AND velocity to the sequential state."""
         net, ctx = self.net, self.net.ctx
+        if self._twin is not None:
+            for k, X in enumerate(self.nets):             # parked slab sums / costs of steps in flight
+                ctx.call("tn_stream_select", k)
+                ctx.call("tn_defer_reductions", 0)
+                self._finish_cost(X)
+            ctx.call("tn_stream_select", 0)
         if self._twin is not None and self.t > 0:
             self.sync_weights()
             # the velocity is one gradient behind (that of step t-1, held by the stream that ran it)
@@ -300,10 +317,23 @@ class _PipeTrainFn:
         if self._seq is not None:
             return self._seq.fetch()
         X = self._last
+        if X._cost_pending:
+            X.ctx.call("tn_stream_select", self.nets.index(X))
+            self._finish_cost(X)
+            X.ctx.call("tn_stream_select", 0)
         X.ctx.sync()
         cost = X.d_cost.get_value()[0]
         logprob = X.tr_layers[-1].logprob.get_value()
         return [cost, logprob, logprob]
+
+    @staticmethod
+    def _finish_cost(X):
+        """The cost of X's last step, if nothing has summed it yet (on the stream currently selected)."""
+        if getattr(X, "_cost_pending", False):
+            out = X.tr_layers[-1]
+            X.ctx.call("tn_sgd_update_multi_cost", None, 0, 0, X.cur_learn_rate.ptr, 1.0, None,
+                       out.rowloss.ptr, X.local_bsz, 1.0 / X.batch_sz, X.d_cost.ptr)
+            X._cost_pending = False
 
     def __call__(self, i):
         self.enqueue(i)
@@ -741,7 +771,10 @@ class NeuralNet():
         # costs it rides in the update launch at the end of the step (tn_sgd_update_multi_cost);
         # with them it must exist before tn_wtcost accumulates onto it: a leaf reduction here.
         rider = self._cost_rider and not pipe_stride
-        if not rider:
+        lazy_pipe = bool(pipe_stride) and getattr(self, "_pipe_lazy", False) and self._cost_rider_ok
+        if lazy_pipe:
+            self._cost_pending = True             # summed by the launch that opens this stream's next step
+        elif not rider:
             if pipe_stride and self._cost_rider_ok:
                 # the cost block of the update launch on its own: the same summation order as the
                 # one-step-at-a-time schedule, so the reported cost is bit-identical too
@@ -802,7 +835,7 @@ class NeuralNet():
             lazy = lazy and not tail
             if tail:
                 ctx.call("tn_defer_flush_step", self.d_step.ptr)      # the counter advances here
-            elif not lazy:
+            elif not lazy and not lazy_pipe:
                 ctx.call("tn_defer_reductions", 0)
         if pipe_stride:
             # two steps in flight (_PipeTrainFn): this stream's next step starts with the update.
