@@ -298,6 +298,10 @@ int tn_defer_reductions(tn_ctx* ctx, int on);
 /* tn_defer_reductions(ctx, 0) that also advances a device counter (the RNG step counter) in the same
  * launch, so that everything enqueued afterwards already sees the next step's value.            */
 int tn_defer_flush_step(tn_ctx* ctx, uint32_t* d_step);
+/* A pipelined step may leave its window open (tn_sgd_update_multi_pipe closes it a step later; the window
+ * travels with its stream across tn_stream_select).  tn_defer_discard forgets the recorded sums of both
+ * streams without running them -- for windows whose owner (its gradient buffers) is gone.               */
+int tn_defer_discard(tn_ctx* ctx);
 
 /* ---- momentum SGD + maxnorm (replaces Layer.get_updates; layer.py:70-107) ----
  * g' = g*gscale + L1*sign(p) + 2*L2*p ; v_new = m*v + (1-m)*g' ; p_new = p - rate*lr*v_OLD

@@ -94,6 +94,7 @@ SIGNATURES = {
     "tn_maxnorm": (c_int, [CTX, P, c_int, c_int, c_int, c_float]),
     "tn_defer_reductions": (c_int, [CTX, c_int]),
     "tn_defer_flush_step": (c_int, [CTX, P]),
+    "tn_defer_discard": (c_int, [CTX]),
     "tn_elastic_convpool_supported": (c_int, [c_int] * 10),
     "tn_elastic_convpool_fwd_mask": (c_int, [CTX, P, c_int64, P, P, c_int, c_int, c_int, c_int, c_int,
                                              P, P, P, c_float, P, c_uint64, c_uint32, P, c_int64,

@@ -148,6 +148,16 @@ __device__ __forceinline__ float tn_act_grad_from_out(float a, int act, float pr
 }
 
 // ---------------------------------------------------------------------------
+// The two expressions of the momentum-SGD update (layer.py:82-86), with their roundings spelled out:
+// several kernels apply them (one step at a time / lazy slabs / delayed / two steps in flight) and the
+// weight trajectories of all schedules must agree bit for bit, so the compiler must not be free to
+// contract them differently from kernel to kernel.
+//   v' = m*v + (1-m)*g  := fma(m, v, rn((1-m)*g))          p' = p - step*v  := fma(-step, v, p)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float tn_vel(float m, float v, float g) { return __fmaf_rn(m, v, __fmul_rn(1.f - m, g)); }
+__device__ __forceinline__ float tn_stepped(float p, float step, float v) { return __fmaf_rn(-step, v, p); }
+
+// ---------------------------------------------------------------------------
 // Philox4x32-10 counter RNG: key = seed, counter = (lo(idx), hi(idx), step, stream)
 // ---------------------------------------------------------------------------
 struct u32x4 {

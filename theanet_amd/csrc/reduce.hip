@@ -156,6 +156,14 @@ extern "C" int tn_defer_flush_step(tn_ctx* ctx, uint32_t* d_step) {
     return tn_red_flush_inc(ctx, d_step);
 }
 
+// Forget every recorded-but-unfinished reduction of BOTH streams (their outputs belong to a net that no
+// longer exists: finishing them would write through dangling pointers).
+extern "C" int tn_defer_discard(tn_ctx* ctx) {
+    ctx->npend = 0; ctx->scratch_off = 0; ctx->defer = false;
+    for (int k = 0; k < 2; ++k) { ctx->npend_slot[k] = 0; ctx->scratch_off_slot[k] = 0; ctx->defer_slot[k] = false; }
+    return TN_OK;
+}
+
 extern "C" int tn_defer_reductions(tn_ctx* ctx, int on) {
     if (on) {
         ctx->defer = true;

@@ -17,8 +17,8 @@ __global__ __launch_bounds__(256) void sgd_update_kernel(float* __restrict__ p, 
         float gg = g[i] * gscale;
         if (L1 != 0.f) gg += L1 * ((pv > 0.f) - (pv < 0.f));
         if (L2 != 0.f) gg += 2.f * L2 * pv;
-        v[i] = momentum * vv + (1.f - momentum) * gg;
-        p[i] = pv - step * vv;
+        v[i] = tn_vel(momentum, vv, gg);
+        p[i] = tn_stepped(pv, step, vv);
     }
 }
 
@@ -58,12 +58,12 @@ __global__ __launch_bounds__(256) void sgd_update_delayed_kernel(const tn_sgd_se
         float vv = v[i];
         if (mode != 2) {
             const float gg = g[i] * gscale;
-            vv = m * vv + (1.f - m) * gg;
+            vv = tn_vel(m, vv, gg);
             v[i] = vv;
         }
         if (mode != 3) {
             const float pv = p[i];
-            p[i] = pv - step * vv;
+            p[i] = tn_stepped(pv, step, vv);
         }
     }
 }
@@ -92,11 +92,11 @@ __global__ __launch_bounds__(256) void sgd_update_pipe_kernel(const tn_pipe_seg*
         float vv = v[i];
         if (update_v) {
             const float gg = g[i];
-            vv = m * vv + (1.f - m) * gg;
+            vv = tn_vel(m, vv, gg);
             v[i] = vv;
         }
         const float pv = ps[i];
-        p[i] = pv - step * vv;
+        p[i] = tn_stepped(pv, step, vv);
     }
 }
 
@@ -115,8 +115,8 @@ __device__ __forceinline__ void sgd_apply(float& pv, float& vv, float gg, float 
     if (L1 != 0.f) gg += L1 * ((pv > 0.f) - (pv < 0.f));
     if (L2 != 0.f) gg += 2.f * L2 * pv;
     const float vo = vv;
-    vv = m * vo + (1.f - m) * gg;
-    pv = pv - step * vo;
+    vv = tn_vel(m, vo, gg);
+    pv = tn_stepped(pv, step, vo);
 }
 
 __global__ __launch_bounds__(256) void sgd_update_lazy_kernel(const tn_sgd_seg* __restrict__ segs, int nseg,
@@ -245,10 +245,10 @@ __global__ __launch_bounds__(256) void sgd_update_pipe_lazy_kernel(const tn_pipe
         for (size_t i = (size_t)bx * 256 + threadIdx.x; i < n; i += (size_t)nbx * 256) {
             float vv = v[i];
             if (update_v) {
-                vv = m * vv + (1.f - m) * g[i];
+                vv = tn_vel(m, vv, g[i]);
                 v[i] = vv;
             }
-            p[i] = ps[i] - step * vv;
+            p[i] = tn_stepped(ps[i], step, vv);
         }
         return;
     }
@@ -268,12 +268,12 @@ __global__ __launch_bounds__(256) void sgd_update_pipe_lazy_kernel(const tn_pipe
                 }
                 float4 vv = *reinterpret_cast<const float4*>(v + i4);
                 const float4 pv = *reinterpret_cast<const float4*>(ps + i4);
-                vv.x = m * vv.x + (1.f - m) * s.x; vv.y = m * vv.y + (1.f - m) * s.y;
-                vv.z = m * vv.z + (1.f - m) * s.z; vv.w = m * vv.w + (1.f - m) * s.w;
+                vv.x = tn_vel(m, vv.x, s.x); vv.y = tn_vel(m, vv.y, s.y);
+                vv.z = tn_vel(m, vv.z, s.z); vv.w = tn_vel(m, vv.w, s.w);
                 *reinterpret_cast<float4*>(g + i4) = s;
                 *reinterpret_cast<float4*>(v + i4) = vv;
-                *reinterpret_cast<float4*>(p + i4) = make_float4(pv.x - step * vv.x, pv.y - step * vv.y,
-                                                                 pv.z - step * vv.z, pv.w - step * vv.w);
+                *reinterpret_cast<float4*>(p + i4) = make_float4(tn_stepped(pv.x, step, vv.x), tn_stepped(pv.y, step, vv.y),
+                                                                 tn_stepped(pv.z, step, vv.z), tn_stepped(pv.w, step, vv.w));
             }
         } else {
             for (uint32_t i = bx * 256u + threadIdx.x; i < n; i += nbx * 256u) {
@@ -285,8 +285,8 @@ __global__ __launch_bounds__(256) void sgd_update_pipe_lazy_kernel(const tn_pipe
                 float s = 0.f;
 #pragma unroll 8
                 for (uint32_t z = 0; z < S; ++z) s += src[(size_t)z * stride + j];
-                const float vv = m * v[i] + (1.f - m) * s;
-                g[i] = s; v[i] = vv; p[i] = ps[i] - step * vv;
+                const float vv = tn_vel(m, v[i], s);
+                g[i] = s; v[i] = vv; p[i] = tn_stepped(ps[i], step, vv);
             }
         }
         return;
@@ -310,8 +310,8 @@ __global__ __launch_bounds__(256) void sgd_update_pipe_lazy_kernel(const tn_pipe
             float t = red[0][ol];
 #pragma unroll
             for (int l = 1; l < 16; ++l) t += red[l][ol];
-            const float vv = m * v[i] + (1.f - m) * t;
-            g[i] = t; v[i] = vv; p[i] = ps[i] - step * vv;
+            const float vv = tn_vel(m, v[i], t);
+            g[i] = t; v[i] = vv; p[i] = tn_stepped(ps[i], step, vv);
         }
         __syncthreads();
     }

@@ -38,7 +38,7 @@ __device__ __forceinline__ void sgd_update_multi_block(const tn_sgd_seg* __restr
         float gg = g[i] * gscale;
         if (L1 != 0.f) gg += L1 * ((pv > 0.f) - (pv < 0.f));
         if (L2 != 0.f) gg += 2.f * L2 * pv;
-        v[i] = m * vv + (1.f - m) * gg;
-        p[i] = pv - step * vv;
+        v[i] = tn_vel(m, vv, gg);
+        p[i] = tn_stepped(pv, step, vv);
     }
 }

@@ -574,6 +574,7 @@ int tn_error_stats(tn_ctx*, const int32_t* pred, const int32_t* y, int64_t y_row
 // ================================== reductions window (trivial: every op finishes its own sums) ==========
 int tn_defer_reductions(tn_ctx*, int) { return TN_OK; }
 int tn_defer_flush_step(tn_ctx*, uint32_t* d_step) { if (d_step) *d_step += 1; return TN_OK; }
+int tn_defer_discard(tn_ctx*) { return TN_OK; }
 
 // ================================== momentum SGD + maxnorm (layer.py:70-107) ==================================
 static void sgd_seg(float* p, float* v, const float* g, size_t n, float m, float rate, float lr, float L1, float L2,

@@ -13,6 +13,7 @@ gradient buffer (+ the scalar cost) is sum-all-reduced once per step over RCCL.
 """
 import os
 import sys
+import weakref
 from functools import reduce
 from operator import mul
 
@@ -145,6 +146,7 @@ class _PipeTrainFn:
         import copy
         twin = NeuralNet.__new__(NeuralNet)
         twin._is_twin = True
+        twin._main = net
         tp = dict(net.tr_prms)
         tp.setdefault('SEED', 0)      # (a net loaded from a checkpoint has none; weights and stream seeds are copied below)
         twin.__init__(copy.deepcopy(net.layers), tp)
@@ -221,6 +223,7 @@ class _PipeTrainFn:
         """weights (and velocity) for step t on the stream that will run it"""
         ctx, k = self.net.ctx, t & 1
         X = self.nets[k]
+        self.net._apply_dtype()
         ctx.call("tn_stream_select", k)
         ctx.call("tn_event_wait", self._ev[1 - k])
         if self._lr_set[k] != self._lr_prev:              # the rate step t-1 was enqueued under
@@ -254,15 +257,22 @@ class _PipeTrainFn:
         ctx.call("tn_stream_select", 0)
         ctx.sync()
 
+    def _flush_parked(self):
+        """Finish the slab sums and costs the last steps left parked with their streams (the gradients
+        become ordinary buffers; the next update simply reads them)."""
+        if self._twin is None or self._seq is not None:
+            return
+        ctx = self.net.ctx
+        for k, X in enumerate(self.nets):
+            ctx.call("tn_stream_select", k)
+            ctx.call("tn_defer_reductions", 0)
+            self._finish_cost(X)
+        ctx.call("tn_stream_select", 0)
+
     def _fall_back(self):
         """Leave the pipelined schedule for good: bring weights AND velocity to the sequential state."""
         net, ctx = self.net, self.net.ctx
-        if self._twin is not None:
-            for k, X in enumerate(self.nets):             # parked slab sums / costs of steps in flight
-                ctx.call("tn_stream_select", k)
-                ctx.call("tn_defer_reductions", 0)
-                self._finish_cost(X)
-            ctx.call("tn_stream_select", 0)
+        self._flush_parked()
         if self._twin is not None and self.t > 0:
             self.sync_weights()
             # the velocity is one gradient behind (that of step t-1, held by the stream that ran it)
@@ -549,8 +559,25 @@ class NeuralNet():
                     conv.out_sz, pool.pool_sz, pool.out_sz, pool.out_sz) and not pool.ignore_border:
                 el.fused_conv, pool.fused_elastic = conv, el
 
+    _ctx_owner = None       # weakref to the net whose pipelined steps may have work parked in the context
+
     def _apply_dtype(self):
+        """Called at the start of everything this net enqueues: sets the context's matmul dtype and takes
+        over the context from whichever net used it last.  A pipelined training function leaves a step's
+        slab sums and cost parked with its stream until the stream's next step; before another net's work
+        goes onto those streams they are finished (the other net is alive: its buffers exist) or forgotten
+        (it has been collected: the recorded outputs are dangling)."""
         self.ctx.set_matmul_dtype(self.dtype, self.grad_scale)
+        me = getattr(self, "_main", self)
+        ref = NeuralNet._ctx_owner
+        prev = ref() if ref is not None else None
+        if prev is me:
+            return
+        if prev is not None and getattr(prev, "_pipe_fn", None) is not None:
+            prev._pipe_fn._flush_parked()
+        elif ref is not None:
+            self.ctx.call("tn_defer_discard")
+        NeuralNet._ctx_owner = weakref.ref(me)
 
     # ------------------------------------------------------------------------------
     def _group(self):
