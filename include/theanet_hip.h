@@ -281,6 +281,20 @@ int tn_softmax_nll_cost(tn_ctx* ctx, const float* z, const int32_t* y, int64_t y
                         const int64_t* d_row0, float* logprob, float* rowloss, int32_t* pred,
                         float* rowp, float* dz, int B, int n_out, float inv_batch,
                         float cost_scale, float* cost, void* ws);
+/* ---- the other output heads and losses (replaces outlayers.py:38-64 losses, :105-126 ExpLossLayer, :129-147
+ * HingeLayer, :153-224 CenteredOutLayer) as one row kernel.  head: 0 SOFTMAX (a = logits), 1 EXPLOSS (a = linear
+ * output; feat receives a - mean(a)), 2 HINGE (a = linear output), 3 LOGIT / 4 RBF (a = the hidden layer's
+ * activated features (B, n), centers (ncls, n); logprob has ncls / ncls+1 columns).  loss (head SOFTMAX only;
+ * the other heads have their own): 0 nll, 1 nllsq, 2 nll truncated (loss_param = log threshold), 3 hinge and
+ * 4 exp on the softmax output.  rowloss[n]: cost = mean(rowloss); pred = argmax (first maximum); rowstat[n]: the
+ * reference's second error statistic per row (P(label); raw output for HINGE; share of wrong bits for LOGIT);
+ * da = d cost / d a scaled by inv_batch -- for the centered heads already multiplied by act'(a) (act, act_param =
+ * the hidden activation: sigmoid / scaled_tanh), i.e. d cost / d z; dcenters (RBF, may be NULL) accumulates
+ * d cost / d centers into a buffer the caller zeroed.  Outputs other than logprob may be NULL.            */
+int tn_head_rows(tn_ctx* ctx, int head, int loss, float loss_param, const float* a, const float* centers,
+                 int ncls, const int32_t* y, int64_t y_row0, const int64_t* d_row0, float* feat,
+                 float* logprob, float* rowloss, int32_t* pred, float* rowstat, float* da, float* dcenters,
+                 int B, int n, float inv_batch, float junk_dist, int act, float act_param);
 /* out[0] = scale * sum(v[0..n))  (+ out[0] if accumulate) -- cost and error-rate scalars */
 int tn_reduce_sum(tn_ctx* ctx, const float* v, size_t n, float scale, float* out, int accumulate);
 /* out[0] (+)= L1*sum|p| + L2*sum p^2  (layer.py:109-117)                                 */
@@ -433,6 +447,27 @@ int tn_elastic_apply(tn_ctx* ctx, const float* x, int64_t x_row0, const int64_t*
                      const int32_t* map_idx, const float* map_fy, const float* map_fx,
                      float pflip, const uint8_t* flipmask, uint64_t seed, uint32_t step,
                      const uint32_t* d_step, int64_t row_global0);
+/* Backward of tn_elastic_apply for an ElasticLayer in the MIDDLE of a net (neuralnet.py:132-142; Theano
+ * differentiates through the gather, the inversion and the flip): dx[n,c,src] = sum_p g[n,c,p] * w(p,src)
+ * * (invert ? -1 : 1) * (flipped(p) ? -1 : 1), then * act'(prev_a) of the layer below (NULL: none).  The flip
+ * noise is regenerated from the same (seed, step, global index) as in the forward.                     */
+int tn_elastic_apply_bwd(tn_ctx* ctx, const float* g, float* dx, int N, int C, int h, int w, int invert, int nearest,
+                         const int32_t* map_idx, const float* map_fy, const float* map_fx, float pflip,
+                         const uint8_t* flipmask, uint64_t seed, uint32_t step, const uint32_t* d_step,
+                         int64_t row_global0, const float* prev_a, int prev_act, float prev_act_param);
+
+/* ---- ColorLayer (replaces color.py:9-52) ----
+ * fac[(n*C+c)*3 + k] = exp(ln(balance|gamma|gamma) * u_k), u_k ~ U(-1,1): three random variables of shape
+ * (N, C).  draws (float32, [3][N][C]) injects the uniforms (parity runs); NULL -> Philox(seed, step + *d_step,
+ * global image index * C + c).  tn_color_apply: out = x/maxval*b -> clip(0,1) -> **g1 -> 1-(1-.)**g2 -> *maxval,
+ * rows read from x_row0.  tn_color_apply_bwd: dx = g * d out/d x (Clip's gradient is inclusive) * act'(prev_a). */
+int tn_color_factors(tn_ctx* ctx, float* fac, int N, int C, double balance, double gamma, const float* draws,
+                     uint64_t seed, uint32_t step, const uint32_t* d_step, int64_t row_global0);
+int tn_color_apply(tn_ctx* ctx, const float* x, int64_t x_row0, const float* fac, float* out,
+                   int N, int C, int hw, float maxval);
+int tn_color_apply_bwd(tn_ctx* ctx, const float* x, int64_t x_row0, const float* fac, const float* g, float* dx, int N,
+                       int C, int hw, float maxval, const float* prev_a, int prev_act, float prev_act_param);
+
 /* extras/deformer.py:7-18 -- per-IMAGE deformation, in place semantics of Deformer:
  * trans = indices + scale*noise ; each plane gaussian_filter(sigma, truncate 2, nearest) ;
  * bilinear map_coordinates(mode constant, cval).  noise (N,2,h,w) float32 U(-1,1) given,

@@ -270,6 +270,113 @@ def nll_dlogits(logprob, y):
 
 
 # --------------------------------------------------------------------------- #
+# the other losses and output heads  (outlayers.py:12-64, 105-224)
+# --------------------------------------------------------------------------- #
+
+
+def parse_loss(loss):
+    """outlayers.py:12-36 -> (name, threshold)."""
+    if loss in ("nll", "nllsq", "hinge", "exp"):
+        return loss, None
+    if isinstance(loss, str) and loss.startswith("nll"):
+        try:
+            threshold = float(np.clip(int(loss[-2:]) / 100, 0, 1))     # :22-24
+        except ValueError:
+            threshold = 1.0                                           # :25-27
+        return "nlltrunc", threshold
+    raise NotImplementedError("Loss : " + str(loss))
+
+
+def softmax_head(z, y, loss="nll"):
+    """SoftmaxLayer with any of its losses (outlayers.py:83-102 + :38-64).  Returns
+    (logprob, preds, second_stat_rows, cost, dz) with dz = d cost / d z."""
+    lp = log_softmax(z)
+    p = np.exp(lp)
+    B, n = z.shape
+    r = np.arange(B)
+    name, thr = parse_loss(loss)
+    onehot = np.zeros_like(z)
+    onehot[r, y] = 1
+    if name == "nll":
+        cost, glp = -lp[r, y].mean(), -np.ones(B) / B                              # :50-51
+    elif name == "nllsq":
+        cost, glp = (lp[r, y] ** 2).mean(), 2 * lp[r, y] / B                       # :41-42
+    elif name == "nlltrunc":
+        with np.errstate(divide="ignore"):
+            t = np.log(thr) - lp[r, y]                                             # :44-48
+        cost, glp = np.maximum(0, t).mean(), -(t >= 0).astype(z.dtype) / B
+    if name in ("nll", "nllsq", "nlltrunc"):
+        dz = glp[:, None] * (onehot - p)
+    else:
+        if name == "hinge":                                                        # :60-62 on self.output = probs
+            m = p + 1 - p[r, y][:, None]
+            cost = np.maximum(0, m).mean()
+            gp = (m >= 0).astype(z.dtype) / (B * n)
+            gp[r, y] = 0
+            gp[r, y] = -gp.sum(1)          # d/dp_y of every other margin (the c == y margin is the constant 1)
+        else:                                                                      # :38-39
+            cost = np.exp(-p[r, y]).mean()
+            gp = np.zeros_like(z)
+            gp[r, y] = -np.exp(-p[r, y]) / B
+        dz = p * (gp - (gp * p).sum(1, keepdims=True))
+    return lp, p.argmax(1), p[r, y], cost, dz
+
+
+def exploss_head(z, y):
+    """ExpLossLayer (outlayers.py:105-126): preds from the raw output (:111), output -= row mean (:112),
+    probs = softmax(output) (:115), features = output (:117), cost = mean exp(-output[n, y_n]) (:38-39)."""
+    B, n = z.shape
+    r = np.arange(B)
+    o = z - z.mean(1, keepdims=True)
+    lp = log_softmax(o)
+    e = np.exp(-o[r, y])
+    go = np.zeros_like(z)
+    go[r, y] = -e / B
+    dz = go - go.mean(1, keepdims=True)
+    return lp, z.argmax(1), np.exp(lp)[r, y], e.mean(), dz, o
+
+
+def hinge_head(z, y):
+    """HingeLayer (outlayers.py:129-147): logprob = probs = features = output; cost = mean over ALL (n, c) of
+    max(0, out + 1 - out[n, y_n]) (:60-62); second statistic = probs[n, y_n] = the raw output (:77-78)."""
+    B, n = z.shape
+    r = np.arange(B)
+    m = z + 1 - z[r, y][:, None]
+    g = (m >= 0).astype(z.dtype) / (B * n)
+    g[r, y] = 0
+    g[r, y] = -g.sum(1)
+    return z.copy(), z.argmax(1), z[r, y], np.maximum(0, m).mean(), g
+
+
+def centered_head(v, centers, y, kind, junk_dist=np.inf):
+    """CenteredOutLayer on the hidden features v (outlayers.py:186-210).  Loss: -mean logprob[n, y_n] (the
+    reference never sets ``loss`` on this layer; see theanet_amd/layer/outlayers.py).  Returns (logprob, preds,
+    second_stat_rows, cost, dv, dcenters)."""
+    B, nf = v.shape
+    r = np.arange(B)
+    c = centers[None, :, :]
+    if kind == "LOGIT":
+        eps = .001                                                                  # :198
+        vp = (v * (1 - 2 * eps) + eps)[:, None, :]                                  # :199
+        bitprob = c * vp + (1 - c) * (1 - vp)                                       # :200
+        lp = np.log(bitprob).sum(2)                                                 # :201
+        stat = (bitprob[r, y] < .5).mean(1)                                         # :73-74 (mean over n and f)
+        dv = -(1 - 2 * eps) * (2 * centers[y] - 1) / bitprob[r, y] / B
+        return lp, lp.argmax(1), stat, -lp[r, y].mean(), dv, np.zeros_like(centers)
+    d = v[:, None, :] - c
+    dists = (d ** 2).sum(2)                                                         # :205
+    full = np.concatenate([dists, np.full((B, 1), junk_dist)], axis=1)              # :206-207
+    lp = log_softmax(-full)                                                         # :208-209
+    p = np.exp(lp)
+    onehot = np.zeros_like(full)
+    onehot[r, y] = 1
+    gd = ((onehot - p) / B)[:, :-1]            # d cost / d dists
+    dv = 2 * (gd[:, :, None] * d).sum(1)
+    dc = -2 * (gd[:, :, None] * d).sum(0)
+    return lp, p.argmax(1), p[r, y], -lp[r, y].mean(), dv, dc
+
+
+# --------------------------------------------------------------------------- #
 # update  (layer.py:70-117)
 # --------------------------------------------------------------------------- #
 
@@ -468,6 +575,78 @@ class ElasticStage:
 # --------------------------------------------------------------------------- #
 
 
+def elastic_apply_bwd(g, target, nearest, flipmask=None, invert=False):
+    """Gradient of ``elastic_apply(1 - x if invert else x, ...)`` w.r.t. x (Theano's grad through the
+    advanced-indexing gather = scatter-add, inlayers.py:126-142, :63-64)."""
+    N, C, h, w = g.shape
+    g = np.asarray(g, np.float64)
+    if flipmask is not None:
+        g = g * (1 - 2 * np.asarray(flipmask, np.float64))          # d/dout [(1-out) m + out (1-m)]
+    dx = np.zeros((N, C, h * w))
+    gf = g.reshape(N, C, h * w)
+    if target is None:
+        dx += gf
+    else:
+        transy = np.clip(target[0], 0, h - 1 - .001)
+        transx = np.clip(target[1], 0, w - 1 - .001)
+        if nearest:
+            idx = (np.rint(transy).astype(np.int64) * w + np.rint(transx).astype(np.int64)).reshape(-1)
+            for k, wt in ((idx, 1.0),):
+                np.add.at(dx, (slice(None), slice(None), k), gf * wt)
+        else:
+            topp, left = transy.astype(np.int64), transx.astype(np.int64)
+            fy = (transy - topp).astype(np.float32).astype(np.float64).reshape(-1)
+            fx = (transx - left).astype(np.float32).astype(np.float64).reshape(-1)
+            i00 = (topp * w + left).reshape(-1)
+            for off, wt in ((0, (1 - fy) * (1 - fx)), (1, (1 - fy) * fx), (w, fy * (1 - fx)), (w + 1, fy * fx)):
+                np.add.at(dx, (slice(None), slice(None), i00 + off), gf * wt)
+    if invert:
+        dx = -dx
+    return dx.reshape(N, C, h, w)
+
+
+class ColorStage:
+    """ColorLayer with its RandomStreams (color.py:9-52): three uniform(-1, 1) variables of shape
+    (batch, num_maps), created in the order balance, gamma, gamma."""
+
+    def __init__(self, img_sz, num_maps=3, rand_gen=None, balance=1, gamma=1, maxval=1):
+        self.img_sz, self.num_maps = img_sz, num_maps
+        self.balance, self.gamma, self.maxval = balance, gamma, maxval
+        self.active = not (gamma == 1 and balance == 1)               # :27-29
+        if not self.active:
+            return
+        assert gamma > 0 and balance > 0
+        srs = RandomStreams(rand_gen.randint(1e6) if rand_gen else None)   # :31-32
+        self.rv = [srs.uniform(None, -1), srs.uniform(None, -1), srs.uniform(None, -1)]   # :34 (one per pos_rand)
+
+    def draw(self, batch):
+        return np.stack([rv.draw((batch, self.num_maps)) for rv in self.rv])
+
+    def factors(self, u):
+        lnb, lng = np.log(self.balance), np.log(self.gamma)
+        return [np.exp(ln * np.asarray(uk, np.float32).astype(np.float64))[:, :, None, None]
+                for ln, uk in zip((lnb, lng, lng), u)]
+
+    def forward(self, x, u=None, train=True):
+        if not self.active or not train:
+            return x, None
+        if u is None:
+            u = self.draw(x.shape[0])
+        b, g1, g2 = [f.astype(np.float32).astype(x.dtype) for f in self.factors(u)]   # .astype(float_x), :35
+        o1 = x / x.dtype.type(self.maxval) * b                                        # :38-39
+        o2 = np.clip(o1, 0, 1)                                                        # :40
+        o3 = o2 ** g1                                                                 # :41
+        out = (1 - (1 - o3) ** g2) * x.dtype.type(self.maxval)                        # :42-44
+        return out.astype(x.dtype), (b, g1, g2, o1, o2, o3)
+
+    def backward(self, g, saved):
+        b, g1, g2, o1, o2, o3 = saved
+        with np.errstate(divide="ignore", invalid="ignore"):
+            d = g2 * (1 - o3) ** (g2 - 1) * g1 * o2 ** (g1 - 1) * b
+        d = np.where((o1 >= 0) & (o1 <= 1), d, 0.0)                  # theano Clip.grad is inclusive
+        return g * d
+
+
 def gaussian_kernel1d(sigma, truncate=2.0):
     """scipy.ndimage.gaussian_filter1d kernel: radius int(truncate*sigma + .5), normalised."""
     r = int(truncate * float(sigma) + 0.5)
@@ -577,7 +756,7 @@ class OracleNet:
     def _append(self, ltype, a, wts, first):
         dt = self.dtype
         if first:
-            assert ltype in ("InputLayer", "ElasticLayer"), \
+            assert ltype in ("InputLayer", "ElasticLayer", "ColorLayer"), \
                 "First layer needs to be Input or Elastic or Color Layer"
         if ltype == "InputLayer":
             self.L.append(_L("Input", num_maps=a.get("num_maps", 1), out_sz=a["img_sz"],
@@ -588,6 +767,13 @@ class OracleNet:
                 a["num_maps"], a["img_sz"] = self._prev_maps()
             st = ElasticStage(rand_gen=self.rand_gen, **a)
             self.L.append(_L("Elastic", stage=st, num_maps=st.num_maps, out_sz=st.img_sz,
+                             n_out=st.num_maps * st.img_sz ** 2))
+        elif ltype == "ColorLayer":
+            if not first:
+                a.pop("num_maps", None), a.pop("img_sz", None)
+                a["num_maps"], a["img_sz"] = self._prev_maps()
+            st = ColorStage(rand_gen=self.rand_gen, **a)
+            self.L.append(_L("Color", stage=st, num_maps=st.num_maps, out_sz=st.img_sz,
                              n_out=st.num_maps * st.img_sz ** 2))
         elif ltype == "ConvLayer":
             C, in_sz = self._prev_maps()
@@ -616,14 +802,40 @@ class OracleNet:
                 srs = RandomStreams(self.rand_gen.randint(1e6) if self.rand_gen else None)
                 l.mask_rv = srs.binomial(None, n=1, p=1 - pdrop)
             self.L.append(l)
-        elif ltype in ("HiddenLayer", "SoftmaxLayer"):
+        elif ltype == "CenteredOutLayer":
+            n_in = self.L[-1].n_out
+            kind = a.get("kind", "LOGIT")
+            actvn = {"LOGIT": "sigmoid", "RBF": "scaled_tanh"}[kind]                # outlayers.py:150
+            centers = None
+            if wts is not None and len(wts) > 2:
+                centers = np.array(wts[2], dtype=dt)
+            nf = a.get("n_features") or (wts[0].shape[1] if wts is not None and len(wts) else centers.shape[1])
+            l = _L("Centered", n_in=n_in, n_out=nf, actvn=actvn, pdrop=0, mask_rv=None, ckind=kind,
+                   learn_centers=a.get("learn_centers", False), junk_dist=a.get("junk_dist", np.inf), loss="nll")
+            fio = n_in + nf
+            l.params = self._init(wts[:2] if wts is not None and len(wts) else None, (n_in, nf), (nf,), fio, fio, actvn)
+            if centers is None:                                                     # :171-179
+                ncls = a["n_classes"]
+                if kind == "LOGIT":
+                    centers = self.rand_gen.binomial(n=1, p=.5, size=(ncls, nf))
+                else:
+                    centers = self.rand_gen.uniform(low=0, high=1, size=(ncls, nf))
+                centers = np.asarray(np.asarray(centers, np.float32), dt)
+            l.centers = centers
+            if l.learn_centers:
+                l.params.append(l.centers)                                          # :186-187
+            l.reg = dict(DEFAULT_REG, **dict(a.get("reg", ())))
+            self.L.append(l)
+        elif ltype in ("HiddenLayer", "SoftmaxLayer", "ExpLossLayer", "HingeLayer"):
             n_in = self.L[-1].n_out
             n_out = a["n_out"]
             if ltype == "SoftmaxLayer":
                 actvn, pdrop = "Softmax", 0
+            elif ltype in ("ExpLossLayer", "HingeLayer"):
+                actvn, pdrop = "linear", 0
             else:
                 actvn, pdrop = a.get("actvn", "relu01"), a.get("pdrop", 0)
-            l = _L("Softmax" if ltype == "SoftmaxLayer" else "Hidden",
+            l = _L({"SoftmaxLayer": "Softmax", "ExpLossLayer": "ExpLoss", "HingeLayer": "Hinge"}.get(ltype, "Hidden"),
                    n_in=n_in, n_out=n_out, actvn=actvn, pdrop=pdrop, mask_rv=None,
                    loss=a.get("loss", "nll"))
             fio = n_in + n_out                                      # hidden.py:21-27
@@ -660,7 +872,14 @@ class OracleNet:
             if l.kind == "Input":
                 pass
             elif l.kind == "Elastic":
-                h, c["target"] = l.stage.forward(h, draws.get(i), train)
+                h = h.reshape(h.shape[0], l.num_maps, l.out_sz, l.out_sz)
+                c["draws"] = draws.get(i)
+                if train and l.stage.active and c["draws"] is None:
+                    c["draws"] = l.stage.draw(h.shape)
+                h, c["target"] = l.stage.forward(h, c["draws"], train)
+            elif l.kind == "Color":
+                h = h.reshape(h.shape[0], l.num_maps, l.out_sz, l.out_sz)
+                h, c["saved"] = l.stage.forward(h, draws.get(i), train)
             elif l.kind == "Conv":
                 z = conv2d_fwd(h, l.params[0], l.params[1], l.stride, l.mode, f16=self.f16)
                 c["z"] = z
@@ -679,13 +898,17 @@ class OracleNet:
                         h = h * c["mask"]
                     else:
                         h = h * self.dtype.type(1 - l.pdrop)       # dropout.py:28-31
-            elif l.kind in ("Hidden", "Softmax"):
+            elif l.kind in ("Hidden", "Softmax", "ExpLoss", "Hinge", "Centered"):
                 h = h.reshape(h.shape[0], -1)                       # flatten(2), neuralnet.py:169
                 c["in"] = h
                 z = (h @ l.params[0] + l.params[1]).astype(self.dtype)
                 c["z"] = z
                 if l.kind == "Softmax":
                     h = log_softmax(z)
+                elif l.kind in ("ExpLoss", "Hinge"):
+                    h = z                                           # the head itself is applied in head_eval
+                elif l.kind == "Centered":
+                    h = activation(l.actvn)[0](z)
                 else:
                     h = activation(l.actvn)[0](z)
                     if l.pdrop:
@@ -705,23 +928,35 @@ class OracleNet:
     def backward(self, cache, y):
         """Gradients of cost = nll + sum wtcost w.r.t. every parameter."""
         grads = [None] * len(self.L)
-        logprob = cache[-1]["out"]
-        g = nll_dlogits(logprob, y)       # d cost / d logits
+        g = None
         first_param = min(i for i, l in enumerate(self.L) if l.params)
         for i in range(len(self.L) - 1, -1, -1):
             l, c = self.L[i], cache[i]
+            dcent = None
             if l.kind == "Softmax":
-                dz = g
+                if l.loss in (None, "nll"):
+                    dz = nll_dlogits(c["out"], y)       # d cost / d logits
+                else:
+                    dz = softmax_head(c["z"], y, l.loss)[4].astype(self.dtype)
+            elif l.kind in ("ExpLoss", "Hinge", "Centered"):
+                hd = self.head(c["out"], y)
+                dz = hd["dA"]
+                if l.kind == "Centered":
+                    dz = dz * activation(l.actvn)[1](c["z"])
+                    dcent = hd["dcenters"]
+                dz = dz.astype(self.dtype)
             elif l.kind == "Hidden":
                 if "mask" in c:
                     g = g * c["mask"]
                 dz = (g * activation(l.actvn)[1](c["z"])).astype(self.dtype)
-            if l.kind in ("Softmax", "Hidden"):
+            if l.kind in ("Softmax", "Hidden", "ExpLoss", "Hinge", "Centered"):
                 xin = c["in"]
                 dW = (xin.T @ dz).astype(self.dtype)
                 db = dz.sum(axis=0, dtype=self.dtype)
                 grads[i] = [dW + wtcost_grad(l.params[0], l.reg),
                             db + wtcost_grad(l.params[1], l.reg)]
+                if l.kind == "Centered" and l.learn_centers:
+                    grads[i].append(dcent.astype(self.dtype) + wtcost_grad(l.params[2], l.reg))
                 g = (dz @ l.params[0].T).astype(self.dtype) if i > first_param else None
             elif l.kind == "DropOut":
                 if "mask" in c:
@@ -736,28 +971,59 @@ class OracleNet:
                                        need_dx=i > first_param, f16=self.f16, grad_scale=self.grad_scale)
                 grads[i] = [dW + wtcost_grad(l.params[0], l.reg),
                             db + wtcost_grad(l.params[1], l.reg)]
-            elif l.kind in ("Input", "Elastic"):
+            elif l.kind == "Input" or i <= first_param:
                 g = None
+            elif l.kind == "Elastic":
+                st, d = l.stage, c.get("draws")
+                g = elastic_apply_bwd(g.reshape(c["out"].shape), c.get("target") if st.active else None, st.nearest,
+                                      getattr(d, "flipmask", None) if d is not None else None,
+                                      st.invert).astype(self.dtype)
+            elif l.kind == "Color":
+                g = g.reshape(c["out"].shape)
+                if c.get("saved") is not None:
+                    g = l.stage.backward(g, c["saved"]).astype(self.dtype)
             if g is None:
                 break
         return grads
 
     # -- public steps ---------------------------------------------------------
-    def cost(self, logprob, y):
-        c = nll(logprob, y)
+    def head(self, h, y):
+        """Everything the output head derives from the last layer's output h (logprob for Softmax, the
+        linear output for ExpLoss / Hinge, the hidden features for CenteredOut)."""
+        l = self.L[-1]
+        if l.kind == "Softmax":
+            lp, preds, stat, cost, dA = softmax_head(h, y, l.loss or "nll")   # log_softmax(logprob) == logprob
+            return dict(logprob=lp, preds=preds, stat=stat, cost=cost, dA=dA, feats=lp)
+        if l.kind == "ExpLoss":
+            lp, preds, stat, cost, dA, o = exploss_head(h, y)
+            return dict(logprob=lp, preds=preds, stat=stat, cost=cost, dA=dA, feats=o)
+        if l.kind == "Hinge":
+            lp, preds, stat, cost, dA = hinge_head(h, y)
+            return dict(logprob=lp, preds=preds, stat=stat, cost=cost, dA=dA, feats=lp)
+        centers = l.params[2] if l.learn_centers else l.centers
+        lp, preds, stat, cost, dA, dc = centered_head(h, centers, y, l.ckind, l.junk_dist)
+        return dict(logprob=lp, preds=preds, stat=stat, cost=cost, dA=dA, dcenters=dc, feats=h)
+
+    def cost(self, h, y):
+        l = self.L[-1]
+        c = nll(h, y) if (l.kind == "Softmax" and l.loss in (None, "nll")) else self.head(h, y)["cost"]
         for l in self.L:
             if l.params:
                 c = c + wtcost(l.params, l.reg)
         return self.dtype.type(c)
 
     def grads(self, x, y, draws=None):
-        logprob, cache = self.forward(x, True, draws)
+        logprob, cache = self.forward(x, True, draws)        # (the head's input for the non-Softmax heads)
         return self.cost(logprob, y), logprob, self.backward(cache, y), cache
 
     def train_step(self, x, y, draws=None):
         """One call of the function built by get_trin_model (neuralnet.py:203-241):
         returns [cost, features, logprob] and applies the simultaneous updates."""
         cost, logprob, grads, _ = self.grads(x, y, draws)
+        feats = logprob
+        if self.L[-1].kind != "Softmax":
+            hd = self.head(logprob, y)
+            feats, logprob = hd["feats"], hd["logprob"]
         for l, g in zip(self.L, grads):
             if not l.params or not l.reg["rate"]:                    # layer.py:74-75
                 continue
@@ -766,11 +1032,14 @@ class OracleNet:
             for j in range(len(l.params)):
                 l.params[j], l.vel[j] = sgd_update(l.params[j], l.vel[j], g[j],
                                                    self.cur_learn_rate, l.reg)
-        return cost, logprob, logprob
+        return cost, feats, logprob
 
     def test(self, x, y):
         """get_test_model outputs (neuralnet.py:257-277; outlayers.py:69-80)."""
         logprob, _ = self.forward(x, False)
+        if self.L[-1].kind != "Softmax":
+            hd = self.head(logprob, y)
+            return np.mean(hd["preds"] != y), np.mean(hd["stat"]), hd["logprob"], hd["preds"]
         preds = logprob.argmax(axis=1)
         sym_err = np.mean(preds != y)
         p_mle = np.exp(logprob)[np.arange(len(y)), y].mean()

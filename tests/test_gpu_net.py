@@ -243,8 +243,11 @@ def test_errors_mirror_the_reference():
         NeuralNet([("InputLayer", {"img_sz": 8}),
                    ("ConvLayer", {"num_maps": 2, "filter_sz": 3, "stride": 1, "actvn": "nope"}),
                    ("SoftmaxLayer", {"n_out": 3})], dict(tr))
-    with pytest.raises(NotImplementedError):
-        NeuralNet([("InputLayer", {"img_sz": 8}), ("HingeLayer", {"n_out": 3})], dict(tr))
+    with pytest.raises(NotImplementedError):        # the aux-input layers are not built
+        NeuralNet([("InputLayer", {"img_sz": 8}), ("SoftAuxLayer", {"n_out": 3})], dict(tr))
+    net = NeuralNet([("InputLayer", {"img_sz": 8}), ("SoftmaxLayer", {"n_out": 3, "loss": "bogus"})], dict(tr))
+    with pytest.raises(NotImplementedError, match="Loss"):          # outlayers.py:36
+        net.get_trin_model(np.zeros((4, 1, 8, 8), np.float32), np.zeros(4, np.int32))
     with pytest.raises(AttributeError):
         NeuralNet([("InputLayer", {"img_sz": 8}), ("BogusLayer", {})], dict(tr))
 
@@ -735,3 +738,135 @@ def test_hip_trajectory_matches_the_torch_fixture():
         np.testing.assert_array_equal(lp.argmax(1), gold["logprob_%d" % s].argmax(1))
     for i, w in enumerate([w for l in net.tr_layers for w in l.get_wts()]):
         xchk_compare(gold, "w3_%d" % i, w, 1e-4, 1e-6)
+
+
+def _aug_net_layers(first):
+    return [
+        first,
+        ("ConvLayer", {"num_maps": 5, "filter_sz": 3, "stride": 1, "mode": "same", "actvn": "tanh"}),
+        ("ColorLayer", {"balance": 1.3, "gamma": 1.6, "maxval": 1}),               # mid-net (neuralnet.py:132-142)
+        ("ElasticLayer", {"translation": 1.5, "zoom": 1.2, "magnitude": 20, "sigma": 3, "pflip": .05,
+                          "angle": 10, "nearest": False}),
+        ("ConvLayer", {"num_maps": 6, "filter_sz": 3, "stride": 1, "actvn": "relu10"}),
+        ("ElasticLayer", {"translation": 1, "nearest": True, "invert_image": True}),
+        ("PoolLayer", {"pool_sz": 2}),
+        ("HiddenLayer", {"n_out": 30, "pdrop": .3}),
+        ("SoftmaxLayer", {"n_out": 7}),
+    ]
+
+
+@pytest.mark.parametrize("first", [("InputLayer", {"img_sz": 12, "num_maps": 3}),
+                                   ("ColorLayer", {"img_sz": 12, "num_maps": 3, "balance": 1.5, "gamma": 1.4, "maxval": 2})],
+                         ids=["input-first", "color-first"])
+def test_color_layer_and_mid_net_distortion_layers_match_oracle(first):
+    """ColorLayer (color.py:9-52) as first layer and in the middle of a net, ElasticLayers
+    in the middle of a net (bilinear with every distortion + flip noise; nearest + inversion): forward,
+    the gradient THROUGH them (Theano differentiates through the gather / clip / pow chain) and two
+    update steps against the float64 oracle with injected draws."""
+    import copy
+    from theanet_amd import NeuralNet
+    layers = _aug_net_layers(first)
+    B, img = 6, 12
+    tr = {"SEED": 21, "BATCH_SZ": B, "INIT_LEARNING_RATE": .05, "EPOCHS_TO_HALF_RATE": 1}
+    rng = np.random.RandomState(4)
+    x = (rng.rand(2 * B, 3, img, img) * (2 if first[0] == "ColorLayer" else 1)).astype(np.float32)
+    y = rng.randint(0, 7, 2 * B).astype(np.int32)
+    net = NeuralNet(copy.deepcopy(layers), dict(tr))
+    ora = O.OracleNet(copy.deepcopy(layers), dict(tr), dtype=np.float64)
+    fn = net.get_trin_model(x, y)
+    for s in range(2):
+        draws = {}
+        for i, l in enumerate(ora.L):
+            if l.kind == "Elastic" and l.stage.active:
+                d = l.stage.draw((B, l.num_maps, l.out_sz, l.out_sz))
+                draws[i] = d
+                net.tr_layers[i].inject(**{k: getattr(d, k) for k in d.__slots__})
+            if l.kind == "Color" and l.stage.active:
+                u = l.stage.draw(B)
+                draws[i] = u
+                net.tr_layers[i].inject(u)
+            if getattr(l, "mask_rv", None) is not None:
+                m = l.mask_rv.draw((B, l.n_out))
+                draws[i] = m
+                net.tr_layers[i].drop.inject(m)
+        cost_w, lp_w, _ = ora.train_step(x[s * B:(s + 1) * B], y[s * B:(s + 1) * B], draws)
+        cost, _, lp = fn(s)
+        assert_close(lp, lp_w, 2e-4, 2e-5, what="aug net logprob step %d" % s)
+        assert_close(cost, cost_w, 2e-4, 1e-5, what="aug net cost step %d" % s)
+    for i, (lyr, ol) in enumerate(zip(net.tr_layers, ora.L)):
+        for j, w in enumerate(lyr.get_wts()):
+            assert_close(w, ol.params[j], 5e-4, 2e-6, what="aug net w %d %d" % (i, j))
+    # the test twins are the identity (+ inversion) ...
+    te = net.get_test_model(x, y)
+    sym, pm = te(0)
+    ow = ora.test(x[:B], y[:B])
+    assert abs(sym - ow[0]) < 1e-6 and abs(pm - ow[1]) < 1e-4
+    # ... and the device generators run too (no injection)
+    for lyr in net.tr_layers:
+        if hasattr(lyr, "inject") and not hasattr(lyr, "drop"):
+            lyr.inject()
+    for lyr in net.tr_layers:
+        if getattr(lyr, "drop", None) is not None:
+            lyr.drop.inject(None)
+    assert np.isfinite(fn(0)[0])
+    print(net)
+
+
+HEADS = [
+    ("SoftmaxLayer", {"n_out": 6, "loss": "nllsq"}),
+    ("SoftmaxLayer", {"n_out": 6, "loss": "nll40"}),
+    ("SoftmaxLayer", {"n_out": 6, "loss": "hinge"}),
+    ("SoftmaxLayer", {"n_out": 6, "loss": "exp", "reg": {"L2": .001}}),
+    ("ExpLossLayer", {"n_out": 6}),
+    ("HingeLayer", {"n_out": 6, "reg": {"maxnorm": 2}}),
+    ("CenteredOutLayer", {"n_features": 12, "n_classes": 6, "kind": "LOGIT"}),
+    ("CenteredOutLayer", {"n_features": 9, "n_classes": 6, "kind": "RBF"}),
+    ("CenteredOutLayer", {"n_features": 9, "n_classes": 6, "kind": "RBF", "learn_centers": True, "junk_dist": 3.0}),
+]
+
+
+@pytest.mark.parametrize("head", HEADS, ids=lambda h: h[0][:-5] + "-" + str(h[1].get("loss", h[1].get("kind", ""))) +
+                         ("-learn" if h[1].get("learn_centers") else ""))
+def test_output_heads_and_losses_match_oracle(head):
+    """the remaining losses of SoftmaxLayer (outlayers.py:38-64) and the other heads
+    (ExpLossLayer :105-126, HingeLayer :129-147, CenteredOutLayer LOGIT / RBF :153-224): two training steps
+    (cost, features, logprob, every weight incl. learned centers) and the test function's two error
+    statistics against the float64 oracle, whose head gradients are pinned by finite differences
+    (tests/test_oracle_kat.py)."""
+    import copy
+    from theanet_amd import NeuralNet
+    layers = [("InputLayer", {"img_sz": 8, "num_maps": 2}),
+              ("ConvLayer", {"num_maps": 4, "filter_sz": 3, "stride": 1, "actvn": "relu10"}),
+              ("HiddenLayer", {"n_out": 20, "actvn": "tanh"}),
+              head]
+    B = 10
+    tr = {"SEED": 77, "BATCH_SZ": B, "INIT_LEARNING_RATE": .2, "EPOCHS_TO_HALF_RATE": 1}
+    rng = np.random.RandomState(8)
+    x = rng.rand(2 * B, 2, 8, 8).astype(np.float32)
+    y = rng.randint(0, 6, 2 * B).astype(np.int32)
+    net = NeuralNet(copy.deepcopy(layers), dict(tr))
+    ora = O.OracleNet(copy.deepcopy(layers), dict(tr), dtype=np.float64)
+    fn = net.get_trin_model(x, y)
+    for s in range(3):
+        cost_w, feats_w, lp_w = ora.train_step(x[(s % 2) * B:(s % 2 + 1) * B], y[(s % 2) * B:(s % 2 + 1) * B])
+        cost, feats, lp = fn(s % 2)
+        fin = np.isfinite(lp_w)
+        assert_close(np.where(fin, lp, 0), np.where(fin, lp_w, 0), 2e-4, 2e-5, what="%s logprob step %d" % (head[0], s))
+        assert (lp[~fin] < -1e30).all()                      # the junk column of an RBF head with junk_dist = inf
+        assert_close(feats, feats_w if feats_w.shape == feats.shape else lp_w, 2e-4, 2e-5, what="features step %d" % s)
+        assert_close(cost, cost_w, 2e-4, 1e-5, what="%s cost step %d" % (head[0], s))
+    for i, (lyr, ol) in enumerate(zip(net.tr_layers, ora.L)):
+        got = lyr.get_wts()
+        for j, p in enumerate(ol.params):
+            assert_close(got[j], p, 5e-4, 2e-6, what="%s w %d %d" % (head[0], i, j))
+    te = net.get_test_model(x, y, preds_feats=True)
+    sym, stat, feats, preds = te(1)
+    sym_w, stat_w, lp_w, preds_w = ora.test(x[B:], y[B:])
+    np.testing.assert_array_equal(preds, preds_w)
+    assert abs(sym - sym_w) < 1e-6 and abs(stat - stat_w) < 2e-4 * max(1, abs(stat_w))
+    assert net.tr_layers[-1].kind in ("SOFTMAX", "ExpLoss", "Hinge", "LOGIT", "RBF")
+    # a checkpoint of the net rebuilds it (centers included)
+    ck = net.get_init_params()
+    net2 = NeuralNet(ck["layers"], dict(ck["training_params"]), ck["allwts"])
+    a, b2 = net.get_data_test_model()(x[:B]), net2.get_data_test_model()(x[:B])
+    np.testing.assert_array_equal(a[1], b2[1])

@@ -263,3 +263,40 @@ def test_whole_net_trajectory_matches_the_torch_fixture():
         np.testing.assert_allclose(cost, gold["cost_%d" % s], rtol=1e-10)
     for i, w in enumerate([w for l in net.L for w in l.params]):
         xchk_compare(gold, "w3_%d" % i, w, 1e-9, 1e-13)
+
+
+def test_oracle_gradients_through_mid_net_color_and_elastic_layers_fd():
+    """Finite differences (float64) through ColorLayer and ElasticLayers in the middle of a net: the
+    oracle's hand-written backward of the clip / pow chain and of the gather (scatter-add, flip and
+    inversion signs) -- what Theano's grad does through color.py:38-44 and inlayers.py:63-142."""
+    import copy
+    layers = [
+        ("InputLayer", {"img_sz": 10, "num_maps": 2}),
+        ("ConvLayer", {"num_maps": 3, "filter_sz": 3, "stride": 1, "mode": "same", "actvn": "sigmoid"}),
+        ("ColorLayer", {"balance": 1.4, "gamma": 1.7}),
+        ("ElasticLayer", {"translation": 1.2, "zoom": 1.15, "magnitude": 15, "sigma": 2, "pflip": .1, "angle": 8}),
+        ("ConvLayer", {"num_maps": 4, "filter_sz": 3, "stride": 1, "actvn": "tanh"}),
+        ("ElasticLayer", {"translation": 1, "nearest": True, "invert_image": True}),
+        ("SoftmaxLayer", {"n_out": 5}),
+    ]
+    tr = {"SEED": 3, "BATCH_SZ": 4, "INIT_LEARNING_RATE": .1, "EPOCHS_TO_HALF_RATE": 1}
+    net = O.OracleNet(copy.deepcopy(layers), dict(tr), dtype=np.float64)
+    rng = np.random.RandomState(0)
+    x = rng.rand(4, 2, 10, 10)
+    y = rng.randint(0, 5, 4)
+    draws = {2: net.L[2].stage.draw(4), 3: net.L[3].stage.draw((4, 3, 10, 10)), 5: net.L[5].stage.draw((4, 4, 8, 8))}
+    cost, _, grads, _ = net.grads(x, y, draws)
+    eps = 1e-6
+    for i in (1, 4):                       # conv below the color/elastic pair, conv between the elastic layers
+        for j, p in enumerate(net.L[i].params):
+            flat = p.reshape(-1)
+            for idx in rng.choice(flat.size, min(6, flat.size), replace=False):
+                old = flat[idx]
+                flat[idx] = old + eps
+                cp = net.cost(net.forward(x, True, draws)[0], y)
+                flat[idx] = old - eps
+                cm = net.cost(net.forward(x, True, draws)[0], y)
+                flat[idx] = old
+                fd = (cp - cm) / (2 * eps)
+                an = grads[i][j].reshape(-1)[idx]
+                assert abs(fd - an) <= 1e-7 + 2e-5 * abs(fd), (i, j, idx, fd, an)

@@ -87,6 +87,8 @@ SIGNATURES = {
     "tn_fc_softmax_train": (c_int, [CTX, P, P, P, P, c_int, c_int, c_int, P, c_int64, P, P, P, P, P, P,
                                     c_float, P, P, P, P, P, c_int, c_float, P]),
     "tn_softmax_nll": (c_int, [CTX, P, P, c_int64, P, P, P, P, P, P, c_int, c_int, c_float]),
+    "tn_head_rows": (c_int, [CTX, c_int, c_int, c_float, P, P, c_int, P, c_int64, P, P, P, P, P, P, P, P,
+                             c_int, c_int, c_float, c_float, c_int, c_float]),
     "tn_reduce_sum": (c_int, [CTX, P, c_size_t, c_float, P, c_int]),
     "tn_wtcost": (c_int, [CTX, P, c_size_t, c_float, c_float, P, c_int]),
     "tn_error_stats": (c_int, [CTX, P, P, c_int64, P, c_int, P]),
@@ -136,6 +138,11 @@ SIGNATURES = {
                                      c_double, c_int, c_double, c_int, P, P, P, P]),
     "tn_elastic_apply": (c_int, [CTX, P, c_int64, P, P, c_int, c_int, c_int, c_int, c_int, c_int,
                                  P, P, P, c_float, P, c_uint64, c_uint32, P, c_int64]),
+    "tn_elastic_apply_bwd": (c_int, [CTX, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, c_float, P,
+                                     c_uint64, c_uint32, P, c_int64, P, c_int, c_float]),
+    "tn_color_factors": (c_int, [CTX, P, c_int, c_int, c_double, c_double, P, c_uint64, c_uint32, P, c_int64]),
+    "tn_color_apply": (c_int, [CTX, P, c_int64, P, P, c_int, c_int, c_int, c_float]),
+    "tn_color_apply_bwd": (c_int, [CTX, P, c_int64, P, P, P, c_int, c_int, c_int, c_float, P, c_int, c_float]),
     "tn_deformer_transform": (c_int, [CTX, P, P, c_int, c_int, c_int, c_double, c_double, c_double,
                                       P, c_uint64, c_int64]),
     "tn_gather_rows": (c_int, [CTX, P, P, P, c_int, c_size_t]),

@@ -557,6 +557,121 @@ int tn_fc_softmax_train(tn_ctx* ctx, const float* x, const float* W, const float
     if (rc) return rc;
     return tn_fc_bwd(ctx, x, dz, W, dW, db, dx, B, n_in, n_out, ws, prev_a, prev_act, prm, prev_mask);
 }
+// ---- the other output heads / losses (outlayers.py:38-64, 105-224): see csrc/heads.hip ----
+int tn_head_rows(tn_ctx* ctx, int head, int loss, float loss_param, const float* a, const float* centers, int ncls,
+                 const int32_t* y, int64_t y_row0, const int64_t* d_row0, float* feat, float* logprob, float* rowloss,
+                 int32_t* pred, float* rowstat, float* da, float* dcenters, int B, int n, float inv_batch, float junk_dist,
+                 int act, float act_prm) {
+    REQUIRE(B > 0 && n > 0 && a && logprob && head >= 0 && head <= 4 && loss >= 0 && loss <= 4, "tn_head_rows: bad arguments");
+    REQUIRE(head < 3 || (centers && ncls > 0), "tn_head_rows: centered heads need centers");
+    REQUIRE(y != nullptr || (rowloss == nullptr && da == nullptr && rowstat == nullptr),
+            "tn_head_rows: labels required for loss / gradient outputs");
+    const int64_t yoff = y_row0 + (d_row0 ? *d_row0 : 0);
+    const float eps = 0.001f;
+    for (int row = 0; row < B; ++row) {                 // (dcenters accumulates: rows stay sequential)
+        const float* ar = a + (size_t)row * n;
+        const int label = y ? y[yoff + row] : -1;
+        auto argmax = [](const float* v, int m) { int am = 0; for (int c = 1; c < m; ++c) if (v[c] > v[am]) am = c; return am; };
+        if (head <= 2) {
+            float* lp = logprob + (size_t)row * n;
+            if (pred) pred[row] = argmax(ar, n);
+            if (head == 2) {
+                const float zy = label >= 0 ? ar[label] : 0.f;
+                float s = 0.f, cnt = 0.f;
+                for (int c = 0; c < n; ++c) {
+                    lp[c] = ar[c];
+                    if (label < 0) continue;
+                    const float t = ar[c] + 1.f - zy;
+                    s += std::fmax(0.f, t);
+                    const float ac = (c != label && t >= 0.f) ? 1.f : 0.f;
+                    cnt += ac;
+                    if (da && c != label) da[(size_t)row * n + c] = ac * inv_batch / n;
+                }
+                if (label >= 0) {
+                    if (rowloss) rowloss[row] = s / n;
+                    if (rowstat) rowstat[row] = zy;
+                    if (da) da[(size_t)row * n + label] = -cnt * inv_batch / n;
+                }
+                continue;
+            }
+            float mean = 0.f;
+            if (head == 1) { for (int c = 0; c < n; ++c) mean += ar[c]; mean /= n; }
+            float m = -INFINITY, s = 0.f;
+            for (int c = 0; c < n; ++c) m = std::fmax(m, ar[c] - mean);
+            for (int c = 0; c < n; ++c) s += std::exp(ar[c] - mean - m);
+            const float lse = std::log(s);
+            for (int c = 0; c < n; ++c) { lp[c] = ar[c] - mean - m - lse; if (feat) feat[(size_t)row * n + c] = ar[c] - mean; }
+            if (label < 0) continue;
+            const float lpy = lp[label], py = std::exp(lpy);
+            if (rowstat) rowstat[row] = py;
+            float rl = 0.f;
+            if (head == 1) {
+                const float e = std::exp(-(ar[label] - mean));
+                rl = e;
+                if (da) for (int c = 0; c < n; ++c) da[(size_t)row * n + c] = -e * inv_batch * ((c == label ? 1.f : 0.f) - 1.f / n);
+            } else if (loss <= 2) {
+                float gl;
+                if (loss == 0) { rl = -lpy; gl = -1.f; }
+                else if (loss == 1) { rl = lpy * lpy; gl = 2.f * lpy; }
+                else { const float t = loss_param - lpy; rl = std::fmax(0.f, t); gl = t >= 0.f ? -1.f : 0.f; }
+                if (da) for (int c = 0; c < n; ++c) da[(size_t)row * n + c] = gl * inv_batch * ((c == label ? 1.f : 0.f) - std::exp(lp[c]));
+            } else {
+                float dot = 0.f, hs = 0.f;
+                auto gp = [&](int c) { return loss == 3 ? (c == label ? -(float)(n - 1) / n : 1.f / n) : (c == label ? -std::exp(-py) : 0.f); };
+                for (int c = 0; c < n; ++c) { const float pc = std::exp(lp[c]); hs += std::fmax(0.f, pc + 1.f - py); dot += gp(c) * pc; }
+                rl = loss == 3 ? hs / n : std::exp(-py);
+                if (da) for (int c = 0; c < n; ++c) da[(size_t)row * n + c] = inv_batch * std::exp(lp[c]) * (gp(c) - dot);
+            }
+            if (rowloss) rowloss[row] = rl;
+            continue;
+        }
+        const int ncol = head == 4 ? ncls + 1 : ncls;
+        float* lp = logprob + (size_t)row * ncol;
+        for (int k = 0; k < ncls; ++k) {
+            const float* ck = centers + (size_t)k * n;
+            float s = 0.f;
+            for (int f = 0; f < n; ++f) {
+                if (head == 3) { const float v = ar[f] * (1.f - 2.f * eps) + eps; s += std::log(ck[f] * v + (1.f - ck[f]) * (1.f - v)); }
+                else { const float d = ar[f] - ck[f]; s += d * d; }
+            }
+            lp[k] = head == 3 ? s : -s;
+        }
+        if (head == 4) {
+            lp[ncls] = -junk_dist;
+            float m = -INFINITY, s = 0.f;
+            for (int c = 0; c < ncol; ++c) m = std::fmax(m, lp[c]);
+            for (int c = 0; c < ncol; ++c) s += std::exp(lp[c] - m);
+            const float lse = std::log(s);
+            for (int c = 0; c < ncol; ++c) lp[c] = lp[c] - m - lse;
+        }
+        if (pred) pred[row] = argmax(lp, ncol);
+        if (label < 0) continue;
+        if (rowloss) rowloss[row] = -lp[label];
+        const float* cy = centers + (size_t)label * n;
+        if (head == 3) {
+            float wrong = 0.f;
+            for (int f = 0; f < n; ++f) {
+                const float v = ar[f] * (1.f - 2.f * eps) + eps, bp = cy[f] * v + (1.f - cy[f]) * (1.f - v);
+                wrong += bp < .5f ? 1.f : 0.f;
+                if (da) da[(size_t)row * n + f] = -inv_batch * (1.f - 2.f * eps) * (2.f * cy[f] - 1.f) / bp * act_grad_from_out(ar[f], act, act_prm);
+            }
+            if (rowstat) rowstat[row] = wrong / n;
+        } else {
+            if (rowstat) rowstat[row] = std::exp(lp[label]);
+            for (int f = 0; f < n; ++f) {
+                float gv = 0.f;
+                for (int k = 0; k < ncls; ++k) {
+                    const float w = ((k == label ? 1.f : 0.f) - std::exp(lp[k])) * inv_batch, d = ar[f] - centers[(size_t)k * n + f];
+                    gv += w * 2.f * d;
+                    if (dcenters) dcenters[(size_t)k * n + f] += -w * 2.f * d;
+                }
+                if (da) da[(size_t)row * n + f] = gv * act_grad_from_out(ar[f], act, act_prm);
+            }
+        }
+    }
+    return TN_OK;
+}
+
 int tn_wtcost(tn_ctx*, const float* p, size_t n, float L1, float L2, float* out, int accumulate) {
     double a = 0.0, s = 0.0;
     for (size_t i = 0; i < n; ++i) { a += std::fabs(p[i]); s += (double)p[i] * p[i]; }
@@ -840,6 +955,88 @@ int tn_elastic_apply(tn_ctx*, const float* x, int64_t x_row0, const int64_t* d_r
             out[t] = v;
         }
     }
+    return TN_OK;
+}
+
+// ---- backward of the resampling (mid-net ElasticLayer) ----
+int tn_elastic_apply_bwd(tn_ctx* ctx, const float* g, float* dx, int N, int C, int h, int w, int invert, int nearest,
+                         const int32_t* map_idx, const float* map_fy, const float* map_fx, float pflip,
+                         const uint8_t* flipmask, uint64_t seed, uint32_t step, const uint32_t* d_step,
+                         int64_t row_global0, const float* prev_a, int prev_act, float prm) {
+    REQUIRE(g && dx && N > 0 && C > 0 && h > 0 && w > 0, "tn_elastic_apply_bwd: bad arguments");
+    const int hw = h * w;
+    const uint32_t st = step + (d_step ? *d_step : 0u);
+#pragma omp parallel for
+    for (long long img = 0; img < (long long)N * C; ++img) {
+        float* d = dx + (size_t)img * hw;
+        std::memset(d, 0, sizeof(float) * hw);
+        for (int p = 0; p < hw; ++p) {
+            const size_t t = (size_t)img * hw + p;
+            float gv = g[t];
+            bool flip = false;
+            if (flipmask) flip = flipmask[t] != 0;
+            else if (pflip > 0.f) flip = u01(philox_word((uint64_t)row_global0 * C * hw + (uint64_t)t, st, STREAM_FLIP, seed)) < pflip;
+            if (flip) gv = -gv;
+            if (invert) gv = -gv;
+            if (!map_idx) d[p] += gv;
+            else if (nearest) d[map_idx[p]] += gv;
+            else {
+                const int i00 = map_idx[p];
+                const float fy = map_fy[p], fx = map_fx[p];
+                d[i00] += gv * (1.f - fy) * (1.f - fx); d[i00 + 1] += gv * (1.f - fy) * fx;
+                d[i00 + w] += gv * fy * (1.f - fx); d[i00 + w + 1] += gv * fy * fx;
+            }
+        }
+        if (prev_a && prev_act != TN_ACT_LINEAR)
+            for (int i = 0; i < hw; ++i) d[i] *= act_grad_from_out(prev_a[(size_t)img * hw + i], prev_act, prm);
+    }
+    return TN_OK;
+}
+
+// ---- ColorLayer (color.py:9-52) ----
+int tn_color_factors(tn_ctx* ctx, float* fac, int N, int C, double balance, double gamma, const float* draws,
+                     uint64_t seed, uint32_t step, const uint32_t* d_step, int64_t row_global0) {
+    REQUIRE(fac && N > 0 && C > 0 && balance > 0 && gamma > 0, "tn_color_factors: bad arguments");
+    const int NC = N * C;
+    const double lnb = std::log(balance), lng = std::log(gamma);
+    for (int i = 0; i < NC; ++i) {
+        float u[3];
+        if (draws) { u[0] = draws[i]; u[1] = draws[NC + i]; u[2] = draws[2 * NC + i]; }
+        else {
+            const uint64_t e = (uint64_t)row_global0 * C + (uint64_t)i;
+            const u32x4 r = philox4x32((uint32_t)e, (uint32_t)(e >> 32), step + (d_step ? *d_step : 0u), 5u, (uint32_t)seed, (uint32_t)(seed >> 32));
+            u[0] = -1.f + 2.f * u01(r.x); u[1] = -1.f + 2.f * u01(r.y); u[2] = -1.f + 2.f * u01(r.z);
+        }
+        fac[3 * i] = (float)std::exp(lnb * (double)u[0]);
+        fac[3 * i + 1] = (float)std::exp(lng * (double)u[1]);
+        fac[3 * i + 2] = (float)std::exp(lng * (double)u[2]);
+    }
+    return TN_OK;
+}
+static void color_pass(bool bwd, const float* x, const float* fac, const float* g, float* out, long long total, int hw,
+                       float maxval, const float* prev_a, int prev_act, float prm) {
+#pragma omp parallel for
+    for (long long t = 0; t < total; ++t) {
+        const long long img = t / hw;
+        const float b = fac[3 * img], g1 = fac[3 * img + 1], g2 = fac[3 * img + 2];
+        const float o1 = x[t] / maxval * b, o2 = std::fmin(std::fmax(o1, 0.f), 1.f), o3 = std::pow(o2, g1);
+        if (!bwd) { out[t] = (1.f - std::pow(1.f - o3, g2)) * maxval; continue; }
+        float d = g2 * std::pow(1.f - o3, g2 - 1.f) * g1 * std::pow(o2, g1 - 1.f) * b;
+        if (!(o1 >= 0.f && o1 <= 1.f)) d = 0.f;
+        float v = g[t] * d;
+        if (prev_a && prev_act != TN_ACT_LINEAR) v *= act_grad_from_out(prev_a[t], prev_act, prm);
+        out[t] = v;
+    }
+}
+int tn_color_apply(tn_ctx* ctx, const float* x, int64_t x_row0, const float* fac, float* out, int N, int C, int hw, float maxval) {
+    REQUIRE(x && fac && out && N > 0 && C > 0 && hw > 0 && maxval > 0, "tn_color_apply: bad arguments");
+    color_pass(false, x + (size_t)x_row0 * C * hw, fac, nullptr, out, (long long)N * C * hw, hw, maxval, nullptr, 0, 0.f);
+    return TN_OK;
+}
+int tn_color_apply_bwd(tn_ctx* ctx, const float* x, int64_t x_row0, const float* fac, const float* g, float* dx, int N, int C,
+                       int hw, float maxval, const float* prev_a, int prev_act, float prm) {
+    REQUIRE(x && fac && g && dx && N > 0 && C > 0 && hw > 0 && maxval > 0, "tn_color_apply_bwd: bad arguments");
+    color_pass(true, x + (size_t)x_row0 * C * hw, fac, g, dx, (long long)N * C * hw, hw, maxval, prev_a, prev_act, prm);
     return TN_OK;
 }
 

@@ -1,14 +1,13 @@
-from .inlayers import InputLayer, ElasticLayer, InputSlot
+from .inlayers import InputLayer, ElasticLayer, ColorLayer, InputSlot
 from .convpool import ConvLayer, PoolLayer, MeanLayer
 from .hidden import HiddenLayer
 from .dropout import DropOutLayer
-from .outlayers import SoftmaxLayer
+from .outlayers import SoftmaxLayer, CenteredOutLayer, HingeLayer, ExpLossLayer, OutputLayer
 from .layer import Layer, activation_by_name
 
 # Reference layer types outside the accelerated hot path: naming them
 # keeps NeuralNet's getattr(layer, name) lookup giving a clear error instead of AttributeError.
-_OUT_OF_SCOPE = ("ColorLayer", "CenteredOutLayer", "HingeLayer", "ExpLossLayer",
-                 "SoftAuxLayer", "AuxConcatLayer")
+_OUT_OF_SCOPE = ("SoftAuxLayer", "AuxConcatLayer")
 
 
 def __getattr__(name):

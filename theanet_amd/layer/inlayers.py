@@ -198,6 +198,29 @@ class ElasticLayer(Layer):
             return                      # the conv block's forward resamples while it loads (PoolLayer)
         self.ctx.call("tn_elastic_apply", *self._apply_args)
 
+    def backward(self, gout, need_gin, below):
+        """An ElasticLayer in the middle of a net (neuralnet.py:132-142): the gradient w.r.t. its input --
+        the transposed gather, with the signs of the inversion and of the flip noise."""
+        if not need_gin or isinstance(self.inpt, InputSlot):
+            return None
+        from .. import _lib
+        b_out, b_act, b_prm, b_mask = below.act_info()
+        assert b_mask is None
+        if getattr(self, "gin", None) is None:
+            self.gin = self.ctx.empty(self.inpt.shape)
+        h = w = self.img_sz
+        fuse = b_out is not None and b_act != _lib.TN_ACT_LINEAR
+        if self.active:
+            a = self._apply_args
+            self.ctx.call("tn_elastic_apply_bwd", gout.ptr, self.gin.ptr, self.batch_sz, self.num_maps, h, w,
+                          a[8], a[9], a[10], a[11], a[12], a[13], a[14], a[15], a[16], a[17], a[18],
+                          b_out.ptr if fuse else None, b_act, b_prm)
+        else:
+            self.ctx.call("tn_elastic_apply_bwd", gout.ptr, self.gin.ptr, self.batch_sz, self.num_maps, h, w,
+                          int(self.invert), 1, None, None, None, 0.0, None, 0, 0, None, 0,
+                          b_out.ptr if fuse else None, b_act, b_prm)
+        return self.gin
+
     def _field(self, m):
         h = w = self.img_sz
         self.ctx.call("tn_elastic_field", self.draws.ptr, h, w, float(self.translation),
@@ -211,3 +234,94 @@ class ElasticLayer(Layer):
             return [self.output.get_value(), np.zeros(2)]
         h = w = self.img_sz
         return [self.output.get_value(), self.target.get_value() - np.indices((h, w))]
+
+
+class ColorLayer(Layer):
+    """theanet/layer/color.py:9-52 -- per-(image, channel) colour balance and gamma jitter:
+    ``out = x/maxval * b -> clip(0,1) -> ** g1 -> 1 - (1 - .) ** g2 -> * maxval`` with
+    ``b = exp(ln(balance) u0)``, ``g1 = exp(ln(gamma) u1)``, ``g2 = exp(ln(gamma) u2)``, three U(-1,1)
+    random variables of shape (batch, num_maps).  balance == gamma == 1: identity (no stream is created,
+    the seed chain is not consumed).  The test version is the identity (color.py:44-52).  Draws come from
+    the device's Philox stream (keyed by the global image index) or are injected (``inject``)."""
+
+    def __init__(self, inpt, img_sz,
+                 num_maps=3,
+                 rand_gen=None,
+                 balance=1,
+                 gamma=1,
+                 maxval=1):
+        self.params = []
+        self.inpt = inpt
+        self.out_sz = img_sz
+        self.num_maps = num_maps
+        self.n_out = self.num_maps * self.out_sz ** 2
+        self.balance, self.gamma, self.maxval = balance, gamma, maxval
+        self.representation = 'Color Maps:{} Size:{:2d} Balance:{:.2f} ' \
+                              'Gamma:{:.2f} Maxval:{}'.format(
+            num_maps, img_sz, balance, gamma, maxval)
+        from ..device import get_context
+        self.ctx = ctx = get_context()
+        self.batch_sz = inpt.batch if isinstance(inpt, InputSlot) else inpt.shape[0]
+        self.output = ctx.empty((self.batch_sz, num_maps, img_sz, img_sz))
+        self.active = not (gamma == 1 and balance == 1)
+        self.d_step = None
+        self._inj = None
+        self.gin = None
+        if not self.active:
+            return
+        assert gamma > 0 and balance > 0
+        # the stream seed consumes the seed chain like color.py:31-32
+        self.seed = int(rand_gen.randint(1e6)) if rand_gen is not None else int(np.random.randint(0, 1e6))
+        self.fac = ctx.empty((self.batch_sz * num_maps * 3,))
+
+    def TestVersion(self, inpt):
+        return ColorLayer(inpt,
+                          self.out_sz,
+                          num_maps=self.num_maps,
+                          rand_gen=None,
+                          balance=1,
+                          gamma=1,
+                          maxval=1)
+
+    def inject(self, u=None):
+        """Replace the device RNG by explicit uniforms, shape (3, batch, num_maps): the draws of the
+        reference's three ``srs.uniform`` variables in creation order.  None: back to the generator."""
+        self._inj = None if u is None else self.ctx.array(
+            np.ascontiguousarray(np.asarray(u, np.float32).reshape(3, self.batch_sz, self.num_maps)))
+
+    def _source(self):
+        s = self.inpt
+        if isinstance(s, InputSlot):
+            return s.data.ptr, int(s.row0), int(s.row_global0)
+        return s.ptr, 0, 0
+
+    def forward(self, train=True):
+        x_ptr, row0, rg0 = self._source()
+        hw = self.out_sz * self.out_sz
+        if not self.active:
+            self.ctx.call("tn_elastic_apply", x_ptr, row0, None, self.output.ptr, self.batch_sz, self.num_maps,
+                          self.out_sz, self.out_sz, 0, 1, None, None, None, 0.0, None, 0, 0, None, rg0)
+            return
+        self.ctx.call("tn_color_factors", self.fac.ptr, self.batch_sz, self.num_maps, float(self.balance),
+                      float(self.gamma), self._inj.ptr if self._inj is not None else None, self.seed, 0,
+                      self.d_step.ptr if self.d_step is not None else None, rg0)
+        self.ctx.call("tn_color_apply", x_ptr, row0, self.fac.ptr, self.output.ptr, self.batch_sz,
+                      self.num_maps, hw, float(self.maxval))
+
+    def backward(self, gout, need_gin, below):
+        if not need_gin or isinstance(self.inpt, InputSlot):
+            return None
+        from .. import _lib
+        b_out, b_act, b_prm, b_mask = below.act_info()
+        assert b_mask is None
+        fuse = b_out is not None and b_act != _lib.TN_ACT_LINEAR
+        if self.gin is None:
+            self.gin = self.ctx.empty(self.inpt.shape)
+        if not self.active:
+            self.ctx.call("tn_scale_mask", gout.ptr, None, 1.0, self.gin.ptr, self.gin.size,
+                          b_out.ptr if fuse else None, b_act, b_prm)
+        else:
+            self.ctx.call("tn_color_apply_bwd", self.inpt.ptr, 0, self.fac.ptr, gout.ptr, self.gin.ptr,
+                          self.batch_sz, self.num_maps, self.out_sz * self.out_sz, float(self.maxval),
+                          b_out.ptr if fuse else None, b_act, b_prm)
+        return self.gin

@@ -21,8 +21,8 @@ import numpy as np
 
 from . import comm, layer
 from .device import DeviceArray, get_context, share
-from .layer import (ConvLayer, DropOutLayer, ElasticLayer, HiddenLayer, InputLayer, InputSlot,
-                    MeanLayer, PoolLayer, SoftmaxLayer)
+from .layer import (CenteredOutLayer, ColorLayer, ConvLayer, DropOutLayer, ElasticLayer, ExpLossLayer, HiddenLayer,
+                    HingeLayer, InputLayer, InputSlot, MeanLayer, OutputLayer, PoolLayer, SoftmaxLayer)
 
 # ########################### Helper Functions #################################
 
@@ -60,6 +60,14 @@ _GRAD_ALIGN = 64      # floats: every tensor in the flat gradient buffer starts 
 # ###############################################################################
 #                            Compiled step functions
 # ###############################################################################
+
+
+def _features_logprob(out):
+    """[features, logprob] of the output head (neuralnet.py:236-241); for Softmax and Hinge heads features IS
+    logprob (outlayers.py:92-93, :137-139)."""
+    logprob = out.logprob.get_value()
+    feats = logprob if out.features is out.logprob else out.features.get_value()
+    return [feats, logprob]
 
 
 class _TrainFn:
@@ -105,8 +113,7 @@ class _TrainFn:
         if getattr(net, "_dp_pending", False):
             net.ctx.sync()                        # the cost travels with the all-reduce on the second stream
         cost = net.d_cost.get_value()[0]
-        logprob = out.logprob.get_value()
-        return [cost, logprob, logprob]      # features IS logprob for Softmax (outlayers.py:92-93)
+        return [cost] + _features_logprob(out)
 
     def __call__(self, i):
         self.enqueue(i)
@@ -164,6 +171,8 @@ class _PipeTrainFn:
                 b.drop.seed = a.drop.seed
             for pa, pb in zip(a.params, b.params):
                 ctx.call("tn_d2d", pb.ptr, pa.ptr, pa.size * 4)
+            if hasattr(a, "centers") and not a.learn_centers:        # fixed class centers: the same on both streams
+                ctx.call("tn_d2d", b.centers.ptr, a.centers.ptr, a.centers.size * 4)
             if a.params:
                 b.accumulated_updates = a.accumulated_updates        # ONE velocity per tensor
         # the twin's own velocity buffers are gone with that: its update table must name the shared ones
@@ -214,6 +223,7 @@ class _PipeTrainFn:
         for lyr in net.tr_layers:
             drop = getattr(lyr, "drop", None)
             if (drop is not None and drop.injected) or getattr(lyr, "_inj_draws", False) or \
+                    getattr(lyr, "_inj", None) is not None or \
                     getattr(lyr, "_inj_flip", None) is not None:
                 return True
         return net.ctx.ev_hook is not None
@@ -333,8 +343,7 @@ class _PipeTrainFn:
             X.ctx.call("tn_stream_select", 0)
         X.ctx.sync()
         cost = X.d_cost.get_value()[0]
-        logprob = X.tr_layers[-1].logprob.get_value()
-        return [cost, logprob, logprob]
+        return [cost] + _features_logprob(X.tr_layers[-1])
 
     @staticmethod
     def _finish_cost(X):
@@ -433,7 +442,7 @@ class NeuralNet():
         self.cur_learn_rate = self.ctx.zeros((1,), np.float32)
         # Input Layer
         input_layer_type = getattr(layer, layers[0][0])
-        assert input_layer_type in (InputLayer, ElasticLayer), \
+        assert input_layer_type in (InputLayer, ElasticLayer, ColorLayer), \
             "First layer needs to be Input or Elastic or Color Layer"
 
         self.tr_layers.append(input_layer_type(self.x, rand_gen=self.rand_gen,
@@ -449,13 +458,13 @@ class NeuralNet():
             self._fuse(self.tr_layers)
             self._fuse(self.te_layers)
 
-        assert isinstance(self.tr_layers[-1], SoftmaxLayer), \
-            "the accelerated path ends in a SoftmaxLayer (other heads: SURVEY.md 8f)"
+        assert isinstance(self.tr_layers[-1], OutputLayer), \
+            "the last layer must be an output head (Softmax, ExpLoss, Hinge or CenteredOut layer)"
 
         # random streams read the device step counter; masks/noise are keyed by the
         # position inside the GLOBAL minibatch so that sharding does not change them
         for lyr in self.tr_layers:
-            if isinstance(lyr, ElasticLayer):
+            if isinstance(lyr, (ElasticLayer, ColorLayer)):
                 lyr.d_step = self.d_step
             drop = getattr(lyr, "drop", None)
             if drop is not None:
@@ -482,7 +491,7 @@ class NeuralNet():
         te_inpt = prev_te_layer.output
         curr_layer_type = getattr(layer, layer_type)
 
-        if curr_layer_type in (ElasticLayer, ConvLayer, PoolLayer, MeanLayer):
+        if curr_layer_type in (ElasticLayer, ColorLayer, ConvLayer, PoolLayer, MeanLayer):
             if type(prev_tr_layer) is DropOutLayer:
                 use_tr_layer = self.tr_layers[self.num_layers - 2]
             else:
@@ -493,15 +502,15 @@ class NeuralNet():
                 tr_inpt = tr_inpt.reshape(self.local_bsz, num_prev_maps, prev_out_sz, prev_out_sz)
                 te_inpt = te_inpt.reshape(self.local_bsz, num_prev_maps, prev_out_sz, prev_out_sz)
 
-        if curr_layer_type is ElasticLayer:
+        if curr_layer_type in (ElasticLayer, ColorLayer):
             layer_args = dict(layer_args)
             layer_args.pop("num_maps", None)
             layer_args.pop("img_sz", None)
-            curr_layer = ElasticLayer(tr_inpt,
-                                      num_maps=num_prev_maps,
-                                      img_sz=prev_out_sz,
-                                      rand_gen=self.rand_gen,
-                                      **layer_args)
+            curr_layer = curr_layer_type(tr_inpt,
+                                         num_maps=num_prev_maps,
+                                         img_sz=prev_out_sz,
+                                         rand_gen=self.rand_gen,
+                                         **layer_args)
 
         elif curr_layer_type is ConvLayer:
             curr_layer = ConvLayer(tr_inpt,
@@ -524,7 +533,20 @@ class NeuralNet():
                                       prev_tr_layer.n_out,
                                       **layer_args)
 
-        elif curr_layer_type in (HiddenLayer, SoftmaxLayer):
+        elif curr_layer_type is CenteredOutLayer:
+            # Needs the hidden layer's weights (or a seed) and CENTERS (n_classes x n_features): neuralnet.py:175-194
+            centers = None
+            if wts:
+                centers = wts[2] if len(wts) > 2 else None
+                wts = wts[:2]
+            te_inpt = te_inpt.flatten(2)
+            curr_layer = CenteredOutLayer(tr_inpt.flatten(2),
+                                          wts, centers,
+                                          self.rand_gen,
+                                          prev_tr_layer.n_out,
+                                          **layer_args)
+
+        elif curr_layer_type in (HiddenLayer, SoftmaxLayer, HingeLayer, ExpLossLayer):
             te_inpt = te_inpt.flatten(2)
             curr_layer = curr_layer_type(tr_inpt.flatten(2),
                                          wts,
@@ -787,7 +809,8 @@ class NeuralNet():
         # the weight-gradient ops only record their finishing slab sums; one launch does them all
         ctx.call("tn_defer_reductions", 1)
         n_lyr = len(self.tr_layers)
-        fuse_out = n_lyr >= 2 and self._need_gin[n_lyr - 1] and os.environ.get("TN_SOFTMAX_TRAIN", "1") != "0"
+        fuse_out = n_lyr >= 2 and self._need_gin[n_lyr - 1] and os.environ.get("TN_SOFTMAX_TRAIN", "1") != "0" \
+            and isinstance(out, SoftmaxLayer) and out.loss == "nll"
         try:
             out.forward(True, y=y, y_row0=y_row0, d_row0=d_row0,
                         below=self.tr_layers[-2] if fuse_out else None)
@@ -961,6 +984,7 @@ class NeuralNet():
         has_wtcost = any(getattr(l, 'reg', None) and l.params and (l.reg['L1'] or l.reg['L2'])
                          for l in self.tr_layers)
         inject = any((getattr(l, "drop", None) is not None and l.drop.injected) or getattr(l, "_inj_draws", False)
+                     or getattr(l, "_inj", None) is not None
                      or getattr(l, "_inj_flip", None) is not None for l in self.tr_layers)
         if self._dp and os.environ.get("TN_DP_PIPELINE", "1") == "0":
             return False
