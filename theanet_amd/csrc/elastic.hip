@@ -480,7 +480,7 @@ int tn_step_tail(tn_ctx* ctx, const tn_sgd_seg* d_segs, int nseg, size_t max_n, 
                                     sigma, angle, nearest, map_idx, map_fy, map_fx, target);
     }
     int bx = cdiv(max_n, 1024);
-    if (bx > 256) bx = 256;
+    if (bx > 2048) bx = 2048;
     if (bx < 1) bx = 1;
     const int n_upd = nseg + (rider ? 1 : 0);
     const int gx = bx > cdiv(h * w, 4) ? bx : cdiv(h * w, 4);

@@ -924,6 +924,32 @@ static int fc_fwd_splitk(tn_ctx* ctx, GemmArgs g, int S, const uint8_t* mask) {
     return TN_OK;
 }
 
+__global__ __launch_bounds__(256) void fc_dgrad_finish_kernel(const float* __restrict__ ws, int S, size_t MN,
+                                                             const float* __restrict__ prev_a,
+                                                             const uint8_t* __restrict__ mask, float* __restrict__ out,
+                                                             int act, float prm) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= MN) return;
+    float v = 0.f;
+    for (int z = 0; z < S; ++z) v += ws[(size_t)z * MN + i];
+    if (prev_a) v *= tn_act_grad_from_out(prev_a[i], act, prm);
+    if (mask) v = mask[i] ? v : 0.f;
+    out[i] = v;
+}
+
+static int fc_dgrad_splits(tn_ctx* ctx, int B, int n_in, int n_out) {
+    static int force = -1;
+    if (force < 0) {
+        const char* e = getenv("TN_FC_DGRAD_SPLIT");
+        force = e ? atoi(e) : 0;
+    }
+    if (force > 0) return force;
+    if (B > 256 || n_out < 32 * BK || n_in < 2048) return 1;
+    int S = n_out / (8 * BK);                  // >= 8 K-tiles per slab
+    if (S > 8) S = 8;
+    return S < 2 ? 1 : S;
+}
+
 int tn_fc_fwd(tn_ctx* ctx, const float* x, const float* W, const float* b, float* a, int B, int n_in,
               int n_out, int act, float act_param, const uint8_t* mask) {
     TN_REQUIRE(B > 0 && n_in > 0 && n_out > 0, "tn_fc_fwd: bad shape");
@@ -1049,7 +1075,7 @@ int tn_fc_bwd(tn_ctx* ctx, const float* x, const float* dz, const float* W, floa
         tn_fc_skinny_ok(n_in, n_out, dx, prev_a, prev_mask))
         return tn_fc_skinny_bwd(ctx, x, dz, W, dW, db, dx, B, n_in, n_out, (float*)ws, prev_a, prev_act,
                                 prev_act_param, prev_mask);
-    if (pair_on && n_out > SK_MAX) {
+    if (pair_on && n_out > SK_MAX && fc_dgrad_splits(ctx, B, n_in, n_out) == 1) {
         // weight gradient (split-K slabs) and input gradient as ONE launch of interleaved blocks
         const int S = wgrad_splits(B, n_in, n_out);
         float* wsC = (float*)ws;
@@ -1123,6 +1149,25 @@ int tn_fc_dgrad(tn_ctx* ctx, const float* dz, const float* W, float* dx, int B, 
     g.kchunk = cdiv(n_out, BK) * BK;
     g.epi = EPI_DGRAD; g.prev_a = prev_a; g.mask = prev_mask; g.act = prev_act; g.act_prm = prev_act_param;
     g.a_vec = vec_ok(dz, n_out); g.b_vec = vec_ok(W, n_out);
+    const int S = fc_dgrad_splits(ctx, B, n_in, n_out);
+    if (S > 1) {
+        // few rows, a long reduction and a big weight matrix (wide6's 128 x 16384 <- 1024): a block per output
+        // tile is a long latency-bound chain over its 64 weight rows; S slabs of the reduction put S times
+        // as many blocks in flight, a finishing kernel adds them in order and applies act' * mask
+        const size_t MN = (size_t)B * n_in;
+        g.kchunk = cdiv(cdiv(n_out, S), BK) * BK;
+        const int Sx = cdiv(n_out, g.kchunk);
+        float* ws;
+        int rc = tn_scratch_get(ctx, (size_t)Sx * MN * sizeof(float), &ws);
+        if (rc) return rc;
+        g.C = ws; g.epi = EPI_PLAIN; g.prev_a = nullptr; g.mask = nullptr;
+        launch_gemm<true, true, false>(ctx, g, Sx);
+        TN_LAUNCH_CHECK();
+        fc_dgrad_finish_kernel<<<cdiv(MN, 256), 256, 0, ctx->stream>>>(ws, Sx, MN, prev_a, prev_mask, dx, prev_act,
+                                                                      prev_act_param);
+        TN_LAUNCH_CHECK();
+        return TN_OK;
+    }
     launch_gemm<true, true, false>(ctx, g, 1);
     TN_LAUNCH_CHECK();
     return TN_OK;

@@ -88,6 +88,22 @@ __global__ __launch_bounds__(256) void sgd_update_pipe_kernel(const tn_pipe_seg*
     const float* __restrict__ g = sg.g;
     const size_t n = sg.n;
     const float m = sg.momentum;
+    if ((n & 3) == 0 && (((uintptr_t)p | (uintptr_t)ps | (uintptr_t)v | (uintptr_t)g) & 15) == 0) {
+        // 16-byte accesses: the big tensors (wide6's 16.8 M-element FC weight) are pure HBM streaming
+        for (size_t i = ((size_t)bx * 256 + threadIdx.x) * 4; i < n; i += (size_t)nbx * 1024) {
+            float4 vv = *reinterpret_cast<const float4*>(v + i);
+            if (update_v) {
+                const float4 gg = *reinterpret_cast<const float4*>(g + i);
+                vv.x = tn_vel(m, vv.x, gg.x); vv.y = tn_vel(m, vv.y, gg.y);
+                vv.z = tn_vel(m, vv.z, gg.z); vv.w = tn_vel(m, vv.w, gg.w);
+                *reinterpret_cast<float4*>(v + i) = vv;
+            }
+            const float4 pv = *reinterpret_cast<const float4*>(ps + i);
+            *reinterpret_cast<float4*>(p + i) = make_float4(tn_stepped(pv.x, step, vv.x), tn_stepped(pv.y, step, vv.y),
+                                                            tn_stepped(pv.z, step, vv.z), tn_stepped(pv.w, step, vv.w));
+        }
+        return;
+    }
     for (size_t i = (size_t)bx * 256 + threadIdx.x; i < n; i += (size_t)nbx * 256) {
         float vv = v[i];
         if (update_v) {
@@ -242,6 +258,21 @@ __global__ __launch_bounds__(256) void sgd_update_pipe_lazy_kernel(const tn_pipe
     const int ri = lb.rec_of_seg[by];
     if (ri < 0 || !update_v) {
         const size_t n = sg.n;
+        if ((n & 3) == 0 && (((uintptr_t)p | (uintptr_t)ps | (uintptr_t)v | (uintptr_t)g) & 15) == 0) {
+            for (size_t i = ((size_t)bx * 256 + threadIdx.x) * 4; i < n; i += (size_t)nbx * 1024) {
+                float4 vv = *reinterpret_cast<const float4*>(v + i);
+                if (update_v) {
+                    const float4 gg = *reinterpret_cast<const float4*>(g + i);
+                    vv.x = tn_vel(m, vv.x, gg.x); vv.y = tn_vel(m, vv.y, gg.y);
+                    vv.z = tn_vel(m, vv.z, gg.z); vv.w = tn_vel(m, vv.w, gg.w);
+                    *reinterpret_cast<float4*>(v + i) = vv;
+                }
+                const float4 pv = *reinterpret_cast<const float4*>(ps + i);
+                *reinterpret_cast<float4*>(p + i) = make_float4(tn_stepped(pv.x, step, vv.x), tn_stepped(pv.y, step, vv.y),
+                                                                tn_stepped(pv.z, step, vv.z), tn_stepped(pv.w, step, vv.w));
+            }
+            return;
+        }
         for (size_t i = (size_t)bx * 256 + threadIdx.x; i < n; i += (size_t)nbx * 256) {
             float vv = v[i];
             if (update_v) {
@@ -403,7 +434,7 @@ int tn_sgd_update_multi_cost(tn_ctx* ctx, const tn_sgd_seg* d_segs, int nseg, si
     TN_REQUIRE(!rider || (d_cost != nullptr && nrow > 0), "tn_sgd_update_multi_cost: bad cost arguments");
     if (nseg < 0) nseg = 0;
     int bx = cdiv(max_n, 1024);
-    if (bx > 256) bx = 256;
+    if (bx > 2048) bx = 2048;
     if (bx < 1) bx = 1;
     sgd_update_multi_kernel<<<dim3(bx, nseg + (rider ? 1 : 0)), 256, 0, ctx->stream>>>(
         d_segs, nseg, d_lr, gscale, d_step_inc, rowloss, nrow, cost_scale, d_cost);
@@ -415,7 +446,7 @@ int tn_sgd_update_multi_delayed(tn_ctx* ctx, const tn_sgd_seg* d_segs, int nseg,
                                 const float* d_lr, float gscale, uint32_t* d_step_inc, int mode) {
     TN_REQUIRE(nseg > 0 && d_segs && d_lr && mode >= 1 && mode <= 3, "tn_sgd_update_multi_delayed: bad arguments");
     int bx = cdiv(max_n, 1024);
-    if (bx > 256) bx = 256;
+    if (bx > 2048) bx = 2048;
     if (bx < 1) bx = 1;
     sgd_update_delayed_kernel<<<dim3(bx, nseg), 256, 0, ctx->stream>>>(d_segs, nseg, d_lr, gscale, d_step_inc, mode);
     TN_LAUNCH_CHECK();
@@ -429,7 +460,7 @@ int tn_sgd_update_multi_pipe(tn_ctx* ctx, const tn_pipe_seg* d_segs, const tn_pi
     const bool rider = rowloss != nullptr;
     TN_REQUIRE(!rider || (d_cost != nullptr && nrow > 0), "tn_sgd_update_multi_pipe: bad cost arguments");
     int bx = cdiv(max_n, 1024);
-    if (bx > 256) bx = 256;
+    if (bx > 2048) bx = 2048;
     if (bx < 1) bx = 1;
     // this stream's pending slab sums whose output is the gradient of one of the segments are folded into
     // the update; the others are finished by the ordinary reduction launch first
@@ -495,7 +526,7 @@ int tn_sgd_update_multi_lazy(tn_ctx* ctx, const tn_sgd_seg* d_segs, const tn_sgd
         return tn_sgd_update_multi_cost(ctx, d_segs, nseg, max_n, d_lr, gscale, d_step_inc, rowloss, nrow,
                                         cost_scale, d_cost);
     int bx = cdiv(max_n, 1024);
-    if (bx > 256) bx = 256;
+    if (bx > 2048) bx = 2048;
     if (bx < 1) bx = 1;
     sgd_update_lazy_kernel<<<dim3(bx, nseg + (rider ? 1 : 0)), 256, 0, ctx->stream>>>(
         d_segs, nseg, d_lr, gscale, d_step_inc, rowloss, nrow, cost_scale, d_cost, lb);
