@@ -21,6 +21,8 @@
 //   (32 filters x 32 channels) pair and keeps all nine taps (9 x 16 accumulators).
 #include "conv_tile_common.h"
 
+#include <type_traits>
+
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4v __attribute__((ext_vector_type(4)));
 typedef int int4v __attribute__((ext_vector_type(4)));
@@ -77,7 +79,7 @@ __device__ __forceinline__ half8 c16_pack(float a0, float a1, float a2, float a3
 
 // NS: staging slots per thread for the input tile (1 or 2)
 template <int FT, bool DGRAD, bool POOL, int NS>
-__global__ __launch_bounds__(256) void conv_tile16_kernel(ConvTG g) {
+__global__ __launch_bounds__(256, (FT <= 2 && NS == 1) ? 2 : 1) void conv_tile16_kernel(ConvTG g) {
     extern __shared__ __attribute__((aligned(16))) float ct_smem[];
     constexpr int KBF = 32 * FT;
     constexpr int WB = 9 * 2 * KBF * 16;              // bytes of one weight chunk
@@ -93,6 +95,8 @@ __global__ __launch_bounds__(256) void conv_tile16_kernel(ConvTG g) {
     const int n0 = grp * g.NI, r0 = rt * g.TH;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, hi = lane >> 5;
     const int HW = g.H * g.Wd;
+    unsigned long long* dbg = (g.dbg && t == 0) ? g.dbg + 8 * (size_t)bid : nullptr;
+    if (dbg) { dbg[0] = __builtin_readcyclecounter(); dbg[4] = wall_clock64(); }
 
     for (int i = t * 16; i < 2 * XB; i += 4096) *reinterpret_cast<float4*>(Xs + i) = make_float4(0.f, 0.f, 0.f, 0.f);
 
@@ -122,12 +126,18 @@ __global__ __launch_bounds__(256) void conv_tile16_kernel(ConvTG g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    float4 xr[NS][8];
+    // The input tile is fetched TWO chunks ahead (two register sets, alternating by chunk parity): a chunk's
+    // MFMAs last ~1.2 k cycles, less than an HBM round trip under load, so one chunk of look-ahead left every
+    // block waiting for its loads (cycle stamps: 4 k cycles per chunk).  Weights come from L2: one chunk ahead.
+    // (the pooled-gradient variant forms dz from three loads per value: two sets would halve its occupancy)
+    constexpr bool LA2 = !(DGRAD && POOL);
+    float4 xr[LA2 ? 2 : 1][NS][8];
     // weight staging slots live in named registers (an indexed array ended up in scratch memory)
     uint4 wr0, wr1, wr2, wr3, wr4, wr5, wr6, wr7, wr8;
 #define C16_WL(J, R) if (WS > J) R = *reinterpret_cast<const uint4*>(w_ + min(4096 * J, WB - 16 - 16 * t))
 #define C16_WST(J, R) if (WS > J && (4096 * (J + 1) <= WB || 16 * t + 4096 * J < WB)) *reinterpret_cast<uint4*>(wb + 4096 * J) = R
-    auto gload = [&](int chunk) {
+    auto gloadx = [&](int chunk, auto Pc) __attribute__((always_inline)) {
+        constexpr int P = decltype(Pc)::value;
         const int ch = min(chunk, g.nchunk - 1);
 #pragma unroll
         for (int s = 0; s < NS; ++s)
@@ -135,56 +145,62 @@ __global__ __launch_bounds__(256) void conv_tile16_kernel(ConvTG g) {
             for (int e = 0; e < 8; ++e) {
                 // channels beyond C meet zero weights: any finite value will do (clamped re-read)
                 const int cc = min(ch * 16 + 8 * sl[s].o + e, g.C - 1);
-                if (DGRAD && POOL) xr[s][e] = pool_expand4(g.ps, sl[s].n * g.C + cc, sl[s].row, sl[s].col);
-                else xr[s][e] = *reinterpret_cast<const float4*>(g.x + sl[s].g + cc * HW);
+                if (DGRAD && POOL) xr[P][s][e] = pool_expand4(g.ps, sl[s].n * g.C + cc, sl[s].row, sl[s].col);
+                else xr[P][s][e] = *reinterpret_cast<const float4*>(g.x + sl[s].g + cc * HW);
             }
+    };
+    auto gloadw = [&](int chunk) __attribute__((always_inline)) {
+        const int ch = min(chunk, g.nchunk - 1);
         const char* w_ = wsrc + (size_t)ch * WB;
         C16_WL(0, wr0); C16_WL(1, wr1); C16_WL(2, wr2); C16_WL(3, wr3); C16_WL(4, wr4);
         C16_WL(5, wr5); C16_WL(6, wr6); C16_WL(7, wr7); C16_WL(8, wr8);
     };
-    auto lstore = [&](int buf) {
+    auto lstore = [&](int buf, auto Pc) __attribute__((always_inline)) {
+        constexpr int P = decltype(Pc)::value;
         char* xb = Xs + buf * XB;
         char* wb = Ws + buf * WB + 16 * t;
-        const float sc = g.iscale;
+        const float sc = DGRAD ? g.iscale : 1.f;
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             if (sl[s].ok) {
                 half8* dst = reinterpret_cast<half8*>(xb + sl[s].l);
+#define q xr[P][s]
                 if (DGRAD) {
-                    dst[0] = c16_pack(sc * xr[s][0].x, sc * xr[s][1].x, sc * xr[s][2].x, sc * xr[s][3].x,
-                                      sc * xr[s][4].x, sc * xr[s][5].x, sc * xr[s][6].x, sc * xr[s][7].x);
-                    dst[1] = c16_pack(sc * xr[s][0].y, sc * xr[s][1].y, sc * xr[s][2].y, sc * xr[s][3].y,
-                                      sc * xr[s][4].y, sc * xr[s][5].y, sc * xr[s][6].y, sc * xr[s][7].y);
-                    dst[2] = c16_pack(sc * xr[s][0].z, sc * xr[s][1].z, sc * xr[s][2].z, sc * xr[s][3].z,
-                                      sc * xr[s][4].z, sc * xr[s][5].z, sc * xr[s][6].z, sc * xr[s][7].z);
-                    dst[3] = c16_pack(sc * xr[s][0].w, sc * xr[s][1].w, sc * xr[s][2].w, sc * xr[s][3].w,
-                                      sc * xr[s][4].w, sc * xr[s][5].w, sc * xr[s][6].w, sc * xr[s][7].w);
+                    dst[0] = c16_pack(sc * q[0].x, sc * q[1].x, sc * q[2].x, sc * q[3].x, sc * q[4].x, sc * q[5].x, sc * q[6].x, sc * q[7].x);
+                    dst[1] = c16_pack(sc * q[0].y, sc * q[1].y, sc * q[2].y, sc * q[3].y, sc * q[4].y, sc * q[5].y, sc * q[6].y, sc * q[7].y);
+                    dst[2] = c16_pack(sc * q[0].z, sc * q[1].z, sc * q[2].z, sc * q[3].z, sc * q[4].z, sc * q[5].z, sc * q[6].z, sc * q[7].z);
+                    dst[3] = c16_pack(sc * q[0].w, sc * q[1].w, sc * q[2].w, sc * q[3].w, sc * q[4].w, sc * q[5].w, sc * q[6].w, sc * q[7].w);
                 } else {
-                    dst[0] = c16_pack(xr[s][0].x, xr[s][1].x, xr[s][2].x, xr[s][3].x, xr[s][4].x, xr[s][5].x,
-                                      xr[s][6].x, xr[s][7].x);
-                    dst[1] = c16_pack(xr[s][0].y, xr[s][1].y, xr[s][2].y, xr[s][3].y, xr[s][4].y, xr[s][5].y,
-                                      xr[s][6].y, xr[s][7].y);
-                    dst[2] = c16_pack(xr[s][0].z, xr[s][1].z, xr[s][2].z, xr[s][3].z, xr[s][4].z, xr[s][5].z,
-                                      xr[s][6].z, xr[s][7].z);
-                    dst[3] = c16_pack(xr[s][0].w, xr[s][1].w, xr[s][2].w, xr[s][3].w, xr[s][4].w, xr[s][5].w,
-                                      xr[s][6].w, xr[s][7].w);
+                    dst[0] = c16_pack(q[0].x, q[1].x, q[2].x, q[3].x, q[4].x, q[5].x, q[6].x, q[7].x);
+                    dst[1] = c16_pack(q[0].y, q[1].y, q[2].y, q[3].y, q[4].y, q[5].y, q[6].y, q[7].y);
+                    dst[2] = c16_pack(q[0].z, q[1].z, q[2].z, q[3].z, q[4].z, q[5].z, q[6].z, q[7].z);
+                    dst[3] = c16_pack(q[0].w, q[1].w, q[2].w, q[3].w, q[4].w, q[5].w, q[6].w, q[7].w);
                 }
+#undef q
             }
         }
         C16_WST(0, wr0); C16_WST(1, wr1); C16_WST(2, wr2); C16_WST(3, wr3); C16_WST(4, wr4);
         C16_WST(5, wr5); C16_WST(6, wr6); C16_WST(7, wr7); C16_WST(8, wr8);
     };
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
 
-    gload(0);
+    gloadx(0, P0{});
+    gloadw(0);
+    if constexpr (LA2) gloadx(1, P1{});
     __syncthreads();                 // the clearing is done
-    lstore(0);
+    lstore(0, P0{});
     __syncthreads();
+    if (dbg) dbg[1] = __builtin_readcyclecounter();
     const int RS16 = g.RS * 16;
-    for (int chunk = 0; chunk < g.nchunk; ++chunk) {
-        gload(chunk + 1);
-        const char* x0 = Xs + (chunk & 1) * XB + boff[0];
-        const char* x1 = Xs + (chunk & 1) * XB + boff[1];
-        const char* Wb = Ws + (chunk & 1) * WB + aoff;
+    auto body = [&](int chunk, auto Pc) __attribute__((always_inline)) {
+        constexpr int P = decltype(Pc)::value;
+        gloadw(chunk + 1);
+        if constexpr (LA2) gloadx(chunk + 2, Pc);
+        else gloadx(chunk + 1, P0{});
+        const char* x0 = Xs + P * XB + boff[0];
+        const char* x1 = Xs + P * XB + boff[1];
+        const char* Wb = Ws + P * WB + aoff;
         // nine taps: the LDS operands of tap s+1 (FT A vectors, 2 B vectors of 8 halfs) are requested
         // before the 2*FT MFMAs of tap s are issued
         half8 a[2][FT], b[2][2];
@@ -212,9 +228,15 @@ __global__ __launch_bounds__(256) void conv_tile16_kernel(ConvTG g) {
             __builtin_amdgcn_sched_group_barrier(0x100, FT + 2, 0);       // DS reads of the next tap
             __builtin_amdgcn_sched_group_barrier(0x008, 2 * FT, 0);       // then this tap's MFMAs
         }
-        if (chunk + 1 < g.nchunk) lstore((chunk + 1) & 1);
+        // chunk + 1 (fetched a chunk ago into the other register set) goes into the other LDS buffer
+        if (chunk + 1 < g.nchunk) lstore(P ^ 1, std::integral_constant<int, LA2 ? (P ^ 1) : 0>{});
         __syncthreads();
+    };
+    for (int chunk = 0; chunk < g.nchunk; chunk += 2) {
+        body(chunk, P0{});
+        if (chunk + 1 < g.nchunk) body(chunk + 1, P1{});
     }
+    if (dbg) dbg[2] = __builtin_readcyclecounter();
     if (DGRAD) {
         const float os = g.oscale;
 #pragma unroll
@@ -225,6 +247,7 @@ __global__ __launch_bounds__(256) void conv_tile16_kernel(ConvTG g) {
                 for (int r = 0; r < 16; ++r) acc[f][pt][r] *= os;
     }
     ct_epilogue<FT, DGRAD, POOL>(g, acc, ct_smem, kt, n0, r0, lane, wave, l31, hi);
+    if (dbg) { dbg[3] = __builtin_readcyclecounter(); dbg[5] = wall_clock64(); }
 #undef C16_WL
 #undef C16_WST
 }
@@ -287,12 +310,25 @@ static size_t c16_lds_bytes(const ConvTG& g, int FT) {
     return loop > epi ? loop : epi;
 }
 
+static unsigned long long* c16_dbg_buf = nullptr;
+// debugging aid (not part of the C-ABI): the cycle stamps of the last stamped launch (TN_CT_DBG=1)
+extern "C" int tn_conv_tile16_dbg_read(tn_ctx* ctx, unsigned long long* host, int nblocks) {
+    if (!c16_dbg_buf) return -1;
+    hipStreamSynchronize(ctx->stream);
+    return hipMemcpy(host, c16_dbg_buf, (size_t)nblocks * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+}
+
 template <int FT, bool DGRAD, bool POOL>
 static int c16_launch(tn_ctx* ctx, ConvTG& g) {
     static bool attr_set[2] = {false, false};
-    const size_t lds = c16_lds_bytes(g, FT);
+    size_t lds = c16_lds_bytes(g, FT);
+    if (const char* e = getenv("TN_C16_LDS")) lds = (size_t)atoi(e) > lds ? (size_t)atoi(e) : lds;
     const int ns = g.nx4 > 256 ? 2 : 1;
     const int grid = 8 * cdiv(g.MT, 8) * g.KT;
+    if (getenv("TN_CT_DBG")) {
+        if (!c16_dbg_buf) TN_HIP(hipMalloc(&c16_dbg_buf, 8 * sizeof(unsigned long long) * 65536));
+        g.dbg = grid <= 65536 ? c16_dbg_buf : nullptr;
+    }
     if (ns == 1) {
         if (!attr_set[0]) {
             TN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_tile16_kernel<FT, DGRAD, POOL, 1>),

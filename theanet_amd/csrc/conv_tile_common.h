@@ -58,11 +58,34 @@ struct ConvTG {
 
 // Epilogue of conv_tile_kernel / conv_tile16_kernel: the block's accumulators (FT filter tiles x 2 pixel tiles per
 // wave, MFMA C/D layout) -> bias + act (+ 2x2 max-pool + mask) or act' of the layer below -> HBM.
-template <int FT, bool DGRAD, bool POOL>
-__device__ __forceinline__ void ct_epilogue(const ConvTG& g, f32x16 (&acc)[FT][2], float* ct_smem, int kt, int n0,
-                                            int r0, int lane, int wave, int l31, int hi) {
+// ACT >= 0: the activation kind is a compile-time constant (leaky-ReLU, the nets' usual one): with a run-time
+// kind every element of the epilogue paid for the whole switch of tn_act_fwd / tn_act_grad_from_out -- 12 k
+// of a 17 k-cycle forward epilogue (cycle stamps, tools/dbg_c16.py).
+template <int FT, bool DGRAD, bool POOL, int ACT>
+__device__ __forceinline__ void ct_epilogue_impl(const ConvTG& g_, f32x16 (&acc)[FT][2], float* ct_smem, int kt, int n0,
+                                                 int r0, int lane, int wave, int l31, int hi) {
+    // a view of g whose .act folds to the constant
+    struct G {
+        const float* x; const float* wt; float* out; const float* bias; const float* prev_a;
+        int N, K, Ho, Wo, act; float prm; int TH, TP, vec_out; uint8_t* mask_out;
+    } g{g_.x, g_.wt, g_.out, g_.bias, g_.prev_a, g_.N, g_.K, g_.Ho, g_.Wo, ACT >= 0 ? ACT : g_.act, g_.prm, g_.TH, g_.TP, g_.vec_out,
+        g_.mask_out};
     constexpr int KBF = 32 * FT;
     const int HoWo = g.Ho * g.Wo;
+    if (!DGRAD) {
+        // bias joins the accumulators here: all of a lane's bias loads are in flight together, instead of one
+        // dependent global load per filter inside the store loops below
+        float bv[FT][16];
+#pragma unroll
+        for (int f = 0; f < FT; ++f)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                bv[f][r] = g.bias[min(kt * KBF + f * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi, g.K - 1)];
+#pragma unroll
+        for (int f = 0; f < FT; ++f)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[f][0][r] += bv[f][r]; acc[f][1][r] += bv[f][r]; }
+    }
     if (!DGRAD && POOL) {
         // ---- pooled epilogue: tile -> LDS [filter][pixel]; lane = one pooled pixel, wave = one filter
         float* Os = ct_smem;
@@ -88,7 +111,7 @@ __device__ __forceinline__ void ct_epilogue(const ConvTG& g, f32x16 (&acc)[FT][2
                 if (k >= g.K) break;
                 const float2 t0 = *reinterpret_cast<const float2*>(Os + kl * 256 + p00);
                 const float2 t1 = *reinterpret_cast<const float2*>(Os + kl * 256 + p00 + g.Wo);
-                const float bk = g.bias[k];
+                const float bk = 0.f;
                 const float a00 = tn_act_fwd(t0.x + bk, g.act, g.prm), a01 = tn_act_fwd(t0.y + bk, g.act, g.prm);
                 const float a10 = tn_act_fwd(t1.x + bk, g.act, g.prm), a11 = tn_act_fwd(t1.y + bk, g.act, g.prm);
                 const float m = fmaxf(fmaxf(a00, a01), fmaxf(a10, a11));
@@ -135,7 +158,7 @@ __device__ __forceinline__ void ct_epilogue(const ConvTG& g, f32x16 (&acc)[FT][2
                         v.w *= tn_act_grad_from_out(pa.w, g.act, g.prm);
                     }
                 } else {
-                    const float bk = g.bias[k];
+                    const float bk = 0.f;
                     v.x = tn_act_fwd(v.x + bk, g.act, g.prm);
                     v.y = tn_act_fwd(v.y + bk, g.act, g.prm);
                     v.z = tn_act_fwd(v.z + bk, g.act, g.prm);
@@ -173,7 +196,7 @@ __device__ __forceinline__ void ct_epilogue(const ConvTG& g, f32x16 (&acc)[FT][2
                         if (DGRAD) {
                             if (g.prev_a) v *= tn_act_grad_from_out(pa[q], g.act, g.prm);
                         } else {
-                            v = tn_act_fwd(v + g.bias[k], g.act, g.prm);
+                            v = tn_act_fwd(v, g.act, g.prm);
                         }
                         g.out[pbase + (size_t)k * HoWo] = v;
                     }
@@ -181,4 +204,11 @@ __device__ __forceinline__ void ct_epilogue(const ConvTG& g, f32x16 (&acc)[FT][2
             }
         }
     }
+}
+
+template <int FT, bool DGRAD, bool POOL>
+__device__ __forceinline__ void ct_epilogue(const ConvTG& g, f32x16 (&acc)[FT][2], float* ct_smem, int kt, int n0,
+                                            int r0, int lane, int wave, int l31, int hi) {
+    if (g.act == TN_ACT_LEAKY) ct_epilogue_impl<FT, DGRAD, POOL, TN_ACT_LEAKY>(g, acc, ct_smem, kt, n0, r0, lane, wave, l31, hi);
+    else ct_epilogue_impl<FT, DGRAD, POOL, -1>(g, acc, ct_smem, kt, n0, r0, lane, wave, l31, hi);
 }
