@@ -86,6 +86,15 @@ def cpu_baseline(prms, hw, c, batch, budget_s=15.0):
                       % (prms.get("_name", "net"), rec["steps"], batch, rec["seconds"], threads)}
 
 
+def _pmc_table(config):
+    """{kernel: {hbm_bytes_corrected, mfma_busy_frac, ...}} of one profiled configuration (profiles/r02_traffic.json)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r02_traffic.json")) as fh:
+            return json.load(fh)["configs"].get(config, {})
+    except (OSError, KeyError, ValueError):
+        return {}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -247,18 +256,17 @@ def main():
             # the per-kernel leg always runs one step at a time: with two steps in flight the launches
             # of the two streams share the GPU and a kernel's own duration cannot be separated
             roof["measured_in"] = "one-step-at-a-time schedule (bench.py --sequential)"
-            # HBM traffic of the dominant kernel: measured offline with rocprofv3 --pmc (separate
-            # FETCH_SIZE / WRITE_SIZE passes, gfx950 correction) by tools/collect_profiles.sh
-            try:
-                with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as fh:
-                    tr_pmc = json.load(fh)["kernels"]
-                key = roof["kernel"].split(" ")[0]
-                for name, rec in tr_pmc.items():
+            # HBM traffic / matrix-core utilisation of these kernels: measured offline with rocprofv3 --pmc
+            # (separate FETCH_SIZE / WRITE_SIZE / MFMA passes, gfx950 FETCH correction) by
+            # tools/collect_profiles.sh, tabulated in profiles/r02_traffic.json
+            pmc = _pmc_table("mnist_bs4096")
+            for rec in [roof] + others:
+                key = rec["kernel"].split(" ")[0]
+                for name, vals in pmc.items():
                     if name.startswith(key):
-                        roof["traffic"] = rec["hbm_bytes_corrected"]
-                        roof["traffic_source"] = "profiles/r01_traffic.json (rocprofv3 --pmc)"
-            except (OSError, KeyError, ValueError):
-                pass
+                        rec["traffic"] = vals.get("hbm_bytes_corrected")
+                        rec["mfma_busy_frac_pmc"] = vals.get("mfma_busy_frac")
+                        rec["traffic_source"] = "profiles/r02_traffic.json (rocprofv3 --pmc)"
 
     else:
         # conv nets (cifar_like, wide6): every conv product of the step, grouped into forward and
@@ -298,6 +306,13 @@ def main():
         if others:
             others.sort(key=lambda r: -r["ms_per_step"])
             roof, others = others[0], others[1:]
+            pmc = _pmc_table("%s_%s" % (args.prms.split(".")[0], args.dtype))
+            conv = {k: v for k, v in pmc.items() if k.startswith(("conv_tile", "convpool", "conv_"))}
+            if conv:
+                roof["pmc_per_kernel"] = {k: {"hbm_MB_per_launch": round(v.get("hbm_bytes_corrected", 0) / 1e6, 2),
+                                              "mfma_busy_frac": round(v.get("mfma_busy_frac", 0.0), 3)}
+                                          for k, v in conv.items()}
+                roof["traffic_source"] = "profiles/r02_traffic.json (rocprofv3 --pmc, per launch)"
 
     if world.rank != 0:
         return
