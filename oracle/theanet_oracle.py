@@ -11,7 +11,10 @@ What it restates (all paths relative to /root/reference):
   theanet/layer/convpool.py   ConvLayer :14-95, PoolLayer :97-127, MeanLayer :129-144
   theanet/layer/hidden.py     HiddenLayer :11-55
   theanet/layer/dropout.py    drop_output :9-13, DropOutLayer :15-31
-  theanet/layer/outlayers.py  SoftmaxLayer :83-102, nll :50-51, error rates :69-80
+  theanet/layer/outlayers.py  SoftmaxLayer :83-102, losses :12-64, error rates :69-80,
+                              ExpLossLayer :105-126, HingeLayer :129-147,
+                              CenteredOutLayer :153-224
+  theanet/layer/color.py      ColorLayer :9-52
   theanet/layer/weights.py    init_wb :25-81
   theanet/layer/inlayers.py   InputLayer :12-26, ElasticLayer :29-163
   theanet/neuralnet.py        NeuralNet :60-111,:113-201,:203-241,:257-277,:303-311
@@ -26,12 +29,20 @@ no padding; MaxPoolGrad credits every tied maximum; Maximum/Minimum gradients
 use eq(out, x) (ties feed both branches); log(softmax(x)) is the stable
 log-softmax; simultaneous ``updates`` read pre-step values.
 
-PARITY UNPINNED for everything except ``deformer_transform`` (pinned against the
-reference's own extras/deformer.py:7-18 executed in the build container, fixture
-tests/golden/deformer.npz): the reference holds no golden vectors, no asserts
-(tests/test_elastic.py has none) and cannot run.  The remaining functions are
-pinned by analytic known-answer tests, float64 finite-difference gradient checks
-and an independent torch-CPU cross-check (tests/test_oracle_*.py).
+PARITY UNPINNED against the reference itself for everything except
+``deformer_transform`` (pinned against the reference's own extras/deformer.py:7-18
+executed in the build container, fixture tests/golden/deformer.npz): the reference
+holds no golden vectors, no asserts (tests/test_elastic.py has none) and cannot run.
+The remaining functions are pinned by analytic known-answer tests, float64
+finite-difference gradient checks (whole nets, every head / loss, mid-net Color and
+Elastic layers) and by an INDEPENDENT second implementation: a whole mnist.prms
+training trajectory (forward, all gradients, three old-velocity updates) computed by
+torch CPU autograd (tests/golden/make_torch_xchk.py -> torch_xchk.npz), which this
+module reproduces to 1e-9 (tests/test_oracle_kat.py).
+
+Beyond the reference (it is float32-only, weights.py:8): ``r16`` and the ``f16=True``
+modes of conv2d_fwd / conv2d_bwd specify the build's DTYPE='float16' (fp16-rounded
+operands, exact products, float64 sums).
 """
 import math
 
