@@ -468,6 +468,16 @@ int tn_color_apply(tn_ctx* ctx, const float* x, int64_t x_row0, const float* fac
 int tn_color_apply_bwd(tn_ctx* ctx, const float* x, int64_t x_row0, const float* fac, const float* g, float* dx, int N,
                        int C, int hw, float maxval, const float* prev_a, int prev_act, float prev_act_param);
 
+/* ---- aux-input layers (replaces auxiliary.py:14-160; their two small dense maps run on tn_fc_*) ----
+ * tn_aux_mix: LocationInfo's input (:27-36).  aux (N, 2, d) float32, rows from row0: train: out[n,:] =
+ * boost * (aux[n,0,:]*u_n + aux[n,1,:]*(1-u_n)), u_n ~ U(0,1) (u_inj (B) injected, or Philox(seed, step + *d_step,
+ * row_global0 + n)); test: boost * mean of the two.  tn_copy_cols: dst[n, col_dst+j] = src[n, col_src+j] for j <
+ * ncols (* act'(prev_a[n, col_dst+j])): the concatenation of AuxConcatLayer and the split of its gradient.   */
+int tn_aux_mix(tn_ctx* ctx, const float* aux, int64_t row0, float* out, int B, int d, float boost, int train,
+               const float* u_inj, uint64_t seed, uint32_t step, const uint32_t* d_step, int64_t row_global0);
+int tn_copy_cols(tn_ctx* ctx, const float* src, int ld_src, int col_src, float* dst, int ld_dst, int col_dst, int ncols,
+                 int B, const float* prev_a, int prev_act, float prev_act_param);
+
 /* extras/deformer.py:7-18 -- per-IMAGE deformation, in place semantics of Deformer:
  * trans = indices + scale*noise ; each plane gaussian_filter(sigma, truncate 2, nearest) ;
  * bilinear map_coordinates(mode constant, cval).  noise (N,2,h,w) float32 U(-1,1) given,

@@ -15,6 +15,7 @@ What it restates (all paths relative to /root/reference):
                               ExpLossLayer :105-126, HingeLayer :129-147,
                               CenteredOutLayer :153-224
   theanet/layer/color.py      ColorLayer :9-52
+  theanet/layer/auxiliary.py  LocationInfo :14-58, AuxConcatLayer :64-101, SoftAuxLayer :104-160
   theanet/layer/weights.py    init_wb :25-81
   theanet/layer/inlayers.py   InputLayer :12-26, ElasticLayer :29-163
   theanet/neuralnet.py        NeuralNet :60-111,:113-201,:203-241,:257-277,:303-311
@@ -716,6 +717,49 @@ def deformer_transform(img, scale, sigma, cval=0, noise=None, rng=np.random):
 DEFAULT_REG = {"L1": 0, "L2": 0, "momentum": .95, "rate": 1, "maxnorm": 0}
 
 
+class LocationInfoStage:
+    """auxiliary.py:14-58: the two candidate locations (B, 2, 2) mixed with one U(0,1) draw per sample (train)
+    or averaged (test), times ``boost``, through relu50(2 -> n_hid) and relu01(n_hid -> n_out)."""
+
+    def __init__(self, wts, rand_gen, n_aux, boost, dtype):
+        self.boost, self.dtype = boost, dtype
+        self.rv = None
+        if rand_gen is not None or wts is None:
+            srs = RandomStreams(rand_gen.randint(1e6) if rand_gen else None)          # :25-26
+            self.rv = srs.uniform(None)                                                # :27
+        nh, no = n_aux
+        if wts is None:
+            self.params = list(init_wb(rand_gen, (2, nh), nh, nh + 2, nh + 2, "relu50", dtype)) + \
+                list(init_wb(rand_gen, (nh, no), no, no + nh, no + nh, "relu01", dtype))  # :39-54
+        else:
+            self.params = [np.array(w, dtype=dtype) for w in wts]
+
+    def draw(self, batch):
+        return self.rv.draw((batch,))
+
+    def forward(self, aux, u, train):
+        aux = np.asarray(aux, self.dtype)
+        if train:
+            u = np.asarray(u, np.float32).astype(self.dtype)[:, None]
+            loc = aux[:, 0, :] * u + aux[:, 1, :] * (1 - u)                              # :28
+        else:
+            loc = aux.mean(axis=1)                                                     # :31
+        loc = loc * self.dtype.type(self.boost)                                        # :33
+        w1, b1, w2, b2 = self.params
+        z1 = loc @ w1 + b1
+        h = activation("relu50")[0](z1)
+        z2 = h @ w2 + b2
+        return activation("relu01")[0](z2), (loc, z1, h, z2)
+
+    def backward(self, gout, saved):
+        """gout = d cost / d output -> [dW1, db1, dW2, db2]"""
+        loc, z1, h, z2 = saved
+        w1, b1, w2, b2 = self.params
+        dz2 = gout * activation("relu01")[1](z2)
+        dz1 = (dz2 @ w2.T) * activation("relu50")[1](z1)
+        return [loc.T @ dz1, dz1.sum(0), h.T @ dz2, dz2.sum(0)]
+
+
 class _L:
     """One layer's static description + parameters."""
 
@@ -743,6 +787,7 @@ class OracleNet:
             training_params['CUR_EPOCH'] = 0                       # :108-109
         # DTYPE='float16' (this build's extension; the reference is float32-only): conv products on
         # fp16-rounded operands, dz scaled by GRAD_SCALE before rounding
+        self._aux = None
         self.f16 = training_params.get('DTYPE', 'float32') == 'float16'
         self.grad_scale = float(training_params.get('GRAD_SCALE', 4096.))
         self.L = []
@@ -837,6 +882,27 @@ class OracleNet:
                 l.params.append(l.centers)                                          # :186-187
             l.reg = dict(DEFAULT_REG, **dict(a.get("reg", ())))
             self.L.append(l)
+        elif ltype == "AuxConcatLayer":
+            n_in = self.L[-1].n_out
+            assert a.get("aux_type") == "LocationInfo"
+            st = LocationInfoStage(wts if wts is not None and len(wts) else None, self.rand_gen,
+                                   a["n_aux"], a.get("boost", 1), dt)
+            l = _L("AuxConcat", n_in=n_in, n_out=n_in + a["n_aux"][-1], aux=st)          # auxiliary.py:64-101
+            l.params = st.params
+            self.L.append(l)                                                           # (no reg: never updated)
+        elif ltype == "SoftAuxLayer":
+            n_in, n_out = self.L[-1].n_out, a["n_out"]
+            assert a.get("aux_type") == "LocationInfo"
+            have = wts is not None and len(wts)
+            l = _L("SoftAux", n_in=n_in, n_out=n_out, actvn="linear", pdrop=0, mask_rv=None, loss=a.get("loss", "nll"))
+            fio = n_in + n_out
+            l.params = self._init(wts[:2] if have else None, (n_in, n_out), (n_out,), fio, fio, "linear")   # :116-119
+            l.aux = LocationInfoStage(wts[2:6] if have else None, self.rand_gen, a["n_aux"], a.get("boost", 1), dt)
+            nao = a["n_aux"][-1]
+            cross = self._init(wts[6:] if have else None, (nao, n_out), (n_out,), nao + n_out, nao + n_out, "softmax")
+            l.params = l.params + l.aux.params + cross                                 # :142-144
+            l.reg = dict(DEFAULT_REG, **dict(a.get("reg", ())))
+            self.L.append(l)
         elif ltype in ("HiddenLayer", "SoftmaxLayer", "ExpLossLayer", "HingeLayer"):
             n_in = self.L[-1].n_out
             n_out = a["n_out"]
@@ -873,9 +939,10 @@ class OracleNet:
         return [[p.copy() for p in l.params] for l in self.L]
 
     # -- forward --------------------------------------------------------------
-    def forward(self, x, train, draws=None, keep=False):
-        """draws: {layer_index: ElasticDraws | mask ndarray}.  Returns (logprob, cache)."""
+    def forward(self, x, train, draws=None, keep=False, aux=None):
+        """draws: {layer_index: ElasticDraws | mask ndarray | aux mixing draw}.  Returns (logprob, cache)."""
         draws = draws or {}
+        aux = self._aux if aux is None else aux
         cache = []
         h = np.asarray(x, dtype=self.dtype)
         for i, l in enumerate(self.L):
@@ -909,6 +976,19 @@ class OracleNet:
                         h = h * c["mask"]
                     else:
                         h = h * self.dtype.type(1 - l.pdrop)       # dropout.py:28-31
+            elif l.kind == "AuxConcat":
+                h = h.reshape(h.shape[0], -1)
+                ao, c["aux_saved"] = l.aux.forward(aux, draws.get(i), train)
+                h = np.concatenate([h, ao], axis=1)                 # auxiliary.py:83
+            elif l.kind == "SoftAux":
+                h = h.reshape(h.shape[0], -1)
+                c["in"] = h
+                l.aux.params = l.params[2:6]
+                ao, c["aux_saved"] = l.aux.forward(aux, draws.get(i), train)
+                c["aux_out"] = ao
+                z = (h @ l.params[0] + l.params[1] + l.params[7] + ao @ l.params[6]).astype(self.dtype)   # :138-139
+                c["z"] = z
+                h = log_softmax(z)
             elif l.kind in ("Hidden", "Softmax", "ExpLoss", "Hinge", "Centered"):
                 h = h.reshape(h.shape[0], -1)                       # flatten(2), neuralnet.py:169
                 c["in"] = h
@@ -969,6 +1049,16 @@ class OracleNet:
                 if l.kind == "Centered" and l.learn_centers:
                     grads[i].append(dcent.astype(self.dtype) + wtcost_grad(l.params[2], l.reg))
                 g = (dz @ l.params[0].T).astype(self.dtype) if i > first_param else None
+            elif l.kind == "SoftAux":
+                dz = (nll_dlogits(c["out"], y) if l.loss in (None, "nll")
+                      else softmax_head(c["z"], y, l.loss)[4]).astype(self.dtype)
+                ga = l.aux.backward(dz @ l.params[6].T, c["aux_saved"])
+                gr = [c["in"].T @ dz, dz.sum(0)] + ga + [c["aux_out"].T @ dz, dz.sum(0)]
+                grads[i] = [np.asarray(gg, self.dtype) + wtcost_grad(p, l.reg) for gg, p in zip(gr, l.params)]
+                g = (dz @ l.params[0].T).astype(self.dtype) if i > first_param else None
+            elif l.kind == "AuxConcat":
+                grads[i] = [np.zeros_like(p) for p in l.params]     # no reg: never updated (layer.py:74-75)
+                g = g[:, :l.n_in]
             elif l.kind == "DropOut":
                 if "mask" in c:
                     g = g.reshape(c["mask"].shape) * c["mask"]
@@ -1002,7 +1092,7 @@ class OracleNet:
         """Everything the output head derives from the last layer's output h (logprob for Softmax, the
         linear output for ExpLoss / Hinge, the hidden features for CenteredOut)."""
         l = self.L[-1]
-        if l.kind == "Softmax":
+        if l.kind in ("Softmax", "SoftAux"):
             lp, preds, stat, cost, dA = softmax_head(h, y, l.loss or "nll")   # log_softmax(logprob) == logprob
             return dict(logprob=lp, preds=preds, stat=stat, cost=cost, dA=dA, feats=lp)
         if l.kind == "ExpLoss":
@@ -1017,11 +1107,15 @@ class OracleNet:
 
     def cost(self, h, y):
         l = self.L[-1]
-        c = nll(h, y) if (l.kind == "Softmax" and l.loss in (None, "nll")) else self.head(h, y)["cost"]
+        c = nll(h, y) if (l.kind in ("Softmax", "SoftAux") and l.loss in (None, "nll")) else self.head(h, y)["cost"]
         for l in self.L:
-            if l.params:
+            if l.params and l.reg:
                 c = c + wtcost(l.params, l.reg)
         return self.dtype.type(c)
+
+    def set_aux(self, aux):
+        """The auxiliary input of the minibatch about to be processed (neuralnet.py:216-226)."""
+        self._aux = aux
 
     def grads(self, x, y, draws=None):
         logprob, cache = self.forward(x, True, draws)        # (the head's input for the non-Softmax heads)
@@ -1032,11 +1126,11 @@ class OracleNet:
         returns [cost, features, logprob] and applies the simultaneous updates."""
         cost, logprob, grads, _ = self.grads(x, y, draws)
         feats = logprob
-        if self.L[-1].kind != "Softmax":
+        if self.L[-1].kind not in ("Softmax", "SoftAux"):
             hd = self.head(logprob, y)
             feats, logprob = hd["feats"], hd["logprob"]
         for l, g in zip(self.L, grads):
-            if not l.params or not l.reg["rate"]:                    # layer.py:74-75
+            if not l.params or not l.reg or not l.reg["rate"]:       # layer.py:74-75 (no reg: AuxConcatLayer)
                 continue
             if l.vel is None:
                 l.vel = [np.zeros_like(p) for p in l.params]
@@ -1048,7 +1142,7 @@ class OracleNet:
     def test(self, x, y):
         """get_test_model outputs (neuralnet.py:257-277; outlayers.py:69-80)."""
         logprob, _ = self.forward(x, False)
-        if self.L[-1].kind != "Softmax":
+        if self.L[-1].kind not in ("Softmax", "SoftAux"):
             hd = self.head(logprob, y)
             return np.mean(hd["preds"] != y), np.mean(hd["stat"]), hd["logprob"], hd["preds"]
         preds = logprob.argmax(axis=1)

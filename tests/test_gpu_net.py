@@ -243,8 +243,9 @@ def test_errors_mirror_the_reference():
         NeuralNet([("InputLayer", {"img_sz": 8}),
                    ("ConvLayer", {"num_maps": 2, "filter_sz": 3, "stride": 1, "actvn": "nope"}),
                    ("SoftmaxLayer", {"n_out": 3})], dict(tr))
-    with pytest.raises(NotImplementedError):        # the aux-input layers are not built
-        NeuralNet([("InputLayer", {"img_sz": 8}), ("SoftAuxLayer", {"n_out": 3})], dict(tr))
+    with pytest.raises(NotImplementedError, match="Unknown Activation"):     # layer.py:54
+        NeuralNet([("InputLayer", {"img_sz": 8}), ("HiddenLayer", {"n_out": 3, "actvn": "selu"}),
+                   ("SoftmaxLayer", {"n_out": 3})], dict(tr))
     net = NeuralNet([("InputLayer", {"img_sz": 8}), ("SoftmaxLayer", {"n_out": 3, "loss": "bogus"})], dict(tr))
     with pytest.raises(NotImplementedError, match="Loss"):          # outlayers.py:36
         net.get_trin_model(np.zeros((4, 1, 8, 8), np.float32), np.zeros(4, np.int32))
@@ -870,3 +871,69 @@ def test_output_heads_and_losses_match_oracle(head):
     net2 = NeuralNet(ck["layers"], dict(ck["training_params"]), ck["allwts"])
     a, b2 = net.get_data_test_model()(x[:B]), net2.get_data_test_model()(x[:B])
     np.testing.assert_array_equal(a[1], b2[1])
+
+
+@pytest.mark.parametrize("take_index_list", [False, True], ids=["batch-index", "index-list"])
+def test_aux_input_layers_match_oracle(take_index_list):
+    """AuxConcatLayer and SoftAuxLayer with their LocationInfo perceptron
+    (auxiliary.py:14-160) and the aux_data path of get_trin_model / get_test_model / get_data_test_model
+    (neuralnet.py:216-234,266-269,289-290): three training steps (injected mixing draws), every weight
+    (the AuxConcat perceptron is never updated: it has no reg, layer.py:74-75) and the test-mode averaging
+    against the float64 oracle."""
+    import copy
+    from theanet_amd import NeuralNet
+    layers = [("InputLayer", {"img_sz": 8, "num_maps": 1}),
+              ("ConvLayer", {"num_maps": 3, "filter_sz": 3, "stride": 1, "actvn": "relu10"}),
+              ("HiddenLayer", {"n_out": 16, "actvn": "tanh"}),
+              ("AuxConcatLayer", {"n_aux": (5, 4), "aux_type": "LocationInfo", "boost": 2})]
+    with pytest.raises(AssertionError, match="Multiple Aux Inputs"):
+        NeuralNet(copy.deepcopy(layers) + [("SoftAuxLayer", {"n_out": 6, "n_aux": (4, 3), "aux_type": "LocationInfo"})],
+                  {"SEED": 1, "BATCH_SZ": 4, "INIT_LEARNING_RATE": .1, "EPOCHS_TO_HALF_RATE": 1})
+    for variant in ("concat", "softaux"):
+        lyrs = copy.deepcopy(layers)
+        if variant == "concat":
+            lyrs.append(("SoftmaxLayer", {"n_out": 6}))
+        else:
+            lyrs[3] = ("SoftAuxLayer", {"n_out": 6, "n_aux": (4, 3), "aux_type": "LocationInfo", "boost": 1.5,
+                                        "reg": {"L2": .001, "maxnorm": 3}})
+        B = 8
+        tr = {"SEED": 31, "BATCH_SZ": B, "INIT_LEARNING_RATE": .2, "EPOCHS_TO_HALF_RATE": 1}
+        rng = np.random.RandomState(12)
+        x = rng.rand(3 * B, 1, 8, 8).astype(np.float32)
+        y = rng.randint(0, 6, 3 * B).astype(np.int32)
+        aux = rng.rand(3 * B, 2, 2).astype(np.float32)
+        net = NeuralNet(copy.deepcopy(lyrs), dict(tr))
+        assert net.takes_aux()
+        ora = O.OracleNet(copy.deepcopy(lyrs), dict(tr), dtype=np.float64)
+        with pytest.raises(AssertionError, match="Auxillary data not supplied"):
+            net.get_trin_model(x, y)
+        fn = net.get_trin_model(x, y, aux, take_index_list=take_index_list)
+        ai = [i for i, l in enumerate(ora.L) if l.kind in ("AuxConcat", "SoftAux")][0]
+        for s in range(3):
+            rows = rng.permutation(3 * B)[:B] if take_index_list else np.arange(s * B, (s + 1) * B)
+            u = ora.L[ai].aux.draw(B)
+            net.tr_layers[ai].aux.inject(u)
+            ora.set_aux(aux[rows])
+            cost_w, _, lp_w = ora.train_step(x[rows], y[rows], {ai: u})
+            cost, _, lp = fn(rows.astype(np.int32) if take_index_list else s)
+            assert_close(lp, lp_w, 2e-4, 2e-5, what="%s logprob step %d" % (variant, s))
+            assert_close(cost, cost_w, 2e-4, 1e-5, what="%s cost step %d" % (variant, s))
+        for i, (lyr, ol) in enumerate(zip(net.tr_layers, ora.L)):
+            for j, w in enumerate(lyr.get_wts()):
+                assert_close(w, ol.params[j], 5e-4, 2e-6, what="%s w %d %d" % (variant, i, j))
+        te = net.get_test_model(x, y, aux, preds_feats=True)
+        sym, pm, feats, preds = te(2)
+        ora.set_aux(aux[2 * B:])
+        sym_w, pm_w, lp_w, preds_w = ora.test(x[2 * B:], y[2 * B:])
+        assert_close(feats, lp_w, 2e-4, 2e-5, what=variant + " test logprob")
+        np.testing.assert_array_equal(preds, preds_w)
+        assert abs(sym - sym_w) < 1e-6 and abs(pm - pm_w) < 1e-4
+        out = net.get_data_test_model()(x[:B], aux[:B])
+        ora.set_aux(aux[:B])
+        assert_close(out[0], ora.test(x[:B], y[:B])[2], 2e-4, 2e-5, what=variant + " data test model")
+        net.tr_layers[ai].aux.inject(None)
+        assert np.isfinite(fn(rng.permutation(3 * B)[:B].astype(np.int32) if take_index_list else 0)[0])   # device RNG
+        ck = net.get_init_params()                                  # checkpoint round trip
+        net2 = NeuralNet(ck["layers"], dict(ck["training_params"]), ck["allwts"])
+        np.testing.assert_array_equal(net2.get_data_test_model()(x[:B], aux[:B])[1],
+                                      net.get_data_test_model()(x[:B], aux[:B])[1])

@@ -300,3 +300,39 @@ def test_oracle_gradients_through_mid_net_color_and_elastic_layers_fd():
                 fd = (cp - cm) / (2 * eps)
                 an = grads[i][j].reshape(-1)[idx]
                 assert abs(fd - an) <= 1e-7 + 2e-5 * abs(fd), (i, j, idx, fd, an)
+
+
+@pytest.mark.parametrize("variant", ["concat", "softaux"])
+def test_oracle_gradients_of_aux_input_layers_fd(variant):
+    """Finite differences (float64) through AuxConcatLayer / SoftAuxLayer and their LocationInfo perceptron
+    (auxiliary.py:14-160): the eight parameter tensors of the SoftAux layer, the layers below both."""
+    import copy
+    layers = [("InputLayer", {"img_sz": 6, "num_maps": 1}),
+              ("HiddenLayer", {"n_out": 7, "actvn": "tanh"}),
+              ("AuxConcatLayer", {"n_aux": (5, 4), "aux_type": "LocationInfo", "boost": 2}),
+              ("SoftmaxLayer", {"n_out": 4})]
+    if variant == "softaux":
+        layers[2:] = [("SoftAuxLayer", {"n_out": 4, "n_aux": (4, 3), "aux_type": "LocationInfo", "boost": 1.5})]
+    tr = {"SEED": 5, "BATCH_SZ": 5, "INIT_LEARNING_RATE": .1, "EPOCHS_TO_HALF_RATE": 1}
+    net = O.OracleNet(copy.deepcopy(layers), dict(tr), dtype=np.float64)
+    rng = np.random.RandomState(1)
+    x, y = rng.rand(5, 1, 6, 6), rng.randint(0, 4, 5)
+    net.set_aux(rng.rand(5, 2, 2))
+    draws = {2: net.L[2].aux.draw(5)}
+    for p in net.L[2].params[2:6] if variant == "softaux" else net.L[2].params:
+        p += .05 * rng.rand(*p.shape)                          # away from the relu kinks, biases non-zero
+    cost, _, grads, _ = net.grads(x, y, draws)
+    eps, worst = 1e-6, 0.0
+    check = [1, 2] if variant == "softaux" else [1, 3]          # AuxConcat's own weights have no gradient slot
+    for i in check:
+        for j, p in enumerate(net.L[i].params):
+            flat = p.reshape(-1)
+            for idx in rng.choice(flat.size, min(5, flat.size), replace=False):
+                old = flat[idx]
+                flat[idx] = old + eps
+                cp = net.cost(net.forward(x, True, draws)[0], y)
+                flat[idx] = old - eps
+                cm = net.cost(net.forward(x, True, draws)[0], y)
+                flat[idx] = old
+                fd, an = (cp - cm) / (2 * eps), grads[i][j].reshape(-1)[idx]
+                assert abs(fd - an) <= 1e-7 + 2e-5 * abs(fd), (i, j, idx, fd, an)

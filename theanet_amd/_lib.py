@@ -143,6 +143,8 @@ SIGNATURES = {
     "tn_color_factors": (c_int, [CTX, P, c_int, c_int, c_double, c_double, P, c_uint64, c_uint32, P, c_int64]),
     "tn_color_apply": (c_int, [CTX, P, c_int64, P, P, c_int, c_int, c_int, c_float]),
     "tn_color_apply_bwd": (c_int, [CTX, P, c_int64, P, P, P, c_int, c_int, c_int, c_float, P, c_int, c_float]),
+    "tn_aux_mix": (c_int, [CTX, P, c_int64, P, c_int, c_int, c_float, c_int, P, c_uint64, c_uint32, P, c_int64]),
+    "tn_copy_cols": (c_int, [CTX, P, c_int, c_int, P, c_int, c_int, c_int, c_int, P, c_int, c_float]),
     "tn_deformer_transform": (c_int, [CTX, P, P, c_int, c_int, c_int, c_double, c_double, c_double,
                                       P, c_uint64, c_int64]),
     "tn_gather_rows": (c_int, [CTX, P, P, P, c_int, c_size_t]),

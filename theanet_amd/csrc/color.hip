@@ -105,7 +105,65 @@ __global__ __launch_bounds__(256) void elastic_apply_bwd_kernel(
     }
 }
 
+// ---- aux-input layers (theanet/layer/auxiliary.py:14-160): the two elementwise pieces around their tiny MLPs ----
+enum { TN_STREAM_AUX = 6 };
+// LocationInfo's input mix (:27-36): train: a[n,0,:]*u_n + a[n,1,:]*(1-u_n), u_n ~ U(0,1) per row; test: mean of the two
+__global__ __launch_bounds__(256) void aux_mix_kernel(const float* __restrict__ aux, float* __restrict__ out, int B, int d,
+                                                     float boost, int train, const float* __restrict__ u_inj, uint32_t k0,
+                                                     uint32_t k1, uint32_t step, const uint32_t* d_step, int64_t row_global0) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * d) return;
+    const int n = i / d, j = i - n * d;
+    const float a0 = aux[(size_t)n * 2 * d + j], a1 = aux[(size_t)n * 2 * d + d + j];
+    float v;
+    if (train) {
+        float u;
+        if (u_inj) u = u_inj[n];
+        else {
+            const uint64_t e = (uint64_t)row_global0 + (uint64_t)n;
+            u = tn_u01(philox4x32((uint32_t)e, (uint32_t)(e >> 32), step + (d_step ? *d_step : 0u), TN_STREAM_AUX, k0, k1).x);
+        }
+        v = a0 * u + a1 * (1.f - u);
+    } else {
+        v = (a0 + a1) / 2.f;
+    }
+    out[i] = v * boost;
+}
+
+// dst[n, col_dst + j] = src[n, col_src + j] (* act'(prev_a[n, col_dst + j])), j < ncols: concatenation and its split
+__global__ __launch_bounds__(256) void copy_cols_kernel(const float* __restrict__ src, int ld_src, int col_src,
+                                                       float* __restrict__ dst, int ld_dst, int col_dst, int ncols, int B,
+                                                       const float* __restrict__ prev_a, int prev_act, float prm) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)B * ncols) return;
+    const int n = (int)(i / ncols), j = (int)(i - (long long)n * ncols);
+    float v = src[(size_t)n * ld_src + col_src + j];
+    const size_t o = (size_t)n * ld_dst + col_dst + j;
+    if (prev_a && prev_act != TN_ACT_LINEAR) v *= tn_act_grad_from_out(prev_a[o], prev_act, prm);
+    dst[o] = v;
+}
+
 extern "C" {
+
+int tn_aux_mix(tn_ctx* ctx, const float* aux, int64_t row0, float* out, int B, int d, float boost, int train,
+               const float* u_inj, uint64_t seed, uint32_t step, const uint32_t* d_step, int64_t row_global0) {
+    TN_REQUIRE(aux && out && B > 0 && d > 0, "tn_aux_mix: bad arguments");
+    aux_mix_kernel<<<cdiv((long long)B * d, 256), 256, 0, ctx->stream>>>(aux + (size_t)row0 * 2 * d, out, B, d, boost, train,
+                                                                        u_inj, (uint32_t)seed, (uint32_t)(seed >> 32), step,
+                                                                        d_step, row_global0);
+    TN_LAUNCH_CHECK();
+    return TN_OK;
+}
+
+int tn_copy_cols(tn_ctx* ctx, const float* src, int ld_src, int col_src, float* dst, int ld_dst, int col_dst, int ncols,
+                 int B, const float* prev_a, int prev_act, float prev_act_param) {
+    TN_REQUIRE(src && dst && B > 0 && ncols > 0 && col_src + ncols <= ld_src && col_dst + ncols <= ld_dst,
+               "tn_copy_cols: bad arguments");
+    copy_cols_kernel<<<cdiv((long long)B * ncols, 256), 256, 0, ctx->stream>>>(src, ld_src, col_src, dst, ld_dst, col_dst,
+                                                                              ncols, B, prev_a, prev_act, prev_act_param);
+    TN_LAUNCH_CHECK();
+    return TN_OK;
+}
 
 int tn_color_factors(tn_ctx* ctx, float* fac, int N, int C, double balance, double gamma, const float* draws,
                      uint64_t seed, uint32_t step, const uint32_t* d_step, int64_t row_global0) {

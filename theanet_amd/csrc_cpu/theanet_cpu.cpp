@@ -1040,6 +1040,41 @@ int tn_color_apply_bwd(tn_ctx* ctx, const float* x, int64_t x_row0, const float*
     return TN_OK;
 }
 
+// ---- aux-input layers (auxiliary.py:14-160): input mix and column copies ----
+int tn_aux_mix(tn_ctx* ctx, const float* aux, int64_t row0, float* out, int B, int d, float boost, int train,
+               const float* u_inj, uint64_t seed, uint32_t step, const uint32_t* d_step, int64_t row_global0) {
+    REQUIRE(aux && out && B > 0 && d > 0, "tn_aux_mix: bad arguments");
+    const float* a = aux + (size_t)row0 * 2 * d;
+    const uint32_t st = step + (d_step ? *d_step : 0u);
+    for (int n = 0; n < B; ++n) {
+        float u = 0.f;
+        if (train) {
+            if (u_inj) u = u_inj[n];
+            else {
+                const uint64_t e = (uint64_t)row_global0 + (uint64_t)n;
+                u = u01(philox4x32((uint32_t)e, (uint32_t)(e >> 32), st, 6u, (uint32_t)seed, (uint32_t)(seed >> 32)).x);
+            }
+        }
+        for (int j = 0; j < d; ++j) {
+            const float a0 = a[(size_t)n * 2 * d + j], a1 = a[(size_t)n * 2 * d + d + j];
+            out[(size_t)n * d + j] = (train ? a0 * u + a1 * (1.f - u) : (a0 + a1) / 2.f) * boost;
+        }
+    }
+    return TN_OK;
+}
+int tn_copy_cols(tn_ctx* ctx, const float* src, int ld_src, int col_src, float* dst, int ld_dst, int col_dst, int ncols,
+                 int B, const float* prev_a, int prev_act, float prm) {
+    REQUIRE(src && dst && B > 0 && ncols > 0 && col_src + ncols <= ld_src && col_dst + ncols <= ld_dst, "tn_copy_cols: bad arguments");
+    for (int n = 0; n < B; ++n)
+        for (int j = 0; j < ncols; ++j) {
+            float v = src[(size_t)n * ld_src + col_src + j];
+            const size_t o = (size_t)n * ld_dst + col_dst + j;
+            if (prev_a && prev_act != TN_ACT_LINEAR) v *= act_grad_from_out(prev_a[o], prev_act, prm);
+            dst[o] = v;
+        }
+    return TN_OK;
+}
+
 // ---- extras/deformer.py:7-18: per-image deformation, float64 like scipy ----
 int tn_deformer_transform(tn_ctx* ctx, const float* imgs, float* out, int N, int h, int w, double scale, double sigma,
                           double cval, const float* noise, uint64_t seed, int64_t img_global0) {

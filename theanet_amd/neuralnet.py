@@ -21,7 +21,7 @@ import numpy as np
 
 from . import comm, layer
 from .device import DeviceArray, get_context, share
-from .layer import (CenteredOutLayer, ColorLayer, ConvLayer, DropOutLayer, ElasticLayer, ExpLossLayer, HiddenLayer,
+from .layer import (AuxConcatLayer, SoftAuxLayer, CenteredOutLayer, ColorLayer, ConvLayer, DropOutLayer, ElasticLayer, ExpLossLayer, HiddenLayer,
                     HingeLayer, InputLayer, InputSlot, MeanLayer, OutputLayer, PoolLayer, SoftmaxLayer)
 
 # ########################### Helper Functions #################################
@@ -75,8 +75,9 @@ class _TrainFn:
     (neuralnet.py:236-241).  ``enqueue(i)`` issues the step without reading anything
     back (the GPU runs ahead of the host); ``fetch()`` copies the last step's outputs."""
 
-    def __init__(self, net, x_data, y_data, take_index_list):
+    def __init__(self, net, x_data, y_data, take_index_list, aux_data=None):
         self.net, self.x_data, self.y_data = net, x_data, y_data
+        self.aux_data = aux_data
         self.take_index_list = take_index_list
         ctx = net.ctx
         if take_index_list:
@@ -85,6 +86,8 @@ class _TrainFn:
             self.y_stage = ctx.empty((net.local_bsz,), np.int32)
             self.idx_dev = ctx.empty((net.local_bsz,), np.int32)
             self.row_bytes = row * 4
+            if aux_data is not None:
+                self.aux_stage = ctx.empty((net.local_bsz,) + tuple(aux_data.shape[1:]))
 
     def enqueue(self, i):
         net, ctx = self.net, self.net.ctx
@@ -100,11 +103,21 @@ class _TrainFn:
                      net.local_bsz, 4)
             slot.bind(self.x_stage)
             slot.row0, y, y_row0 = 0, self.y_stage, 0
+            if self.aux_data is not None:                  # neuralnet.py:233-234
+                ctx.call("tn_gather_rows", self.aux_data.ptr, self.idx_dev.ptr, self.aux_stage.ptr, net.local_bsz,
+                         int(np.prod(self.aux_data.shape[1:])) * 4)
+                net.aux_inpt_tr.bind(self.aux_stage)
+                net.aux_inpt_tr.row0 = 0
         else:
             slot.bind(self.x_data)
             slot.row0 = int(i) * B + lo
             y, y_row0 = self.y_data, slot.row0
+            if self.aux_data is not None:                  # neuralnet.py:225-226
+                net.aux_inpt_tr.bind(self.aux_data)
+                net.aux_inpt_tr.row0 = slot.row0
         slot.row_global0 = lo
+        if self.aux_data is not None:
+            net.aux_inpt_tr.row_global0 = int(i) * B + lo if not self.take_index_list else lo
         net._train_step(y, y_row0)
 
     def fetch(self):
@@ -362,8 +375,9 @@ class _PipeTrainFn:
 class _TestFn:
     """``get_test_model``'s function: ``fn(i) -> [sym_err, P(MLE)](, features, y_preds)``."""
 
-    def __init__(self, net, x_data, y_data, preds_feats):
+    def __init__(self, net, x_data, y_data, preds_feats, aux_data=None):
         self.net, self.x_data, self.y_data, self.preds_feats = net, x_data, y_data, preds_feats
+        self.aux_data = aux_data
 
     def __call__(self, i):
         net, ctx = self.net, self.net.ctx
@@ -373,6 +387,9 @@ class _TestFn:
         slot.bind(self.x_data)
         slot.row0 = int(i) * net.batch_sz + net.shard_lo
         slot.row_global0 = net.shard_lo
+        if self.aux_data is not None:                      # neuralnet.py:266-269
+            net.aux_inpt_te.bind(self.aux_data)
+            net.aux_inpt_te.row0 = slot.row0
         out = net.te_layers[-1]
         for lyr in net.te_layers[:-1]:
             lyr.forward(False)
@@ -457,6 +474,14 @@ class NeuralNet():
         if self.fuse_conv_pool:
             self._fuse(self.tr_layers)
             self._fuse(self.te_layers)
+
+        # Handle Auxiliary input (neuralnet.py:100-105)
+        for tr_layer, te_layer in zip(self.tr_layers, self.te_layers):
+            if type(tr_layer) in (AuxConcatLayer, SoftAuxLayer):
+                assert not hasattr(self, 'aux_inpt_tr'), "Multiple Aux Inputs"
+                self.aux_inpt_tr = tr_layer.aux_inpt
+                self.aux_inpt_te = te_layer.aux_inpt
+                tr_layer.aux.d_step = self.d_step
 
         assert isinstance(self.tr_layers[-1], OutputLayer), \
             "the last layer must be an output head (Softmax, ExpLoss, Hinge or CenteredOut layer)"
@@ -546,7 +571,7 @@ class NeuralNet():
                                           prev_tr_layer.n_out,
                                           **layer_args)
 
-        elif curr_layer_type in (HiddenLayer, SoftmaxLayer, HingeLayer, ExpLossLayer):
+        elif curr_layer_type in (AuxConcatLayer, HiddenLayer, SoftmaxLayer, SoftAuxLayer, HingeLayer, ExpLossLayer):
             te_inpt = te_inpt.flatten(2)
             curr_layer = curr_layer_type(tr_inpt.flatten(2),
                                          wts,
@@ -963,13 +988,17 @@ class NeuralNet():
                        take_index_list=False):
         print('Compiling training function...')
         self.tr_layers[-1].cost(None)            # validates the loss name (outlayers.py:12-36)
-        assert aux_data is None, "auxiliary inputs are outside the accelerated path"
+        if hasattr(self, 'aux_inpt_tr'):
+            assert aux_data is not None, "Auxillary data not supplied"        # neuralnet.py:216-217
+            aux_data = share(aux_data)
+        else:
+            aux_data = None
         self._prepare_training()
         if getattr(self, "_pipe_fn", None) is not None:
             self._pipe_fn._fall_back()           # an earlier training function: bring the net up to date
-        if self._pipe_ok(take_index_list):
+        if aux_data is None and self._pipe_ok(take_index_list):
             return _PipeTrainFn(self, share(x_data), share(y_data, np.int32))
-        return _TrainFn(self, share(x_data), share(y_data, np.int32), take_index_list)
+        return _TrainFn(self, share(x_data), share(y_data, np.int32), take_index_list, aux_data)
 
     def _sync_weights(self):
         """With two steps in flight (_PipeTrainFn) the net's own weight buffers lag behind: catch up."""
@@ -1005,11 +1034,15 @@ class NeuralNet():
 
     def get_test_model(self, x_data, y_data, aux_data=None, preds_feats=False):
         print('Compiling testing function... ')
-        assert aux_data is None, "auxiliary inputs are outside the accelerated path"
-        return _TestFn(self, share(x_data), share(y_data, np.int32), preds_feats)
+        if hasattr(self, 'aux_inpt_te'):
+            assert aux_data is not None, "Auxillary data not supplied"        # neuralnet.py:266-267
+            aux_data = share(aux_data)
+        else:
+            aux_data = None
+        return _TestFn(self, share(x_data), share(y_data, np.int32), preds_feats, aux_data)
 
     def takes_aux(self):
-        return False
+        return hasattr(self, 'aux_inpt_te')
 
     def get_data_test_model(self, get_output_of_layers=()):
         print('Compiling full test function...')
@@ -1024,11 +1057,15 @@ class NeuralNet():
             if isinstance(lyr, ConvLayer) and lyr.fused_pool is not None:
                 lyr.fused_pool.fused_conv, lyr.fused_pool = None, None
 
-        def fn(x):
+        def fn(x, aux=None):
             self._sync_weights()
             self._apply_dtype()
             x = np.ascontiguousarray(x, np.float32).reshape(stage.shape)
             stage.set_value(x)
+            if self.takes_aux():                           # neuralnet.py:289-290
+                assert aux is not None, "Auxillary data not supplied"
+                self.aux_inpt_te.bind(share(np.ascontiguousarray(aux, np.float32)))
+                self.aux_inpt_te.row0 = 0
             slot = self.test_x
             slot.bind(stage)
             slot.row0 = slot.row_global0 = 0
