@@ -676,3 +676,18 @@ def test_scale_mask_gather_axpby():
     yd = dev(x)
     call("tn_axpby", yd.ptr, dev(x[::-1].copy()).ptr, 1000, 2.0, -1.0)
     assert_close(yd.get_value(), 2 * x[::-1] - x)
+
+
+def test_activation_gradient_at_an_exact_zero():
+    """KAT of the activation derivative taken from the stored OUTPUT (documented deviations):
+    leaky slopes s > 0 give Theano's tie value 1 + s at an exact 0 (grad of max(0,z) + min(0,z)*s, KAT-3 of the
+    oracle); for slope 0 an output of exactly 0 is read as z < 0: gradient 0 where Theano gives 1 at z == 0 --
+    the one documented, measure-zero deviation."""
+    a = np.array([-.2, 0., 3.], np.float32)         # layer outputs
+    g = np.ones(3, np.float32)
+    for name, want in (("relu10", [.1, 1.1, 1.]), ("relu05", [.05, 1.05, 1.]), ("relu", [0., 0., 1.])):
+        kind, prm = act_code(name)
+        out = empty((3,))
+        call("tn_scale_mask", dev(g).ptr, None, 1.0, out.ptr, 3, dev(a if name != "relu" else np.abs(a) * (a > 0)).ptr,
+             kind, prm)
+        np.testing.assert_allclose(out.get_value(), want, rtol=1e-6, err_msg=name)
