@@ -70,6 +70,14 @@ int tn_alloc(tn_ctx* ctx, size_t bytes, void** dptr);
 int tn_free(tn_ctx* ctx, void* dptr);
 int tn_h2d(tn_ctx* ctx, void* dst, const void* src, size_t bytes);   /* returns after the copy */
 int tn_d2h(tn_ctx* ctx, void* dst, const void* src, size_t bytes);   /* returns after the copy */
+/* Outputs a caller reads every step (the [cost, features, logprob] of neuralnet.py:236-240's function) leave
+ * as soon as they exist: tn_d2h_early orders a copy into page-locked host memory (tn_host_alloc) behind the
+ * work enqueued so far on the current stream and runs it on a copy stream, under the kernels enqueued
+ * afterwards; tn_copy_sync waits for every such copy.                                                   */
+int tn_host_alloc(tn_ctx* ctx, size_t bytes, void** out);
+int tn_host_free(tn_ctx* ctx, void* p);
+int tn_d2h_early(tn_ctx* ctx, void* host_dst, const void* src, size_t bytes);
+int tn_copy_sync(tn_ctx* ctx);
 int tn_d2d(tn_ctx* ctx, void* dst, const void* src, size_t bytes);   /* enqueued                */
 int tn_memset(tn_ctx* ctx, void* dst, int byte_value, size_t bytes); /* enqueued                */
 int tn_set_u32(tn_ctx* ctx, uint32_t* d_dst, uint32_t value);        /* enqueued scalar store   */

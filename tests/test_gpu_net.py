@@ -579,7 +579,12 @@ def test_pipelined_steps_equal_sequential(monkeypatch, name, img, ch, B):
                 fn.enqueue(s % 4)
             if s in (2, 5):                       # reading weights / testing mid-training
                 mids.append((te(1), [w.copy() for l in net.tr_layers for w in l.get_wts()]))
-        outs.append(fn.fetch())
+        last = fn.fetch()
+        if every:       # outputs that left ahead of the backward pass (fn(i)) == a blocking read after the step
+            assert last[0] == outs[-1][0]
+            np.testing.assert_array_equal(last[1], outs[-1][1])
+            np.testing.assert_array_equal(last[2], outs[-1][2])
+        outs.append(last)
         if pipe == "1":
             assert fn._seq is None and fn.t == 9
         runs.append((net, outs, mids))

@@ -47,6 +47,10 @@ SIGNATURES = {
     "tn_free": (c_int, [CTX, P]),
     "tn_h2d": (c_int, [CTX, P, P, c_size_t]),
     "tn_d2h": (c_int, [CTX, P, P, c_size_t]),
+    "tn_host_alloc": (c_int, [CTX, c_size_t, ctypes.POINTER(P)]),
+    "tn_host_free": (c_int, [CTX, P]),
+    "tn_d2h_early": (c_int, [CTX, P, P, c_size_t]),
+    "tn_copy_sync": (c_int, [CTX]),
     "tn_d2d": (c_int, [CTX, P, P, c_size_t]),
     "tn_memset": (c_int, [CTX, P, c_int, c_size_t]),
     "tn_set_u32": (c_int, [CTX, P, c_uint32]),

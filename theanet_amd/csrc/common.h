@@ -39,6 +39,8 @@ struct tn_ctx {
     int device = 0;
     hipStream_t stream = nullptr;          // the stream ops are currently issued on
     hipStream_t streams[2] = {nullptr, nullptr};   // [0] main, [1] side (leaf work: weight gradients)
+    hipStream_t copy_stream = nullptr;     // device-to-host copies that run under later kernels (tn_d2h_early)
+    hipEvent_t copy_ev = nullptr;
     hipEvent_t sync_ev[2] = {nullptr, nullptr};
     int num_cus = 256;
     // matmul operand precision of the 3x3 conv products (tn_set_matmul_dtype): 0 fp32, 1 fp16 operands /

@@ -30,6 +30,8 @@ int tn_ctx_create(int device, tn_ctx** out) {
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->streams[1], hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->sync_ev[0], hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->sync_ev[1], hipEventDisableTiming);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->copy_ev, hipEventDisableTiming);
     if (e != hipSuccess) {
         delete c;
         return tn_fail(nullptr, TN_E_HIP, "hipStreamCreate -> %s", hipGetErrorString(e));
@@ -61,6 +63,11 @@ int tn_ctx_destroy(tn_ctx* ctx) {
     hipEventDestroy(ctx->sync_ev[1]);
     hipStreamDestroy(ctx->streams[0]);
     hipStreamDestroy(ctx->streams[1]);
+    if (ctx->copy_stream) {
+        hipStreamSynchronize(ctx->copy_stream);
+        hipStreamDestroy(ctx->copy_stream);
+    }
+    if (ctx->copy_ev) hipEventDestroy(ctx->copy_ev);
     delete ctx;
     return TN_OK;
 }
@@ -153,6 +160,30 @@ int tn_d2h(tn_ctx* ctx, void* dst, const void* src, size_t bytes) {
     TN_HIP(hipStreamSynchronize(ctx->streams[1]));
     TN_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->streams[0]));
     TN_HIP(hipStreamSynchronize(ctx->streams[0]));
+    return TN_OK;
+}
+
+int tn_host_alloc(tn_ctx* ctx, size_t bytes, void** out) {
+    TN_REQUIRE(out != nullptr && bytes > 0, "tn_host_alloc: bad arguments");
+    TN_HIP(hipHostMalloc(out, bytes, hipHostMallocDefault));
+    return TN_OK;
+}
+
+int tn_host_free(tn_ctx* ctx, void* p) {
+    if (p) TN_HIP(hipHostFree(p));
+    return TN_OK;
+}
+
+int tn_d2h_early(tn_ctx* ctx, void* host_dst, const void* src, size_t bytes) {
+    if (!bytes) return TN_OK;
+    TN_HIP(hipEventRecord(ctx->copy_ev, ctx->stream));
+    TN_HIP(hipStreamWaitEvent(ctx->copy_stream, ctx->copy_ev, 0));
+    TN_HIP(hipMemcpyAsync(host_dst, src, bytes, hipMemcpyDeviceToHost, ctx->copy_stream));
+    return TN_OK;
+}
+
+int tn_copy_sync(tn_ctx* ctx) {
+    TN_HIP(hipStreamSynchronize(ctx->copy_stream));
     return TN_OK;
 }
 

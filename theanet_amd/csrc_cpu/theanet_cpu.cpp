@@ -184,6 +184,15 @@ int tn_alloc(tn_ctx* ctx, size_t bytes, void** dptr) {
 int tn_free(tn_ctx*, void* p) { free(p); return TN_OK; }
 int tn_h2d(tn_ctx*, void* d, const void* s, size_t n) { std::memcpy(d, s, n); return TN_OK; }
 int tn_d2h(tn_ctx*, void* d, const void* s, size_t n) { std::memcpy(d, s, n); return TN_OK; }
+int tn_host_alloc(tn_ctx* ctx, size_t bytes, void** out) {
+    REQUIRE(out != nullptr && bytes > 0, "tn_host_alloc: bad arguments");
+    *out = std::malloc(bytes);
+    REQUIRE(*out != nullptr, "tn_host_alloc: out of memory");
+    return TN_OK;
+}
+int tn_host_free(tn_ctx*, void* p) { std::free(p); return TN_OK; }
+int tn_d2h_early(tn_ctx*, void* d, const void* s, size_t n) { std::memcpy(d, s, n); return TN_OK; }
+int tn_copy_sync(tn_ctx*) { return TN_OK; }
 int tn_d2d(tn_ctx*, void* d, const void* s, size_t n) { std::memmove(d, s, n); return TN_OK; }
 int tn_memset(tn_ctx*, void* d, int v, size_t n) { std::memset(d, v, n); return TN_OK; }
 int tn_set_u32(tn_ctx*, uint32_t* d, uint32_t v) { *d = v; return TN_OK; }

@@ -199,6 +199,27 @@ class DeviceArray:
         return "DeviceArray(shape=%s, dtype=%s, ptr=0x%x)" % (self.shape, self.dtype, self.ptr)
 
 
+class HostBuffer:
+    """Page-locked host memory (tn_host_alloc) viewed as a numpy array: the target of tn_d2h_early copies."""
+
+    def __init__(self, ctx, shape, dtype=np.float32):
+        self.ctx = ctx
+        self.nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        p = ctypes.c_void_p()
+        ctx.call("tn_host_alloc", self.nbytes, ctypes.byref(p))
+        self.ptr = p.value
+        self.array = np.frombuffer((ctypes.c_char * self.nbytes).from_address(self.ptr), dtype=dtype).reshape(shape)
+
+    def __del__(self):
+        if getattr(self, "ptr", None):
+            try:
+                self.array = None
+                self.ctx.lib.tn_host_free(self.ctx.h, self.ptr)
+            except Exception:   # interpreter teardown
+                pass
+            self.ptr = 0
+
+
 def share(data, dtype=np.float32, borrow=True):
     """train.py:18-19 ``share()``: put a host array in HBM once."""
     if isinstance(data, DeviceArray):

@@ -70,6 +70,24 @@ def _features_logprob(out):
     return [feats, logprob]
 
 
+def _step_outputs(net, out):
+    """[cost, features, logprob] of the step ``net`` ran last, on the stream currently selected (the one that
+    holds the launch summing the cost).  When the step sent features / logprob ahead (``NeuralNet._send_outputs``:
+    copies into page-locked memory that ran under the backward pass) the cost follows them through the copy
+    stream and one wait covers all three; otherwise three blocking copies."""
+    early = getattr(net, "_early", None)
+    if early is not None and early["live"]:
+        early["live"] = False
+        if not early["cost_sent"]:
+            net.ctx.call("tn_d2h_early", early["cost"].ptr, net.d_cost.ptr, 4)
+        net.ctx.call("tn_copy_sync")
+        logprob = early["logprob"].array.copy()
+        feats = logprob if out.features is out.logprob else early["features"].array.copy()
+        return [np.float32(early["cost"].array[0]), feats, logprob]
+    cost = net.d_cost.get_value()[0]
+    return [cost] + _features_logprob(out)
+
+
 class _TrainFn:
     """What ``get_trin_model`` returns: ``fn(i) -> [cost, features, logprob]``
     (neuralnet.py:236-241).  ``enqueue(i)`` issues the step without reading anything
@@ -125,11 +143,14 @@ class _TrainFn:
         out = net.tr_layers[-1]
         if getattr(net, "_dp_pending", False):
             net.ctx.sync()                        # the cost travels with the all-reduce on the second stream
-        cost = net.d_cost.get_value()[0]
-        return [cost] + _features_logprob(out)
+        return _step_outputs(net, out)
 
     def __call__(self, i):
-        self.enqueue(i)
+        self.net._want_outputs = True       # features / logprob leave right after the forward pass
+        try:
+            self.enqueue(i)
+        finally:
+            self.net._want_outputs = False
         return self.fetch()
 
 
@@ -319,7 +340,11 @@ class _PipeTrainFn:
         if self._seq is None and self._blocked():
             self._fall_back()
         if self._seq is not None:
-            return self._seq.enqueue(i)
+            self.net._want_outputs = getattr(self, "_want", False)
+            try:
+                return self._seq.enqueue(i)
+            finally:
+                self.net._want_outputs = False
         if self._twin is None:
             self._build()
         net, ctx, t = self.net, self.net.ctx, self.t
@@ -339,9 +364,11 @@ class _PipeTrainFn:
         slot.bind(self.x_data)
         slot.row0 = int(i) * net.batch_sz + net.shard_lo
         slot.row_global0 = net.shard_lo
+        X._want_outputs = getattr(self, "_want", False)
         try:
             X._train_step(self.y_data, slot.row0, pipe_stride=2)
         finally:
+            X._want_outputs = False
             ctx.call("tn_stream_select", 0)
         self._last = X
         self.t = t + 1
@@ -350,13 +377,17 @@ class _PipeTrainFn:
         if self._seq is not None:
             return self._seq.fetch()
         X = self._last
-        if X._cost_pending:
-            X.ctx.call("tn_stream_select", self.nets.index(X))
-            self._finish_cost(X)
+        X.ctx.call("tn_stream_select", self.nets.index(X))
+        try:
+            early = getattr(X, "_early", None)
+            sent = early is not None and early["live"]
+            if not (sent and early["cost_sent"]):
+                self._finish_cost(X)
+            if not sent:
+                X.ctx.sync()
+            return _step_outputs(X, X.tr_layers[-1])
+        finally:
             X.ctx.call("tn_stream_select", 0)
-        X.ctx.sync()
-        cost = X.d_cost.get_value()[0]
-        return [cost] + _features_logprob(X.tr_layers[-1])
 
     @staticmethod
     def _finish_cost(X):
@@ -368,7 +399,11 @@ class _PipeTrainFn:
             X._cost_pending = False
 
     def __call__(self, i):
-        self.enqueue(i)
+        self._want = True                   # features / logprob leave right after the forward pass
+        try:
+            self.enqueue(i)
+        finally:
+            self._want = False
         return self.fetch()
 
 
@@ -818,6 +853,25 @@ class NeuralNet():
                 sys.stderr.write("theanet_amd: data-parallel schedule '%s' (%s)\n" % (
                     self.dp_schedule, ", ".join("%s %.1f us/step" % (c, 1e3 * m) for c, m in zip(cands, ms))))
 
+    def _send_outputs(self, out, with_cost=False):
+        """The step's features / logprob start travelling to page-locked host memory now (ordered behind the
+        output layer's forward, on the context's copy stream): the copies run under the backward pass instead
+        of after the step (the drop-in call fn(i) reads them every step, neuralnet.py:236-241)."""
+        from .device import HostBuffer
+        early = getattr(self, "_early", None)
+        if early is None:
+            early = self._early = {"live": False, "logprob": HostBuffer(self.ctx, out.logprob.shape),
+                                   "cost": HostBuffer(self.ctx, (1,))}
+            if out.features is not out.logprob:
+                early["features"] = HostBuffer(self.ctx, out.features.shape)
+        self.ctx.call("tn_d2h_early", early["logprob"].ptr, out.logprob.ptr, out.logprob.nbytes)
+        if out.features is not out.logprob:
+            self.ctx.call("tn_d2h_early", early["features"].ptr, out.features.ptr, out.features.nbytes)
+        if with_cost:
+            self.ctx.call("tn_d2h_early", early["cost"].ptr, self.d_cost.ptr, 4)
+        early["cost_sent"] = with_cost
+        early["live"] = True
+
     def _train_step(self, y, y_row0, d_row0=None, pipe_stride=0):
         """forward + backward + all-reduce + update for the minibatch the input slot
         currently points at.  Everything is enqueued; nothing is read back."""
@@ -842,14 +896,26 @@ class NeuralNet():
         except Exception:
             ctx.call("tn_defer_reductions", 0)
             raise
+        want = getattr(self, "_want_outputs", False)
+        cost_sent = False
+        if want:
+            if self._cost_rider_ok and not self._dp:
+                # the caller reads [cost, features, logprob] of this step: the cost is summed now (the cost block
+                # of the update launch on its own: same summation order, same bits) and leaves with the outputs
+                ctx.call("tn_sgd_update_multi_cost", None, 0, 0, self.cur_learn_rate.ptr, 1.0, None,
+                         out.rowloss.ptr, self.local_bsz, 1.0 / self.batch_sz, self.d_cost.ptr)
+                cost_sent = True
+            self._send_outputs(out, cost_sent)
         # cost = -mean logprob[n, y_n] (this rank's share of the global mean).  Without weight
         # costs it rides in the update launch at the end of the step (tn_sgd_update_multi_cost);
         # with them it must exist before tn_wtcost accumulates onto it: a leaf reduction here.
         rider = self._cost_rider and not pipe_stride
         lazy_pipe = bool(pipe_stride) and getattr(self, "_pipe_lazy", False) and self._cost_rider_ok
-        if lazy_pipe:
+        if cost_sent:
+            self._cost_pending = False
+        if lazy_pipe and not cost_sent:
             self._cost_pending = True             # summed by the launch that opens this stream's next step
-        elif not rider:
+        elif not rider and not cost_sent:
             if pipe_stride and self._cost_rider_ok:
                 # the cost block of the update launch on its own: the same summation order as the
                 # one-step-at-a-time schedule, so the reported cost is bit-identical too
