@@ -213,8 +213,8 @@ def main():
     # heavy kernels of the SAME workload; the dominant one (largest share of the step) is
     # reported as `roofline`, the rest as `roofline_others`.
     roof, others = None, []
-    if args.no_roofline:
-        pass
+    if args.no_roofline or os.environ.get("THEANET_BACKEND", "hip") == "cpu":
+        pass                                    # the roofline leg times HIP kernels
     elif args.prms == "mnist.prms":
         conv2, fc1 = net.tr_layers[3], net.tr_layers[5]
         B_ = per_gpu
