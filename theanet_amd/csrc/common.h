@@ -57,6 +57,8 @@ struct tn_ctx {
     size_t scratch_bytes = 0;
     float* scratch_slot[2] = {nullptr, nullptr};   // parked scratch of the other stream (tn_stream_select):
     size_t scratch_slot_bytes[2] = {0, 0};         // two pipelined steps never share slab memory
+    void* tmp[2] = {nullptr, nullptr};             // per stream: a tensor that lives from one launch to the next (tn_tmp_get)
+    size_t tmp_bytes[2] = {0, 0};
     // ... and its parked deferral window: a pipelined step leaves its slab sums pending, the update that
     // opens the stream's NEXT step folds them in (tn_sgd_update_multi_pipe)
     bool defer_slot[2] = {false, false};
@@ -75,6 +77,9 @@ struct tn_ctx {
 };
 
 int tn_scratch_get(tn_ctx* ctx, size_t bytes, float** out);
+// a buffer of the current stream that only has to survive until the launches enqueued right after it have run
+int tn_tmp_get(tn_ctx* ctx, size_t bytes, float** out);
+int tn_tmp_get(tn_ctx* ctx, size_t bytes, float** out);
 int tn_red_push(tn_ctx* ctx, const float* src, float* out, uint32_t n, uint32_t S, uint32_t stride,
                 uint32_t flip);
 int tn_red_commit(tn_ctx* ctx);

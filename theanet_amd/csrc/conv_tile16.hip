@@ -747,6 +747,17 @@ int tn_conv_tile16_pool_fwd(tn_ctx* ctx, const float* x, const float* W, const f
 
 // dW, db (dW != NULL) and the input gradient (dx != NULL) of the fused block from the pooled gradient g_,
 // the pooled output y and the pooling mask
+// dz = MaxPoolGrad(g) * act'(y) of a pooled block as a tensor of its own (4 pixels of a row per thread)
+__global__ __launch_bounds__(256) void pool_expand_kernel(PoolSrc ps, float* __restrict__ dz, int H, int q4,
+                                                         size_t total4) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total4) return;
+    const int c4 = (int)(i % q4);
+    const size_t pr = i / q4;
+    const int row = (int)(pr % H), plane = (int)(pr / H);
+    reinterpret_cast<float4*>(dz)[i] = pool_expand4(ps, plane, row, 4 * c4);
+}
+
 int tn_conv_tile16_pool_bwd(tn_ctx* ctx, const float* x, const float* W, const float* g_, const float* y,
                             const uint8_t* mask, float* dx, float* dW, float* db, int N, int C, int H, int Wd,
                             int K, int act, float prm, const float* prev_a, int prev_act, float prev_prm) {
@@ -754,6 +765,29 @@ int tn_conv_tile16_pool_bwd(tn_ctx* ctx, const float* x, const float* W, const f
     ps.g = g_; ps.y = y; ps.mask = mask; ps.Hp = H / 2; ps.Wp = Wd / 2; ps.act = act; ps.prm = prm;
     TN_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(g_) | reinterpret_cast<uintptr_t>(y)) & 15) == 0 &&
                (reinterpret_cast<uintptr_t>(mask) & 3) == 0, "conv_tile16_pool_bwd: misaligned operand");
+    // With fp16 operands the two products are bound by the traffic and the latency of their loads, and forming
+    // dz inside them (three narrow loads and the mask arithmetic per 4 pixels, twice) costs more than writing
+    // it once: one streaming launch materialises dz (a buffer that lives until the two launches behind it have
+    // run), the plain kernels consume it.  TN_C16_UNPOOL=0: the fused forms.
+    static int unpool = -1;
+    if (unpool < 0) {
+        const char* e = getenv("TN_C16_UNPOOL");
+        unpool = e ? atoi(e) : 1;
+    }
+    if (unpool && (dW || dx)) {
+        float* dz;
+        const size_t total4 = (size_t)N * K * H * (Wd / 4);
+        int rc = tn_tmp_get(ctx, total4 * 16, &dz);
+        if (rc) return rc;
+        pool_expand_kernel<<<(unsigned)cdiv(total4, 256), 256, 0, ctx->stream>>>(ps, dz, H, Wd / 4, total4);
+        TN_LAUNCH_CHECK();
+        if (dW) {
+            rc = tn_conv_tile16_wgrad(ctx, x, dz, dW, db, N, C, H, Wd, K);
+            if (rc) return rc;
+        }
+        if (dx) return tn_conv_tile16_dgrad(ctx, dz, W, dx, N, C, H, Wd, K, 1, H, Wd, prev_a, prev_act, prev_prm);
+        return TN_OK;
+    }
     if (dW) {
         ConvWG16 w{};
         w.x = x; w.ps = ps;

@@ -57,8 +57,10 @@ int tn_ctx_destroy(tn_ctx* ctx) {
     hipStreamSynchronize(ctx->streams[0]);
     hipStreamSynchronize(ctx->streams[1]);
     if (ctx->scratch) hipFree(ctx->scratch);
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 2; ++i) {
         if (ctx->scratch_slot[i]) hipFree(ctx->scratch_slot[i]);
+        if (ctx->tmp[i]) hipFree(ctx->tmp[i]);
+    }
     hipEventDestroy(ctx->sync_ev[0]);
     hipEventDestroy(ctx->sync_ev[1]);
     hipStreamDestroy(ctx->streams[0]);

@@ -151,6 +151,21 @@ int tn_scratch_get(tn_ctx* ctx, size_t bytes, float** out) {
     return TN_OK;
 }
 
+int tn_tmp_get(tn_ctx* ctx, size_t bytes, float** out) {
+    const int k = ctx->stream == ctx->streams[1] ? 1 : 0;
+    if (bytes > ctx->tmp_bytes[k]) {
+        TN_HIP(hipStreamSynchronize(ctx->streams[k]));       // launches may still read the old buffer
+        if (ctx->tmp[k]) TN_HIP(hipFree(ctx->tmp[k]));
+        ctx->tmp[k] = nullptr; ctx->tmp_bytes[k] = 0;
+        const size_t nb = bytes + (bytes >> 3);
+        hipError_t e = hipMalloc(&ctx->tmp[k], nb);
+        if (e != hipSuccess) return tn_fail(ctx, TN_E_NOMEM, "tmp hipMalloc(%zu) failed", nb);
+        ctx->tmp_bytes[k] = nb;
+    }
+    *out = reinterpret_cast<float*>(ctx->tmp[k]);
+    return TN_OK;
+}
+
 extern "C" int tn_defer_flush_step(tn_ctx* ctx, uint32_t* d_step) {
     ctx->defer = false;
     return tn_red_flush_inc(ctx, d_step);

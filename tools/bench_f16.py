@@ -70,6 +70,15 @@ for name, ns, C, H, K in SHAPES:
         t_d = timeit(lambda: ctx.call("tn_conv2d_dgrad", dz.ptr, W.ptr, dx.ptr, *geom, None, 0, 0.0), args.iters) \
             if C * 9 > 32 else float("nan")
         t_w = timeit(lambda: ctx.call("tn_conv2d_wgrad", x.ptr, dz.ptr, dW.ptr, db.ptr, *geom), args.iters)
+        if dtype == "float16" and H % 4 == 0 and lib.tn_convpool_f16_supported(N, C, H, H, K, 3, 1, 1, H, H, 2, H // 2, H // 2):
+            yp = ctx.empty((N, K, H // 2, H // 2)); mk = ctx.empty((N, K, H // 2, H // 2), np.uint8)
+            gp = ctx.array((rng.standard_normal((N, K, H // 2, H // 2)) * 1e-4).astype(np.float32))
+            pg = (N, C, H, H, K, 3, 1, H, H, 2, H // 2, H // 2, LEAKY, 0.1)
+            t_pf = timeit(lambda: ctx.call("tn_convpool_fwd_mask", x.ptr, W.ptr, b.ptr, yp.ptr, mk.ptr, *pg), args.iters)
+            t_pb = timeit(lambda: ctx.call("tn_convpool_bwd_mask_dx", x.ptr, W.ptr, gp.ptr, yp.ptr, mk.ptr,
+                                           dx.ptr if C * 9 > 32 else None, dW.ptr, db.ptr, *pg, None, 0, 0.0), args.iters)
+            print("%-14s pooled block: forward %6.0f us, backward (dW, db%s) %6.0f us" % (
+                name, t_pf, ", dx" if C * 9 > 32 else "", t_pb))
         print("%-14s %-6s %s   %.0f" % (name, "f16" if dtype == "float16" else "f32", " ".join(
             "%6.0f|%5.0f" % (t, flops / t / 1e6) for t in (t_f, t_d, t_w)), floor))
     ctx.set_matmul_dtype("float32")

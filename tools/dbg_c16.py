@@ -13,7 +13,11 @@ b = dev(rng.randn(K).astype(np.float32)); a = empty((N, K, H, H)); dx = empty((N
 kind, prm = act_code("relu10")
 c_ = ctx(); c_.set_matmul_dtype("float16", 4096.)
 for it in range(3):
-    if op == "fwd":
+    if op == "fwdpool":
+        y = empty((N, K, H // 2, H // 2)); m = empty((N, K, H // 2, H // 2), np.uint8)
+        call("tn_convpool_fwd_mask", x.ptr, W.ptr, b.ptr, y.ptr, m.ptr, N, C, H, H, K, 3, 1, H, H, 2, H // 2, H // 2,
+             kind, prm)
+    elif op == "fwd":
         call("tn_conv2d_fwd", x.ptr, W.ptr, b.ptr, a.ptr, N, C, H, H, K, 3, 1, 1, H, H, kind, prm)
     else:
         call("tn_conv2d_dgrad", a.ptr, W.ptr, dx.ptr, N, C, H, H, K, 3, 1, 1, H, H, None, 0, 0.0)
