@@ -420,7 +420,10 @@ FC_CASES = [(64, 720, 500, "relu01"), (33, 500, 10, "linear"), (5, 7, 3, "tanh")
             # few outputs, n_in % 4 == 0: the 16-byte-access kernels of fc_skinny.hip
             (300, 500, 10, "linear"), (129, 64, 16, "tanh"), (17, 8, 1, "relu05"), (515, 1028, 7, "sigmoid"),
             (1024, 128, 96, "relu01"),                   # long batch: split-K weight gradient
-            (40, 2304, 100, "relu10")]                   # short and deep: split-K forward + finishing kernel
+            (40, 2304, 100, "relu10"),                   # short and deep: split-K forward + finishing kernel
+            # few 64 x 64 tiles, moderate reduction: gemm_f32_deep (waves split K, operands straight from global
+            # memory): the 512-image shard of the sharded step, a K tail (500 = 31.25 tiles) with ragged M / N
+            (512, 720, 500, "relu01"), (97, 500, 36, "relu10")]
 
 
 @pytest.mark.parametrize("B,n_in,n_out,act", FC_CASES)
@@ -531,7 +534,8 @@ def test_fc_softmax_train_fused(B, n_in, n_out):
 
 
 @pytest.mark.parametrize("B,n_in,n_out", [(64, 720, 500), (70, 36, 132), (33, 50, 10), (40, 64, 101),
-                                          (48, 4096, 128)])       # split-K forward
+                                          (48, 4096, 128),        # split-K forward
+                                          (512, 720, 500), (97, 500, 36)])   # gemm_f32_deep epilogue
 def test_fc_fwd_dropout_matches_separate_mask(B, n_in, n_out):
     """tn_fc_fwd_dropout draws the mask inside the GEMM epilogue (or falls back to two launches):
     the mask must be bit-identical to tn_dropout_mask and the output the masked activation."""

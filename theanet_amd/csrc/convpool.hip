@@ -131,7 +131,11 @@ __global__ __launch_bounds__(256) void convpool_fwd_kernel(
 #pragma unroll
         for (int dj = 0; dj < P; ++dj) valid[di][dj] = (pi * P + di < Ho) && (pj * P + dj < Wo);
     float* yn = y + (size_t)n * K * HpWp + q;
-    for (int k = 0; k < K; ++k) {
+    // short batches: gridDim.y slices of the filters, so that the launch has enough waves and a thread's serial
+    // chain (K * C * F * F * P * P dependent-free FMAs, but one wave at a time per SIMD) is gridDim.y times shorter
+    const int kper = (K + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int kbeg = (int)blockIdx.y * kper, kend = min(K, kbeg + kper);
+    for (int k = kbeg; k < kend; ++k) {
         float z[P][P];
         window_conv<F, P, C, PADDED>(pt, W + (size_t)k * C * F * F, b[k], z);
         float m = -INFINITY;
@@ -408,8 +412,20 @@ static int launch_fwd(tn_ctx* ctx, const float* x, const float* W, const float* 
                       float prm) {
     const long long total = (long long)N * Hp * Wp;
     TN_REQUIRE(total < (1ll << 31), "tn_convpool_fwd: too many outputs for 32-bit indexing");
+    // filter slices (blockIdx.y) until the launch has about two blocks per CU
+    int ks = 1;
+    while (ks < 8 && ks * 2 <= K && (long long)cdiv(total, 256) * ks < 2 * ctx->num_cus) ks *= 2;
+    {
+        static int force = -1;
+        if (force < 0) {
+            const char* e = getenv("TN_CONVPOOL_KS");
+            force = e ? atoi(e) : 0;
+        }
+        if (force > 0) ks = force;
+    }
+    const dim3 grid(cdiv(total, 256), ks);
 #define CP_L(ACT_, PAD_)                                                                          \
-    convpool_fwd_kernel<F, P, C, ACT_, PAD_><<<cdiv(total, 256), 256, 0, ctx->stream>>>(           \
+    convpool_fwd_kernel<F, P, C, ACT_, PAD_><<<grid, 256, 0, ctx->stream>>>(                       \
         x, W, b, y, mask, N, H, Wd, K, pad, Ho, Wo, Hp, Wp, act, prm)
     if (act == TN_ACT_LEAKY) {
         if (pad) CP_L(TN_ACT_LEAKY, true); else CP_L(TN_ACT_LEAKY, false);

@@ -496,6 +496,127 @@ __global__ __launch_bounds__(256) void gemm_f32_pair(GemmArgs g1, GemmArgs g2, i
         gemm_fast_body<A2, B2, S2, 1, 1, 16>(g2, smem, idx * 8 + l8);
 }
 
+// ---- DEEP kernel: few output tiles, a reduction long enough to split ---------------------------------
+// A short batch (one rank of a sharded step: 512 x 500 <- 720) has 64 tiles of 64 x 64, each a chain of 45
+// dependent K-tiles behind an LDS round trip and a barrier: 64 blocks on 256 CUs and 20-27 us of latency for
+// 0.37 GFLOP.  Here a block owns a 32 x 32 tile and its NW waves split the REDUCTION: every wave multiplies its
+// own K range with operands loaded straight from global memory into the MFMA register layout (lane (r, hi) of
+// v_mfma_f32_32x32x2_f32 supplies A[r][k] and B[k][r] for the k of its half: with k-contiguous A that is two
+// 16-byte loads per K-tile, with row-contiguous B eight dword loads that are 128 B contiguous across lanes),
+// DEPTH tiles per trip in flight, no LDS and no barrier in the loop; the NW partial tiles are added in wave order through
+// LDS and the 16-byte epilogue of the other kernels (bias + activation + inline dropout / act' * mask) runs once.
+// The price is operand re-reads from L2 (no sharing between the tiles of a block row): M*N*K/4 bytes, so the
+// host only picks it while that is small (gemm_deep_ok).
+template <bool BKC, int NW>
+__global__ __launch_bounds__(64 * NW) void gemm_f32_deep(GemmArgs g) {
+    constexpr int DEPTH = 6;
+    __shared__ __attribute__((aligned(16))) float red[NW][32][36];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6, r = lane & 31, hi = lane >> 5;
+    const int mt = blockIdx.x / g.NT, nt = blockIdx.x - mt * g.NT;
+    const int m0 = 32 * mt, n0 = 32 * nt;
+    // K-tiles of this wave
+    const int ktiles = (g.K + 15) >> 4, per = (ktiles + NW - 1) / NW;
+    const int tb = w * per, te = min(ktiles, tb + per);
+    const int kend = min(g.K, 16 * te);
+    const int ntl = max(te - tb, 0), ntp = (ntl + DEPTH - 1) / DEPTH * DEPTH;
+    const float* pa = g.A + (size_t)min(m0 + r, g.M - 1) * g.lda;            // A(m, k) = A[m*lda + k]
+    const int nc = min(n0 + r, g.N - 1);
+    const float* pb = BKC ? g.B + (size_t)nc * g.ldb : g.B + nc;             // BKC: B(k, n) = B[n*ldb + k]
+
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    float4 ra[DEPTH][2];
+    float rb[DEPTH][8];
+#define DLOAD(SLOT, TILE)                                                                         \
+    {                                                                                             \
+        const int k0_ = 16 * (tb + (TILE)) + 8 * hi;                                              \
+        const int ka_ = min(k0_, g.K - 4), kb_ = min(k0_ + 4, g.K - 4);                           \
+        ra[SLOT][0] = *reinterpret_cast<const float4*>(pa + ka_);                                 \
+        ra[SLOT][1] = *reinterpret_cast<const float4*>(pa + kb_);                                 \
+        if (BKC) {                                                                                \
+            const float4 u_ = *reinterpret_cast<const float4*>(pb + ka_);                         \
+            const float4 v_ = *reinterpret_cast<const float4*>(pb + kb_);                         \
+            rb[SLOT][0] = u_.x; rb[SLOT][1] = u_.y; rb[SLOT][2] = u_.z; rb[SLOT][3] = u_.w;       \
+            rb[SLOT][4] = v_.x; rb[SLOT][5] = v_.y; rb[SLOT][6] = v_.z; rb[SLOT][7] = v_.w;       \
+        } else {                                                                                  \
+            _Pragma("unroll") for (int s_ = 0; s_ < 8; ++s_)                                      \
+                rb[SLOT][s_] = pb[(size_t)min(k0_ + s_, g.K - 1) * g.ldb];                        \
+        }                                                                                         \
+    }
+    // tiles past the wave's range (padding of the unrolled loop, the K tail) multiply by zero
+#define DMMA(SLOT, TILE)                                                                          \
+    {                                                                                             \
+        const int k0_ = 16 * (tb + (TILE)) + 8 * hi;                                              \
+        const float av_[8] = {ra[SLOT][0].x, ra[SLOT][0].y, ra[SLOT][0].z, ra[SLOT][0].w,         \
+                              ra[SLOT][1].x, ra[SLOT][1].y, ra[SLOT][1].z, ra[SLOT][1].w};        \
+        _Pragma("unroll") for (int s_ = 0; s_ < 8; ++s_) {                                        \
+            const float bv_ = (k0_ + s_ < kend) ? rb[SLOT][s_] : 0.f;                             \
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av_[s_], bv_, acc, 0, 0, 0);               \
+        }                                                                                         \
+    }
+    // a trip = DEPTH tiles: all their loads are issued back to back, then the MFMAs follow under counted waits.
+    // (Carrying refilled slots from one trip to the next did not survive the compiler: the values were copied
+    // at the loop latch, which waits for the loads -- so the look-ahead across trips comes from the block's other
+    // waves instead.)
+    for (int tile = 0; tile < ntp; tile += DEPTH) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) DLOAD(d, tile + d);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) DMMA(d, tile + d);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#undef DLOAD
+#undef DMMA
+    // ---- add the NW partial tiles in wave order; thread = 4 consecutive columns of a row ----------------
+#pragma unroll
+    for (int i = 0; i < 16; ++i) red[w][(i & 3) + 8 * (i >> 2) + 4 * hi][r] = acc[i];
+    __syncthreads();
+    if (t >= 256) return;
+    const int rl = t >> 3, c4 = 4 * (t & 7);
+    float4 v = *reinterpret_cast<const float4*>(&red[0][rl][c4]);
+#pragma unroll
+    for (int q = 1; q < NW; ++q) {
+        const float4 u = *reinterpret_cast<const float4*>(&red[q][rl][c4]);
+        v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+    }
+    const int row = m0 + rl, col = n0 + c4;
+    if (row >= g.M || col >= g.N) return;                 // N % 4 == 0: a group is inside or outside
+    const size_t o = (size_t)row * g.ldc + col;
+    uint32_t pm = g.mask ? *reinterpret_cast<const uint32_t*>(g.mask + o) : 0x01010101u;
+    if (g.epi == EPI_FWD) {
+        if (g.bias) {
+            v.x += g.bias[col]; v.y += g.bias[col + 1]; v.z += g.bias[col + 2]; v.w += g.bias[col + 3];
+        }
+        v.x = tn_act_fwd(v.x, g.act, g.act_prm);
+        v.y = tn_act_fwd(v.y, g.act, g.act_prm);
+        v.z = tn_act_fwd(v.z, g.act, g.act_prm);
+        v.w = tn_act_fwd(v.w, g.act, g.act_prm);
+        if (g.drop_out) {      // same numbers as gemm_epilogue_vec / tn_dropout_mask
+            const uint32_t dst = g.dstep + (g.d_step ? *g.d_step : 0u);
+            const uint64_t cq = (g.elem0 + (uint64_t)row * (uint64_t)g.N + (uint64_t)col) >> 2;
+            const u32x4 rr = philox4x32((uint32_t)cq, (uint32_t)(cq >> 32), dst, TN_STREAM_DROPOUT, g.dk0, g.dk1);
+            pm = (tn_u01(rr.x) >= g.pdrop ? 1u : 0u) | (tn_u01(rr.y) >= g.pdrop ? 0x100u : 0u) |
+                 (tn_u01(rr.z) >= g.pdrop ? 0x10000u : 0u) | (tn_u01(rr.w) >= g.pdrop ? 0x1000000u : 0u);
+            *reinterpret_cast<uint32_t*>(g.drop_out + o) = pm;
+        }
+    } else if (g.epi == EPI_DGRAD && g.prev_a) {
+        const float4 pa4 = *reinterpret_cast<const float4*>(g.prev_a + o);
+        v.x *= tn_act_grad_from_out(pa4.x, g.act, g.act_prm);
+        v.y *= tn_act_grad_from_out(pa4.y, g.act, g.act_prm);
+        v.z *= tn_act_grad_from_out(pa4.z, g.act, g.act_prm);
+        v.w *= tn_act_grad_from_out(pa4.w, g.act, g.act_prm);
+    }
+    if (g.epi != EPI_PLAIN && (g.mask || g.drop_out)) {
+        v.x *= (float)(pm & 0xffu);
+        v.y *= (float)((pm >> 8) & 0xffu);
+        v.z *= (float)((pm >> 16) & 0xffu);
+        v.w *= (float)(pm >> 24);
+    }
+    *reinterpret_cast<float4*>(g.C + o) = v;
+}
+
 // ---- generic kernel (any alignment / extent): guarded loads, single-stage prefetch ---------
 template <bool AKC, bool BKC, bool BSUM>
 __global__ __launch_bounds__(256) void gemm_f32_generic(GemmArgs g) {
@@ -621,6 +742,37 @@ static bool gemm_cvec_ok(const GemmArgs& g) {
     auto al = [](const void* p, uintptr_t m) { return (reinterpret_cast<uintptr_t>(p) & m) == 0; };
     return vec_on && g.ldc % 4 == 0 && g.N % 4 == 0 && g.N >= 4 && al(g.C, 15) && al(g.prev_a, 15) &&
            al(g.mask, 3) && al(g.drop_out, 3) && (g.elem0 & 3) == 0;
+}
+
+// DEEP pays while the 64 x 64 tiles cannot fill the chip and the L2 re-reads (M*N*K/4 bytes) stay small
+static int tn_tune_deep() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("TN_GEMM_DEEP");   // 0 off, 1 auto (default), 4 / 8: force that many waves
+        v = e ? atoi(e) : 1;
+    }
+    return v;
+}
+template <bool BKC>
+static bool gemm_deep_ok(tn_ctx* ctx, const GemmArgs& g) {
+    if (!tn_tune_deep() || !g.a_vec || !g.b_vec || !gemm_cvec_ok(g) || g.K % 4 != 0 || g.K < 128) return false;
+    if (tn_tune_deep() > 1) return true;
+    const long long tiles64 = (long long)cdiv(g.M, 64) * cdiv(g.N, 64);
+    return tiles64 <= ctx->num_cus && (long long)g.M * g.N * g.K / 4 <= (128ll << 20);
+}
+template <bool BKC>
+static void launch_deep(tn_ctx* ctx, GemmArgs& g) {
+    g.S = 1;
+    g.c_vec = 1;
+    g.MT = cdiv(g.M, 32);
+    g.NT = cdiv(g.N, 32);
+    const int grid = g.MT * g.NT;
+    int nw = (grid <= 2 * ctx->num_cus && g.K >= 512) ? 8 : 4;
+    if (tn_tune_deep() == 4 || tn_tune_deep() == 8) nw = tn_tune_deep();
+    if (nw == 8)
+        gemm_f32_deep<BKC, 8><<<grid, 512, 0, ctx->stream>>>(g);
+    else
+        gemm_f32_deep<BKC, 4><<<grid, 256, 0, ctx->stream>>>(g);
 }
 
 template <bool AKC, bool BKC, bool BSUM>
@@ -971,7 +1123,10 @@ int tn_fc_fwd(tn_ctx* ctx, const float* x, const float* W, const float* b, float
     g.a_vec = vec_ok(x, n_in); g.b_vec = vec_ok(W, n_out);
     const int S = fc_fwd_splits(ctx, B, n_in, n_out);
     if (S > 1) return fc_fwd_splitk(ctx, g, S, mask);
-    launch_gemm<true, false, false>(ctx, g, 1);
+    if (gemm_deep_ok<false>(ctx, g))
+        launch_deep<false>(ctx, g);
+    else
+        launch_gemm<true, false, false>(ctx, g, 1);
     TN_LAUNCH_CHECK();
     return TN_OK;
 }
@@ -991,7 +1146,10 @@ int tn_fc_fwd_dropout(tn_ctx* ctx, const float* x, const float* W, const float* 
     g.dstep = step; g.d_step = d_step; g.elem0 = elem0;
     if (n_out > SK_MAX && fc_fwd_splits(ctx, B, n_in, n_out) == 1 && gemm_fast_ok<true, false>(g) &&
         gemm_cvec_ok(g)) {
-        launch_gemm<true, false, false>(ctx, g, 1);      // mask drawn in the epilogue
+        if (gemm_deep_ok<false>(ctx, g))
+            launch_deep<false>(ctx, g);
+        else
+            launch_gemm<true, false, false>(ctx, g, 1);  // mask drawn in the epilogue
         TN_LAUNCH_CHECK();
         return TN_OK;
     }
