@@ -370,6 +370,7 @@ __global__ __launch_bounds__(256) void maxnorm_rows_kernel(float* __restrict__ p
     }
     __syncthreads();
     const float sc = scale_s;
+    if (sc == 1.f) return;       // norm within the bound: (1e-7 + n) / (1e-7 + n) is exactly 1, nothing to rewrite
     for (int i = threadIdx.x; i < rest; i += 256) row[i] *= sc;
 }
 
@@ -401,6 +402,9 @@ __global__ __launch_bounds__(256) void maxnorm_cols_scale(float* __restrict__ p,
     for (int z = 0; z < R; ++z) s += partial[(size_t)z * cols + c];
     const float nrm = sqrtf(s);
     const float sc = (1e-7f + fminf(fmaxf(nrm, 0.f), mx)) / (1e-7f + nrm);
+    // columns within the bound have sc == 1 exactly: their 4 * rows bytes are neither read nor written (a wave
+    // whose 64 columns are all within the bound -- the usual case -- leaves without touching the matrix)
+    if (sc == 1.f) return;
     const int rb = blockIdx.y * rchunk, re = min(rows, rb + rchunk);
     for (int r = rb + r0; r < re; r += 4) p[(size_t)r * cols + c] *= sc;
 }

@@ -36,6 +36,7 @@ class Context:
         self.mm_dtype = "float32"  # operand precision of the conv products (NeuralNet's DTYPE training param)
         self._mm_set = ("float32", 1.0)
         self.ev_hook = None       # (name, nth) -> HIP-event bracket around that C-ABI call
+        self._fns = {}            # name -> bound ctypes function (the attribute lookup costs per call otherwise)
         self._ev_seen = 0
         self.ev_pairs = []
 
@@ -45,7 +46,10 @@ class Context:
             self._ev_seen += 1
             if self._ev_seen == hook[1] or hook[1] == 0:         # nth 0: every call
                 return self._timed_call(name, args)
-        rc = getattr(self.lib, name)(self.h, *args)
+        fn = self._fns.get(name)
+        if fn is None:
+            fn = self._fns[name] = getattr(self.lib, name)
+        rc = fn(self.h, *args)
         if rc != 0:
             _lib.check(self.h, rc, name)
 

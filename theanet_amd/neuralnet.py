@@ -459,6 +459,10 @@ class NeuralNet():
             self.rand_gen = None
 
         self.ctx = get_context()             # raises without libtheanet_hip.so / a GPU
+        # the A/B switches a step consults, read once per net: a step makes ~14 C-ABI calls
+        # and every environment lookup in between costs as much host time as a tenth of a launch
+        self._fl = {n: os.environ.get(n, "1") != "0"
+                    for n in ("TN_SOFTMAX_TRAIN", "TN_STEP_TAIL", "TN_FIELD_RIDER", "TN_LAZY_UPDATE")}
         # DTYPE: 'float32' (default = the reference's floatX, weights.py:8) or 'float16' = fp16 operands /
         # fp32 accumulation for the conv products, fp32 master weights; GRAD_SCALE: power of two applied
         # to dz before it is rounded to fp16 (results are scaled back: exact)
@@ -888,7 +892,7 @@ class NeuralNet():
         # the weight-gradient ops only record their finishing slab sums; one launch does them all
         ctx.call("tn_defer_reductions", 1)
         n_lyr = len(self.tr_layers)
-        fuse_out = n_lyr >= 2 and self._need_gin[n_lyr - 1] and os.environ.get("TN_SOFTMAX_TRAIN", "1") != "0" \
+        fuse_out = n_lyr >= 2 and self._need_gin[n_lyr - 1] and self._fl["TN_SOFTMAX_TRAIN"] \
             and isinstance(out, SoftmaxLayer) and out.loss == "nll"
         try:
             out.forward(True, y=y, y_row0=y_row0, d_row0=d_row0,
@@ -931,7 +935,7 @@ class NeuralNet():
         # launch build it beside the update instead (tn_step_tail).
         ahead = (isinstance(first, ElasticLayer) and first.active and first.has_field and
                  not first._inj_draws and first.d_step is not None and (self._n_segs or rider) and
-                 os.environ.get("TN_STEP_TAIL", "1") != "0")
+                 self._fl["TN_STEP_TAIL"])
         if ahead:
             nxt = 1 - first._cur
             m = first._maps[nxt]
@@ -939,7 +943,7 @@ class NeuralNet():
             field_args = (hw, hw, float(first.translation), float(first.zoom), float(first.magnitude),
                           int(first.sigma), float(first.angle), int(first.nearest), m[0].ptr, m[1].ptr,
                           m[2].ptr, m[3].ptr)
-            if os.environ.get("TN_FIELD_RIDER", "1") != "0":
+            if self._fl["TN_FIELD_RIDER"]:
                 ctx.call("tn_rider_elastic_field", first.draws.ptr, first.seed, pipe_stride or 1,
                          self.d_step.ptr, *field_args)
         tail = False
@@ -964,12 +968,12 @@ class NeuralNet():
                 if g is None:
                     break
             lazy = (not self._dp and 0 < self._n_segs <= 16 and
-                    os.environ.get("TN_LAZY_UPDATE", "1") != "0")
+                    self._fl["TN_LAZY_UPDATE"])
         finally:
             waiting = bool(ctx.lib.tn_rider_pending(ctx.h))
             if waiting:
                 ctx.call("tn_rider_cancel")       # nobody carried it: it joins the update launch
-            rode = ahead and not waiting and os.environ.get("TN_FIELD_RIDER", "1") != "0"
+            rode = ahead and not waiting and self._fl["TN_FIELD_RIDER"]
             tail = ahead and not rode
             if pipe_stride:                       # pipelined schedule: the update is not part of the step
                 ahead, tail, lazy = rode, False, False
