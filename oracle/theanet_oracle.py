@@ -30,10 +30,14 @@ no padding; MaxPoolGrad credits every tied maximum; Maximum/Minimum gradients
 use eq(out, x) (ties feed both branches); log(softmax(x)) is the stable
 log-softmax; simultaneous ``updates`` read pre-step values.
 
-PARITY UNPINNED against the reference itself for everything except
-``deformer_transform`` (pinned against the reference's own extras/deformer.py:7-18
-executed in the build container, fixture tests/golden/deformer.npz): the reference
-holds no golden vectors, no asserts (tests/test_elastic.py has none) and cannot run.
+PARITY UNPINNED against the reference itself for everything except the two pieces of it
+that run without Theano: ``deformer_transform`` (pinned against the reference's own
+extras/deformer.py:7-18 executed in the build container, fixture tests/golden/deformer.npz)
+and ``init_wb`` + the numpy seed chain (pinned against the reference's own draw lines,
+theanet/layer/weights.py:51-65, compiled in place: fixture tests/golden/init_ref.npz holds
+the initial weights of mnist.prms and one layer per scale / bias rule, reproduced bit for
+bit).  The reference holds no golden vectors, no asserts (tests/test_elastic.py has none)
+and the rest of it cannot run.
 The remaining functions are pinned by analytic known-answer tests, float64
 finite-difference gradient checks (whole nets, every head / loss, mid-net Color and
 Elastic layers) and by an INDEPENDENT second implementation: a whole mnist.prms

@@ -1,5 +1,6 @@
 """Regenerates the committed golden fixtures (run in the BUILD container only:
 `python tests/golden/make_golden.py`).  Everything comes from the oracle except
+init_ref.npz (the draw arithmetic of theanet/layer/weights.py:51-65, compiled from /root/reference) and
 deformer.npz, whose expected outputs come from the reference's own
 extras/deformer.py:7-18 executed from /root/reference (the module cannot be
 imported under python3 -- it has py2 print statements from line 92 -- so only its
@@ -165,8 +166,74 @@ def make_deformer():
     np.savez_compressed(os.path.join(HERE, "deformer.npz"), **out)
 
 
+def ref_init_draws():
+    """The reference's own draw arithmetic: theanet/layer/weights.py:51-65 (the body of `if wb is None:` in init_wb,
+    pure numpy) compiled from /root/reference where it lies -- the module itself cannot be imported (it imports theano
+    at :2) and nothing of Theano is stubbed: the lines that wrap the arrays in theano.shared (:73-79) are not run."""
+    import textwrap
+    ref = "/root/reference/theanet/layer/weights.py"
+    with open(ref) as fh:
+        lines = fh.readlines()
+    body = textwrap.dedent("".join(lines[50:65]))
+    assert body.lstrip().startswith("if len(size_w) == 4:") and "b_values += .5" in body, body
+    code = compile(body, ref, "exec")
+
+    def draw(rand_gen, size_w, size_b, fan_in, fan_out, actvn):
+        ns = dict(np=np, float_x="float32", rand_gen=rand_gen, size_w=size_w, size_b=size_b, fan_in=fan_in,
+                  fan_out=fan_out, actvn=actvn)
+        exec(code, ns)
+        return ns["w_values"], ns["b_values"]
+    return draw
+
+
+def make_init_ref():
+    """INIT-REF: initial weights of mnist.prms (SEED 555555) and of single layers with the other activation
+    rules, drawn by the REFERENCE's lines through the seed chain of neuralnet.py:65-68 / inlayers.py:72 /
+    dropout.py:10 (those three `randint(1e6)` / RandomState calls are one-liners restated here)."""
+    draw = ref_init_draws()
+    prms = load_prms("mnist.prms", 28)
+    out = {}
+    rg = np.random.RandomState(prms["training_params"]["SEED"])          # neuralnet.py:66
+    maps, sz, n_prev = 1, 28, None
+    for i, (kind, a) in enumerate(prms["layers"]):
+        if kind == "ElasticLayer":
+            if any(a.get(k) for k in ("translation", "magnitude", "pflip", "angle")) or a.get("zoom", 1) != 1:
+                rg.randint(1e6)                                          # inlayers.py:72-73
+        elif kind == "ConvLayer":
+            f, k = a["filter_sz"], a["num_maps"]
+            w, b = draw(rg, (k, maps, f, f), (k,), maps * f * f, None, a.get("actvn", "relu50"))   # convpool.py:43-50
+            out["mnist_%d_W" % i], out["mnist_%d_b" % i] = w, b
+            sz, maps = (sz if a.get("mode", "valid") == "same" else sz - f + 1) // a.get("stride", 1), k
+            n_prev = maps * sz * sz
+        elif kind == "PoolLayer":
+            sz = -(-sz // a["pool_sz"])
+            n_prev = maps * sz * sz
+        elif kind in ("HiddenLayer", "SoftmaxLayer"):
+            n_out = a["n_out"]
+            act = a.get("actvn", "relu01") if kind == "HiddenLayer" else "Softmax"
+            fan = n_prev + n_out                                         # hidden.py:21-27: n_in + n_out, twice
+            w, b = draw(rg, (n_prev, n_out), (n_out,), fan, fan, act)   # SoftmaxLayer is a HiddenLayer (outlayers.py:87)
+            out["mnist_%d_W" % i], out["mnist_%d_b" % i] = w, b
+            if kind == "HiddenLayer" and a.get("pdrop"):
+                rg.randint(1e6)                                          # dropout.py:10
+            n_prev = n_out
+    for j, (act, size_w) in enumerate([("sigmoid", (7, 5)), ("softplus", (3, 2, 3, 3)), ("relu", (6, 4)),
+                                       ("relu10", (2, 3, 5, 5)), ("relu05", (9, 2)), ("tanh", (4, 1, 3, 3))]):
+        rg = np.random.RandomState(1000 + j)
+        fan_in = int(np.prod(size_w[1:])) if len(size_w) == 4 else size_w[0]
+        w, b = draw(rg, size_w, (size_w[0] if len(size_w) == 4 else size_w[1],), fan_in, size_w[-1], act)
+        out["case%d_W" % j], out["case%d_b" % j] = w, b
+        out["case%d_act" % j] = np.array(act)
+    for k in [k for k, v in out.items() if v.size > 20000]:          # big tensors: digest + every 37th value
+        v = out.pop(k)
+        out[k + "_sha256"] = np.array(hashlib.sha256(np.ascontiguousarray(v).tobytes()).hexdigest())
+        out[k + "_every37"] = v.ravel()[::37].copy()
+    np.savez_compressed(os.path.join(HERE, "init_ref.npz"), **out)
+
+
 if __name__ == "__main__":
     make_kat()
+    make_init_ref()
     make_gold_net("gold_a.npz", elastic_on=False)
     make_gold_net("gold_b.npz", elastic_on=True)
     make_deformer()

@@ -40,6 +40,28 @@ def fuse(request):
     NeuralNet.fuse_conv_pool = old
 
 
+def test_initial_weights_match_the_reference_drawn_fixture():
+    """NeuralNet(mnist.prms, SEED 555555) starts from the weights the REFERENCE's own init lines draw
+    (tests/golden/init_ref.npz: theanet/layer/weights.py:51-65 compiled from /root/reference in the build
+    container), bit for bit: seed chain order, fan-in quirks, bias rules, float32 cast."""
+    import hashlib
+    from theanet_amd import NeuralNet
+    ref = np.load(os.path.join(G, "init_ref.npz"))
+    prms = load_prms("mnist.prms", 28, batch=8)
+    net = NeuralNet(prms["layers"], prms["training_params"])
+    seen = 0
+    for i, lyr in enumerate(net.tr_layers):
+        for w, n in zip(lyr.get_wts(), "Wb"):
+            name = "mnist_%d_%s" % (i, n)
+            if name in ref.files:
+                np.testing.assert_array_equal(w, ref[name])
+            else:
+                assert hashlib.sha256(np.ascontiguousarray(w).tobytes()).hexdigest() == str(ref[name + "_sha256"])
+                np.testing.assert_array_equal(np.asarray(w).ravel()[::37], ref[name + "_every37"])
+            seen += 1
+    assert seen == 8
+
+
 @pytest.mark.parametrize("fname,elastic_on", [("gold_a.npz", False), ("gold_b.npz", True)])
 def test_gold_mnist_three_steps(fname, elastic_on, fuse):
     from theanet_amd import NeuralNet

@@ -128,6 +128,40 @@ def test_kat6_seed_chain_init_hashes():
             assert h == str(golden["init_sha_%d_%d" % (i, j)])
 
 
+def _check_against_init_ref(name, arr, ref):
+    if name in ref.files:
+        assert np.array_equal(arr, ref[name]), name
+    else:                                   # big tensor: digest + every 37th value
+        assert hashlib.sha256(np.ascontiguousarray(arr).tobytes()).hexdigest() == str(ref[name + "_sha256"]), name
+        assert np.array_equal(arr.ravel()[::37], ref[name + "_every37"]), name
+
+
+def test_init_matches_the_reference_drawn_fixture():
+    """tests/golden/init_ref.npz was drawn by the REFERENCE's own lines (theanet/layer/weights.py:51-65 compiled
+    from /root/reference by tests/golden/make_golden.py::make_init_ref): the oracle's restatement of init_wb and of
+    the seed chain must reproduce it bit for bit -- mnist.prms under SEED 555555 and one layer per bias / scale
+    rule (sigmoid x4, softplus / relu / relu0x -> b = .5, relu10 / tanh -> 0)."""
+    ref = np.load(os.path.join(ROOT, "tests", "golden", "init_ref.npz"))
+    prms = _mnist_prms()
+    prms["layers"][0][1]["img_sz"] = 28
+    prms["training_params"]["SEED"] = 555555
+    net = O.OracleNet(prms["layers"], prms["training_params"])
+    seen = 0
+    for i, l in enumerate(net.L):
+        for p, n in zip(l.params, "Wb"):
+            assert p.dtype == np.float32
+            _check_against_init_ref("mnist_%d_%s" % (i, n), p, ref)
+            seen += 1
+    assert seen == 8
+    for j, (act, size_w) in enumerate([("sigmoid", (7, 5)), ("softplus", (3, 2, 3, 3)), ("relu", (6, 4)),
+                                       ("relu10", (2, 3, 5, 5)), ("relu05", (9, 2)), ("tanh", (4, 1, 3, 3))]):
+        assert str(ref["case%d_act" % j]) == act
+        fan_in = int(np.prod(size_w[1:])) if len(size_w) == 4 else size_w[0]
+        w, b = O.init_wb(np.random.RandomState(1000 + j), size_w, (size_w[0] if len(size_w) == 4 else size_w[1],),
+                         fan_in, size_w[-1], act)
+        assert np.array_equal(w, ref["case%d_W" % j]) and np.array_equal(b, ref["case%d_b" % j]), act
+
+
 def test_kat7_lr_schedule():
     prms = _mnist_prms()
     prms["layers"][0][1]["img_sz"] = 28
