@@ -231,9 +231,50 @@ def make_init_ref():
     np.savez_compressed(os.path.join(HERE, "init_ref.npz"), **out)
 
 
+def make_train_helpers():
+    """TRAIN-REF: the caller's two pure-python helpers run from the reference text -- fixdim (train.py:22-34: dataset
+    arrays -> NCHW) and get_test_indices (train.py:170-176: rolling windows of minibatch indices for the periodic
+    tests) -- on a few inputs; only inputs / outputs are stored."""
+    import textwrap
+    ref = "/root/reference/train.py"
+    with open(ref) as fh:
+        lines = fh.readlines()
+    ns = {"np": np}
+    exec(compile("".join(lines[21:35]), ref, "exec"), ns)
+    assert "fixdim" in ns
+    out = {}
+    rng = np.random.RandomState(5)
+    for k, shape in enumerate([(6, 49), (5, 7, 7), (4, 3, 6, 6), (3, 1, 5, 5), (2, 784)]):
+        a = rng.rand(*shape).astype(np.float32)
+        out["fixdim_in%d" % k], out["fixdim_out%d" % k] = a, ns["fixdim"](a)
+    cases = [(60000, 20, 5000), (10000, 20, 5000), (70, 20, 60), (65536, 4096, 16384), (1000, 128, 500)]
+    body = textwrap.dedent("".join(lines[169:177]))
+    assert body.startswith("def get_test_indices(") and "yield" in body, body
+    for k, (tot, bsz, samp) in enumerate(cases):
+        g = {"tr_prms": {"TEST_SAMP_SZ": samp}, "batch_sz": bsz}
+        exec(compile(body, ref, "exec"), g)
+        it = g["get_test_indices"](tot)
+        out["win_case%d" % k] = np.array([tot, bsz, samp])
+        out["win_seq%d" % k] = np.array([next(it) for _ in range(9)])
+    # the report strings train.py prints (neuralnet.py:16-51: get_layers_info / get_wts_info / get_training_params_info)
+    nref = "/root/reference/theanet/neuralnet.py"
+    with open(nref) as fh:
+        nlines = fh.readlines()
+    g = {}
+    exec(compile("".join(nlines[15:51]), nref, "exec"), g)
+    prms = load_prms("mnist.prms", 28)
+    wts = [[p for p in l.params] for l in O.OracleNet(prms["layers"], prms["training_params"]).L]
+    out["info_layers"] = np.array(g["get_layers_info"](prms["layers"]))
+    out["info_prms"] = np.array(g["get_training_params_info"](prms["training_params"]))
+    out["info_wts"] = np.array(g["get_wts_info"](wts))
+    out["info_wts_detailed"] = np.array(g["get_wts_info"](wts, True))
+    np.savez_compressed(os.path.join(HERE, "train_helpers.npz"), **out)
+
+
 if __name__ == "__main__":
     make_kat()
     make_init_ref()
+    make_train_helpers()
     make_gold_net("gold_a.npz", elastic_on=False)
     make_gold_net("gold_b.npz", elastic_on=True)
     make_deformer()

@@ -95,3 +95,40 @@ def test_product_never_imports_the_oracle():
     if re.search(r"^\s*(from|import)\s+oracle\b", src, re.M):
         bad.append("train.py")
     assert not bad, bad
+
+
+def test_train_py_helpers_match_the_reference_run_fixture():
+    """train.py's dataset coercion and rolling test windows against tests/golden/train_helpers.npz, which holds what
+    the REFERENCE's own fixdim (train.py:22-34) and get_test_indices (train.py:170-176) return (run from
+    /root/reference by tests/golden/make_golden.py::make_train_helpers; only inputs / outputs are stored)."""
+    import importlib.util
+    import numpy as np
+    spec = importlib.util.spec_from_file_location("tn_train", os.path.join(ROOT, "train.py"))
+    tr = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tr)                 # defines helpers only; run() needs a device
+    ref = np.load(os.path.join(ROOT, "tests", "golden", "train_helpers.npz"))
+    for k in range(5):
+        got = tr.as_nchw(ref["fixdim_in%d" % k])
+        assert got.shape == ref["fixdim_out%d" % k].shape and np.array_equal(got, ref["fixdim_out%d" % k])
+    with pytest.raises(ValueError):
+        tr.as_nchw(np.zeros((2, 2, 2, 2, 2), np.float32))
+    with pytest.raises(AssertionError):
+        tr.as_nchw(np.zeros((2, 50), np.float32))
+    for k in range(5):
+        tot, bsz, samp = (int(v) for v in ref["win_case%d" % k])
+        w = tr.BatchWindows(tot, bsz, samp)
+        seq = np.array([w.next() for _ in range(9)])
+        assert np.array_equal(seq, ref["win_seq%d" % k]), (tot, bsz, samp)
+    # the report strings of neuralnet.py:16-51, from the reference's own functions
+    import ast
+    from theanet_amd import neuralnet as nn
+    from oracle import theanet_oracle as O
+    with open(os.path.join(ROOT, "params", "mnist.prms")) as fh:
+        prms = ast.literal_eval(fh.read())
+    prms["layers"][0][1]["img_sz"] = 28
+    prms["training_params"]["SEED"] = 555555
+    wts = [[p for p in l.params] for l in O.OracleNet(prms["layers"], prms["training_params"]).L]   # adds CUR_EPOCH
+    assert nn.get_layers_info(prms["layers"]) == str(ref["info_layers"])
+    assert nn.get_training_params_info(prms["training_params"]) == str(ref["info_prms"])
+    assert nn.get_wts_info(wts) == str(ref["info_wts"])
+    assert nn.get_wts_info(wts, True) == str(ref["info_wts_detailed"])
