@@ -268,6 +268,17 @@ def make_train_helpers():
     out["info_prms"] = np.array(g["get_training_params_info"](prms["training_params"]))
     out["info_wts"] = np.array(g["get_wts_info"](wts))
     out["info_wts_detailed"] = np.array(g["get_wts_info"](wts, True))
+    # the elastic stage's gaussian (inlayers.py:87-91, pure numpy), from the reference text
+    iref = "/root/reference/theanet/layer/inlayers.py"
+    with open(iref) as fh:
+        ilines = fh.readlines()
+    fbody = textwrap.dedent("".join(ilines[86:91]))
+    assert fbody.startswith("var = sigma ** 2") and "filt /= 2 * np.pi * var" in fbody, fbody
+    fcode = compile(fbody, iref, "exec")
+    for sigma in (1, 2, 3, 4, 8):
+        g2 = {"np": np, "sigma": sigma, "float_x": "float32"}
+        exec(fcode, g2)
+        out["elastic_filt_sigma%d" % sigma] = g2["filt"]
     np.savez_compressed(os.path.join(HERE, "train_helpers.npz"), **out)
 
 

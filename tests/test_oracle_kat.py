@@ -162,6 +162,17 @@ def test_init_matches_the_reference_drawn_fixture():
         assert np.array_equal(w, ref["case%d_W" % j]) and np.array_equal(b, ref["case%d_b" % j]), act
 
 
+def test_elastic_gaussian_matches_the_reference_lines():
+    """The gaussian of the elastic stage as the REFERENCE's own lines build it (inlayers.py:87-91, run in place by
+    tests/golden/make_golden.py): float64 exponentials cast to float32, then a float32 division."""
+    ref = np.load(os.path.join(ROOT, "tests", "golden", "train_helpers.npz"))
+    for sigma in (1, 2, 3, 4, 8):
+        want = ref["elastic_filt_sigma%d" % sigma]
+        got = O.elastic_filter(sigma)
+        assert got.dtype == np.float32 and got.shape == (2 * sigma + 1, 2 * sigma + 1)
+        assert np.array_equal(got, want), sigma
+
+
 def test_kat7_lr_schedule():
     prms = _mnist_prms()
     prms["layers"][0][1]["img_sz"] = 28
