@@ -471,14 +471,15 @@ __global__ __launch_bounds__(256) void gemm_f32_fast(GemmArgs g) {
 // co-resident on every CU -- the prologue / epilogue of one product overlaps the main loop of the
 // other, and a kernel boundary disappears.
 template <bool A1, bool B1, bool S1, bool A2, bool B2, bool S2>
-__global__ __launch_bounds__(256) void gemm_f32_pair(GemmArgs g1, GemmArgs g2, int n1, int n2, ElField rider) {
+__global__ __launch_bounds__(256, 6) void gemm_f32_pair(GemmArgs g1, GemmArgs g2, int n1, int n2, ElField rider) {
     __shared__ __attribute__((aligned(16))) float smem[gemm_smem_floats<1, 1, 16>()];
     const int bid = blockIdx.x, grp = bid >> 3, l8 = bid & 7;
     if (bid >= n1 + n2) {
         // rider blocks behind the two products: a light independent job of the step (the elastic
         // field of the next minibatch) that disappears under the GEMMs instead of owning a launch
-        extern __shared__ float rider_lds[];
-        elastic_field_block<true>(rider, rider_lds, bid - n1 - n2);
+        // (it works in the GEMM tile's LDS: a launch-wide dynamic allocation on top of it would cost every block
+        // of the two products a sixth resident block per CU)
+        elastic_field_block<true>(rider, smem, bid - n1 - n2);
         return;
     }
     const int G1 = n1 >> 3, G2 = n2 >> 3, Gm = min(G1, G2);
@@ -1263,10 +1264,10 @@ int tn_fc_bwd(tn_ctx* ctx, const float* x, const float* dz, const float* W, floa
             int nrider = 0;
             size_t rlds = 0;
             ElField rider{};
-            if (ctx->rider_valid) {
+            if (ctx->rider_valid && ctx->rider_lds <= sizeof(float) * gemm_smem_floats<1, 1, 16>()) {
                 rider = ctx->rider;
                 nrider = cdiv(rider.h * rider.w, 4);
-                rlds = ctx->rider_lds;
+                rlds = 0;                                  // the rider works in the tile's static LDS
                 ctx->rider_valid = false;
             }
             gemm_f32_pair<false, false, true, true, true, false><<<n1 + n2 + nrider, 256, rlds, ctx->stream>>>(
