@@ -154,6 +154,39 @@ __device__ __forceinline__ float tn_act_grad_from_out(float a, int act, float pr
     }
 }
 
+// Four values behind ONE wave-uniform test of the activation kind.  Epilogues that called the two functions above
+// per element paid the whole switch every time (fc_skinny_softmax_train's input-gradient phase: 401 scalar branches
+// for 32 elements, 5.5 of the block's 12.6 us); the leaky-ReLU family -- every default of the reference
+// (convpool.py:19, hidden.py:16) -- is straight-line code here, same expressions, same bits.
+__device__ __forceinline__ void tn_act_fwd4(float4& v, int act, float prm) {
+    if (act == TN_ACT_LEAKY) {
+        v.x = fmaxf(0.f, v.x) + fminf(0.f, v.x) * prm;
+        v.y = fmaxf(0.f, v.y) + fminf(0.f, v.y) * prm;
+        v.z = fmaxf(0.f, v.z) + fminf(0.f, v.z) * prm;
+        v.w = fmaxf(0.f, v.w) + fminf(0.f, v.w) * prm;
+    } else if (act != TN_ACT_LINEAR) {
+        v.x = tn_act_fwd(v.x, act, prm);
+        v.y = tn_act_fwd(v.y, act, prm);
+        v.z = tn_act_fwd(v.z, act, prm);
+        v.w = tn_act_fwd(v.w, act, prm);
+    }
+}
+// s *= act'(a), a = the layer's OUTPUT
+__device__ __forceinline__ void tn_act_grad4(float4& s, const float4& a, int act, float prm) {
+    if (act == TN_ACT_LEAKY) {
+        const float tie = prm > 0.f ? 1.f + prm : 0.f;
+        s.x *= a.x > 0.f ? 1.f : (a.x < 0.f ? prm : tie);
+        s.y *= a.y > 0.f ? 1.f : (a.y < 0.f ? prm : tie);
+        s.z *= a.z > 0.f ? 1.f : (a.z < 0.f ? prm : tie);
+        s.w *= a.w > 0.f ? 1.f : (a.w < 0.f ? prm : tie);
+    } else if (act != TN_ACT_LINEAR) {
+        s.x *= tn_act_grad_from_out(a.x, act, prm);
+        s.y *= tn_act_grad_from_out(a.y, act, prm);
+        s.z *= tn_act_grad_from_out(a.z, act, prm);
+        s.w *= tn_act_grad_from_out(a.w, act, prm);
+    }
+}
+
 // ---------------------------------------------------------------------------
 // The two expressions of the momentum-SGD update (layer.py:82-86), with their roundings spelled out:
 // several kernels apply them (one step at a time / lazy slabs / delayed / two steps in flight) and the

@@ -189,10 +189,8 @@ __device__ __forceinline__ void gemm_epilogue_vec(const GemmArgs& g, f32x16 (&ac
         float4 v = *reinterpret_cast<const float4*>(sC + rl * LDC + c4);
         const size_t o = (size_t)min(row, g.M - 1) * g.ldc + colc;
         if (g.epi == EPI_FWD) {
-            v.x = tn_act_fwd(v.x + bias.x, g.act, g.act_prm);
-            v.y = tn_act_fwd(v.y + bias.y, g.act, g.act_prm);
-            v.z = tn_act_fwd(v.z + bias.z, g.act, g.act_prm);
-            v.w = tn_act_fwd(v.w + bias.w, g.act, g.act_prm);
+            v.x += bias.x; v.y += bias.y; v.z += bias.z; v.w += bias.w;
+            tn_act_fwd4(v, g.act, g.act_prm);
             if (g.drop_out) {
                 // element e = elem0 + row*N + col uses word (e & 3) of philox(e >> 2): same
                 // numbers as tn_dropout_mask (dropout_mask_kernel)
@@ -206,10 +204,7 @@ __device__ __forceinline__ void gemm_epilogue_vec(const GemmArgs& g, f32x16 (&ac
                 if (cok && row < g.M) *reinterpret_cast<uint32_t*>(g.drop_out + o) = m;
             }
         } else if (g.epi == EPI_DGRAD && g.prev_a) {
-            v.x *= tn_act_grad_from_out(pa[p].x, g.act, g.act_prm);
-            v.y *= tn_act_grad_from_out(pa[p].y, g.act, g.act_prm);
-            v.z *= tn_act_grad_from_out(pa[p].z, g.act, g.act_prm);
-            v.w *= tn_act_grad_from_out(pa[p].w, g.act, g.act_prm);
+            tn_act_grad4(v, pa[p], g.act, g.act_prm);
         }
         if (g.epi != EPI_PLAIN && (g.mask || g.drop_out)) {
             v.x *= (float)(pm[p] & 0xffu);
@@ -590,10 +585,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_f32_deep(GemmArgs g) {
         if (g.bias) {
             v.x += g.bias[col]; v.y += g.bias[col + 1]; v.z += g.bias[col + 2]; v.w += g.bias[col + 3];
         }
-        v.x = tn_act_fwd(v.x, g.act, g.act_prm);
-        v.y = tn_act_fwd(v.y, g.act, g.act_prm);
-        v.z = tn_act_fwd(v.z, g.act, g.act_prm);
-        v.w = tn_act_fwd(v.w, g.act, g.act_prm);
+        tn_act_fwd4(v, g.act, g.act_prm);
         if (g.drop_out) {      // same numbers as gemm_epilogue_vec / tn_dropout_mask
             const uint32_t dst = g.dstep + (g.d_step ? *g.d_step : 0u);
             const uint64_t cq = (g.elem0 + (uint64_t)row * (uint64_t)g.N + (uint64_t)col) >> 2;
@@ -604,10 +596,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_f32_deep(GemmArgs g) {
         }
     } else if (g.epi == EPI_DGRAD && g.prev_a) {
         const float4 pa4 = *reinterpret_cast<const float4*>(g.prev_a + o);
-        v.x *= tn_act_grad_from_out(pa4.x, g.act, g.act_prm);
-        v.y *= tn_act_grad_from_out(pa4.y, g.act, g.act_prm);
-        v.z *= tn_act_grad_from_out(pa4.z, g.act, g.act_prm);
-        v.w *= tn_act_grad_from_out(pa4.w, g.act, g.act_prm);
+        tn_act_grad4(v, pa4, g.act, g.act_prm);
     }
     if (g.epi != EPI_PLAIN && (g.mask || g.drop_out)) {
         v.x *= (float)(pm & 0xffu);
@@ -1269,6 +1258,19 @@ int tn_fc_bwd(tn_ctx* ctx, const float* x, const float* dz, const float* W, floa
                 nrider = cdiv(rider.h * rider.w, 4);
                 rlds = 0;                                  // the rider works in the tile's static LDS
                 ctx->rider_valid = false;
+            }
+            {
+                // Residency cap: 8 KB of unused dynamic LDS per block = five blocks per CU instead of six.  Alone on
+                // the GPU six are faster (60.2 vs 61.5 us); with two steps in flight the launch shares the chip with
+                // the other stream's forward kernels, and five blocks x 80 registers leave them a fifth of the
+                // register file (six leave 32 registers per lane: nothing else fits and the streams take turns):
+                // 176-177 vs 180 us per step (TN_PAIR_LDS_PAD=0 / 12000 / 20000 for the A/B).
+                static int pad = -1;
+                if (pad < 0) {
+                    const char* e = getenv("TN_PAIR_LDS_PAD");
+                    pad = e ? atoi(e) : 8192;
+                }
+                rlds += (size_t)pad;
             }
             gemm_f32_pair<false, false, true, true, true, false><<<n1 + n2 + nrider, 256, rlds, ctx->stream>>>(
                 g1, g2, n1, n2, rider);

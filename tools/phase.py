@@ -32,3 +32,23 @@ for i, (s, e, n) in enumerate(act):
 tot = sum(ov.values())
 for k, v in ov.most_common(14):
     print("  %5.1f %%  %s  |  %s" % (100 * v / tot, k[0], k[1]))
+
+# ---- per queue: where the idle time sits (gap in front of each kernel, mean over the steady-state window)
+from collections import defaultdict
+byq = defaultdict(list)
+for s, e, n, q in rows:
+    if t0 <= s < t1:
+        byq[q].append((s, e, n))
+for q, ks in byq.items():
+    if len(ks) < 100:
+        continue
+    gaps, durs = defaultdict(list), defaultdict(list)
+    for (s0, e0, n0), (s1, e1, n1) in zip(ks, ks[1:]):
+        gaps[n1].append(max(0, s1 - e0) / 1e3)
+        durs[n1].append((e1 - s1) / 1e3)
+    tot_g = sum(sum(v) for v in gaps.values())
+    tot_d = sum(sum(v) for v in durs.values())
+    nst = sum(1 for _, _, n in ks if n.startswith("sgd_update_pipe"))
+    print("queue %s: %d steps, kernels %.1f us/step, idle %.1f us/step" % (q, nst, tot_d / nst, tot_g / nst))
+    for n in sorted(gaps, key=lambda k: -sum(gaps[k])):
+        print("    gap before %-32s %6.1f us (kernel %6.1f us)" % (n, sum(gaps[n]) / len(gaps[n]), sum(durs[n]) / len(durs[n])))
