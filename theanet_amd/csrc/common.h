@@ -43,6 +43,9 @@ struct tn_ctx {
     hipEvent_t copy_ev = nullptr;
     hipEvent_t sync_ev[2] = {nullptr, nullptr};
     int num_cus = 256;
+    // heavy launches since the second stream was last selected: small = two steps in flight share the GPU
+    // (tn_fc_bwd then leaves the other stream's kernels a share of the register file), large = this stream has it alone
+    int heavy_since_side = 1 << 20;
     // matmul operand precision of the 3x3 conv products (tn_set_matmul_dtype): 0 fp32, 1 fp16 operands /
     // fp32 accumulate; grad_scale: power of two applied to dz before it is rounded to fp16
     int mm_f16 = 0;

@@ -111,6 +111,7 @@ int tn_stream_select(tn_ctx* ctx, int idx) {
         for (int i = 0; i < ctx->npend; ++i) ctx->pend[i] = ctx->pend_slot[idx][i];
         ctx->defer_slot[idx] = false; ctx->scratch_off_slot[idx] = 0; ctx->npend_slot[idx] = 0;
     }
+    if (idx == 1) ctx->heavy_since_side = 0;
     ctx->stream = ctx->streams[idx];
     return TN_OK;
 }

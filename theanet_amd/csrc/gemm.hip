@@ -1260,17 +1260,23 @@ int tn_fc_bwd(tn_ctx* ctx, const float* x, const float* dz, const float* W, floa
                 ctx->rider_valid = false;
             }
             {
-                // Residency cap: 8 KB of unused dynamic LDS per block = five blocks per CU instead of six.  Alone on
-                // the GPU six are faster (60.2 vs 61.5 us); with two steps in flight the launch shares the chip with
-                // the other stream's forward kernels, and five blocks x 80 registers leave them a fifth of the
-                // register file (six leave 32 registers per lane: nothing else fits and the streams take turns):
-                // 176-177 vs 180 us per step (TN_PAIR_LDS_PAD=0 / 12000 / 20000 for the A/B).
-                static int pad = -1;
-                if (pad < 0) {
+                // Residency cap while two steps are in flight: 8 KB of unused dynamic LDS per block = five blocks per
+                // CU instead of six.  Alone on the GPU six are faster (60.2 vs 63.2 us); with two steps in flight the
+                // launch shares the chip with the other stream's forward kernels, and five blocks x 80 registers
+                // leave them a fifth of the register file (six leave 32 registers per lane: nothing else fits and the
+                // streams take turns): 176-177 vs 180 us per step.  "In flight" = the second stream was selected
+                // within the last few heavy launches (tn_stream_select); TN_PAIR_LDS_PAD=n forces a pad for an A/B.
+                static int pad = -2;
+                if (pad == -2) {
                     const char* e = getenv("TN_PAIR_LDS_PAD");
-                    pad = e ? atoi(e) : 8192;
+                    pad = e ? atoi(e) : -1;
                 }
-                rlds += (size_t)pad;
+                if (pad >= 0)
+                    rlds += (size_t)pad;
+                else if (ctx->heavy_since_side < 3) {
+                    ctx->heavy_since_side++;
+                    rlds += 8192;
+                }
             }
             gemm_f32_pair<false, false, true, true, true, false><<<n1 + n2 + nrider, 256, rlds, ctx->stream>>>(
                 g1, g2, n1, n2, rider);
