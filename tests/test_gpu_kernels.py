@@ -643,6 +643,30 @@ def test_sgd_update_and_maxnorm():
     assert_close(cost.get_value()[0], 2 + .01 * np.abs(p).sum() + .02 * (p * p).sum())
 
 
+def test_maxnorm_leaves_tensors_within_the_bound_untouched():
+    """layer.py:88-103 with columns / kernels on both sides of the bound: those within it have a factor of exactly
+    (1e-7 + n) / (1e-7 + n) = 1 and must come back bit for bit (the kernels skip them), the others are rescaled."""
+    rng = np.random.RandomState(3)
+    W = rng.randn(300, 130).astype(np.float32)
+    W[:, ::2] *= 0.01                                   # every other column far inside the bound
+    Wd = dev(W)
+    call("tn_maxnorm", Wd.ptr, 2, 300, 130, 2.0)
+    got = Wd.get_value()
+    assert np.array_equal(got[:, ::2], W[:, ::2])
+    nrm = np.sqrt((W.astype(np.float64) ** 2).sum(0))
+    want = W * ((1e-7 + np.clip(nrm, 0, 2.0)) / (1e-7 + nrm))
+    assert_close(got, want, atol=1e-6, what="2-D maxnorm")
+    K = rng.randn(12, 3, 3, 3).astype(np.float32)
+    K[::3] *= 0.01
+    Kd = dev(K)
+    call("tn_maxnorm", Kd.ptr, 4, 12, 27, 1.0)
+    got = Kd.get_value()
+    assert np.array_equal(got[::3], K[::3])
+    nrm = np.sqrt((K.astype(np.float64) ** 2).sum((1, 2, 3)))
+    assert_close(got, K * ((1e-7 + np.clip(nrm, 0, 1.0)) / (1e-7 + nrm))[:, None, None, None], atol=1e-6,
+                 what="4-D maxnorm")
+
+
 def test_dropout_mask_statistics_and_sharding_invariance():
     n = 4096 * 500
     m = empty((n,), np.uint8)
