@@ -162,6 +162,38 @@ def test_cifar_like_net_matches_oracle(fuse):
     _random_net_case(layers, 32, 16, 3, 10)
 
 
+@pytest.mark.parametrize("B", [1, 3, 20, 37])
+def test_ragged_and_minimum_batches_match_oracle(B, fuse):
+    """mnist.prms-shaped net at batch sizes that fill no tile: one image, odd counts, the .prms file's own 20 --
+    partial MFMA tiles in every product, partial last pooling windows (11 -> 6), short split-K, one-block grids."""
+    layers = [
+        ("InputLayer", {"img_sz": 28, "num_maps": 1}),
+        ("ConvLayer", {"num_maps": 4, "filter_sz": 3, "stride": 1, "actvn": "relu10"}),
+        ("PoolLayer", {"pool_sz": 2}),
+        ("ConvLayer", {"num_maps": 20, "filter_sz": 3, "stride": 1, "actvn": "relu05"}),
+        ("PoolLayer", {"pool_sz": 2}),
+        ("HiddenLayer", {"n_out": 500, "pdrop": .5, "actvn": "relu01"}),
+        ("SoftmaxLayer", {"n_out": 10}),
+    ]
+    _random_net_case(layers, B, 28, 1, 10, seed=B)
+
+
+def test_strided_conv_ignore_border_pool_and_odd_maps_match_oracle():
+    """stride-2 convolution, floor-mode pooling (ignore_border: last row / column in no window), 5x5 filters, odd
+    map sizes, a stand-alone DropOutLayer in front of a MeanLayer."""
+    layers = [
+        ("InputLayer", {"img_sz": 26, "num_maps": 2}),
+        ("ConvLayer", {"num_maps": 6, "filter_sz": 5, "stride": 2, "actvn": "relu05"}),        # 26 -> 22 -> 11 (stride 2)
+        ("PoolLayer", {"pool_sz": 2, "ignore_border": True}),
+        ("ConvLayer", {"num_maps": 7, "filter_sz": 3, "stride": 1, "mode": "same", "actvn": "sigmoid"}),
+        ("DropOutLayer", {"pdrop": .3}),
+        ("MeanLayer", {}),
+        ("HiddenLayer", {"n_out": 33, "actvn": "softplus"}),
+        ("SoftmaxLayer", {"n_out": 5}),
+    ]
+    _random_net_case(layers, 9, 26, 2, 5, seed=11)      # pool: 11 -> 5 (the last row / column is dropped)
+
+
 def test_mlp_3flat_like_net_matches_oracle():
     layers = [
         ("InputLayer", {"img_sz": 12, "num_maps": 1}),
