@@ -165,9 +165,25 @@ def main():
         tune_steps += 1
     # ... and every run takes a few untimed set-up steps (the twin net of the two-steps-in-flight
     # schedule is built on the first call; clocks and allocators settle) before the W warm-up steps
-    setup_steps = tune_steps + 48
+    # (the GPU comes out of seconds of idle while the net was built: 48 + 5 steps = 10 ms of load left the first 20
+    # timed steps at 193-196 us, 180 ms of load at 180-182 us, the steady state being 177 -- tools/probe_start.py: a
+    # 50 ms host pause alone costs the next 20 steps 25 %.  So the set-up runs for at least 0.2 s, synchronised.)
+    # Every rank must take the same number of steps (each one is a collective): the first 48 are timed and the
+    # count that fills 0.2 s is the maximum over ranks.
+    t_setup = time.perf_counter()
     for i in range(48):
         fn.enqueue(i % n_batches)
+    ctx.sync()
+    per_step = max((time.perf_counter() - t_setup) / 48, 1e-6)
+    more = float(min(20000, max(0, int(0.2 / per_step) - 48)))
+    if group is not None:
+        more = group.rdzv.gather_max(more)
+    n_setup = 48 + 16 * ((int(more) + 15) // 16)
+    for i in range(48, n_setup):
+        fn.enqueue(i % n_batches)
+        if i % 16 == 15:
+            ctx.sync()
+    setup_steps = tune_steps + n_setup
     for i in range(args.warmup):
         fn.enqueue(i % n_batches)
     barrier()
