@@ -1275,7 +1275,9 @@ int tn_fc_bwd(tn_ctx* ctx, const float* x, const float* dz, const float* W, floa
                     rlds += (size_t)pad;
                 else if (ctx->heavy_since_side < 3) {
                     ctx->heavy_since_side++;
-                    rlds += 8192;
+                    // (launches with many block rounds per CU gain nothing from sharing: cifar_like's 3072-block
+                    // fc backward is 0.7 % of a step slower with the pad)
+                    if (n1 + n2 <= 8 * ctx->num_cus) rlds += 8192;
                 }
             }
             gemm_f32_pair<false, false, true, true, true, false><<<n1 + n2 + nrider, 256, rlds, ctx->stream>>>(
