@@ -29,7 +29,10 @@ stats mnist512_pipe --batch 512 --steps 200 --warmup 20 --no-roofline
 # ---- the wider configurations (BASELINE.json configs 4 and 5), fp32 and fp16 operands
 for c in cifar_like wide6; do
     for d in f32 f16; do
-        stats ${c}_${d} --prms $c.prms --dtype $d --steps 10 --warmup 3
+        # one step at a time, like the roofline leg of bench.py: with two steps in flight the launches of the two
+        # streams share the GPU and a kernel's duration in the trace is not its own
+        stats ${c}_${d} --prms $c.prms --dtype $d --sequential --steps 10 --warmup 3
+        stats ${c}_${d}_pipe --prms $c.prms --dtype $d --steps 10 --warmup 3 --no-roofline
         pmc ${c}_${d}_fetch FETCH_SIZE --prms $c.prms --dtype $d --sequential --steps 3 --warmup 1
         pmc ${c}_${d}_write WRITE_SIZE --prms $c.prms --dtype $d --sequential --steps 3 --warmup 1
         pmc ${c}_${d}_mfma "$MFMA" --prms $c.prms --dtype $d --sequential --steps 3 --warmup 1

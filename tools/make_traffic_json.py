@@ -33,10 +33,14 @@ CONFIGS = {  # name -> (stats dir, pmc prefix, description)
     "mnist_bs4096_pipelined": ("mnist_pipe", None, "mnist.prms, 4096 images/step, two steps in flight (default schedule)"),
     "mnist_bs512": ("mnist512_seq", None, "mnist.prms, 512 images/step (one rank of the 8-GPU strong-scaling run), one step at a time"),
     "mnist_bs512_pipelined": ("mnist512_pipe", None, "mnist.prms, 512 images/step, two steps in flight"),
-    "cifar_like_f32": ("cifar_like_f32", "cifar_like_f32", "cifar_like.prms, 2048 images/step, fp32"),
-    "cifar_like_f16": ("cifar_like_f16", "cifar_like_f16", "cifar_like.prms, 2048 images/step, fp16 conv operands"),
-    "wide6_f32": ("wide6_f32", "wide6_f32", "wide6.prms 64x64x3, 128 images/step, fp32"),
-    "wide6_f16": ("wide6_f16", "wide6_f16", "wide6.prms 64x64x3, 128 images/step, fp16 conv operands"),
+    "cifar_like_f32": ("cifar_like_f32", "cifar_like_f32", "cifar_like.prms, 2048 images/step, fp32, one step at a time (bench.py --sequential)"),
+    "cifar_like_f16": ("cifar_like_f16", "cifar_like_f16", "cifar_like.prms, 2048 images/step, fp16 conv operands, one step at a time"),
+    "wide6_f32": ("wide6_f32", "wide6_f32", "wide6.prms 64x64x3, 128 images/step, fp32, one step at a time"),
+    "wide6_f16": ("wide6_f16", "wide6_f16", "wide6.prms 64x64x3, 128 images/step, fp16 conv operands, one step at a time"),
+    "cifar_like_f32_pipelined": ("cifar_like_f32_pipe", None, "cifar_like.prms, 2048 images/step, fp32, two steps in flight (default schedule: kernel durations include the other stream's share of the GPU)"),
+    "cifar_like_f16_pipelined": ("cifar_like_f16_pipe", None, "cifar_like.prms, 2048 images/step, fp16 conv operands, two steps in flight"),
+    "wide6_f32_pipelined": ("wide6_f32_pipe", None, "wide6.prms 64x64x3, 128 images/step, fp32, two steps in flight"),
+    "wide6_f16_pipelined": ("wide6_f16_pipe", None, "wide6.prms 64x64x3, 128 images/step, fp16 conv operands, two steps in flight"),
 }
 
 
