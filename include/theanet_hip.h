@@ -333,6 +333,16 @@ int tn_defer_discard(tn_ctx* ctx);
 int tn_sgd_update(tn_ctx* ctx, float* p, float* v, const float* g, size_t n,
                   float momentum, float rate, const float* d_lr, float L1, float L2, float gscale);
 int tn_maxnorm(tn_ctx* ctx, float* p, int ndim, int d0, int rest, float maxnorm);
+/* The same projection for EVERY tensor of the net in one call (layer.py:88-103 runs once per parameter): the 1-D and
+ * 4-D tensors -- biases and conv kernels, a few hundred to a few thousand values each -- share ONE launch instead
+ * of one launch per tensor (13 launch-bound kernels per step of wide6.prms), 2-D tensors take tn_maxnorm's two-pass
+ * path.  h_segs: HOST array of nseg <= 32 descriptors.                                                     */
+typedef struct tn_mn_seg {
+    float* p;
+    int32_t ndim, d0, rest;
+    float maxnorm;
+} tn_mn_seg;
+int tn_maxnorm_multi(tn_ctx* ctx, const tn_mn_seg* h_segs, int nseg);
 /* The same update for EVERY parameter tensor of the net in one launch.  d_segs = device
  * array of nseg descriptors; max_n = largest n among them (sizes the grid).               */
 typedef struct tn_sgd_seg {

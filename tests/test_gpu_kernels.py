@@ -667,6 +667,27 @@ def test_maxnorm_leaves_tensors_within_the_bound_untouched():
                  what="4-D maxnorm")
 
 
+def test_maxnorm_multi_equals_per_tensor_calls():
+    """tn_maxnorm_multi (every tensor of a net in one call: the 1-D / 4-D ones share a launch) gives the same bits as
+    tn_maxnorm per tensor; maxnorm 0 and NULL entries are skipped."""
+    rng = np.random.RandomState(5)
+    shapes = [(20, 4, 3, 3), (20,), (300, 130), (130,), (64, 32, 3, 3), (64,), (7, 1, 5, 5), (700,)]
+    mxs = [1.0, 0.5, 2.0, 0.3, 3.0, 0.0, 0.8, 0.9]
+    hosts = [rng.randn(*sh).astype(np.float32) for sh in shapes]
+    a, b = [dev(h) for h in hosts], [dev(h) for h in hosts]
+    dt = np.dtype([('p', 'u8'), ('ndim', 'i4'), ('d0', 'i4'), ('rest', 'i4'), ('mx', 'f4')])
+    tab = np.array([(d.ptr, len(sh), sh[0], 1 if len(sh) == 1 else int(np.prod(sh[1:])), mx)
+                    for d, sh, mx in zip(a, shapes, mxs)], dtype=dt)
+    call("tn_maxnorm_multi", tab.ctypes.data, len(tab))
+    for d, sh, mx in zip(b, shapes, mxs):
+        if mx:
+            call("tn_maxnorm", d.ptr, len(sh), sh[0], 1 if len(sh) == 1 else int(np.prod(sh[1:])), mx)
+    for x, y, h, mx in zip(a, b, hosts, mxs):
+        assert np.array_equal(x.get_value(), y.get_value())
+        assert mx or np.array_equal(x.get_value(), h)
+        assert not mx or not np.array_equal(x.get_value(), h)
+
+
 def test_dropout_mask_statistics_and_sharding_invariance():
     n = 4096 * 500
     m = empty((n,), np.uint8)

@@ -98,6 +98,7 @@ SIGNATURES = {
     "tn_error_stats": (c_int, [CTX, P, P, c_int64, P, c_int, P]),
     "tn_sgd_update": (c_int, [CTX, P, P, P, c_size_t, c_float, c_float, P, c_float, c_float, c_float]),
     "tn_maxnorm": (c_int, [CTX, P, c_int, c_int, c_int, c_float]),
+    "tn_maxnorm_multi": (c_int, [CTX, P, c_int]),
     "tn_defer_reductions": (c_int, [CTX, c_int]),
     "tn_defer_flush_step": (c_int, [CTX, P]),
     "tn_defer_discard": (c_int, [CTX]),

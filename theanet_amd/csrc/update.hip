@@ -434,6 +434,43 @@ __global__ __launch_bounds__(256) void maxnorm_cols_scale(float* __restrict__ p,
     for (int r = rb + r0; r < re; r += 4) p[(size_t)r * cols + c] *= sc;
 }
 
+// every 1-D / 4-D tensor of a net in one launch: blockIdx.y = tensor, blockIdx.x = leading index (4-D: one block
+// per kernel, the arithmetic of maxnorm_rows_kernel) or 256-element chunk (1-D: clip_kernel)
+struct MnBatch {
+    float* p[32];
+    int32_t kind[32], d0[32], rest[32];     // kind: 1 or 4
+    float mx[32];
+};
+__global__ __launch_bounds__(256) void maxnorm_multi_kernel(MnBatch b) {
+    __shared__ float red[4];
+    __shared__ float scale_s;
+    const int s = blockIdx.y;
+    float* __restrict__ p = b.p[s];
+    const float mx = b.mx[s];
+    if (b.kind[s] == 1) {
+        const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+        if (i < (size_t)b.d0[s]) p[i] = fminf(fmaxf(p[i], -mx), mx);
+        return;
+    }
+    if ((int)blockIdx.x >= b.d0[s]) return;
+    const int rest = b.rest[s];
+    float* row = p + (size_t)blockIdx.x * rest;
+    float a = 0.f;
+    for (int i = threadIdx.x; i < rest; i += 256) a += row[i] * row[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float nrm = sqrtf(red[0] + red[1] + red[2] + red[3]);
+        scale_s = (1e-7f + fminf(fmaxf(nrm, 0.f), mx)) / (1e-7f + nrm);
+    }
+    __syncthreads();
+    const float sc = scale_s;
+    if (sc == 1.f) return;
+    for (int i = threadIdx.x; i < rest; i += 256) row[i] *= sc;
+}
+
 extern "C" {
 
 int tn_sgd_update(tn_ctx* ctx, float* p, float* v, const float* g, size_t n, float momentum,
@@ -589,6 +626,31 @@ int tn_maxnorm(tn_ctx* ctx, float* p, int ndim, int d0, int rest, float maxnorm)
         return tn_fail(ctx, TN_E_ARG, "tn_maxnorm: ndim %d unsupported (1, 2 or 4)", ndim);
     }
     TN_LAUNCH_CHECK();
+    return TN_OK;
+}
+
+int tn_maxnorm_multi(tn_ctx* ctx, const tn_mn_seg* h_segs, int nseg) {
+    TN_REQUIRE(nseg >= 0 && nseg <= 32 && (nseg == 0 || h_segs), "tn_maxnorm_multi: bad arguments");
+    MnBatch b{};
+    int nb = 0, gx = 1;
+    for (int i = 0; i < nseg; ++i) {
+        const tn_mn_seg& sg = h_segs[i];
+        if (sg.maxnorm == 0.f || !sg.p) continue;
+        if (sg.ndim == 2) {
+            int rc = tn_maxnorm(ctx, sg.p, 2, sg.d0, sg.rest, sg.maxnorm);
+            if (rc) return rc;
+            continue;
+        }
+        TN_REQUIRE(sg.ndim == 1 || sg.ndim == 4, "tn_maxnorm_multi: ndim %d unsupported (1, 2 or 4)", sg.ndim);
+        b.p[nb] = sg.p; b.kind[nb] = sg.ndim; b.d0[nb] = sg.d0; b.rest[nb] = sg.rest; b.mx[nb] = sg.maxnorm;
+        const int blocks = sg.ndim == 1 ? cdiv(sg.d0, 256) : sg.d0;
+        if (blocks > gx) gx = blocks;
+        ++nb;
+    }
+    if (nb) {
+        maxnorm_multi_kernel<<<dim3(gx, nb), 256, 0, ctx->stream>>>(b);
+        TN_LAUNCH_CHECK();
+    }
     return TN_OK;
 }
 

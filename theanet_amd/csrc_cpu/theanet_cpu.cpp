@@ -1168,4 +1168,14 @@ int tn_axpby(tn_ctx*, float* y, const float* x, size_t n, float a, float b) {
     return TN_OK;
 }
 
+int tn_maxnorm_multi(tn_ctx* ctx, const tn_mn_seg* h_segs, int nseg) {
+    if (nseg < 0 || nseg > 32 || (nseg && !h_segs)) return fail(ctx, TN_E_ARG, "tn_maxnorm_multi: bad arguments");
+    for (int i = 0; i < nseg; ++i) {
+        if (h_segs[i].maxnorm == 0.f || !h_segs[i].p) continue;
+        int rc = tn_maxnorm(ctx, h_segs[i].p, h_segs[i].ndim, h_segs[i].d0, h_segs[i].rest, h_segs[i].maxnorm);
+        if (rc) return rc;
+    }
+    return TN_OK;
+}
+
 }  // extern "C"

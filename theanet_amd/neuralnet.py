@@ -280,8 +280,7 @@ class _PipeTrainFn:
                  out.rowloss.ptr if rider else None, X.local_bsz, 1.0 / X.batch_sz,
                  X.d_cost.ptr if rider else None)
         X._cost_pending = False
-        for lyr in X.tr_layers:
-            lyr.apply_maxnorm()
+        X._apply_maxnorm_all()
         ctx.call("tn_event_record", self._ev[k])
 
     def sync_weights(self):
@@ -1050,8 +1049,27 @@ class NeuralNet():
             ctx.call("tn_add_u32", self.d_step.ptr, 1)
         if ahead:
             first._cur, first._pre_valid = nxt, True
-        for lyr in self.tr_layers:
-            lyr.apply_maxnorm()
+        self._apply_maxnorm_all()
+
+    def _apply_maxnorm_all(self):
+        """layer.py:88-103 for every parameter of the net in ONE call (tn_maxnorm_multi: the biases and conv kernels
+        share a launch; Layer.apply_maxnorm is the per-layer form of the same projection)."""
+        tab = getattr(self, "_mn_tab", None)
+        if tab is None:
+            rows = []
+            for lyr in self.tr_layers:
+                if not lyr.has_updates() or not lyr.reg['maxnorm']:
+                    continue
+                for p in lyr.params:
+                    if p.ndim in (1, 2, 4):
+                        rows.append((p.ptr, p.ndim, p.shape[0],
+                                     1 if p.ndim == 1 else int(np.prod(p.shape[1:])), float(lyr.reg['maxnorm'])))
+            dt = np.dtype([('p', 'u8'), ('ndim', 'i4'), ('d0', 'i4'), ('rest', 'i4'), ('mx', 'f4')])
+            assert dt.itemsize == 24          # tn_mn_seg
+            tab = self._mn_tab = np.array(rows, dtype=dt) if rows else np.zeros((0,), dt)
+        for i in range(0, len(tab), 32):
+            chunk = tab[i:i + 32]
+            self.ctx.call("tn_maxnorm_multi", chunk.ctypes.data, len(chunk))
 
     # ------------------------------------------------------------------------------
     def get_trin_model(self, x_data, y_data, aux_data=None,
