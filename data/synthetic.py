@@ -25,3 +25,11 @@ _rng = np.random.default_rng(2016)
 _protos = (_rng.random((10, _c, _hw, _hw), dtype=np.float32) > .7).astype(np.float32)
 training_x, training_y = make(_n_tr, _rng, _protos)
 testing_x, testing_y = make(_n_te, _rng, _protos)
+if os.environ.get("THEANET_SYNTH_AUX"):
+    # per-sample side input for AuxConcatLayer / SoftAuxLayer nets (reference train.py:133-137): two candidate 2-D
+    # locations per sample, the second one class-dependent
+    def _aux(n, y):
+        a = _rng.random((n, 2, 2), dtype=np.float32)
+        a[:, 1, 0] = y / 10.0
+        return a
+    training_aux, testing_aux = _aux(_n_tr, training_y), _aux(_n_te, testing_y)

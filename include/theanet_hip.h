@@ -398,7 +398,8 @@ int tn_sgd_update_multi_pipe(tn_ctx* ctx, const tn_pipe_seg* d_segs, const tn_pi
  * still a stack of deferred partial slabs sums them on the fly (same order as the reduction launch:
  * bit-identical), stores the gradient and applies the update -- one launch less per step.  h_segs is
  * the host copy of d_segs (used to match pending sums to segments); pending sums that belong to no
- * segment are finished by the ordinary reduction launch first.  nseg <= 16.                   */
+ * segment are finished by the ordinary reduction launch first.  nseg <= 32 (TN_LAZY_SEGS); the pipelined
+ * form takes any nseg and folds nothing in beyond that (the reduction launch finishes those sums).    */
 int tn_sgd_update_multi_lazy(tn_ctx* ctx, const tn_sgd_seg* d_segs, const tn_sgd_seg* h_segs, int nseg,
                              size_t max_n, const float* d_lr, float gscale, uint32_t* d_step_inc,
                              const float* rowloss, int nrow, float cost_scale, float* d_cost);

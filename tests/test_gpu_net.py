@@ -548,6 +548,31 @@ def test_train_py_end_to_end(tmp_path):
     assert ck["training_params"]["CUR_EPOCH"] >= 2 and len(ck["allwts"]) == 7
 
 
+def test_train_py_passes_aux_data_and_reports_exploss_features(tmp_path):
+    """train.py hands data.training_aux / testing_aux to the three function builders (reference train.py:133-145;
+    round-2 ADVICE: an aux net died at 'Auxillary data not supplied') and keeps the ExpLoss diagnostic of the
+    reference's loop (train.py:216-222)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tp = {"SEED": 5, "BATCH_SZ": 32, "NUM_EPOCHS": 2, "EPOCHS_TO_TEST": 1, "TEST_SAMP_SZ": 64,
+          "INIT_LEARNING_RATE": .05, "EPOCHS_TO_HALF_RATE": 1}
+    nets = {"aux": [("InputLayer", {}), ("ConvLayer", {"num_maps": 3, "filter_sz": 3, "stride": 1}),
+                    ("HiddenLayer", {"n_out": 16}),
+                    ("AuxConcatLayer", {"n_aux": (5, 4), "aux_type": "LocationInfo"}), ("SoftmaxLayer", {"n_out": 10})],
+            "exp": [("InputLayer", {}), ("HiddenLayer", {"n_out": 16}), ("ExpLossLayer", {"n_out": 10})]}
+    for name, layers in nets.items():
+        prm = tmp_path / (name + ".prms")
+        prm.write_text(repr({"layers": layers, "training_params": dict(tp)}))
+        env = dict(os.environ, THEANET_SYNTH_TRAIN="128", THEANET_SYNTH_TEST="64", THEANET_SYNTH_SIZE="12",
+                   THEANET_SYNTH_AUX="1", THEANET_NO_PICKLE="1", PYTHONPATH=root)
+        r = subprocess.run([sys.executable, os.path.join(root, "train.py"), "synthetic", str(prm)],
+                           cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+        rows = [l for l in r.stdout.splitlines() if l.strip().startswith(("0 ", "1 ", "2 "))]
+        assert len(rows) == 3, r.stdout
+
+
 def test_graph_capture_of_abi_ops():
     """tn_graph_begin/_end/_launch: a captured sequence of C-ABI ops replays with values read from
     device memory (the whole-step replay schedule was measured slower than eager launches and is
@@ -653,6 +678,40 @@ def test_pipelined_steps_equal_sequential(monkeypatch, name, img, ch, B):
         for la, lb in zip(runs[a][0].tr_layers, runs[b][0].tr_layers):
             for wa, wb in zip(la.get_wts(), lb.get_wts()):
                 np.testing.assert_array_equal(wa, wb)
+
+
+@pytest.mark.parametrize("n_hidden", [7, 18], ids=["18-tensors", "40-tensors"])
+def test_pipelined_update_with_more_tensors_than_the_lazy_table(monkeypatch, n_hidden):
+    """A net with more parameter tensors than the update launch's slab-sum table (16 in round 2, 32 now:
+    TN_LAZY_SEGS): two steps in flight under enqueue() -- cost rider on -- and the one-step-at-a-time
+    lazy update give the same costs and weights bit for bit (round-2 ADVICE: the pipelined launch indexed
+    its 16-entry table with every segment)."""
+    from theanet_amd import NeuralNet
+    import copy
+    layers = [("InputLayer", {"img_sz": 12, "num_maps": 1}),
+              ("ConvLayer", {"num_maps": 4, "filter_sz": 3, "stride": 1, "mode": "same"}),
+              ("PoolLayer", {"pool_sz": 2})]
+    layers += [("HiddenLayer", {"n_out": 24 + 8 * (i % 3)}) for i in range(n_hidden)]
+    layers += [("SoftmaxLayer", {"n_out": 10})]
+    tp = {"SEED": 77, "BATCH_SZ": 32, "INIT_LEARNING_RATE": .05, "EPOCHS_TO_HALF_RATE": 1, "NUM_EPOCHS": 1}
+    rng = np.random.RandomState(3)
+    x = rng.rand(128, 1, 12, 12).astype(np.float32)
+    y = rng.randint(0, 10, 128).astype(np.int32)
+    runs = []
+    for pipe in ("1", "0"):
+        monkeypatch.setenv("TN_PIPELINE", pipe)
+        net = NeuralNet(copy.deepcopy(layers), dict(tp))
+        fn = net.get_trin_model(x, y)
+        costs = []
+        for s in range(7):
+            fn.enqueue(s % 4)
+            if s in (3, 6):
+                costs.append(fn.fetch()[0])
+        runs.append((costs, [w.copy() for l in net.tr_layers for w in l.get_wts()]))
+    assert len(runs[0][1]) == 2 * (n_hidden + 2)
+    assert runs[0][0] == runs[1][0] and all(np.isfinite(runs[0][0]))
+    for u, v in zip(runs[0][1], runs[1][1]):
+        np.testing.assert_array_equal(u, v)
 
 
 def test_pipelined_equals_sequential_at_full_batch(monkeypatch):
@@ -948,9 +1007,11 @@ def test_aux_input_layers_match_oracle(take_index_list):
     with pytest.raises(AssertionError, match="Multiple Aux Inputs"):
         NeuralNet(copy.deepcopy(layers) + [("SoftAuxLayer", {"n_out": 6, "n_aux": (4, 3), "aux_type": "LocationInfo"})],
                   {"SEED": 1, "BATCH_SZ": 4, "INIT_LEARNING_RATE": .1, "EPOCHS_TO_HALF_RATE": 1})
-    for variant in ("concat", "softaux"):
+    for variant in ("concat", "softaux", "concat-dropout"):
         lyrs = copy.deepcopy(layers)
-        if variant == "concat":
+        if variant == "concat-dropout":      # a Hidden layer's dropout mask right below the concatenation
+            lyrs[2][1]["pdrop"] = .5
+        if variant.startswith("concat"):
             lyrs.append(("SoftmaxLayer", {"n_out": 6}))
         else:
             lyrs[3] = ("SoftAuxLayer", {"n_out": 6, "n_aux": (4, 3), "aux_type": "LocationInfo", "boost": 1.5,
@@ -973,7 +1034,11 @@ def test_aux_input_layers_match_oracle(take_index_list):
             u = ora.L[ai].aux.draw(B)
             net.tr_layers[ai].aux.inject(u)
             ora.set_aux(aux[rows])
-            cost_w, _, lp_w = ora.train_step(x[rows], y[rows], {ai: u})
+            draws = {ai: u}
+            if variant == "concat-dropout":
+                draws[2] = ora.L[2].mask_rv.draw((B, 16))
+                net.tr_layers[2].drop.inject(draws[2])
+            cost_w, _, lp_w = ora.train_step(x[rows], y[rows], draws)
             cost, _, lp = fn(rows.astype(np.int32) if take_index_list else s)
             assert_close(lp, lp_w, 2e-4, 2e-5, what="%s logprob step %d" % (variant, s))
             assert_close(cost, cost_w, 2e-4, 1e-5, what="%s cost step %d" % (variant, s))

@@ -547,8 +547,9 @@ __global__ __launch_bounds__(64 * NW) void gemm_f32_deep(GemmArgs g) {
         const float av_[8] = {ra[SLOT][0].x, ra[SLOT][0].y, ra[SLOT][0].z, ra[SLOT][0].w,         \
                               ra[SLOT][1].x, ra[SLOT][1].y, ra[SLOT][1].z, ra[SLOT][1].w};        \
         _Pragma("unroll") for (int s_ = 0; s_ < 8; ++s_) {                                        \
-            const float bv_ = (k0_ + s_ < kend) ? rb[SLOT][s_] : 0.f;                             \
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av_[s_], bv_, acc, 0, 0, 0);               \
+            const bool in_ = k0_ + s_ < kend;        /* both operands: 0 * inf would be NaN */    \
+            const float bv_ = in_ ? rb[SLOT][s_] : 0.f;                                           \
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(in_ ? av_[s_] : 0.f, bv_, acc, 0, 0, 0);   \
         }                                                                                         \
     }
     // a trip = DEPTH tiles: all their loads are issued back to back, then the MFMAs follow under counted waits.

@@ -120,8 +120,9 @@ __global__ __launch_bounds__(256) void sgd_update_pipe_kernel(const tn_pipe_seg*
 // slabs (the deferred finishing sums of reduce.hip) add the slabs up on the fly -- in exactly the
 // order slab_sum_multi_kernel uses, so the result is bit-identical -- write the gradient out and
 // apply the update, which saves the reduction launch and one round trip of the gradient through HBM.
+#define TN_LAZY_SEGS 32                 // segments whose slab sums an update launch can fold in (others: final gradients)
 struct LazyBatch {
-    int8_t rec_of_seg[16];             // record index of segment s, -1: the gradient is already final
+    int8_t rec_of_seg[TN_LAZY_SEGS];   // record index of segment s, -1: the gradient is already final
     tn_red_rec r[TN_RED_MAX];
 };
 
@@ -143,7 +144,7 @@ __global__ __launch_bounds__(256) void sgd_update_lazy_kernel(const tn_sgd_seg* 
                                                              LazyBatch lb) {
     __shared__ float red[16][17];
     const int bx = blockIdx.x, by = blockIdx.y, nbx = gridDim.x;
-    const int ri = by < nseg ? lb.rec_of_seg[by] : -1;
+    const int ri = (by < nseg && by < TN_LAZY_SEGS) ? lb.rec_of_seg[by] : -1;
     if (ri < 0) {
         sgd_update_multi_block(segs, nseg, d_lr, gscale, d_step_inc, rowloss, nrow, cost_scale, d_cost, bx, by,
                                nbx, &red[0][0]);
@@ -255,7 +256,7 @@ __global__ __launch_bounds__(256) void sgd_update_pipe_lazy_kernel(const tn_pipe
     const float* __restrict__ ps = sg.psrc;
     float* __restrict__ v = sg.v;
     float* __restrict__ g = const_cast<float*>(sg.g);
-    const int ri = lb.rec_of_seg[by];
+    const int ri = by < TN_LAZY_SEGS ? lb.rec_of_seg[by] : -1;
     if (ri < 0 || !update_v) {
         const size_t n = sg.n;
         if ((n & 3) == 0 && (((uintptr_t)p | (uintptr_t)ps | (uintptr_t)v | (uintptr_t)g) & 15) == 0) {
@@ -530,10 +531,10 @@ int tn_sgd_update_multi_pipe(tn_ctx* ctx, const tn_pipe_seg* d_segs, const tn_pi
     if (bx < 1) bx = 1;
     // this stream's pending slab sums whose output is the gradient of one of the segments are folded into
     // the update; the others are finished by the ordinary reduction launch first
-    LazyBatch lb;
-    for (int s = 0; s < 16; ++s) lb.rec_of_seg[s] = -1;
+    LazyBatch lb{};
+    for (int s = 0; s < TN_LAZY_SEGS; ++s) lb.rec_of_seg[s] = -1;
     int nlazy = 0, keep = 0;
-    const bool can = h_segs != nullptr && nseg <= 16 && update_v;
+    const bool can = h_segs != nullptr && nseg <= TN_LAZY_SEGS && update_v;
     for (int i = 0; i < ctx->npend; ++i) {
         int seg = -1;
         if (can)
@@ -564,13 +565,13 @@ int tn_sgd_update_multi_pipe(tn_ctx* ctx, const tn_pipe_seg* d_segs, const tn_pi
 int tn_sgd_update_multi_lazy(tn_ctx* ctx, const tn_sgd_seg* d_segs, const tn_sgd_seg* h_segs, int nseg,
                              size_t max_n, const float* d_lr, float gscale, uint32_t* d_step_inc,
                              const float* rowloss, int nrow, float cost_scale, float* d_cost) {
-    TN_REQUIRE(nseg > 0 && nseg <= 16 && d_segs && h_segs && d_lr, "tn_sgd_update_multi_lazy: bad arguments");
+    TN_REQUIRE(nseg > 0 && nseg <= TN_LAZY_SEGS && d_segs && h_segs && d_lr, "tn_sgd_update_multi_lazy: bad arguments");
     const bool rider = rowloss != nullptr;
     TN_REQUIRE(!rider || (d_cost != nullptr && nrow > 0), "tn_sgd_update_multi_lazy: bad cost arguments");
     // pending slab sums whose output is the gradient of one of the segments are folded into the update;
     // the others (and everything when deferral is off) are finished by the ordinary reduction launch
-    LazyBatch lb;
-    for (int s = 0; s < 16; ++s) lb.rec_of_seg[s] = -1;
+    LazyBatch lb{};
+    for (int s = 0; s < TN_LAZY_SEGS; ++s) lb.rec_of_seg[s] = -1;
     int nlazy = 0, keep = 0;
     for (int i = 0; i < ctx->npend; ++i) {
         int seg = -1;

@@ -128,12 +128,14 @@ class AuxConcatLayer(Layer):
         if not need_gin:
             return None
         b_out, b_act, b_prm, b_mask = below.act_info()
-        assert b_mask is None
         if self.gin is None:
             self.gin = self.ctx.empty(self.inpt.shape)
         fuse = b_out is not None and b_act != _lib.TN_ACT_LINEAR
         self.ctx.call("tn_copy_cols", gout.ptr, self.n_out, 0, self.gin.ptr, self.n_in, 0, self.n_in, self.batch_sz,
                       b_out.ptr if fuse else None, b_act, b_prm)
+        if b_mask is not None:        # a Hidden layer with dropout right below: its mask, after the copy
+            self.ctx.call("tn_scale_mask", self.gin.ptr, b_mask.ptr, 1.0, self.gin.ptr, self.gin.size,
+                          None, _lib.TN_ACT_LINEAR, 0.0)
         return self.gin
 
 

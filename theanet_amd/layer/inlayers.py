@@ -205,7 +205,6 @@ class ElasticLayer(Layer):
             return None
         from .. import _lib
         b_out, b_act, b_prm, b_mask = below.act_info()
-        assert b_mask is None
         if getattr(self, "gin", None) is None:
             self.gin = self.ctx.empty(self.inpt.shape)
         h = w = self.img_sz
@@ -219,6 +218,9 @@ class ElasticLayer(Layer):
             self.ctx.call("tn_elastic_apply_bwd", gout.ptr, self.gin.ptr, self.batch_sz, self.num_maps, h, w,
                           int(self.invert), 1, None, None, None, 0.0, None, 0, 0, None, 0,
                           b_out.ptr if fuse else None, b_act, b_prm)
+        if b_mask is not None:        # a Hidden layer with dropout right below: its mask, after the copy
+            self.ctx.call("tn_scale_mask", self.gin.ptr, b_mask.ptr, 1.0, self.gin.ptr, self.gin.size,
+                          None, _lib.TN_ACT_LINEAR, 0.0)
         return self.gin
 
     def _field(self, m):
@@ -313,7 +315,6 @@ class ColorLayer(Layer):
             return None
         from .. import _lib
         b_out, b_act, b_prm, b_mask = below.act_info()
-        assert b_mask is None
         fuse = b_out is not None and b_act != _lib.TN_ACT_LINEAR
         if self.gin is None:
             self.gin = self.ctx.empty(self.inpt.shape)
@@ -324,4 +325,7 @@ class ColorLayer(Layer):
             self.ctx.call("tn_color_apply_bwd", self.inpt.ptr, 0, self.fac.ptr, gout.ptr, self.gin.ptr,
                           self.batch_sz, self.num_maps, self.out_sz * self.out_sz, float(self.maxval),
                           b_out.ptr if fuse else None, b_act, b_prm)
+        if b_mask is not None:        # a Hidden layer with dropout right below: its mask, after the copy
+            self.ctx.call("tn_scale_mask", self.gin.ptr, b_mask.ptr, 1.0, self.gin.ptr, self.gin.size,
+                          None, _lib.TN_ACT_LINEAR, 0.0)
         return self.gin

@@ -966,7 +966,7 @@ class NeuralNet():
                     dp_async = True
                 if g is None:
                     break
-            lazy = (not self._dp and 0 < self._n_segs <= 16 and
+            lazy = (not self._dp and 0 < self._n_segs <= 32 and
                     self._fl["TN_LAZY_UPDATE"])
         finally:
             waiting = bool(ctx.lib.tn_rider_pending(ctx.h))

@@ -170,6 +170,9 @@ def run(dataset_name, prms_file_name, redirect):
             layers[0][1].setdefault('num_maps', n_maps)
         trin_x, trin_y = share(tr_x), share(data.training_y, 'int32')
         test_x, test_y = share(te_x), share(data.testing_y, 'int32')
+        # datasets for AuxConcatLayer / SoftAuxLayer nets carry per-sample side inputs (reference train.py:133-137)
+        trin_aux = share(data.training_aux) if hasattr(data, 'training_aux') else None
+        test_aux = share(data.testing_aux) if hasattr(data, 'testing_aux') else None
 
         print("\nInitializing the net ... ")
         net = nn.NeuralNet(layers, tr_prms, allwts)
@@ -177,9 +180,9 @@ def run(dataset_name, prms_file_name, redirect):
         print(net.get_wts_info(detailed=True).replace("\n\t", ""))
 
         print("\nCompiling ... ")
-        training_fn = net.get_trin_model(trin_x, trin_y)
-        test_fn_tr = net.get_test_model(trin_x, trin_y)
-        test_fn_te = net.get_test_model(test_x, test_y)
+        training_fn = net.get_trin_model(trin_x, trin_y, trin_aux)
+        test_fn_tr = net.get_test_model(trin_x, trin_y, trin_aux)
+        test_fn_te = net.get_test_model(test_x, test_y, test_aux)
 
         batch_sz = tr_prms['BATCH_SZ']
         n_tr_batches, n_te_batches = len(tr_x) // batch_sz, len(te_x) // batch_sz
@@ -188,6 +191,7 @@ def run(dataset_name, prms_file_name, redirect):
         ckpt = Checkpoints(head, lead and not os.environ.get("THEANET_NO_PICKLE"))
         aux = 'BitErr' if net.tr_layers[-1].kind == 'LOGIT' else 'P(MLE)'
         row = "{:5.2f}%  ({:5.2f}%)      {:5.2f}%  ({:5.2f}%)"
+        exp_head = layers[-1][0][:3] == "Exp"
 
         np.set_printoptions(precision=2)
         print("Training ...")
@@ -195,8 +199,18 @@ def run(dataset_name, prms_file_name, redirect):
         for epoch in range(tr_prms['NUM_EPOCHS']):
             total_cost, t0 = 0, time.perf_counter()
             for ibatch in range(n_tr_batches):
-                cost = training_fn(ibatch)[0]
+                cost, features, _ = training_fn(ibatch)
                 total_cost += cost
+                if exp_head:          # ExpLoss nets: report samples whose true-class feature runs away (train.py:216-222)
+                    labels = np.asarray(data.training_y[ibatch * batch_sz:(ibatch + 1) * batch_sz])
+                    lo = net.shard_lo                     # a data-parallel rank holds its own rows of the batch
+                    own = labels[lo:lo + len(features)]
+                    true_features = features[np.arange(len(own)), own]
+                    if np.min(true_features) < -6:
+                        print("Epoch:{} Iteration:{}".format(epoch, ibatch))
+                        print(own)
+                        print(true_features)
+                        print(net.get_wts_info(detailed=True))
                 if np.isnan(total_cost):
                     print("Epoch:{} Iteration:{}".format(epoch, ibatch))
                     print(net.get_wts_info(detailed=True))
