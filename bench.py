@@ -57,42 +57,255 @@ print("CPULEG " + json.dumps({"steps": n, "seconds": dt, "cost": cost}))
 """
 
 
-def cpu_baseline(prms, hw, c, batch, budget_s=15.0):
+def cpu_baseline(prms, hw, c, batch, budget_s=18.0):
     """The timed CPU baseline: this build's C++/OpenMP backend behind the same C-ABI (theanet_amd/csrc_cpu:
     im2col + blocked SGEMM conv, C loops for pooling, SGEMM for the fully-connected layers -- the algorithms
     Theano's CPU path uses; Theano itself cannot be installed), driving the SAME net at the SAME batch
-    size through the same NeuralNet host code, on this box's host cores, in a subprocess with
-    THEANET_BACKEND=cpu.  Whole training steps until ~budget_s is used (at least one).  A CPU
-    restatement of the reference path, not the reference: baseline only."""
+    size through the same NeuralNet host code, on this box's host cores, in subprocesses with
+    THEANET_BACKEND=cpu.  Whole training steps; the OpenMP thread count is SWEPT (8, 16, 32, 64, 128, capped at
+    the core count; threads pinned to cores) and the best rate is reported with the sweep beside it: round 2 ran
+    128 threads on a 256-core host and was slower than 8 threads of the build container.  A CPU restatement of
+    the reference path, not the reference: baseline only."""
     import subprocess
     p = copy.deepcopy({k: v for k, v in prms.items() if not k.startswith("_")})
     p["training_params"]["BATCH_SZ"] = batch
     p["training_params"].pop("DTYPE", None)                     # the reference's floatX: float32
-    threads = min(os.cpu_count() or 1, 128)
-    env = dict(os.environ, THEANET_BACKEND="cpu", OMP_NUM_THREADS=str(threads), OMP_PROC_BIND="spread",
-               RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
-    code = CPU_LEG % {"root": ROOT, "prms": p, "batch": batch, "c": c, "hw": hw, "budget": budget_s}
-    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
-    line = [l for l in r.stdout.splitlines() if l.startswith("CPULEG ")]
-    if r.returncode != 0 or not line:
-        return {"value": None, "unit": "images/sec", "cores": threads, "kind": "port",
-                "sample": "CPU backend leg failed: " + (r.stderr or r.stdout)[-300:]}
-    rec = json.loads(line[-1][7:])
-    return {"value": batch * rec["steps"] / rec["seconds"], "unit": "images/sec", "cores": threads,
-            "threads": threads, "nproc": os.cpu_count(), "kind": "port",
+    nproc = os.cpu_count() or 1
+    sweep = sorted({min(t, nproc) for t in (8, 16, 32, 64, 128)})
+    per_leg = budget_s / len(sweep)
+    results, err = {}, ""
+    for threads in sweep:
+        env = dict(os.environ, THEANET_BACKEND="cpu", OMP_NUM_THREADS=str(threads), OMP_PLACES="cores",
+                   OMP_PROC_BIND="close", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+        code = CPU_LEG % {"root": ROOT, "prms": p, "batch": batch, "c": c, "hw": hw, "budget": per_leg}
+        try:
+            r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        except subprocess.TimeoutExpired:
+            err = "timeout at %d threads" % threads
+            continue
+        line = [l for l in r.stdout.splitlines() if l.startswith("CPULEG ")]
+        if r.returncode != 0 or not line:
+            err = (r.stderr or r.stdout)[-300:]
+            continue
+        rec = json.loads(line[-1][7:])
+        results[threads] = (batch * rec["steps"] / rec["seconds"], rec["steps"], rec["seconds"])
+    if not results:
+        return {"value": None, "unit": "images/sec", "cores": sweep[-1], "kind": "port",
+                "sample": "CPU backend leg failed: " + err}
+    best = max(results, key=lambda t: results[t][0])
+    return {"value": results[best][0], "unit": "images/sec", "cores": best, "threads": best, "nproc": nproc,
+            "kind": "port", "thread_sweep_images_per_sec": {str(t): round(v[0], 1) for t, v in sorted(results.items())},
             "sample": "C++/OpenMP CPU backend behind the same C-ABI (lib/libtheanet_cpu.so, THEANET_BACKEND=cpu; "
-                      "a CPU restatement of the reference path -- Theano is not installable), %s fwd+bwd+update, "
-                      "%d steps of batch %d in %.1f s on %d OpenMP threads"
-                      % (prms.get("_name", "net"), rec["steps"], batch, rec["seconds"], threads)}
+                      "a CPU restatement of the reference path -- Theano is not installable), %s fwd+bwd+update at "
+                      "batch %d; OpenMP threads swept over %s (OMP_PLACES=cores), best = %d threads: %d steps in %.1f s"
+                      % (prms.get("_name", "net"), batch, sweep, best, results[best][1], results[best][2])}
+
+
+PMC_FILE = "r02_traffic.json"
 
 
 def _pmc_table(config):
-    """{kernel: {hbm_bytes_corrected, mfma_busy_frac, ...}} of one profiled configuration (profiles/r02_traffic.json)."""
+    """{kernel: {hbm_bytes_corrected, mfma_busy_frac, ...}} of one profiled configuration (profiles/r0N_traffic.json)."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r02_traffic.json")) as fh:
+        with open(os.path.join(ROOT, "profiles", PMC_FILE)) as fh:
             return json.load(fh)["configs"].get(config, {})
     except (OSError, KeyError, ValueError):
         return {}
+
+
+DEFAULTS = {"mnist.prms": (4096, 28, 1), "cifar_like.prms": (2048, 32, 3),
+            "wide6.prms": (128, 64, 3), "3flat.prms": (4096, 28, 1)}
+# BASELINE.json configs[3] and configs[4] (one GPU's share of it), reported by the default N=1 run beside the headline
+OTHER_CONFIGS = (("cifar_like.prms", "f32"), ("cifar_like.prms", "f16"), ("wide6.prms", "f32"), ("wide6.prms", "f16"))
+
+
+def plan_batches(prms_name, batch, scaling, world_size):
+    """(global batch, rows per GPU, scaling label).  mnist / cifar_like: N > 1 shards the stated batch (strong
+    scaling, BASELINE configs[2]) unless --scaling weak.  wide6 is stated per node -- "bs1024, 8 x MI355X",
+    configs[4] -- i.e. 128 images per GPU: its default keeps 128 per GPU at every N (weak by definition)."""
+    dB = DEFAULTS.get(prms_name, (4096, 28, 1))[0]
+    base = batch or dB
+    if prms_name == "wide6.prms" and not batch:
+        return base * world_size, base, "weak"
+    if world_size == 1:
+        return base, base, "weak"                 # N = 1: the two coincide
+    if scaling == "strong":
+        assert base % world_size == 0, "batch %d does not divide over %d GPUs" % (base, world_size)
+        return base, base // world_size, "strong"
+    return base * world_size, base, "weak"
+
+
+def build(prms_name, global_batch, per_gpu, img, dtype):
+    from theanet_amd import NeuralNet
+    prms = load_prms(prms_name)
+    prms["_name"] = prms_name
+    _, dimg, C = DEFAULTS.get(prms_name, (4096, 28, 1))
+    img = img or dimg
+    C = prms["layers"][0][1].get("num_maps", C)
+    prms["layers"][0][1]["img_sz"] = img
+    tr = prms["training_params"]
+    tr["SEED"] = 555555
+    tr["BATCH_SZ"] = global_batch
+    if dtype == "f16":
+        tr["DTYPE"] = "float16"
+    net = NeuralNet(copy.deepcopy(prms["layers"]), dict(tr))
+    n_batches = max(2, 65536 // global_batch) if per_gpu * img * img * C < (1 << 24) else 2
+    x, y = synthetic(n_batches * global_batch, C, img)
+    fn = net.get_trin_model(x, y)
+    return prms, tr, net, fn, n_batches, img, C
+
+
+def settle(ctx, fn, n_batches, group, min_seconds=0.2):
+    """Untimed set-up steps (the twin net of the two-steps-in-flight schedule is built on the first call; the GPU
+    comes out of seconds of idle while the net was built: 48 + 5 steps = 10 ms of load left the first 20 timed
+    steps at 193-196 us, 180 ms of load at 180-182 us, the steady state being 177 -- tools/probe_start.py: a 50 ms
+    host pause alone costs the next 20 steps 25 %).  So the set-up runs for at least 0.2 s, synchronised.  Every
+    rank must take the same number of steps (each one is a collective): the first 48 are timed and the count
+    that fills 0.2 s is the maximum over ranks.  Returns the number of steps taken."""
+    for i in range(32):                 # (the first call builds the twin net: not representative)
+        fn.enqueue(i % n_batches)
+    ctx.sync()
+    t_setup = time.perf_counter()
+    for i in range(32, 48):
+        fn.enqueue(i % n_batches)
+    ctx.sync()
+    per_step = max((time.perf_counter() - t_setup) / 16, 1e-6)
+    more = float(min(20000, max(0, int(min_seconds / per_step) - 48)))
+    if group is not None:
+        more = group.rdzv.gather_max(more)
+    n_setup = 48 + 16 * ((int(more) + 15) // 16)
+    for i in range(48, n_setup):
+        fn.enqueue(i % n_batches)
+        if i % 16 == 15:
+            ctx.sync()
+    return n_setup
+
+
+def conv_roofline(ctx, net, fn, n_batches, nsteps, prms_name, dtype):
+    """conv nets (cifar_like, wide6): every conv product of the step, grouped into forward and backward, each as
+    the sum over its launches -> "fraction of the conv roofline" (conv-layer FLOPs / conv-kernel
+    time / MFMA peak; peak = fp32 MFMA for fp32 operands, fp16 MFMA for fp16 operands).  HIP events on the
+    stream the kernels run on, one step at a time.  Fused conv+act+pool blocks count with their conv FLOPs only
+    (pooling, masks and activations ride along).  Returns the two records, slowest first."""
+    from theanet_amd import roofline
+    from theanet_amd.layer import ConvLayer
+    convs = [l for l in net.tr_layers if isinstance(l, ConvLayer)]
+    first_param = next(l for l in net.tr_layers if getattr(l, "params", None))
+    fl_of = lambda l: 2 * l.batch_sz * l.out_sz ** 2 * l.num_maps * l.num_prev_maps * l.filter_sz ** 2
+    groups = (("conv forward, all conv layers (conv_tile / convpool kernels)", net.CONV_FWD_OPS,
+               sum(fl_of(l) for l in convs)),
+              ("conv backward, all conv layers (weight + input gradients)", net.CONV_BWD_OPS,
+               sum(fl_of(l) * (1 if l is first_param else 2) for l in convs)))
+    recs = []
+    f16 = dtype == "f16"
+    peak = roofline.MFMA_F16_PEAK_TFLOPS if f16 else roofline.MFMA_F32_PEAK_TFLOPS
+    for label, ops, fl in groups:
+        ms, launches = 0.0, 0
+        for op in ops:
+            ctx.time_calls(op, 0)
+            for i in range(nsteps):
+                ctx.new_step()
+                fn.enqueue(i % n_batches)
+            ctx.sync()
+            times = ctx.collect_times_ms()
+            ms += float(np.sum(times)) / nsteps
+            launches += len(times) // nsteps
+        if not launches or not fl:
+            continue
+        ach = fl / (ms * 1e-3) / 1e12
+        rec = {"kernel": label, "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+               "frac": ach / peak, "traffic": None, "ms_per_step": ms, "launches_per_step": launches,
+               "flops_per_step": fl}
+        if f16:
+            rec["frac_of_fp32_peak"] = ach / roofline.MFMA_F32_PEAK_TFLOPS
+        recs.append(rec)
+    recs.sort(key=lambda r: -r["ms_per_step"])
+    return recs
+
+
+def other_config_leg(ctx, prms_name, dtype, steps):
+    """One of BASELINE.json's other single-GPU configurations through the same harness, in-process: set-up steps,
+    a timed region of enqueue-only steps bracketed by stream syncs (>= 0.25 s or ``steps``), then the conv
+    roofline legs.  No CPU baseline, no sync-API leg."""
+    import gc
+    from theanet_amd import roofline
+    gb, per_gpu, _ = plan_batches(prms_name, 0, "weak", 1)
+    t_build = time.perf_counter()
+    prms, tr, net, fn, n_batches, img, C = build(prms_name, gb, per_gpu, 0, dtype)
+    n_setup = settle(ctx, fn, n_batches, None, 0.15)
+    ctx.sync()
+    t0 = time.perf_counter()
+    for i in range(8):
+        fn.enqueue(i % n_batches)
+    ctx.sync()
+    est = (time.perf_counter() - t0) / 8
+    n = int(max(steps, min(2000, 0.25 / max(est, 1e-6))))
+    ctx.sync()
+    t0 = time.perf_counter()
+    for i in range(n):
+        fn.enqueue(i % n_batches)
+    ctx.sync()
+    dt = time.perf_counter() - t0
+    cost = float(fn.fetch()[0])
+    legs = conv_roofline(ctx, net, fn, n_batches, 6, prms_name, dtype)
+    step_flops = roofline.net_step_flops(net)
+    first = net.tr_layers[0]
+    stage = "elastic stage on" if type(first).__name__ == "ElasticLayer" and first.active else \
+        "no input distortion (%s)" % type(first).__name__
+    rec = {"config": {"workload": "params/%s %dx%dx%d synthetic, batch %d on 1 GPU, %s"
+                                  % (prms_name, img, img, C, gb, stage),
+                      "global_batch": gb,
+                      "schedule": "two steps in flight" if type(fn).__name__ == "_PipeTrainFn" and fn._twin is not None
+                      else "one step at a time",
+                      "step_gflop_algorithmic": step_flops / 1e9,
+                      "step_tflops_algorithmic": step_flops / (dt / n) / 1e12},
+           "dtype": DTYPE_LABEL[dtype], "steps": n, "setup_steps": n_setup, "ms_per_step": 1e3 * dt / n,
+           "value": gb * n / dt, "unit": "images/sec", "final_cost": cost,
+           "conv_roofline": legs, "measured_in": "conv legs: one step at a time, HIP events on the kernels' stream",
+           "seconds_incl_build": None}
+    assert np.isfinite(cost), "training diverged (%s %s)" % (prms_name, dtype)
+    del fn, net
+    gc.collect()
+    rec["seconds_incl_build"] = time.perf_counter() - t_build
+    return rec
+
+
+DTYPE_LABEL = {"f32": "f32", "f16": "f16 (fp16 tensors and MFMA operands, fp32 accumulate, fp32 master weights)"}
+
+
+def dry_multi(args):
+    """--dry-multi N: what an N-rank launch of this command line WOULD run -- per-rank row shards, the flat
+    gradient buffer every rank all-reduces, the schedule -- built without a communicator (and without a second
+    process), so the scaling command line can be exercised where there is one GPU or none (THEANET_BACKEND=cpu)."""
+    from theanet_amd import comm
+    N = args.dry_multi
+    gb, per_gpu, scaling = plan_batches(args.prms, args.batch, args.scaling, N)
+    ranks = []
+    plan = None
+    for r in (0, N - 1):
+        comm._world = comm.World(r, N, r, dry=True)
+        prms, tr, net, fn, n_batches, img, C = build(args.prms, gb, per_gpu, args.img, args.dtype)
+        ranks.append({"rank": r, "rows_of_minibatch": [net.shard_lo, net.shard_lo + net.local_bsz],
+                      "first_dataset_row_of_minibatch_3": comm.minibatch_row0(3, gb, N, r)})
+        if plan is None:
+            tensors = []
+            for i, lyr in enumerate(net.tr_layers):
+                for p, g in zip(lyr.params, lyr.grads or ()):
+                    tensors.append({"layer": i, "type": type(lyr).__name__, "shape": list(p.shape),
+                                    "offset_floats": (g.ptr - net.flat_grads.ptr) // 4})
+            plan = {"flat_gradient_buffer": {"floats_reduced_per_step": net.n_flat, "bytes": 4 * net.n_flat,
+                                             "cost_slot": net.n_flat - 1, "tensors": tensors},
+                    "schedule": "pipelined (two steps in flight, all-reduce in-stream)"
+                    if type(fn).__name__ == "_PipeTrainFn" else
+                    "one step at a time; all-reduce schedule autotuned among %s" %
+                    (["plain"] + (["overlap"] if net._dp_cand else []) + (["delayed"] if net._dp_can_delay else [])),
+                    "n_batches_resident": n_batches}
+        del fn, net
+    comm._world = None
+    print(json.dumps({"dry_multi": N, "prms": args.prms, "dtype": args.dtype, "scaling": scaling, "global_batch": gb,
+                      "rows_per_gpu": per_gpu, "ranks_shown": ranks, **plan,
+                      "launch": "python -m torch.distributed.run --nnodes=1 --nproc-per-node %d --master-addr 127.0.0.1 "
+                                "--master-port P bench.py --gpus %d --steps K --warmup W" % (N, N)}))
 
 
 def main():
@@ -110,46 +323,29 @@ def main():
     ap.add_argument("--img", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true", help="skip the per-kernel roofline leg")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the cifar_like / wide6 legs the default N=1 mnist run appends (other_configs)")
+    ap.add_argument("--dry-multi", type=int, default=0, metavar="N",
+                    help="print the plan of an N-rank run (shards, flat gradient layout, schedule) and exit")
     ap.add_argument("--sequential", action="store_true",
                     help="one step at a time (TN_PIPELINE=0) instead of two steps in flight")
     ap.add_argument("--time-op", default="", help="C-ABI function to bracket with HIP events, "
                     "e.g. tn_fc_wgrad:1 (nth call inside a step)")
     args = ap.parse_args()
 
-    from theanet_amd import NeuralNet, comm, roofline
+    from theanet_amd import comm, roofline
     from theanet_amd.device import get_context
 
     if args.sequential:
         os.environ["TN_PIPELINE"] = "0"
+    if args.dry_multi:
+        return dry_multi(args)
     world = comm.get_world()
     assert world.size == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
-    prms = load_prms(args.prms)
-    prms["_name"] = args.prms
-    defaults = {"mnist.prms": (4096, 28, 1), "cifar_like.prms": (2048, 32, 3),
-                "wide6.prms": (128, 64, 3), "3flat.prms": (4096, 28, 1)}
-    dB, dimg, C = defaults.get(args.prms, (4096, 28, 1))
-    base_batch = args.batch or dB
-    scaling = args.scaling if world.size > 1 else "weak"     # N = 1: the two coincide
-    if scaling == "strong":
-        assert base_batch % world.size == 0, "batch %d does not divide over %d GPUs" % (base_batch, world.size)
-        per_gpu = base_batch // world.size
-    else:
-        per_gpu = base_batch
-    img = args.img or dimg
-    C = prms["layers"][0][1].get("num_maps", C)
-    prms["layers"][0][1]["img_sz"] = img
-    tr = prms["training_params"]
-    tr["SEED"] = 555555
-    tr["BATCH_SZ"] = per_gpu * world.size
-    if args.dtype == "f16":
-        tr["DTYPE"] = "float16"
+    global_batch, per_gpu, scaling = plan_batches(args.prms, args.batch, args.scaling, world.size)
 
     ctx = get_context()
-    net = NeuralNet(copy.deepcopy(prms["layers"]), dict(tr))
-    n_batches = max(2, 65536 // tr["BATCH_SZ"]) if per_gpu * img * img * C < (1 << 24) else 2
-    x, y = synthetic(n_batches * tr["BATCH_SZ"], C, img)
-    fn = net.get_trin_model(x, y)
-    del x
+    prms, tr, net, fn, n_batches, img, C = build(args.prms, global_batch, per_gpu, args.img, args.dtype)
     group = net._group() if world.size > 1 else None
 
     def barrier():
@@ -163,30 +359,7 @@ def main():
     while getattr(net, "_dp_tune", None) is not None and tune_steps < 1000:
         fn.enqueue(tune_steps % n_batches)
         tune_steps += 1
-    # ... and every run takes a few untimed set-up steps (the twin net of the two-steps-in-flight
-    # schedule is built on the first call; clocks and allocators settle) before the W warm-up steps
-    # (the GPU comes out of seconds of idle while the net was built: 48 + 5 steps = 10 ms of load left the first 20
-    # timed steps at 193-196 us, 180 ms of load at 180-182 us, the steady state being 177 -- tools/probe_start.py: a
-    # 50 ms host pause alone costs the next 20 steps 25 %.  So the set-up runs for at least 0.2 s, synchronised.)
-    # Every rank must take the same number of steps (each one is a collective): the first 48 are timed and the
-    # count that fills 0.2 s is the maximum over ranks.
-    for i in range(32):                 # (the first call builds the twin net: not representative)
-        fn.enqueue(i % n_batches)
-    ctx.sync()
-    t_setup = time.perf_counter()
-    for i in range(32, 48):
-        fn.enqueue(i % n_batches)
-    ctx.sync()
-    per_step = max((time.perf_counter() - t_setup) / 16, 1e-6)
-    more = float(min(20000, max(0, int(0.2 / per_step) - 48)))
-    if group is not None:
-        more = group.rdzv.gather_max(more)
-    n_setup = 48 + 16 * ((int(more) + 15) // 16)
-    for i in range(48, n_setup):
-        fn.enqueue(i % n_batches)
-        if i % 16 == 15:
-            ctx.sync()
-    setup_steps = tune_steps + n_setup
+    setup_steps = tune_steps + settle(ctx, fn, n_batches, group)
     for i in range(args.warmup):
         fn.enqueue(i % n_batches)
     barrier()
@@ -277,7 +450,7 @@ def main():
             roof["measured_in"] = "one-step-at-a-time schedule (bench.py --sequential)"
             # HBM traffic / matrix-core utilisation of these kernels: measured offline with rocprofv3 --pmc
             # (separate FETCH_SIZE / WRITE_SIZE / MFMA passes, gfx950 FETCH correction) by
-            # tools/collect_profiles.sh, tabulated in profiles/r02_traffic.json
+            # tools/collect_profiles.sh, tabulated in profiles/r0N_traffic.json
             pmc = _pmc_table("mnist_bs4096")
             for rec in [roof] + others:
                 key = rec["kernel"].split(" ")[0]
@@ -285,53 +458,18 @@ def main():
                     if name.startswith(key):
                         rec["traffic"] = vals.get("hbm_bytes_corrected")
                         rec["mfma_busy_frac_pmc"] = vals.get("mfma_busy_frac")
-                        rec["traffic_source"] = "profiles/r02_traffic.json (rocprofv3 --pmc)"
-
+                        rec["traffic_source"] = "profiles/%s (rocprofv3 --pmc)" % PMC_FILE
     else:
-        # conv nets (cifar_like, wide6): every conv product of the step, grouped into forward and
-        # backward, each as the sum over its launches -> "fraction of the conv roofline" (SURVEY.md 8d:
-        # conv-layer FLOPs / conv-kernel time / MFMA fp32 peak).  Fused conv+act+pool blocks count
-        # with their conv FLOPs only (pooling, masks and activations ride along).
-        from theanet_amd.layer import ConvLayer
-        convs = [l for l in net.tr_layers if isinstance(l, ConvLayer)]
-        first_param = next(l for l in net.tr_layers if getattr(l, "params", None))
-        fl_of = lambda l: 2 * l.batch_sz * l.out_sz ** 2 * l.num_maps * l.num_prev_maps * l.filter_sz ** 2
-        groups = (("conv forward, all conv layers (conv_tile / convpool kernels)",
-                   ("tn_conv2d_fwd", "tn_convpool_fwd_mask", "tn_elastic_convpool_fwd_mask"),
-                   sum(fl_of(l) for l in convs)),
-                  ("conv backward, all conv layers (weight + input gradients)",
-                   ("tn_conv2d_wgrad", "tn_conv2d_dgrad", "tn_convpool_bwd_mask_dx", "tn_convpool_bwd_mask",
-                    "tn_convblock_bwd_mask", "tn_convblock_bwd", "tn_convpool_bwd"),
-                   sum(fl_of(l) * (1 if l is first_param else 2) for l in convs)))
-        nsteps = min(args.steps, 10)
-        for label, ops, fl in groups:
-            ms, launches = 0.0, 0
-            for op in ops:
-                ctx.time_calls(op, 0)
-                for i in range(nsteps):
-                    ctx.new_step()
-                    fn.enqueue(i % n_batches)
-                ctx.sync()
-                times = ctx.collect_times_ms()
-                ms += float(np.sum(times)) / nsteps
-                launches += len(times) // nsteps
-            if not launches or not fl:
-                continue
-            ach = fl / (ms * 1e-3) / 1e12
-            others.append({"kernel": label, "bound": "mfma", "achieved": ach,
-                           "peak": roofline.MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                           "frac": ach / roofline.MFMA_F32_PEAK_TFLOPS, "traffic": None,
-                           "ms_per_step": ms, "launches_per_step": launches, "flops_per_step": fl})
-        if others:
-            others.sort(key=lambda r: -r["ms_per_step"])
-            roof, others = others[0], others[1:]
+        legs = conv_roofline(ctx, net, fn, n_batches, min(args.steps, 10), args.prms, args.dtype)
+        if legs:
+            roof, others = legs[0], legs[1:]
             pmc = _pmc_table("%s_%s" % (args.prms.split(".")[0], args.dtype))
-            conv = {k: v for k, v in pmc.items() if k.startswith(("conv_tile", "convpool", "conv_"))}
+            conv = {k: v for k, v in pmc.items() if k.startswith(("conv_tile", "convpool", "conv_", "c8_"))}
             if conv:
                 roof["pmc_per_kernel"] = {k: {"hbm_MB_per_launch": round(v.get("hbm_bytes_corrected", 0) / 1e6, 2),
                                               "mfma_busy_frac": round(v.get("mfma_busy_frac", 0.0), 3)}
                                           for k, v in conv.items()}
-                roof["traffic_source"] = "profiles/r02_traffic.json (rocprofv3 --pmc, per launch)"
+                roof["traffic_source"] = "profiles/%s (rocprofv3 --pmc, per launch)" % PMC_FILE
 
     if world.rank != 0:
         return
@@ -340,20 +478,13 @@ def main():
     first = net.tr_layers[0]
     stage = "elastic stage on" if type(first).__name__ == "ElasticLayer" and first.active else \
         "no input distortion (%s)" % type(first).__name__
-    f16 = args.dtype == "f16"
-    if f16:          # the conv legs are priced against the fp16 MFMA peak, the fp32 fraction beside it
-        for rec in ([roof] if roof else []) + others:
-            if rec.get("bound") == "mfma" and "conv" in rec["kernel"]:
-                rec["frac_of_fp32_peak"] = rec["frac"]
-                rec["peak"] = roofline.MFMA_F16_PEAK_TFLOPS
-                rec["frac"] = rec["achieved"] / roofline.MFMA_F16_PEAK_TFLOPS
     line = {
         "metric": "training images/sec (fwd+bwd+update) MNIST-CNN bs4096, 1/2/4/8 MI355X",
         "value": value, "unit": "images/sec", "n_gpus": world.size, "steps": args.steps,
         "warmup": args.warmup, "setup_steps": setup_steps, "ms_per_step": 1e3 * dt / args.steps,
         "higher_is_better": True,
         "scaling": scaling, "vs_baseline": None,
-        "dtype": "f16/f32acc (fp16 conv operands, fp32 accumulate, fp32 master weights)" if f16 else "f32",
+        "dtype": DTYPE_LABEL[args.dtype],
         "data": "synthetic",
         "value_sync_api": value_sync_api,
         "sync_api": {"steps": n_sync, "ms_per_step": 1e3 * dt_sync / n_sync,
@@ -373,6 +504,21 @@ def main():
         "roofline_others": others,
         "final_cost": float(cost),
     }
+    # BASELINE.json's other single-GPU configurations (north_star: images/sec "on synthetic 28x28x1 and 32x32x3
+    # batches ... as fraction of the conv roofline"; the >= 50 % fp32-MFMA target on 3x3 convs; configs[4]'s fp16
+    # path), timed by THIS run after the headline: the default N = 1 mnist run only.
+    if world.size == 1 and args.prms == "mnist.prms" and not args.batch and not args.no_other_configs \
+            and not args.no_roofline and os.environ.get("THEANET_BACKEND", "hip") != "cpu":
+        import gc
+        del fn, net
+        gc.collect()
+        line["other_configs"] = []
+        for name, dt_ in OTHER_CONFIGS:
+            try:
+                line["other_configs"].append(other_config_leg(ctx, name, dt_, args.steps))
+            except Exception as e:          # a leg must never cost the headline its line
+                line["other_configs"].append({"config": {"workload": "params/%s %s" % (name, dt_)},
+                                              "error": "%s: %s" % (type(e).__name__, str(e)[-300:])})
     if world.size == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(prms, img, C, tr["BATCH_SZ"])
     print(json.dumps(line))

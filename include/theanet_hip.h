@@ -97,6 +97,9 @@ int tn_event_record(tn_ctx* ctx, void* ev);
 int tn_event_wait(tn_ctx* ctx, void* ev);            /* the current stream waits for the event */
 int tn_event_elapsed_ms(tn_ctx* ctx, void* ev_start, void* ev_stop, float* ms); /* syncs on stop */
 int tn_event_destroy(tn_ctx* ctx, void* ev);
+/* non-blocking: *done = 1 once everything recorded in front of the event has finished, else 0 (watchdogs
+ * that must raise instead of hanging: the communicator self-test of theanet_amd/comm.py)              */
+int tn_event_query(tn_ctx* ctx, void* ev, int* done);
 
 /* ---- conv (replaces nnconv.conv2d + tt.grad through it; convpool.py:54-72, layer.py:83) ----
  * True convolution (kernel flipped), W layout (K,C,f,f):

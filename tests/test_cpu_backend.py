@@ -105,7 +105,7 @@ def test_product_data_parallel_step_world_size_2(tmp_path, pipe, overlap):
     port = s.getsockname()[1]
     s.close()
     outs = []
-    for world in (1, 2):
+    for world in (1, 2, 4) if pipe == "1" else (1, 2):        # (every DeviceGroup of > 1 rank starts with its self-test)
         out = str(tmp_path / ("w%d.npz" % world))
         procs = []
         for rank in range(world):
@@ -123,11 +123,35 @@ def test_product_data_parallel_step_world_size_2(tmp_path, pipe, overlap):
                 raise
             assert p.returncode == 0, o.decode()[-3000:]
         outs.append(np.load(out))
-    one, two = outs
-    np.testing.assert_allclose(two["costs"], one["costs"], rtol=2e-5)
-    np.testing.assert_allclose(two["stats"], one["stats"], rtol=1e-5, atol=1e-6)
-    for k in one.files:
-        if k.startswith("w"):
-            np.testing.assert_allclose(two[k], one[k], rtol=1e-5, atol=1e-6, err_msg=k)
+    one, two = outs[0], outs[1]
+    for many in outs[1:]:
+        np.testing.assert_allclose(many["costs"], one["costs"], rtol=2e-5)
+        np.testing.assert_allclose(many["stats"], one["stats"], rtol=1e-5, atol=1e-6)
+        for k in one.files:
+            if k.startswith("w"):
+                np.testing.assert_allclose(many[k], one[k], rtol=1e-5, atol=1e-6, err_msg=k)
     want = {"auto": "pipelined", "0": "plain", "1": "overlap", "2": "delayed"}[overlap]
     assert str(two["schedule"]) == want, str(two["schedule"])
+
+
+@pytest.mark.parametrize("prms,extra,rows", [("mnist.prms", [], 512), ("wide6.prms", ["--img", "16"], 128)])
+def test_bench_dry_multi_plans_an_8_rank_run_without_a_communicator(prms, extra, rows):
+    """bench.py --dry-multi 8: the scaling command line's plan (row shards of the first and last rank, the flat
+    gradient buffer every rank all-reduces, the schedule) without a communicator or a second process.  mnist shards
+    BASELINE's 4096 eight ways (512 rows per GPU, configs[2]); wide6 keeps 128 images per GPU = 1024 per node
+    (configs[4]; round 2 sharded 128 into 16 per GPU)."""
+    import json
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-multi", "8", "--prms", prms] + extra,
+                       cwd=ROOT, env=_env(), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    plan = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert plan["rows_per_gpu"] == rows and plan["global_batch"] == 8 * rows
+    assert plan["ranks_shown"][0]["rows_of_minibatch"] == [0, rows]
+    assert plan["ranks_shown"][1]["rows_of_minibatch"] == [7 * rows, 8 * rows]
+    flat = plan["flat_gradient_buffer"]
+    offs = [t["offset_floats"] for t in flat["tensors"]]
+    assert offs == sorted(offs) and all(o % 64 == 0 for o in offs)
+    last = flat["tensors"][-1]
+    assert flat["cost_slot"] >= last["offset_floats"] + int(np.prod(last["shape"]))
+    assert flat["floats_reduced_per_step"] == flat["cost_slot"] + 1
+    assert "pipelined" in plan["schedule"]

@@ -104,3 +104,62 @@ def test_delayed_update_recurrence_is_the_reference_recurrence():
     np.testing.assert_array_equal(np.array(got), np.array(ref_p))
     v = m * v + (1 - m) * pending                # mode 3: leaving the schedule catches v up
     np.testing.assert_array_equal(v, ref_v[-1])
+
+
+def test_communicator_self_test_raises_instead_of_hanging():
+    """DeviceGroup.self_test (run at communicator creation with more than one rank): a rank whose collectives never
+    finish makes the watchdog RAISE after its timeout, and a wrong sum is reported by element -- exercised with a
+    stand-in context (no GPU, no communicator): only the host logic is under test here; the real thing runs in
+    tests/test_cpu_backend.py (world_size 2 and 4) and tests/test_gpu_net.py."""
+    import ctypes
+    from theanet_amd import comm
+
+    class Arr:
+        def __init__(self, a):
+            self.a = np.array(a, np.float32)
+            self.size, self.ptr = self.a.size, 0
+
+        def get_value(self):
+            return self.a
+
+    class Ctx:
+        backend = "hip"
+
+        def __init__(self, finishes, scale):
+            self.finishes, self.scale, self.calls = finishes, scale, []
+            self.h = None
+            self.lib = type("L", (), {"tn_event_destroy": staticmethod(lambda h, e: 0)})()
+
+        def array(self, a):
+            self.last = Arr(a)
+            self.bufs = getattr(self, "bufs", []) + [self.last]
+            return self.last
+
+        def call(self, name, *args):
+            self.calls.append(name)
+            if name == "tn_event_query":
+                ctypes.cast(args[1], ctypes.POINTER(ctypes.c_int))[0] = 1 if self.finishes else 0
+
+    def group(ctx, size=4, rank=1):
+        g = comm.DeviceGroup.__new__(comm.DeviceGroup)
+        g.ctx, g.world = ctx, comm.World(rank, size)
+        g.n_issued, g.order_hash, g.check_every_call = 0, 0, False
+        g.verify_order = lambda: None
+        # stand-in collective: what a correct sum over ``size`` ranks leaves behind (first reduction of a buffer:
+        # the rank stamps add up to size*(size+1)/2; a second one sums ``size`` equal copies), times ``scale``
+        seen = {}
+
+        def allreduce_sum(b, n):
+            first = seen.setdefault(id(b), 0) == 0
+            seen[id(b)] += 1
+            b.a *= ctx.scale * ((size * (size + 1) / 2.0) / (rank + 1) if first else size)
+        g.allreduce_sum = allreduce_sum
+        return g
+
+    hung = Ctx(finishes=False, scale=1.0)
+    with pytest.raises(RuntimeError, match="self-test timed out"):
+        group(hung).self_test(timeout=0.05)
+    assert hung.calls.count("tn_event_query") > 1 and hung.calls[-1] == "tn_stream_select"
+    bad = Ctx(finishes=True, scale=1.5)
+    with pytest.raises(RuntimeError, match="self-test failed on rank 1 of 4: element 0"):
+        group(bad).self_test(timeout=1.0)

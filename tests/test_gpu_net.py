@@ -319,6 +319,9 @@ def test_rccl_single_rank_allreduce_and_dp_plumbing():
     group.allreduce_max(d, 10)
     group.barrier()
     np.testing.assert_array_equal(d.get_value(), a)
+    # the start-up check of every communicator with more than one rank (three collectives alternating between
+    # the context's two streams, watchdog on tn_event_query), here on the one-rank communicator
+    group.self_test(timeout=30.0)
     ctx().call("tn_comm_destroy")
 
 

@@ -66,6 +66,7 @@ SIGNATURES = {
     "tn_event_wait": (c_int, [CTX, P]),
     "tn_event_elapsed_ms": (c_int, [CTX, P, P, POINTER(c_float)]),
     "tn_event_destroy": (c_int, [CTX, P]),
+    "tn_event_query": (c_int, [CTX, P, POINTER(c_int)]),
     "tn_conv2d_fwd": (c_int, [CTX, P, P, P, P] + [c_int] * 10 + [c_int, c_float]),
     "tn_conv2d_wgrad": (c_int, [CTX, P, P, P, P] + [c_int] * 10),
     "tn_conv2d_dgrad": (c_int, [CTX, P, P, P] + [c_int] * 10 + [P, c_int, c_float]),

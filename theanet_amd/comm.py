@@ -23,9 +23,10 @@ RDZV_PORT_OFFSET = 101
 
 
 class World:
-    def __init__(self, rank=0, size=1, local_rank=0, master_addr="127.0.0.1", master_port=29500):
+    def __init__(self, rank=0, size=1, local_rank=0, master_addr="127.0.0.1", master_port=29500, dry=False):
         self.rank, self.size, self.local_rank = rank, size, local_rank
         self.master_addr, self.master_port = master_addr, master_port
+        self.dry = dry          # plan only (bench.py --dry-multi): shards and buffers of this rank, no communicator
 
     @classmethod
     def from_env(cls, env=None):
@@ -217,6 +218,60 @@ class DeviceGroup:
         # schedule alternate on ONE communicator) -- verify_order() compares it across ranks
         self.n_issued, self.order_hash = 0, 0
         self.check_every_call = os.environ.get("TN_DP_CHECK_ORDER") == "1"
+        if world.size > 1 and os.environ.get("TN_COMM_SELFTEST", "1") != "0":
+            self.self_test()
+
+    def self_test(self, timeout=None):
+        """One-shot check of a fresh communicator, run at creation when there is more than one rank: three
+        all-reduces of rank-stamped vectors in exactly the pattern of the two-steps-in-flight schedule (stream
+        0, stream 1, stream 0 again on ONE communicator, each ordered behind the previous by an event), then the
+        sums are verified on every rank.  A watchdog polls the last event (tn_event_query) and RAISES after
+        ``timeout`` seconds (TN_COMM_SELFTEST_TIMEOUT, default 60) instead of hanging in a sync: a device-side
+        ordering problem of the alternation shows up here, by name, and not as a silent stall of the first
+        training step."""
+        import ctypes
+        ctx, R, r = self.ctx, self.world.size, self.world.rank
+        timeout = float(os.environ.get("TN_COMM_SELFTEST_TIMEOUT", 60)) if timeout is None else timeout
+        n = 1024
+        pat = (np.arange(n) % 7 + 1).astype(np.float32)
+        bufs = [ctx.array((r + 1) * pat), ctx.array((r + 1) * 2 * pat)]
+        evs = []
+        for _ in range(3):
+            e = ctypes.c_void_p()
+            ctx.call("tn_event_create", ctypes.byref(e))
+            evs.append(e)
+        try:
+            for k, (stream, b) in enumerate(((0, 0), (1, 1), (0, 0))):
+                ctx.call("tn_stream_select", stream)
+                if k:
+                    ctx.call("tn_event_wait", evs[k - 1])
+                self.allreduce_sum(bufs[b], n)
+                ctx.call("tn_event_record", evs[k])
+            ctx.call("tn_stream_select", 0)
+            done, t0 = ctypes.c_int(0), time.time()
+            while True:
+                ctx.call("tn_event_query", evs[2], ctypes.byref(done))
+                if done.value:
+                    break
+                if time.time() - t0 > timeout:
+                    raise RuntimeError(
+                        "theanet_amd: communicator self-test timed out after %.0f s on rank %d of %d: three all-reduces "
+                        "alternating between the context's two streams did not finish (RCCL / xGMI bring-up, or a rank "
+                        "that never joined)" % (timeout, r, R))
+                time.sleep(0.002)
+            tri = R * (R + 1) / 2.0
+            want = [tri * R * pat, tri * 2 * pat]        # buffer 0 went through two all-reduces
+            for b, w in zip(bufs, want):
+                got = b.get_value()
+                if not np.array_equal(got, w.astype(np.float32)):
+                    bad = int(np.argmax(got != w))
+                    raise RuntimeError("theanet_amd: communicator self-test failed on rank %d of %d: element %d is %r, "
+                                       "expected %r" % (r, R, bad, float(got[bad]), float(w[bad])))
+        finally:
+            ctx.call("tn_stream_select", 0)
+            for e in evs:
+                ctx.lib.tn_event_destroy(ctx.h, e)
+        self.verify_order()
 
     def _note(self, kind, count):
         self.n_issued += 1

@@ -287,6 +287,12 @@ int tn_event_destroy(tn_ctx* ctx, void* ev) {
     if (ev) TN_HIP(hipEventDestroy((hipEvent_t)ev));
     return TN_OK;
 }
+int tn_event_query(tn_ctx* ctx, void* ev, int* done) {
+    const hipError_t e = hipEventQuery((hipEvent_t)ev);
+    if (e != hipSuccess && e != hipErrorNotReady) TN_HIP(e);
+    *done = e == hipSuccess ? 1 : 0;
+    return TN_OK;
+}
 
 }  // extern "C"
 

@@ -448,6 +448,10 @@ class _TestFn:
 
 class NeuralNet():
     fuse_conv_pool = True     # class-level switch (tests run both the fused and unfused paths)
+    # the C-ABI ops that carry a net's conv products (bench.py brackets them for the conv roofline legs)
+    CONV_FWD_OPS = ("tn_conv2d_fwd", "tn_convpool_fwd_mask", "tn_elastic_convpool_fwd_mask")
+    CONV_BWD_OPS = ("tn_conv2d_wgrad", "tn_conv2d_dgrad", "tn_convpool_bwd_mask_dx", "tn_convpool_bwd_mask",
+                    "tn_convblock_bwd_mask", "tn_convblock_bwd", "tn_convpool_bwd")
 
     def __init__(self, layers, training_params, allwts=None,
                  test_x=None):
@@ -704,7 +708,7 @@ class NeuralNet():
         for lyr in self.tr_layers:
             self._need_gin.append(seen)
             seen = seen or lyr.has_updates()
-        if self._dp:
+        if self._dp and not self.world.dry:
             self._group()
             if self.world.size > 1 and not getattr(self, "_is_twin", False):
                 # replicas must start from identical weights (same SEED or same checkpoint on every rank)
