@@ -138,6 +138,34 @@ int tn_conv_f16_supported(int N, int C, int H, int Wd, int K, int f, int stride,
 int tn_convpool_f16_supported(int N, int C, int H, int Wd, int K, int f, int stride, int pad_lo, int Ho, int Wo,
                               int p, int Hp, int Wp);
 
+/* ---- DTYPE 'float16' on fp16-RESIDENT tensors (theanet_amd/csrc/conv_c8.hip, fc_c8.hip) --------------------
+ * BASELINE.json configs[4]: "fp16 inputs / fp32 accum MFMA".  The reference is float32-only (weights.py:8); these
+ * entry points replace the same Theano call sites as tn_conv2d_* / tn_fc_* (convpool.py:54-72,106-107; hidden.py:30;
+ * layer.py:83) for nets built with training param DTYPE = 'float16'.  Activations and the gradients flowing down
+ * the net live in HBM as IEEE halfs in the "c8" layout: logical (N, C, H, W) stored [N][ceil(C/8)][H][W][8]
+ * (16-byte cell = the 8 channels of an octet at one pixel; channels beyond C are zero).  Master weights, biases,
+ * weight gradients, velocities stay fp32.  Gradient tensors hold grad_scale * g (tn_set_matmul_dtype's grad_scale, a
+ * power of two; scaled where the first fp16 gradient is produced, removed in the fp32 epilogues of the weight
+ * gradients).  Arithmetic: operands rounded to half (nearest-even), exact products, fp32 accumulation; bias,
+ * activation and pooling on the fp32 sums; one rounding when a tensor is stored.  Pooling masks: one byte per pooled
+ * value in the same [N][K/8][H/2][W/2][8] order, bits 0-3 = window elements (2*di+dj) equal to the maximum (all of
+ * them on a tie, Theano's MaxPoolGrad), bit 4 / 5 = pooled value > 0 / < 0.                                      */
+int tn_c8_conv_supported(int N, int C, int H, int W, int K, int f, int stride, int pad);
+int tn_c8_conv_wgrad_supported(int N, int C, int H, int W, int K);
+int tn_c8_conv_fwd(tn_ctx* ctx, const void* x, const float* W, const float* b, void* y, uint8_t* mask, int N, int C,
+                   int H, int Wd, int K, int act, float prm, int pool);
+/* dx = conv^T(dz, W) * act'(prev_a) (prev_a NULL: none).  pooled != 0: dz is gathered from the pooled gradient (the
+ * `dz` argument), the block's mask and -- activations other than leaky-ReLU -- its pooled output y, (act, prm) being
+ * the block's own activation: the conv activation, MaxPoolGrad's output and dz never exist in HBM                  */
+int tn_c8_conv_dgrad(tn_ctx* ctx, const void* dz, const float* W, void* dx, int N, int C, int H, int Wd, int K,
+                     const void* prev_a, int prev_act, float prev_prm, int pooled, const uint8_t* mask, const void* y,
+                     int act, float prm);
+int tn_c8_conv_wgrad(tn_ctx* ctx, const void* x, const void* dz, float* dW, float* db, int N, int C, int H, int Wd,
+                     int K, int pooled, const uint8_t* mask, const void* y, int act, float prm);
+/* NCHW fp32 (rows row0.. of a dataset) -> c8 fp16 and back; values are multiplied by scale                        */
+int tn_c8_pack(tn_ctx* ctx, const float* x, int64_t row0, void* out, int N, int C, int HW, float scale);
+int tn_c8_unpack(tn_ctx* ctx, const void* x, float* out, int N, int C, int HW, float scale);
+
 /* 1 if tn_conv2d_* run this shape on the implicit-im2col fp32-MFMA kernels (stride 1, reduction
  * C*f*f >= 32, >= 16 output maps); otherwise the direct VALU kernels are used.              */
 int tn_conv_mfma_supported(int C, int K, int f, int stride);

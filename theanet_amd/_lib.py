@@ -74,6 +74,13 @@ SIGNATURES = {
     "tn_get_matmul_dtype": (c_int, [CTX]),
     "tn_conv_f16_supported": (c_int, [c_int] * 10),
     "tn_convpool_f16_supported": (c_int, [c_int] * 13),
+    "tn_c8_conv_supported": (c_int, [c_int] * 8),
+    "tn_c8_conv_wgrad_supported": (c_int, [c_int] * 5),
+    "tn_c8_conv_fwd": (c_int, [CTX, P, P, P, P, P] + [c_int] * 6 + [c_float, c_int]),
+    "tn_c8_conv_dgrad": (c_int, [CTX, P, P, P] + [c_int] * 5 + [P, c_int, c_float, c_int, P, P, c_int, c_float]),
+    "tn_c8_conv_wgrad": (c_int, [CTX, P, P, P, P] + [c_int] * 5 + [c_int, P, P, c_int, c_float]),
+    "tn_c8_pack": (c_int, [CTX, P, c_int64, P, c_int, c_int, c_int, c_float]),
+    "tn_c8_unpack": (c_int, [CTX, P, P, c_int, c_int, c_int, c_float]),
     "tn_pool_fwd": (c_int, [CTX, P, P] + [c_int] * 6),
     "tn_pool_bwd": (c_int, [CTX, P, P, P, P] + [c_int] * 6 + [c_int, c_float]),
     "tn_mean_fwd": (c_int, [CTX, P, P, c_int, c_int]),

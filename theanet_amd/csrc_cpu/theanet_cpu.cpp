@@ -173,6 +173,18 @@ int tn_set_matmul_dtype(tn_ctx* ctx, int dtype, float grad_scale) {
 }
 int tn_get_matmul_dtype(tn_ctx*) { return 0; }
 int tn_conv_f16_supported(int, int, int, int, int, int, int, int, int, int) { return 0; }
+// DTYPE 'float16' on fp16-resident tensors (conv_c8.hip): MI355X only; the capability queries answer 0 and
+// tn_set_matmul_dtype refuses the mode, so the host never gets here
+int tn_c8_conv_supported(int, int, int, int, int, int, int, int) { return 0; }
+int tn_c8_conv_wgrad_supported(int, int, int, int, int) { return 0; }
+int tn_c8_conv_fwd(tn_ctx* ctx, const void*, const float*, const float*, void*, uint8_t*, int, int, int, int, int, int,
+                   float, int) { NOT_HERE("tn_c8_conv_fwd"); }
+int tn_c8_conv_dgrad(tn_ctx* ctx, const void*, const float*, void*, int, int, int, int, int, const void*, int, float, int,
+                     const uint8_t*, const void*, int, float) { NOT_HERE("tn_c8_conv_dgrad"); }
+int tn_c8_conv_wgrad(tn_ctx* ctx, const void*, const void*, float*, float*, int, int, int, int, int, int, const uint8_t*,
+                     const void*, int, float) { NOT_HERE("tn_c8_conv_wgrad"); }
+int tn_c8_pack(tn_ctx* ctx, const float*, int64_t, void*, int, int, int, float) { NOT_HERE("tn_c8_pack"); }
+int tn_c8_unpack(tn_ctx* ctx, const void*, float*, int, int, int, float) { NOT_HERE("tn_c8_unpack"); }
 int tn_convpool_f16_supported(int, int, int, int, int, int, int, int, int, int, int, int, int) { return 0; }
 
 int tn_alloc(tn_ctx* ctx, size_t bytes, void** dptr) {
