@@ -154,14 +154,27 @@ int tn_c8_conv_supported(int N, int C, int H, int W, int K, int f, int stride, i
 int tn_c8_conv_wgrad_supported(int N, int C, int H, int W, int K);
 int tn_c8_conv_fwd(tn_ctx* ctx, const void* x, const float* W, const float* b, void* y, uint8_t* mask, int N, int C,
                    int H, int Wd, int K, int act, float prm, int pool);
-/* dx = conv^T(dz, W) * act'(prev_a) (prev_a NULL: none).  pooled != 0: dz is gathered from the pooled gradient (the
- * `dz` argument), the block's mask and -- activations other than leaky-ReLU -- its pooled output y, (act, prm) being
- * the block's own activation: the conv activation, MaxPoolGrad's output and dz never exist in HBM                  */
+/* dx = conv^T(dz, W) * act'(prev_a) (prev_a NULL: none; for a pooled block below, prev_a is its POOLED output and dx
+ * has that shape: the gradient a pooled block receives always carries act'(pooled output)).  pooled != 0: dz is not a
+ * tensor: the `dz` argument is the pooled gradient (N, K, H/2, W/2) and dz = (bit of the window element in the block's
+ * mask) ? pooled gradient : 0 is formed while staging: the conv activation, MaxPoolGrad's output and dz never exist
+ * in HBM                                                                                                            */
 int tn_c8_conv_dgrad(tn_ctx* ctx, const void* dz, const float* W, void* dx, int N, int C, int H, int Wd, int K,
-                     const void* prev_a, int prev_act, float prev_prm, int pooled, const uint8_t* mask, const void* y,
-                     int act, float prm);
+                     const void* prev_a, int prev_act, float prev_prm, int pooled, const uint8_t* mask);
 int tn_c8_conv_wgrad(tn_ctx* ctx, const void* x, const void* dz, float* dW, float* db, int N, int C, int H, int Wd,
-                     int K, int pooled, const uint8_t* mask, const void* y, int act, float prm);
+                     int K, int pooled, const uint8_t* mask);
+/* fully-connected products on an fp16-resident input (replaces hidden.py:30 and its gradients, layer.py:83, for the
+ * first dense layer above a c8 conv stack; theanet_amd/csrc/fc_c8.hip): x16 (B, ceil(C/8)*HW*8) halfs is the flattened
+ * c8 tensor of C maps of HW pixels (HW = 1: a plain half matrix), W (C*HW, n_out) fp32 keeps the reference's
+ * NCHW-flattened row order (neuralnet.py:168-173) and is walked through the row map; the layer output a and dz are
+ * fp32.  dgrad writes fp16(grad_scale * dz . W^T * act'(y16)) in x's order (y16 = output of the layer below, NULL:
+ * none); wgrad removes the scale.                                                                                */
+int tn_c8_fc_supported(int B, int C, int HW, int n_out);
+int tn_c8_fc_fwd(tn_ctx* ctx, const void* x, const float* W, const float* b, float* a, int B, int C, int HW, int n_out,
+                 int act, float act_param, const uint8_t* mask);
+int tn_c8_fc_dgrad(tn_ctx* ctx, const float* dz, const float* W, void* dx, int B, int C, int HW, int n_out, const void* y,
+                   int act, float act_param);
+int tn_c8_fc_wgrad(tn_ctx* ctx, const void* x, const float* dz, float* dW, float* db, int B, int C, int HW, int n_out);
 /* NCHW fp32 (rows row0.. of a dataset) -> c8 fp16 and back; values are multiplied by scale                        */
 int tn_c8_pack(tn_ctx* ctx, const float* x, int64_t row0, void* out, int N, int C, int HW, float scale);
 int tn_c8_unpack(tn_ctx* ctx, const void* x, float* out, int N, int C, int HW, float scale);

@@ -84,13 +84,13 @@ def pool2(a):
     return m, bits
 
 
-def unpool_dz(g, bits, slope):
-    """dz of a pooled leaky-ReLU block from the pooled gradient and the mask, as the kernels form it."""
+def unpool_dz(g, bits):
+    """dz of a pooled block from the pooled gradient (which already carries act'(pooled output)) and the mask, as the
+    kernels form it: every window element that attained the maximum receives the pooled gradient."""
     N, K, Hp, Wp = g.shape
-    d = np.where(bits & 16, 1.0, np.where(bits & 32, slope, 1.0 + slope if slope > 0 else 0.0))
     dz = np.zeros((N, K, Hp, 2, Wp, 2))
     for di in range(2):
         for dj in range(2):
             sel = (bits >> (2 * di + dj)) & 1
-            dz[:, :, :, di, :, dj] = np.where(sel, r16(g * d), 0.0)
+            dz[:, :, :, di, :, dj] = np.where(sel, g, 0.0)
     return dz.reshape(N, K, 2 * Hp, 2 * Wp)

@@ -77,8 +77,12 @@ SIGNATURES = {
     "tn_c8_conv_supported": (c_int, [c_int] * 8),
     "tn_c8_conv_wgrad_supported": (c_int, [c_int] * 5),
     "tn_c8_conv_fwd": (c_int, [CTX, P, P, P, P, P] + [c_int] * 6 + [c_float, c_int]),
-    "tn_c8_conv_dgrad": (c_int, [CTX, P, P, P] + [c_int] * 5 + [P, c_int, c_float, c_int, P, P, c_int, c_float]),
-    "tn_c8_conv_wgrad": (c_int, [CTX, P, P, P, P] + [c_int] * 5 + [c_int, P, P, c_int, c_float]),
+    "tn_c8_conv_dgrad": (c_int, [CTX, P, P, P] + [c_int] * 5 + [P, c_int, c_float, c_int, P]),
+    "tn_c8_conv_wgrad": (c_int, [CTX, P, P, P, P] + [c_int] * 5 + [c_int, P]),
+    "tn_c8_fc_supported": (c_int, [c_int] * 4),
+    "tn_c8_fc_fwd": (c_int, [CTX, P, P, P, P] + [c_int] * 5 + [c_float, P]),
+    "tn_c8_fc_dgrad": (c_int, [CTX, P, P, P] + [c_int] * 4 + [P, c_int, c_float]),
+    "tn_c8_fc_wgrad": (c_int, [CTX, P, P, P, P] + [c_int] * 4),
     "tn_c8_pack": (c_int, [CTX, P, c_int64, P, c_int, c_int, c_int, c_float]),
     "tn_c8_unpack": (c_int, [CTX, P, P, c_int, c_int, c_int, c_float]),
     "tn_pool_fwd": (c_int, [CTX, P, P] + [c_int] * 6),

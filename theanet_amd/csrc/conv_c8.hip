@@ -35,13 +35,11 @@ struct C8G {
     const float* bias;        // forward
     const _Float16* prev_a;   // input gradient: output of the layer below (same shape as out) or NULL
     uint8_t* mask_out;        // MODE 1: pooling mask (N, K8, H/2, W/2, 8) bytes, may be NULL
-    const uint8_t* mask_in;   // MODE 3: mask and pooled output of the block whose dz is being gathered
-    const _Float16* y_in;
+    const uint8_t* mask_in;   // MODE 3: pooling mask of the block whose dz is being gathered
     int N, C8, K8, H, W, act;
     float prm;
-    int in_act;
-    float in_prm;
-    int KT, MT, RT, NI, TH, THi, RS, plane, nchunk, TP, nslots;
+    int KT, MT, RT, NI, TH, THi, RS, plane, nchunk, TP, nslots, nwork;
+    unsigned long long* dbg;  // TN_C8_DBG=1: per block {start, prologue done, loop done, end} (s_memtime) + wall clock
 };
 
 __host__ __device__ __forceinline__ int c8_swap23(int j) { return (j & ~12) | ((j & 4) << 1) | ((j & 8) >> 1); }
@@ -67,129 +65,178 @@ __global__ __launch_bounds__(256) void c8_wt_kernel(const float* __restrict__ W,
     wt[idx] = (_Float16)v;
 }
 
-// staging slot e of the halo tile: (octet of the chunk, image, tile row, column) -> 16-byte cell.
-// POOLED: the cell is gathered from the pooled tensors: g = the pooled cell, cstride = cells per octet plane there
-struct C8Slot { int g, l, o, sh; bool ok; };
-template <bool POOLED>
-__device__ __forceinline__ C8Slot c8_slot(const C8G& g, int e, int n0, int r0) {
-    C8Slot s;
-    const bool in = e < g.nslots;
-    int rr = min(e, g.nslots - 1);
-    const int col = rr % g.W; rr /= g.W;
-    const int r = rr % g.THi; rr /= g.THi;
-    const int ni = rr % g.NI;
-    const int o = rr / g.NI;
-    const int row = r0 - 1 + r, n = n0 + ni;
-    s.ok = in && (unsigned)row < (unsigned)g.H && n < g.N;
-    const int nn = min(n, g.N - 1), rw = min(max(row, 0), g.H - 1);
-    s.o = o;
-    s.sh = ((rw & 1) << 1) | (col & 1);
-    if (POOLED) s.g = ((nn * g.C8 + o) * (g.H >> 1) + (rw >> 1)) * (g.W >> 1) + (col >> 1);
-    else s.g = ((nn * g.C8 + o) * g.H + rw) * g.W + col;      // in cells; + 2*chunk*(cells per plane) per chunk
-    s.l = (o * g.plane + (ni * g.THi + r) * g.RS + 1 + col) * 16;
-    return s;
+__device__ __forceinline__ uint4 c8_and4(uint4 v, bool ok) {
+    const unsigned m = ok ? 0xffffffffu : 0u;
+    return make_uint4(v.x & m, v.y & m, v.z & m, v.w & m);
 }
 
-// dz cell of a pooled block: 8 channels at full-resolution pixel (row, col) from the pooled gradient cell, the mask
-// bytes and (activations other than leaky-ReLU) the pooled output:  bit (2*(row&1) + (col&1)) of the mask says whether
-// this window element attained the maximum; bits 4 / 5 = sign of the pooled value
-__device__ __forceinline__ uint4 c8_pool_cell(const uint4 g8, const uint2 m8, const uint4 y8, int sh, int act, float prm) {
-    const half8 gh = __builtin_bit_cast(half8, g8), yh = __builtin_bit_cast(half8, y8);
-    half8 o;
-    const float tie = prm > 0.f ? 1.f + prm : 0.f;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const unsigned m = ((e < 4 ? m8.x : m8.y) >> (8 * (e & 3))) & 0xffu;
-        float d;
-        if (act == TN_ACT_LEAKY) d = (m & 16u) ? 1.f : ((m & 32u) ? prm : tie);
-        else d = tn_act_grad_from_out((float)yh[e], act, prm);
-        const float v = ((m >> sh) & 1u) ? (float)gh[e] * d : 0.f;
-        o[e] = (_Float16)v;
-    }
-    return __builtin_bit_cast(uint4, o);
+// dz cell of a pooled block at window element sh (= 2*(row & 1) + (col & 1)): the pooled gradient cell where bit sh of the
+// channel's mask byte is set (that window element attained the maximum; all of them on a tie: Theano's MaxPoolGrad),
+// zero elsewhere.  The pooled gradient already carries act'(pooled output): whichever kernel produced it multiplied by
+// the derivative taken from the block's stored output (the backward fusion rule of DESIGN.md section 4).
+__device__ __forceinline__ uint4 c8_pool_cell(const uint4 g8, const uint2 m8, int sh) {
+    const unsigned b0 = (m8.x >> sh) & 0x01010101u, b1 = (m8.y >> sh) & 0x01010101u;    // one byte per channel: 0 / 1
+    // two channels per dword: bytes -> 16-bit all-ones masks (v_perm spreads, x 0xffff fills)
+    const unsigned k0 = __umul24(__builtin_amdgcn_perm(0u, b0, 0x0c010c00u), 0xffffu);
+    const unsigned k1 = __umul24(__builtin_amdgcn_perm(0u, b0, 0x0c030c02u), 0xffffu);
+    const unsigned k2 = __umul24(__builtin_amdgcn_perm(0u, b1, 0x0c010c00u), 0xffffu);
+    const unsigned k3 = __umul24(__builtin_amdgcn_perm(0u, b1, 0x0c030c02u), 0xffffu);
+    return make_uint4(g8.x & k0, g8.y & k1, g8.z & k2, g8.w & k3);
 }
 
 // MODE 0: forward (bias + act); 1: forward + 2x2 max-pool + mask; 2: input gradient (x act' of the layer below);
-// 3: input gradient of a pooled block, dz gathered from (g, mask, y)
-template <int FT, int MODE, int NS>
+// 3: input gradient of a pooled block, dz gathered from (g, mask, y).
+// PERSISTENT blocks: a block walks over work items w = blockIdx.x, + gridDim.x, ... (work item = one 256-pixel tile x one
+// filter tile, decoded XCD-aware: the filter tiles of a pixel tile share an L2) with ONE software pipeline across
+// them -- (work item, chunk) pairs form a flat sequence, input cells are fetched two steps ahead and weights one step
+// ahead whatever tile they belong to, so a tile's epilogue stores and the next tile's first loads overlap the matrix
+// work instead of bracketing it (cycle stamps of the one-tile-per-block form, conv2 of wide6: prologue 5.4 k + main
+// loop 11.5 k + epilogue 5.5 k cycles per block, all blocks of a round in the same phase).
+template <int FT, int MODE, int NS, bool LK>
 __global__ __launch_bounds__(256, 2) void c8_conv_kernel(C8G g) {
     extern __shared__ __attribute__((aligned(16))) float ct_smem[];
     constexpr bool DGRAD = MODE >= 2;
+    constexpr bool POOLED = MODE == 3;
     constexpr int KBF = 32 * FT;
     constexpr int WB = 9 * 2 * KBF * 16;              // bytes of one weight chunk
     constexpr int WS = (WB / 16 + 255) / 256;         // 16-byte staging slots per thread (3 or 5)
     const int XB = 2 * g.plane * 16;                  // bytes of one input chunk (two octet planes)
     char* const Xs = reinterpret_cast<char*>(ct_smem);            // [2][XB]
     char* const Ws = Xs + 2 * XB;                                 // [2][WB]
-    // XCD-aware decode: the filter tiles of one pixel tile share an L2
-    const int bid = blockIdx.x, xcd = bid & 7, idx = bid >> 3;
-    const int mt = (idx / g.KT) * 8 + xcd, kt = idx % g.KT;
-    if (mt >= g.MT) return;
-    const int grp = mt / g.RT, rt = mt - grp * g.RT;
-    const int n0 = grp * g.NI, r0 = rt * g.TH;
+    const int bid = blockIdx.x, G = gridDim.x;
+    const int nwork = (g.nwork - bid + G - 1) / G;    // work items of this block (>= 1: the grid is not larger than nwork)
+    const int SEQ = nwork * g.nchunk;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, hi = lane >> 5;
     const int HW = g.H * g.W;
+    unsigned long long* dbg = (g.dbg && t == 0) ? g.dbg + 8 * (size_t)bid : nullptr;
+    if (dbg) { dbg[0] = __builtin_readcyclecounter(); dbg[4] = wall_clock64(); }
 
+    // halo columns and the window overhang stay zero for the life of the block; every other cell is rewritten per step
     for (int i = t * 16; i < 2 * XB; i += 4096) *reinterpret_cast<float4*>(Xs + i) = make_float4(0.f, 0.f, 0.f, 0.f);
 
-    C8Slot sl[NS];
+    // ---- work item i of this block -> tile ----
+    struct Tile { int n0, r0, kt, base; bool dead; };
+    auto decode = [&](int i) __attribute__((always_inline)) {
+        const int w = bid + min(i, nwork - 1) * G, xcd = w & 7, idx = w >> 3;
+        const int mt = (idx / g.KT) * 8 + xcd;
+        Tile tl;
+        tl.kt = idx % g.KT;
+        tl.dead = mt >= g.MT;                         // (MT not a multiple of 8: computed, never stored)
+        const int mtc = min(mt, g.MT - 1), grp = mtc / g.RT, rt = mtc - grp * g.RT;
+        tl.n0 = grp * g.NI; tl.r0 = rt * g.TH;
+        tl.base = POOLED ? tl.n0 * g.C8 * (HW >> 2) + (tl.r0 >> 1) * (g.W >> 1) : tl.n0 * g.C8 * HW + tl.r0 * g.W;
+        return tl;
+    };
+
+    // ---- staging slots of this thread (the same for every tile): slot e = (octet of the chunk, image, tile row, column)
+    // -> LDS cell, cell offset relative to the tile's first cell, flags: bit 0 in use, 1 / 2 top / bottom halo row,
+    // 3-4 window element (2*(row&1) + (col&1)), 5 octet, 8.. image of the tile
+    int sl_l[NS], sl_rel[NS], sl_fl[NS];
 #pragma unroll
-    for (int s = 0; s < NS; ++s) sl[s] = c8_slot<MODE == 3>(g, t + 256 * s, n0, r0);
-    const char* wsrc = reinterpret_cast<const char*>(g.wt) + (size_t)kt * g.nchunk * WB + 16 * t;
+    for (int s = 0; s < NS; ++s) {
+        const int e = t + 256 * s;
+        int rr = min(e, g.nslots - 1);
+        const int col = rr % g.W; rr /= g.W;
+        const int r = rr % g.THi; rr /= g.THi;
+        const int ni = rr % g.NI;
+        const int o = rr / g.NI;
+        sl_l[s] = (o * g.plane + (ni * g.THi + r) * g.RS + 1 + col) * 16;
+        sl_rel[s] = POOLED ? (ni * g.C8 + o) * (HW >> 2) + ((r - 1) >> 1) * (g.W >> 1) + (col >> 1)
+                           : (ni * g.C8 + o) * HW + (r - 1) * g.W + col;
+        sl_fl[s] = (e < g.nslots ? 1 : 0) | (r == 0 ? 2 : 0) | (r == g.THi - 1 ? 4 : 0) | ((((r - 1) & 1) << 1 | (col & 1)) << 3) |
+                   (o << 5) | (ni << 8);
+    }
+    auto slot_ok = [&](int s, const Tile& tl) __attribute__((always_inline)) {
+        const int fl = sl_fl[s];
+        return (fl & 1) && !((fl & 2) && tl.r0 == 0) && !((fl & 4) && tl.r0 + g.TH >= g.H) && tl.n0 + (fl >> 8) < g.N;
+    };
     const uint4* xg = reinterpret_cast<const uint4*>(g.x);
 
     // this lane's two pixels: the two rows of a (2 x W') patch, same column (so that pooling is in-lane)
-    int boff[2], prow[2], pni[2];
-    bool pok[2];
+    int boff[2], prel[2], pni[2];
+    bool pin[2];
     const int L = wave * 32 + l31, pair = L / g.W, pcol = L - pair * g.W;
 #pragma unroll
     for (int pt = 0; pt < 2; ++pt) {
         const int R = 2 * pair + pt;
-        const bool in = R < g.NI * g.TH;
-        const int Rc = in ? R : 0;
+        pin[pt] = R < g.NI * g.TH;
+        const int Rc = pin[pt] ? R : 0;
         const int ni = Rc / g.TH, r = Rc - ni * g.TH;
-        pni[pt] = ni; prow[pt] = r0 + r;
-        pok[pt] = in && n0 + ni < g.N && r0 + r < g.H;
+        pni[pt] = ni; prel[pt] = r;
         boff[pt] = (hi * g.plane + (ni * g.THi + r) * g.RS + pcol) * 16;
     }
     const int aoff = (hi * KBF + l31) * 16;
 
+    // accumulators start from the bias (forward) / zero (gradients): row h*8+e of tile f is filter
+    // 8*(kt*KBF/8 + 4f + 2h + hi) + e.  The bias of the NEXT tile is fetched under the last chunk of the current one.
     f32x16 acc[FT][2];
+    float4 bq[FT][2][2];
+    auto bias_load = [&](int kt) __attribute__((always_inline)) {
+        if (DGRAD) return;
 #pragma unroll
-    for (int a = 0; a < FT; ++a)
+        for (int f = 0; f < FT; ++f)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+            for (int h = 0; h < 2; ++h) {
+                const int ob = min(kt * (KBF / 8) + f * 4 + h * 2 + hi, g.K8 - 1) * 8;
+                bq[f][h][0] = *reinterpret_cast<const float4*>(g.bias + ob);
+                bq[f][h][1] = *reinterpret_cast<const float4*>(g.bias + ob + 4);
+            }
+    };
+    auto acc_init = [&]() __attribute__((always_inline)) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+        for (int f = 0; f < FT; ++f)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    if (DGRAD) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) acc[f][b][h * 8 + e] = 0.f;
+                    } else {
+                        acc[f][b][h * 8 + 0] = bq[f][h][0].x; acc[f][b][h * 8 + 1] = bq[f][h][0].y;
+                        acc[f][b][h * 8 + 2] = bq[f][h][0].z; acc[f][b][h * 8 + 3] = bq[f][h][0].w;
+                        acc[f][b][h * 8 + 4] = bq[f][h][1].x; acc[f][b][h * 8 + 5] = bq[f][h][1].y;
+                        acc[f][b][h * 8 + 6] = bq[f][h][1].z; acc[f][b][h * 8 + 7] = bq[f][h][1].w;
+                    }
+                }
+    };
 
-    // input cells two chunks ahead (two register sets alternating by chunk parity), weights (L2) one chunk ahead
+    // input cells two steps ahead (two register sets alternating by step parity), weights (L2) one step ahead
     uint4 xr[2][NS];
     uint2 mr[2][NS];
-    uint4 yr[2][NS];
+    unsigned okm[2] = {0u, 0u};                       // which slots of the register set hold cells inside their image
     uint4 wr0, wr1, wr2, wr3, wr4;
+    // cursors over the flat (work item, chunk) sequence: input loads, weights / LDS stores, matrix work
+    int xi = 0, xch = 0, si = 0, sch = 0, ci = 0, cch = 0;
+    Tile tx = decode(0);
+    int skt = tx.kt;
+    bias_load(tx.kt);
+    acc_init();
 #define C8_WL(J, R) if (WS > J) R = *reinterpret_cast<const uint4*>(w_ + min(4096 * J, WB - 16 - 16 * t))
 #define C8_WST(J, R) if (WS > J && (4096 * (J + 1) <= WB || 16 * t + 4096 * J < WB)) *reinterpret_cast<uint4*>(wb + 4096 * J) = R
-    auto gloadx = [&](int chunk, auto Pc) __attribute__((always_inline)) {
+    auto gloadx = [&](auto Pc) __attribute__((always_inline)) {
         constexpr int P = decltype(Pc)::value;
-        const int ch = min(chunk, g.nchunk - 1);
+        unsigned m = 0;
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
+            const int o = (sl_fl[s] >> 5) & 1;
             // octets beyond C8 meet zero weights: any finite value will do (clamped re-read)
-            const int oc = min(2 * ch + sl[s].o, g.C8 - 1) - sl[s].o;
-            if (MODE == 3) {
-                const int pc = sl[s].g + oc * (HW >> 2);
-                xr[P][s] = xg[pc];
-                mr[P][s] = reinterpret_cast<const uint2*>(g.mask_in)[pc];
-                if (g.in_act != TN_ACT_LEAKY) yr[P][s] = reinterpret_cast<const uint4*>(g.y_in)[pc];
-            } else {
-                xr[P][s] = xg[sl[s].g + oc * HW];
-            }
+            const int oc = min(2 * xch + o, g.C8 - 1) - o;
+            const bool ok = slot_ok(s, tx);
+            m |= ok ? (1u << s) : 0u;
+            const int pc = tx.base + (ok ? sl_rel[s] + oc * (POOLED ? (HW >> 2) : HW) : 0);
+            xr[P][s] = xg[pc];
+            if (POOLED) mr[P][s] = reinterpret_cast<const uint2*>(g.mask_in)[pc];
         }
+        okm[P] = m;
+        if (++xch == g.nchunk) { xch = 0; tx = decode(++xi); }
     };
-    auto gloadw = [&](int chunk) __attribute__((always_inline)) {
-        const int ch = min(chunk, g.nchunk - 1);
-        const char* w_ = wsrc + (size_t)ch * WB;
+    auto gloadw = [&]() __attribute__((always_inline)) {
+        const char* w_ = reinterpret_cast<const char*>(g.wt) + ((size_t)skt * g.nchunk + sch) * WB + 16 * t;
         C8_WL(0, wr0); C8_WL(1, wr1); C8_WL(2, wr2); C8_WL(3, wr3); C8_WL(4, wr4);
+    };
+    auto sadv = [&]() __attribute__((always_inline)) {
+        if (++sch == g.nchunk) { sch = 0; skt = decode(++si).kt; }
     };
     auto lstore = [&](int buf, auto Pc) __attribute__((always_inline)) {
         constexpr int P = decltype(Pc)::value;
@@ -197,10 +244,11 @@ __global__ __launch_bounds__(256, 2) void c8_conv_kernel(C8G g) {
         char* wb = Ws + buf * WB + 16 * t;
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
-            if (sl[s].ok) {
+            if (sl_fl[s] & 1) {
                 uint4 v = xr[P][s];
-                if (MODE == 3) v = c8_pool_cell(v, mr[P][s], yr[P][s], sl[s].sh, g.in_act, g.in_prm);
-                *reinterpret_cast<uint4*>(xb + sl[s].l) = v;
+                if (POOLED) v = c8_pool_cell(v, mr[P][s], (sl_fl[s] >> 3) & 3);
+                // (a cell outside its image is written too: the buffer held another tile's rows a step ago)
+                *reinterpret_cast<uint4*>(xb + sl_l[s]) = c8_and4(v, (okm[P] >> s) & 1u);
             }
         }
         C8_WST(0, wr0); C8_WST(1, wr1); C8_WST(2, wr2); C8_WST(3, wr3); C8_WST(4, wr4);
@@ -208,17 +256,121 @@ __global__ __launch_bounds__(256, 2) void c8_conv_kernel(C8G g) {
     using P0 = std::integral_constant<int, 0>;
     using P1 = std::integral_constant<int, 1>;
 
-    gloadx(0, P0{});
-    gloadw(0);
-    gloadx(1, P1{});
+    // ---- epilogue of the tile the matrix work has just finished: accumulators 0-7 / 8-15 of a lane are octets
+    // (4f + hi) / (4f + 2 + hi) of its pixel.  (The leaky-ReLU family -- every default of the reference, convpool.py:19 --
+    // as straight-line code: with a run-time kind every element paid the whole switch of tn_act_fwd /
+    // tn_act_grad_from_out.)
+    const int Ho = g.H, Wo = g.W;
+    auto epilogue = [&](const Tile& tl) __attribute__((always_inline)) {
+        const float prm = g.prm, tie = prm > 0.f ? 1.f + prm : 0.f;
+        auto actf = [&](float z) __attribute__((always_inline)) {
+            if (!LK) return tn_act_fwd(z, g.act, prm);
+            // max(z, prm*z) = max(0,z) + min(0,z)*prm for 0 <= prm < 1; the instruction itself: fmaxf() costs a second
+            // v_max (sNaN canonicalisation of its operands) per value
+            float r;
+            const float zp = z * prm;
+            asm("v_max_f32_e32 %0, %1, %2" : "=v"(r) : "v"(z), "v"(zp));
+            return r;
+        };
+        auto actg = [&](float a) __attribute__((always_inline)) {
+            return LK ? (a > 0.f ? 1.f : (a < 0.f ? prm : tie)) : tn_act_grad_from_out(a, g.act, prm);
+        };
+        const int kt = tl.kt;
+        bool pok[2];
+        int prow[2];
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt) {
+            prow[pt] = tl.r0 + prel[pt];
+            pok[pt] = pin[pt] && !tl.dead && tl.n0 + pni[pt] < g.N && prow[pt] < g.H;
+        }
+        if (MODE == 1) {
+            // conv + act + 2x2 max-pool: vertical max in-lane (the lane's two pixels), horizontal with lane ^ 1
+            const int Hp = Ho >> 1, Wp = Wo >> 1;
+            const bool ok = pok[0];
+            const int dj = l31 & 1;
+            const size_t pbase = ((size_t)(tl.n0 + pni[0]) * g.K8 * Hp + (prow[0] >> 1)) * Wp + (pcol >> 1);
+#pragma unroll
+            for (int f = 0; f < FT; ++f)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int oct = kt * (KBF / 8) + f * 4 + h * 2 + hi;
+                    half8 o8;
+                    unsigned mb[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float a0 = actf(acc[f][0][h * 8 + e]);
+                        const float a1 = actf(acc[f][1][h * 8 + e]);
+                        const float mv = fmaxf(a0, a1);
+                        const float m = fmaxf(mv, __shfl_xor(mv, 1, 64));
+                        unsigned bits = (a0 == m ? (1u << dj) : 0u) | (a1 == m ? (4u << dj) : 0u);
+                        bits |= (unsigned)__shfl_xor((int)bits, 1, 64);
+                        bits |= (m > 0.f ? 16u : 0u) | (m < 0.f ? 32u : 0u);
+                        o8[e] = (_Float16)m;
+                        mb[e] = bits;
+                    }
+                    if (ok && dj == 0 && oct < g.K8) {
+                        const size_t o = pbase + (size_t)oct * Hp * Wp;
+                        reinterpret_cast<half8*>(g.out)[o] = o8;
+                        if (g.mask_out) {
+                            uint2 m2;
+                            m2.x = mb[0] | (mb[1] << 8) | (mb[2] << 16) | (mb[3] << 24);
+                            m2.y = mb[4] | (mb[5] << 8) | (mb[6] << 16) | (mb[7] << 24);
+                            reinterpret_cast<uint2*>(g.mask_out)[o] = m2;
+                        }
+                    }
+                }
+            return;
+        }
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt) {
+            const size_t pbase = ((size_t)(tl.n0 + pni[pt]) * g.K8 * Ho + prow[pt]) * Wo + pcol;
+            half8 pa[FT][2];
+            if (DGRAD && g.prev_a && pok[pt]) {
+#pragma unroll
+                for (int f = 0; f < FT; ++f)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int oct = min(kt * (KBF / 8) + f * 4 + h * 2 + hi, g.K8 - 1);
+                        pa[f][h] = reinterpret_cast<const half8*>(g.prev_a)[pbase + (size_t)oct * Ho * Wo];
+                    }
+            }
+#pragma unroll
+            for (int f = 0; f < FT; ++f)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int oct = kt * (KBF / 8) + f * 4 + h * 2 + hi;
+                    half8 o8;
+                    if (DGRAD) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            float v = acc[f][pt][h * 8 + e];
+                            if (g.prev_a) v *= actg((float)pa[f][h][e]);
+                            o8[e] = (_Float16)v;
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) o8[e] = (_Float16)actf(acc[f][pt][h * 8 + e]);
+                    }
+                    if (pok[pt] && oct < g.K8) reinterpret_cast<half8*>(g.out)[pbase + (size_t)oct * Ho * Wo] = o8;
+                }
+        }
+    };
+
+    gloadx(P0{});
+    gloadw();
+    gloadx(P1{});
     __syncthreads();                 // the clearing is done
     lstore(0, P0{});
     __syncthreads();
+    if (dbg) dbg[1] = __builtin_readcyclecounter();
     const int RS16 = g.RS * 16;
-    auto body = [&](int chunk, auto Pc) __attribute__((always_inline)) {
+    unsigned long long d_ls = 0, d_ep = 0, d_bar = 0;          // TN_C8_DBG: cycles in LDS stores / epilogues / barriers
+    auto body = [&](int seq, auto Pc) __attribute__((always_inline)) {
         constexpr int P = decltype(Pc)::value;
-        gloadw(chunk + 1);
-        gloadx(chunk + 2, Pc);
+        sadv();
+        gloadw();                    // step seq + 1
+        gloadx(Pc);                  // step seq + 2
+        if (!DGRAD && cch + 1 == g.nchunk) bias_load(decode(ci + 1).kt);
         const char* x0 = Xs + P * XB + boff[0];
         const char* x1 = Xs + P * XB + boff[1];
         const char* Wb = Ws + P * WB + aoff;
@@ -249,97 +401,32 @@ __global__ __launch_bounds__(256, 2) void c8_conv_kernel(C8G g) {
             __builtin_amdgcn_sched_group_barrier(0x100, FT + 2, 0);       // DS reads of the next tap
             __builtin_amdgcn_sched_group_barrier(0x008, 2 * FT, 0);       // then this tap's MFMAs
         }
-        // chunk + 1 (fetched a chunk ago into the other register set) goes into the other LDS buffer
-        if (chunk + 1 < g.nchunk) lstore(P ^ 1, std::integral_constant<int, P ^ 1>{});
+        // step seq + 1 (fetched a step ago into the other register set) goes into the other LDS buffer
+        unsigned long long s0 = 0, s1 = 0, s2 = 0;
+        if (g.dbg) s0 = __builtin_readcyclecounter();
+        if (seq + 1 < SEQ) lstore(P ^ 1, std::integral_constant<int, P ^ 1>{});
+        if (g.dbg) s1 = __builtin_readcyclecounter();
+        if (++cch == g.nchunk) {
+            const Tile tc = decode(ci);
+            asm volatile("; c8 epilogue begin");
+            epilogue(tc);
+            asm volatile("; c8 epilogue end");
+            acc_init();
+            cch = 0; ++ci;
+        }
+        if (g.dbg) s2 = __builtin_readcyclecounter();
         __syncthreads();
+        if (g.dbg) { d_ls += s1 - s0; d_ep += s2 - s1; d_bar += __builtin_readcyclecounter() - s2; }
     };
-    for (int chunk = 0; chunk < g.nchunk; chunk += 2) {
-        body(chunk, P0{});
-        if (chunk + 1 < g.nchunk) body(chunk + 1, P1{});
+    for (int seq = 0; seq < SEQ; seq += 2) {
+        body(seq, P0{});
+        if (seq + 1 < SEQ) body(seq + 1, P1{});
     }
 #undef C8_WL
 #undef C8_WST
-
-    // ---- epilogue: accumulators 0-7 / 8-15 of a lane are octets (4f + hi) / (4f + 2 + hi) of its pixel ----
-    const int Ho = g.H, Wo = g.W;
-    if (MODE == 1) {
-        // conv + act + 2x2 max-pool: vertical max in-lane (the lane's two pixels), horizontal with lane ^ 1
-        const int Hp = Ho >> 1, Wp = Wo >> 1;
-        const bool ok = pok[0];
-        const int dj = l31 & 1;
-        const size_t pbase = ((size_t)(n0 + pni[0]) * g.K8 * Hp + (prow[0] >> 1)) * Wp + (pcol >> 1);
-#pragma unroll
-        for (int f = 0; f < FT; ++f)
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int oct = kt * (KBF / 8) + f * 4 + h * 2 + hi;
-                const int ob = min(oct, g.K8 - 1) * 8;
-                const float4 b0 = *reinterpret_cast<const float4*>(g.bias + ob);
-                const float4 b1 = *reinterpret_cast<const float4*>(g.bias + ob + 4);
-                const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-                half8 o8;
-                unsigned mb[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float a0 = tn_act_fwd(acc[f][0][h * 8 + e] + bb[e], g.act, g.prm);
-                    const float a1 = tn_act_fwd(acc[f][1][h * 8 + e] + bb[e], g.act, g.prm);
-                    const float mv = fmaxf(a0, a1);
-                    const float m = fmaxf(mv, __shfl_xor(mv, 1, 64));
-                    unsigned bits = (a0 == m ? (1u << dj) : 0u) | (a1 == m ? (4u << dj) : 0u);
-                    bits |= (unsigned)__shfl_xor((int)bits, 1, 64);
-                    bits |= (m > 0.f ? 16u : 0u) | (m < 0.f ? 32u : 0u);
-                    o8[e] = (_Float16)m;
-                    mb[e] = bits;
-                }
-                if (ok && dj == 0 && oct < g.K8) {
-                    const size_t o = pbase + (size_t)oct * Hp * Wp;
-                    reinterpret_cast<half8*>(g.out)[o] = o8;
-                    if (g.mask_out) {
-                        uint2 m2;
-                        m2.x = mb[0] | (mb[1] << 8) | (mb[2] << 16) | (mb[3] << 24);
-                        m2.y = mb[4] | (mb[5] << 8) | (mb[6] << 16) | (mb[7] << 24);
-                        reinterpret_cast<uint2*>(g.mask_out)[o] = m2;
-                    }
-                }
-            }
-        return;
-    }
-#pragma unroll
-    for (int pt = 0; pt < 2; ++pt) {
-        const size_t pbase = ((size_t)(n0 + pni[pt]) * g.K8 * Ho + prow[pt]) * Wo + pcol;
-        half8 pa[FT][2];
-        if (DGRAD && g.prev_a && pok[pt]) {
-#pragma unroll
-            for (int f = 0; f < FT; ++f)
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const int oct = min(kt * (KBF / 8) + f * 4 + h * 2 + hi, g.K8 - 1);
-                    pa[f][h] = reinterpret_cast<const half8*>(g.prev_a)[pbase + (size_t)oct * Ho * Wo];
-                }
-        }
-#pragma unroll
-        for (int f = 0; f < FT; ++f)
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int oct = kt * (KBF / 8) + f * 4 + h * 2 + hi;
-                half8 o8;
-                if (DGRAD) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        float v = acc[f][pt][h * 8 + e];
-                        if (g.prev_a) v *= tn_act_grad_from_out((float)pa[f][h][e], g.act, g.prm);
-                        o8[e] = (_Float16)v;
-                    }
-                } else {
-                    const int ob = min(oct, g.K8 - 1) * 8;
-                    const float4 b0 = *reinterpret_cast<const float4*>(g.bias + ob);
-                    const float4 b1 = *reinterpret_cast<const float4*>(g.bias + ob + 4);
-                    const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) o8[e] = (_Float16)tn_act_fwd(acc[f][pt][h * 8 + e] + bb[e], g.act, g.prm);
-                }
-                if (pok[pt] && oct < g.K8) reinterpret_cast<half8*>(g.out)[pbase + (size_t)oct * Ho * Wo] = o8;
-            }
+    if (dbg) {
+        dbg[2] = __builtin_readcyclecounter(); dbg[5] = wall_clock64();
+        dbg[3] = d_ls; dbg[6] = d_ep; dbg[7] = d_bar;
     }
 }
 
@@ -377,24 +464,47 @@ static int c8_pick_ft(int K) { return K > 32 ? 2 : 1; }
 
 static size_t c8_lds_bytes(const C8G& g, int FT) { return (size_t)2 * (2 * g.plane * 16 + 9 * 2 * 32 * FT * 16); }
 
+static unsigned long long* c8_dbg_buf = nullptr;
+extern "C" int tn_c8_dbg_read(tn_ctx* ctx, unsigned long long* host, int nblocks) {
+    if (!c8_dbg_buf) return -1;
+    (void)ctx;
+    return hipMemcpy(host, c8_dbg_buf, (size_t)nblocks * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+}
+
 template <int FT, int MODE>
 static int c8_launch(tn_ctx* ctx, C8G& g) {
     const size_t lds = c8_lds_bytes(g, FT);
     const int ns = cdiv(g.nslots, 256);
-    const int grid = 8 * cdiv(g.MT, 8) * g.KT;
-#define C8_GO(NS)                                                                                             \
+    g.nwork = 8 * cdiv(g.MT, 8) * g.KT;
+    int grid = 8 * (2 * ctx->num_cus / 8);          // two resident blocks per CU, each walking over its work items
+    if (grid > g.nwork) grid = g.nwork;
+    static int dbg_on = -1;
+    if (dbg_on < 0) {
+        const char* e = getenv("TN_C8_DBG");
+        dbg_on = e ? atoi(e) : 0;
+    }
+    if (dbg_on) {
+        if (!c8_dbg_buf) TN_HIP(hipMalloc(&c8_dbg_buf, 8 * sizeof(unsigned long long) * 65536));
+        TN_HIP(hipMemsetAsync(c8_dbg_buf, 0, 8 * sizeof(unsigned long long) * 65536, ctx->stream));
+        g.dbg = grid <= 65536 ? c8_dbg_buf : nullptr;
+    }
+#define C8_GO(NS, LK)                                                                                         \
     {                                                                                                         \
         static bool attr_set = false;                                                                         \
         if (!attr_set) {                                                                                      \
-            TN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&c8_conv_kernel<FT, MODE, NS>),          \
+            TN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&c8_conv_kernel<FT, MODE, NS, LK>),      \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));              \
             attr_set = true;                                                                                  \
         }                                                                                                     \
-        c8_conv_kernel<FT, MODE, NS><<<grid, 256, lds, ctx->stream>>>(g);                                     \
+        c8_conv_kernel<FT, MODE, NS, LK><<<grid, 256, lds, ctx->stream>>>(g);                                 \
     }
-    if (ns <= 2) C8_GO(2)
-    else if (ns == 3) C8_GO(3)
-    else C8_GO(4)
+    // the epilogue's activation (forward: the layer's own; gradients: that of the layer below) is a compile-time
+    // leaky-ReLU for the reference's defaults; other kinds share one generic instantiation per mode
+    const bool lk = g.act == TN_ACT_LEAKY && g.prm >= 0.f && g.prm < 1.f;
+    if (!lk) C8_GO(4, false)
+    else if (ns <= 2) C8_GO(2, true)
+    else if (ns == 3) C8_GO(3, true)
+    else C8_GO(4, true)
 #undef C8_GO
     TN_LAUNCH_CHECK();
     return TN_OK;
@@ -421,256 +531,316 @@ static int c8_run(tn_ctx* ctx, C8G& g, const float* W, int K, int C) {
 // =================================================================================================
 // Weight gradient of a 3x3 'same' convolution on c8 tensors:
 //   dW[k][c][2-u][2-v] = (1/gs) * sum_{n,i,j} dz16[n,k,i,j] * x16[n,c,i-1+u,j-1+v]        (dz16 = fp16(gs*dz))
-// GEMM rows = filters, columns = input channels at a fixed tap, reduction = pixels, 16 per MFMA; block = 32*NFT
-// filters x 32*NCT channels x a range of 128-pixel tiles; a wave = one (filter tile, channel tile) pair (and, when
-// NFT*NCT < 4, one of PS interleaved step subsets) with all nine taps.  LDS image, MFMA loop and slab layout are
-// conv_tile16.hip's (A = dz[filter][8 consecutive pixels], B = x[channel][the same pixels shifted by the tap]: the
-// centre column an aligned ds_read_b128, the +-1 columns v_alignbit funnel shifts); what differs is the staging:
-// a slot = (octet, 4 consecutive pixels of a row) = 64 contiguous bytes of the c8 tensor, transposed in registers
-// (16 v_perm_b32) into 8 channel rows of 4 pixels.  The bias gradient is the sum of the staged dz16 (v_dot2 with
-// ones: exact fp32 accumulation).
+// GEMM rows = filters, columns = input channels at a fixed tap, reduction = pixels, 16 per MFMA.  Both operands are
+// stored [pixel][8 channels] and the matrix core wants [channel][8 consecutive pixels]: gfx950's transposing LDS read
+// (ds_read_b64_tr_b16: the 16 lanes of a group point at 4 pixels x 16 channels and each receives one channel's 4
+// pixels) does that on the way from LDS to the registers, so
+//   * the LDS images are plain copies of the c8 tensors -- the x halo tile [octet plane][row][W+2 cells] and the dz tile
+//     [octet plane][pixel] -- filled by LDS-DMA (global_load_lds, 16 bytes per lane, 1 KB per wave instruction) with
+//     per-lane source addresses: halo columns, rows outside the image and octets beyond the tensor read a zero cell;
+//   * a tap is an address offset of the B read: no funnel shifts, no register transposes, no staging registers at all;
+//   * three stages of 128 pixels are in flight (two tiles ahead of the matrix work, counted vmcnt + raw s_barrier);
+//   * POOL: the block's dz is not a tensor: the pooled gradient and the pooling mask travel to LDS raw and a pass
+//     over LDS expands them (window bit ? g : 0) into the dz image.
+// block = 32*NFT filters x 32*NCT channels x a slab of tiles; wave = one (filter tile, channel tile) pair with all nine
+// taps (144 accumulators) and, when NFT*NCT < 4, one of PS interleaved step subsets.  The bias gradient rides as a
+// tenth product against a vector of ones in the waves of channel tile 0.
 // =================================================================================================
-#define C8W_DZROW 136
+__device__ uint4 c8_zero_cell_g = {0u, 0u, 0u, 0u};
+
+typedef short c8_short4 __attribute__((ext_vector_type(4)));
+typedef _Float16 half4v __attribute__((ext_vector_type(4)));
+// LDS-DMA of 16 bytes per lane: lane i's bytes from its own source pointer to LDS byte address lds_dst + 16 i (lds_dst
+// wave-uniform, travels in M0).  Inline asm on purpose: hipcc orders every LDS read behind ALL outstanding
+// __builtin_amdgcn_global_load_lds (s_waitcnt vmcnt(0) in front of each group of ds_reads -- it cannot prove that the
+// DMA's stage and the stage being read are different), which serialises the whole pipeline; an asm statement is not in
+// its bookkeeping, the kernels count vmcnt themselves.  M0 is compiler-reserved: saved and restored inside the statement.
+__device__ __forceinline__ void c8_glds16(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ half4v c8_tr16(const char* l) {
+    return __builtin_bit_cast(half4v, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) c8_short4*)l));
+}
 
 struct C8WG {
-    const _Float16* x;     // c8 (N, C8, H, W, 8)
-    const _Float16* dz;    // c8 (N, K8, H, W, 8); POOL: pooled gradient (N, K8, H/2, W/2, 8)
-    const uint8_t* mask;   // POOL
-    const _Float16* y;     // POOL, activations other than leaky-ReLU
+    const uint4* x;        // c8 cells (N, C8, H, W)
+    const uint4* dz;       // c8 cells (N, K8, H, W); POOL: the pooled gradient (N, K8, H/2, W/2)
+    const uint2* mask;     // POOL: 8 mask bytes per pooled cell
     float* ws;             // [S * PS][K*C*9] partial weight gradients, dW layout
-    float* dbws;           // [S][K] partial bias gradients
-    int N, C, C8, H, Wd, K, K8, act;
-    float prm;
-    int KG, CG, S, tpb;    // filter groups, channel groups, slabs, tiles per slab
-    int NI, TH, THi, RT, NTILES;
-    int RS, plane, q4, P, lgW, lgP;
+    float* dbws;           // [S * PS][K] partial bias gradients
+    int N, C, C8, H, Wd, K, K8;
+    int KG, CG, S, tpb, NTILES;            // filter groups, channel groups, slabs, tiles per slab
+    int NI, TH, THi, RT, RS, lgW, lgP;     // tile = NI images x TH rows (128 pixels)
+    int XC, XCH, XPS, DPS, SB;             // x plane: content cells, 1 KB chunks, stride; dz plane stride; stage bytes
+    int offD, offG, offM, offDump;         // dz planes / raw pooled gradient / raw mask / the fillers' dump KB inside a stage
+    int nQx, nQd, NQ;                      // LDS-DMA chunks per stage: x, dz (POOL: pooled gradient), all
+    int nstage;
     float oscale;
+    unsigned long long* dbg;   // TN_C8_DBG: per block {life, DMA wait, barrier, matrix steps} cycles
+    int exp;                   // TN_C8_EXP (experiments): bit 0 no refills inside the loop, bit 1 no matrix steps
 };
 
-__device__ __forceinline__ uint4 c8_and4(uint4 v, bool ok) {
-    const unsigned m = ok ? 0xffffffffu : 0u;
-    return make_uint4(v.x & m, v.y & m, v.z & m, v.w & m);
-}
-// 4 cells (pixels p0..p3, 8 channels each) -> out[e] = the 4 pixels of channel e (8 bytes)
-__device__ __forceinline__ void c8_transpose4(const uint4 (&c)[4], uint2 (&out)[8]) {
-    const unsigned* w0 = reinterpret_cast<const unsigned*>(&c[0]);
-    const unsigned* w1 = reinterpret_cast<const unsigned*>(&c[1]);
-    const unsigned* w2 = reinterpret_cast<const unsigned*>(&c[2]);
-    const unsigned* w3 = reinterpret_cast<const unsigned*>(&c[3]);
-#pragma unroll
-    for (int d = 0; d < 4; ++d) {
-        out[2 * d].x = __builtin_amdgcn_perm(w1[d], w0[d], 0x05040100u);
-        out[2 * d].y = __builtin_amdgcn_perm(w3[d], w2[d], 0x05040100u);
-        out[2 * d + 1].x = __builtin_amdgcn_perm(w1[d], w0[d], 0x07060302u);
-        out[2 * d + 1].y = __builtin_amdgcn_perm(w3[d], w2[d], 0x07060302u);
-    }
-}
-
-template <int NFT, int NCT, bool POOL>
-__global__ __launch_bounds__(256) void c8_wgrad_kernel(C8WG g) {
+template <int NFT, int NCT, bool POOL, int NGX>
+__global__ __launch_bounds__(512) void c8_wgrad_kernel(C8WG g) {
     extern __shared__ __attribute__((aligned(16))) float ct_smem[];
-    constexpr int KBF = 32 * NFT, CBF = 32 * NCT, PS = 4 / (NFT * NCT), SPW = 8 / PS;
-    constexpr int NX = NCT;                           // x staging slots per thread (4 cells each)
-    constexpr int DZSZ = KBF * C8W_DZROW * 2;         // bytes
+    // eight waves = two per SIMD: while one waits for its LDS operands or sits in the issue of an LDS-DMA (~100 cycles
+    // each, nothing else of that wave moves meanwhile) the other feeds the matrix pipe.  One wave per SIMD ran this loop
+    // at DMA issue + address arithmetic + matrix time, the sum (cycle stamps: 1.4 k + 1.4 k + 3.7 k per tile).
+    constexpr int KP = 4 * NFT, CP = 4 * NCT, KBF = 32 * NFT, CBF = 32 * NCT, PS = 8 / (NFT * NCT), SPW = 8 / PS;
     char* const smem = reinterpret_cast<char*>(ct_smem);
-    const int XSZ = CBF * g.plane * 2, BUFSZ = DZSZ + XSZ;
     const int bid = blockIdx.x, per = g.KG * g.CG;
     const int z = ((bid >> 3) / per) * 8 + (bid & 7), rem = (bid >> 3) % per;
     if (z >= g.S) return;
     const int kg = rem / g.CG, cg = rem - kg * g.CG;
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, hi = lane >> 5;
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), l31 = lane & 31, hi = lane >> 5;
     const int ft = wave % NFT, ct = (wave / NFT) % NCT, ps = wave / (NFT * NCT);
     const int tile_beg = z * g.tpb, tile_end = min(g.NTILES, tile_beg + g.tpb);
-    const int Wm = g.Wd - 1, THm = g.TH - 1;
-    const int HW = g.H * g.Wd;
+    const int HW = g.H * g.Wd, Wp = g.Wd >> 1, THm = g.TH - 1, Wm = g.Wd - 1;
+    const char* const zero_src = reinterpret_cast<const char*>(&c8_zero_cell_g);
 
-    for (int i = t * 16; i < 2 * BUFSZ; i += 4096) *reinterpret_cast<float4*>(smem + i) = make_float4(0.f, 0.f, 0.f, 0.f);
-
-    // ---- staging geometry of this thread (the same for every tile) ----
-    // dz slot: octet t >> 5 of the filter group (NFT == 1: threads 128.. idle), pixels 4*(t & 31) .. +3 of the tile
-    const int d_o = t >> 5, dq = t & 31, dp = 4 * dq;
-    const bool d_on = d_o < KBF / 8;
-    const int d_oct = kg * (KBF / 8) + d_o;
-    const bool d_oct_ok = d_on && d_oct < g.K8;
-    const int d_octc = min(d_oct, g.K8 - 1);
-    const int d_ni = dp >> g.lgP, d_row = (dp >> g.lgW) & THm, d_col = dp & Wm;
-    // x slot s: octet (t + 256 s) >> 6 of the channel group, cell (image, tile row, 4-pixel group) = t & 63 of P
-    const int xi = t & 63;
-    const bool x_on = xi < g.P;
-    int xr_ = min(xi, g.P - 1);
-    const int x_q = xr_ % g.q4; xr_ /= g.q4;
-    const int x_r = xr_ % g.THi, x_ni = xr_ / g.THi;
-    const int x_lds0 = DZSZ + ((x_ni * g.THi + x_r) * g.RS + 8 + 4 * x_q) * 2;
-
-    float dbacc[8];
+    // ---- this wave's LDS-DMA chunks of a stage, by kind (compile-time counts: the waits are counted and the issue code
+    // is branch-free): NGX x chunks q = 8 j + wave, then ONE more chunk per wave: a dz chunk (16 of them; POOL: 4 raw
+    // pooled-gradient chunks of two planes and 2 mask chunks of four planes -- the dz image is expanded in LDS).  A
+    // chunk index beyond its kind's count is a filler (zero cell -> the dump KB).  Per chunk (wave-uniform): destination
+    // inside the stage; per lane: the source cell relative to the tile's first cell and flags (bit 0 lane in use,
+    // 1 always zero, 2 / 3 top / bottom halo row, 4 mask bytes (8-byte cells), 8.. image of the tile)
+    constexpr int NGD = POOL ? 1 : (KP * 2 + 7) / 8, NG = NGX + NGD;
+    int gl_rel[NG], gl_fl[NG], gl_dst[NG];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) dbacc[e] = 0.f;
-    uint4 dv[4], xv[NX][4];
-    uint2 dm[2];
-    uint4 dy[2];
-    bool dok = false;
-
-    auto gload = [&](int tile) {
-        const int gi = tile / g.RT, rt = tile - gi * g.RT;
-        const int n0 = gi * g.NI, r0 = rt * g.TH;
-        {
-            const int n = n0 + d_ni, row = r0 + d_row;
-            dok = d_oct_ok && n < g.N;
-            const int nn = min(n, g.N - 1);
-            if (POOL) {
-                const int Hp = g.H >> 1, Wp = g.Wd >> 1;
-                const int pc = ((nn * g.K8 + d_octc) * Hp + (row >> 1)) * Wp + (d_col >> 1);
-                const uint4* gp = reinterpret_cast<const uint4*>(g.dz);
-                dv[0] = gp[pc]; dv[1] = gp[pc + 1];
-                dm[0] = reinterpret_cast<const uint2*>(g.mask)[pc];
-                dm[1] = reinterpret_cast<const uint2*>(g.mask)[pc + 1];
-                if (g.act != TN_ACT_LEAKY) {
-                    dy[0] = reinterpret_cast<const uint4*>(g.y)[pc];
-                    dy[1] = reinterpret_cast<const uint4*>(g.y)[pc + 1];
+    for (int j = 0; j < NG; ++j) {
+        int rel = 0, fl = 1 | 2, dst = g.offDump;              // filler by default
+        if (j < NGX) {
+            const int q = 8 * j + wave;
+            if (q < g.nQx) {
+                const int plane = q / g.XCH, c = (q - plane * g.XCH) * 64 + lane;
+                const int cc = min(c, g.XC - 1), colp = cc % g.RS, rr = cc / g.RS, rowh = rr % g.THi, ni = rr / g.THi;
+                const bool zero = colp == 0 || colp == g.RS - 1 || cg * CP + plane >= g.C8;
+                rel = (ni * g.C8 + plane) * HW + (rowh - 1) * g.Wd + (colp - 1);
+                fl = (c < g.XC ? 1 : 0) | (zero ? 2 : 0) | (rowh == 0 ? 4 : 0) | (rowh == g.THi - 1 ? 8 : 0) | (ni << 8);
+                dst = plane * g.XPS + (q - plane * g.XCH) * 1024;
+            }
+        } else {
+            const int qq = 8 * (j - NGX) + wave;
+            if (!POOL) {
+                if (qq < 2 * KP) {
+                    const int plane = qq >> 1, pp = (qq & 1) * 64 + lane;
+                    const int ni = pp >> g.lgP, row = (pp >> g.lgW) & THm, col = pp & Wm;
+                    rel = (ni * g.K8 + plane) * HW + row * g.Wd + col;
+                    fl = 1 | (kg * KP + plane >= g.K8 ? 2 : 0) | (ni << 8);
+                    dst = g.offD + plane * g.DPS + (qq & 1) * 1024;
                 }
-            } else {
-                const uint4* src = reinterpret_cast<const uint4*>(g.dz) + ((size_t)(nn * g.K8 + d_octc) * g.H + row) * g.Wd + d_col;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) dv[i] = src[i];
+            } else if (qq < KP / 2) {           // raw pooled gradient: two planes of 32 pooled cells
+                const int plane = 2 * qq + hi, pc = l31;
+                const int ni = pc >> (g.lgP - 2), prow = (pc >> (g.lgW - 1)) & ((g.TH >> 1) - 1), pcol = pc & (Wp - 1);
+                rel = (ni * g.K8 + plane) * (HW >> 2) + prow * Wp + pcol;
+                fl = 1 | (kg * KP + plane >= g.K8 ? 2 : 0) | (ni << 8);
+                dst = g.offG + qq * 1024;
+            } else if (qq < KP / 2 + KP / 4) {  // mask bytes: four planes per chunk, two pooled cells per lane
+                const int qm = qq - KP / 2, plane = 4 * qm + (lane >> 4), pc = 2 * (lane & 15);
+                const int ni = pc >> (g.lgP - 2), prow = (pc >> (g.lgW - 1)) & ((g.TH >> 1) - 1), pcol = pc & (Wp - 1);
+                rel = (ni * g.K8 + plane) * (HW >> 2) + prow * Wp + pcol;
+                fl = 1 | 16 | (kg * KP + plane >= g.K8 ? 2 : 0) | (ni << 8);
+                dst = g.offM + qm * 1024;
             }
         }
-        {
-            const int n = n0 + x_ni, row = r0 - 1 + x_r;
-            const bool okr = x_on && n < g.N && (unsigned)row < (unsigned)g.H;
-            const int nn = min(n, g.N - 1), rr = min(max(row, 0), g.H - 1);
-#pragma unroll
-            for (int s = 0; s < NX; ++s) {
-                const int oct = cg * (CBF / 8) + ((t + 256 * s) >> 6);
-                const uint4* src = reinterpret_cast<const uint4*>(g.x) + ((size_t)(nn * g.C8 + min(oct, g.C8 - 1)) * g.H + rr) * g.Wd + 4 * x_q;
-                const bool ok = okr && oct < g.C8;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) xv[s][i] = c8_and4(src[i], ok);
-            }
-        }
-    };
-    auto lstore = [&](int buf, float dbw, int tile) {
-        char* base = smem + buf * BUFSZ;
-        if (d_on) {
-            uint4 c[4];
-            if (POOL) {
-                const int rt = tile % g.RT;
-                const int shr = ((rt * g.TH + d_row) & 1) << 1;
-                c[0] = c8_pool_cell(dv[0], dm[0], dy[0], shr, g.act, g.prm);
-                c[1] = c8_pool_cell(dv[0], dm[0], dy[0], shr | 1, g.act, g.prm);
-                c[2] = c8_pool_cell(dv[1], dm[1], dy[1], shr, g.act, g.prm);
-                c[3] = c8_pool_cell(dv[1], dm[1], dy[1], shr | 1, g.act, g.prm);
-            } else {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) c[i] = dv[i];
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) c[i] = c8_and4(c[i], dok);
-            uint2 tr[8];
-            c8_transpose4(c, tr);
-            const half2v one = {(_Float16)1.f, (_Float16)1.f};
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                *reinterpret_cast<uint2*>(base + ((d_o * 8 + e) * C8W_DZROW + dp) * 2) = tr[e];
-                float sum = __builtin_amdgcn_fdot2(__builtin_bit_cast(half2v, tr[e].x), one, 0.f, false);
-                sum = __builtin_amdgcn_fdot2(__builtin_bit_cast(half2v, tr[e].y), one, sum, false);
-                dbacc[e] += dbw * sum;
-            }
-        }
-        if (x_on) {
-#pragma unroll
-            for (int s = 0; s < NX; ++s) {
-                uint2 tr[8];
-                c8_transpose4(xv[s], tr);
-                const int o = (t + 256 * s) >> 6;
-#pragma unroll
-                for (int e = 0; e < 8; ++e)
-                    *reinterpret_cast<uint2*>(base + x_lds0 + (o * 8 + e) * g.plane * 2) = tr[e];
-            }
+        gl_rel[j] = rel; gl_fl[j] = fl;
+        gl_dst[j] = __builtin_amdgcn_readfirstlane(dst);
+    }
+    // tile being refilled: set by tile_setup(), consumed by the issue_range() calls spread over the matrix steps
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) void*)ct_smem;     // LDS byte address of the image
+    const char* cur_xp = reinterpret_cast<const char*>(g.x);
+    const char* cur_dp = reinterpret_cast<const char*>(g.dz);
+    const char* cur_mp = reinterpret_cast<const char*>(g.mask);
+    int cur_zmask = 0, cur_nlim = 0;
+    unsigned cur_sb = lds0;
+    int rf_gi = tile_beg / g.RT, rf_rt = tile_beg - rf_gi * g.RT, rf_tile = tile_beg;      // refill cursor
+    auto tile_setup = [&](int stage) __attribute__((always_inline)) {
+        // (tiles beyond the slab's end re-read its last tile: the number of DMAs per stage stays constant)
+        const int n0 = rf_gi * g.NI, r0 = rf_rt * g.TH;
+        cur_zmask = 2 | (r0 == 0 ? 4 : 0) | (r0 + g.TH >= g.H ? 8 : 0);
+        cur_nlim = g.N - n0;                       // images n0 + ni with ni >= cur_nlim do not exist
+        cur_xp = reinterpret_cast<const char*>(g.x + ((long long)(n0 * g.C8 + cg * CP) * g.H + r0) * g.Wd);
+        const long long db = POOL ? ((long long)(n0 * g.K8 + kg * KP) * (g.H >> 1) + (r0 >> 1)) * Wp
+                                  : ((long long)(n0 * g.K8 + kg * KP) * g.H + r0) * g.Wd;
+        cur_dp = reinterpret_cast<const char*>(g.dz + db);
+        cur_mp = reinterpret_cast<const char*>(g.mask + db);
+        cur_sb = lds0 + stage * g.SB;
+        if (rf_tile + 1 < tile_end) {
+            ++rf_tile;
+            if (++rf_rt == g.RT) { rf_rt = 0; ++rf_gi; }
         }
     };
-
-    f32x16 acc[9];
+    auto issue_range = [&](auto J0c, auto J1c) __attribute__((always_inline)) {
+        constexpr int J0 = decltype(J0c)::value, J1 = decltype(J1c)::value;
 #pragma unroll
-    for (int a = 0; a < 9; ++a)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+        for (int j = J0; j < J1; ++j) {
+            const int fl = gl_fl[j];
+            const bool zero = (fl & cur_zmask) || (fl >> 8) >= cur_nlim;
+            const char* src = j < NGX ? cur_xp + (long long)gl_rel[j] * 16
+                            : (POOL && (fl & 16)) ? cur_mp + (long long)gl_rel[j] * 8 : cur_dp + (long long)gl_rel[j] * 16;
+            src = zero ? zero_src : src;
+            if ((fl & 1) && !(g.exp & 1)) c8_glds16(src, __builtin_amdgcn_readfirstlane(cur_sb + gl_dst[j]));
+        }
+    };
+    using J_0 = std::integral_constant<int, 0>;
+    using J_N = std::integral_constant<int, NG>;
 
-    gload(tile_beg);
-    __syncthreads();                 // the clearing is done
-    lstore(0, 1.f, tile_beg);
-    __syncthreads();
-
-    const int RS2 = g.RS * 2;
-    int cur = 0;
-    for (int tile = tile_beg; tile < tile_end; ++tile, cur ^= 1) {
-        const bool hasnext = tile + 1 < tile_end;
-        const int nxt = hasnext ? tile + 1 : tile;   // (the last tile re-stages itself: branch-free body)
-        gload(nxt);
-        const char* dzb = smem + cur * BUFSZ + (ft * 32 + l31) * (C8W_DZROW * 2) + 16 * hi;
-        const char* xb = smem + cur * BUFSZ + DZSZ + (ct * 32 + l31) * g.plane * 2 + 16;
-        int4v av[2], xc[2][3];
-        int xl[2][3], xr[2][3];
-        auto ops = [&](int slot, int sg) {
-            const int p = 16 * sg + 8 * hi;
-            av[slot] = *reinterpret_cast<const int4v*>(dzb + 32 * sg);
-            const char* xp = xb + (((p >> g.lgP) * g.THi + ((p >> g.lgW) & THm)) * g.RS + (p & Wm)) * 2;
+    f32x16 acc[9], accb;
 #pragma unroll
-            for (int u = 0; u < 3; ++u) {
-                xl[slot][u] = *reinterpret_cast<const int*>(xp + u * RS2 - 4);
-                xc[slot][u] = *reinterpret_cast<const int4v*>(xp + u * RS2);
-                xr[slot][u] = *reinterpret_cast<const int*>(xp + u * RS2 + 16);
+    for (int a_ = 0; a_ < 9; ++a_)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a_][r] = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accb[r] = 0.f;
+    const bool want_db = cg == 0 && ct == 0;
+    const half8 ones = {(_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f,
+                        (_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f};
+
+    // ---- operand addresses of this lane: group of 16 lanes = 4 pixels x 16 channels; lane (r4, q8) supplies pixel r4,
+    // channels 4 q8 .. + 3 of the group's pair of octet planes and receives channel (lane & 15)'s four pixels
+    const int grp = lane >> 4, r4 = (lane >> 2) & 3, q8 = lane & 3;
+    const int a_off = g.offD + (ft * 4 + 2 * (grp & 1) + (q8 >> 1)) * g.DPS + (q8 & 1) * 8;
+    const int b_off = (ct * 4 + 2 * (grp & 1) + (q8 >> 1)) * g.XPS + (q8 & 1) * 8;
+    const int RS16 = g.RS * 16;
+
+    unsigned long long d_wait = 0, d_bar = 0, d_mm = 0, d_t0 = 0, d_w0 = 0;
+    if (g.dbg) { d_t0 = __builtin_readcyclecounter(); d_w0 = wall_clock64(); }
+    tile_setup(0);
+    issue_range(J_0{}, J_N{});
+    if (g.nstage > 2) {
+        tile_setup(1);
+        issue_range(J_0{}, J_N{});
+    }
+    for (int tile = tile_beg, it = 0; tile < tile_end; ++tile, ++it) {
+        const int stage = it % g.nstage;
+        unsigned long long s0 = 0, s1 = 0, s2 = 0;
+        if (g.dbg) s0 = __builtin_readcyclecounter();
+        // this wave's DMAs of the stage have landed (the following stage's may still be in flight) ...
+        if (g.nstage > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NG) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (g.dbg) s1 = __builtin_readcyclecounter();
+        // ... and everybody's; all waves are also done with the stage that is refilled next
+        __builtin_amdgcn_s_barrier();
+        if (g.dbg) { s2 = __builtin_readcyclecounter(); d_wait += s1 - s0; d_bar += s2 - s1; }
+        char* const sb = smem + stage * g.SB;
+        // the refill of the stage two tiles ahead is spread over this tile's matrix steps
+        tile_setup((it + g.nstage - 1) % g.nstage);
+        if (POOL) {
+            // expand (pooled gradient, mask) -> dz image: thread = one pooled cell of one plane -> its 2 x 2 window
+            const int plane = t >> 5, pc = t & 31;
+            if (plane < KP) {
+                const uint4 gq = *reinterpret_cast<const uint4*>(sb + g.offG + plane * 512 + pc * 16);
+                const uint2 mq = *reinterpret_cast<const uint2*>(sb + g.offM + plane * 256 + pc * 8);
+                const int ni = pc >> (g.lgP - 2), prow = (pc >> (g.lgW - 1)) & ((g.TH >> 1) - 1), pcol = pc & (Wp - 1);
+                char* const d0 = sb + g.offD + plane * g.DPS + ((ni << g.lgP) + ((2 * prow) << g.lgW) + 2 * pcol) * 16;
+                *reinterpret_cast<uint4*>(d0) = c8_pool_cell(gq, mq, 0);
+                *reinterpret_cast<uint4*>(d0 + 16) = c8_pool_cell(gq, mq, 1);
+                *reinterpret_cast<uint4*>(d0 + 16 * g.Wd) = c8_pool_cell(gq, mq, 2);
+                *reinterpret_cast<uint4*>(d0 + 16 * g.Wd + 16) = c8_pool_cell(gq, mq, 3);
             }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        const char* const ab = sb + a_off;
+        const char* const bb = sb + b_off;
+        auto step = [&](auto Ic) __attribute__((always_inline)) {
+            constexpr int i = decltype(Ic)::value;
+            constexpr int J0 = i * NG / SPW, J1 = (i + 1) * NG / SPW;
+            if (g.exp & 2) {
+                issue_range(std::integral_constant<int, J0>{}, std::integral_constant<int, J1>{});
+                return;
+            }
+            const int p = 16 * (ps + PS * i) + 8 * (grp >> 1) + r4;
+            const char* ap = ab + p * 16;
+            const half4v a0 = c8_tr16(ap), a1 = c8_tr16(ap + 64);
+            const char* xp = bb + (((p >> g.lgP) * g.THi + ((p >> g.lgW) & THm)) * g.RS + (p & Wm)) * 16;
+            half4v bv[9][2];
+#pragma unroll
+            for (int u = 0; u < 3; ++u)
+#pragma unroll
+                for (int v = 0; v < 3; ++v) {
+                    bv[u * 3 + v][0] = c8_tr16(xp + u * RS16 + v * 16);
+                    bv[u * 3 + v][1] = c8_tr16(xp + u * RS16 + v * 16 + 64);
+                }
+            const half8 a = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+#pragma unroll
+            for (int tp = 0; tp < 9; ++tp) {
+                const half8 b = {bv[tp][0][0], bv[tp][0][1], bv[tp][0][2], bv[tp][0][3],
+                                 bv[tp][1][0], bv[tp][1][1], bv[tp][1][2], bv[tp][1][3]};
+                acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[tp], 0, 0, 0);
+            }
+            if (want_db) accb = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, ones, accb, 0, 0, 0);
+            issue_range(std::integral_constant<int, J0>{}, std::integral_constant<int, J1>{});
         };
-        ops(0, ps);
-        __builtin_amdgcn_sched_group_barrier(0x100, 10, 0);
-#pragma unroll
-        for (int i = 0; i < SPW; ++i) {
-            const int c_ = i & 1, nx_ = c_ ^ 1;
-            if (i + 1 < SPW) ops(nx_, ps + PS * (i + 1));
-            const half8 a = __builtin_bit_cast(half8, av[c_]);
-#pragma unroll
-            for (int u = 0; u < 3; ++u) {
-                const int4v c = xc[c_][u];
-                const int e0 = __builtin_amdgcn_alignbit(c[0], xl[c_][u], 16);
-                const int e1 = __builtin_amdgcn_alignbit(c[1], c[0], 16);
-                const int e2 = __builtin_amdgcn_alignbit(c[2], c[1], 16);
-                const int e3 = __builtin_amdgcn_alignbit(c[3], c[2], 16);
-                const int e4 = __builtin_amdgcn_alignbit(xr[c_][u], c[3], 16);
-                const int4v b0 = {e0, e1, e2, e3}, b2 = {e1, e2, e3, e4};
-                acc[u * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, __builtin_bit_cast(half8, b0), acc[u * 3 + 0], 0, 0, 0);
-                acc[u * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, __builtin_bit_cast(half8, c), acc[u * 3 + 1], 0, 0, 0);
-                acc[u * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, __builtin_bit_cast(half8, b2), acc[u * 3 + 2], 0, 0, 0);
-            }
-            __builtin_amdgcn_sched_group_barrier(0x100, 10, 0);       // LDS operands of the next step
-            __builtin_amdgcn_sched_group_barrier(0x002, 15, 0);       // this step's funnel shifts
-            __builtin_amdgcn_sched_group_barrier(0x008, 9, 0);        // then its MFMAs
-        }
-        lstore(cur ^ 1, hasnext ? 1.f : 0.f, nxt);
-        __syncthreads();
+        step(std::integral_constant<int, 0>{});
+        if (SPW > 1) step(std::integral_constant<int, 1 % SPW>{});
+        if (SPW > 2) { step(std::integral_constant<int, 2 % SPW>{}); step(std::integral_constant<int, 3 % SPW>{}); }
+        if (g.dbg) d_mm += __builtin_readcyclecounter() - s2;
     }
+    if (g.dbg && t == 0) {
+        unsigned long long* d = g.dbg + 8 * (size_t)bid;
+        d[0] = d_t0; d[1] = d_t0; d[2] = __builtin_readcyclecounter(); d[3] = d_wait; d[6] = d_bar; d[7] = d_mm;
+        d[4] = d_w0; d[5] = wall_clock64();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the trailing refills (clamped tiles) land before LDS is reused
 
-    // bias gradient partial of the slab: per-filter sums of the dz16 this block staged (x 1/gs)
-    if (cg == 0 && d_on) {
+    // ---- the PS step subsets of a (filter tile, channel tile) pair are added up through LDS, upper half onto lower
+    // half, in a fixed order; subset 0 then holds the block's sums.  At most four waves write in a round:
+    // [slot][reg][lane] floats, 36 KB per slot (the bias products take a second, small pass over the same memory)
+    constexpr int NPR = NFT * NCT;
+    const int pr = wave % NPR;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            float v = dbacc[e];
-            v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 4, 64);
-            v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 1, 64);
-            const int k = d_oct * 8 + e;
-            if (l31 == 0 && k < g.K) g.dbws[(size_t)z * g.K + k] = v * g.oscale;
+    for (int h = PS / 2; h >= 1; h >>= 1) {
+        const bool writer = ps >= h && ps < 2 * h, reader = ps < h;
+        float* const slot = ct_smem + (size_t)(((writer ? ps - h : ps) * NPR + pr) * 144) * 64 + lane;
+        __syncthreads();
+        if (writer) {
+#pragma unroll
+            for (int a_ = 0; a_ < 9; ++a_)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) slot[(a_ * 16 + r) * 64] = acc[a_][r];
+        }
+        __syncthreads();
+        if (reader) {
+#pragma unroll
+            for (int a_ = 0; a_ < 9; ++a_)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a_][r] += slot[(a_ * 16 + r) * 64];
+        }
+        __syncthreads();
+        if (writer) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) slot[r * 64] = accb[r];
+        }
+        __syncthreads();
+        if (reader) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accb[r] += slot[r * 64];
         }
     }
-    // slab (z, ps): dW layout, tap (u,v) of the correlation is element (2-u, 2-v)
+    if (ps != 0) return;
+
+    // bias gradient partial of the slab: column 0 of the product against ones
+    const float os = g.oscale;
+    if (want_db && l31 == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int k = kg * KBF + ft * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            if (k < g.K) g.dbws[(size_t)z * g.K + k] = accb[r] * os;
+        }
+    }
+    // slab z: dW layout, tap (u,v) of the correlation is element (2-u, 2-v)
     const int c = cg * CBF + ct * 32 + l31;
     if (c < g.C) {
-        float* wz = g.ws + (size_t)(z * PS + ps) * g.K * g.C * 9;
-        const float os = g.oscale;
+        float* wz = g.ws + (size_t)z * g.K * g.C * 9;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int k = kg * KBF + ft * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
             if (k < g.K) {
 #pragma unroll
-                for (int a = 0; a < 9; ++a) wz[((size_t)k * g.C + c) * 9 + 8 - a] = acc[a][r] * os;
+                for (int a_ = 0; a_ < 9; ++a_) wz[((size_t)k * g.C + c) * 9 + 8 - a_] = acc[a_][r] * os;
             }
         }
     }
@@ -683,7 +853,7 @@ static void c8w_tiles(int K, int C, int& NFT, int& NCT) {
     NCT = C > 32 ? 2 : 1;
 }
 
-static int c8w_geometry(C8WG& g, int num_cus) {
+static int c8w_geometry(C8WG& g, int num_cus, bool pool) {
     const int lgW = c8w_log2(g.Wd);
     if (lgW < 3 || lgW > 6) return 0;                  // rows of 8..64 pixels
     int TH = 128 / g.Wd;
@@ -695,17 +865,27 @@ static int c8w_geometry(C8WG& g, int num_cus) {
     } else if (g.H % TH) {
         return 0;
     }
-    if (c8w_log2(TH) < 0) return 0;
+    if (c8w_log2(TH) < 0 || (TH & 1)) return 0;
     g.TH = TH; g.THi = TH + 2; g.RT = g.H / TH;
     g.lgW = lgW; g.lgP = c8w_log2(TH * g.Wd);
-    g.RS = g.Wd + 8;
-    g.plane = g.NI * g.THi * g.RS;                     // halfs; 16 bytes * odd apart: conflict-free 16-byte reads
-    g.plane += ((g.plane >> 3) & 1) ? 16 : 8;
-    g.q4 = g.Wd / 4;
-    g.P = g.NI * g.THi * g.q4;
-    if (g.P > 64) return 0;
+    g.RS = g.Wd + 2;
     int NFT, NCT;
     c8w_tiles(g.K, g.C, NFT, NCT);
+    const int KP = 4 * NFT, CP = 4 * NCT;
+    g.XC = g.NI * g.THi * g.RS;
+    g.XCH = cdiv(g.XC, 64);
+    // plane strides = 64 (mod 256) bytes: the four octet planes a transposing read touches sit on disjoint banks
+    g.XPS = (g.XC * 16 + 255) / 256 * 256 + 64;
+    g.DPS = 128 * 16 + 64;
+    g.offD = CP * g.XPS;
+    g.offG = g.offD + KP * g.DPS;
+    g.offM = g.offG + (pool ? KP * 512 : 0);
+    g.offDump = (g.offM + (pool ? KP * 256 : 0) + 255) / 256 * 256;      // each stage ends with the fillers' dump KB
+    g.SB = g.offDump + 1024;
+    g.nQx = CP * g.XCH;
+    g.nQd = pool ? KP / 2 + KP / 4 : KP * 2;
+    g.NQ = g.nQx + g.nQd;
+    g.nstage = 3 * g.SB <= 160 * 1024 ? 3 : 2;
     g.KG = cdiv(g.K, 32 * NFT);
     g.CG = cdiv(g.C, 32 * NCT);
     g.NTILES = cdiv(g.N, g.NI) * g.RT;
@@ -718,45 +898,73 @@ static int c8w_geometry(C8WG& g, int num_cus) {
 }
 
 static size_t c8w_lds_bytes(const C8WG& g) {
-    int NFT, NCT;
-    c8w_tiles(g.K, g.C, NFT, NCT);
-    return (size_t)2 * (32 * NFT * C8W_DZROW * 2 + 32 * NCT * g.plane * 2);
+    const size_t a = (size_t)g.nstage * g.SB, red = (size_t)4 * 144 * 64 * sizeof(float);     // stages; the final reduction
+    return a > red ? a : red;
 }
 
-template <int NFT, int NCT, bool POOL>
+template <int NFT, int NCT, bool POOL, int NGX>
 static int c8w_launch(tn_ctx* ctx, C8WG& g) {
     static bool attr_set = false;
     if (!attr_set) {
-        TN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&c8_wgrad_kernel<NFT, NCT, POOL>),
+        TN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&c8_wgrad_kernel<NFT, NCT, POOL, NGX>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
     const int grid = 8 * cdiv(g.S, 8) * g.KG * g.CG;
-    c8_wgrad_kernel<NFT, NCT, POOL><<<grid, 256, c8w_lds_bytes(g), ctx->stream>>>(g);
+    static int dbg_on = -1;
+    if (dbg_on < 0) {
+        const char* e = getenv("TN_C8_DBG");
+        dbg_on = e ? atoi(e) : 0;
+    }
+    if (dbg_on) {
+        if (!c8_dbg_buf) TN_HIP(hipMalloc(&c8_dbg_buf, 8 * sizeof(unsigned long long) * 65536));
+        TN_HIP(hipMemsetAsync(c8_dbg_buf, 0, 8 * sizeof(unsigned long long) * 65536, ctx->stream));
+        g.dbg = grid <= 65536 ? c8_dbg_buf : nullptr;
+    }
+    {
+        static int exp_ = -1;
+        if (exp_ < 0) {
+            const char* e = getenv("TN_C8_EXP");
+            exp_ = e ? atoi(e) : 0;
+        }
+        g.exp = exp_;
+    }
+    c8_wgrad_kernel<NFT, NCT, POOL, NGX><<<grid, 512, c8w_lds_bytes(g), ctx->stream>>>(g);
     TN_LAUNCH_CHECK();
     return TN_OK;
 }
 
+// x chunks per wave and stage: a compile-time count (the waits are counted); shapes land in one of four buckets
+static int c8w_ngx(const C8WG& g) { return cdiv(g.nQx, 8); }
+template <int NFT, int NCT, bool POOL>
+static int c8w_launch_ng(tn_ctx* ctx, C8WG& g) {
+    const int ngx = c8w_ngx(g);
+    if (ngx <= 2) return c8w_launch<NFT, NCT, POOL, 2>(ctx, g);
+    if (ngx <= 3) return c8w_launch<NFT, NCT, POOL, 3>(ctx, g);
+    if (ngx <= 4) return c8w_launch<NFT, NCT, POOL, 4>(ctx, g);
+    TN_REQUIRE(ngx <= 5, "c8 conv wgrad: %d LDS-DMA chunks per x stage", g.nQx);
+    return c8w_launch<NFT, NCT, POOL, 5>(ctx, g);
+}
+
 static int c8w_run(tn_ctx* ctx, C8WG& g, float* dW, float* db, bool pool) {
-    TN_REQUIRE(c8w_geometry(g, ctx->num_cus) && c8w_lds_bytes(g) <= 160 * 1024, "c8 conv wgrad: unsupported shape");
+    TN_REQUIRE(c8w_geometry(g, ctx->num_cus, pool) && c8w_lds_bytes(g) <= 160 * 1024, "c8 conv wgrad: unsupported shape");
     TN_REQUIRE((long long)g.N * g.C8 * g.H * g.Wd < (1ll << 28) && (long long)g.N * g.K8 * g.H * g.Wd < (1ll << 28),
                "c8 conv wgrad: tensor too large for 32-bit cell offsets");
     int NFT, NCT;
     c8w_tiles(g.K, g.C, NFT, NCT);
-    const int PS = 4 / (NFT * NCT);
     const size_t n = (size_t)g.K * g.C * 9;
-    int rc = tn_scratch_get(ctx, ((size_t)g.S * PS * n + (size_t)g.S * g.K) * sizeof(float), &g.ws);
+    int rc = tn_scratch_get(ctx, ((size_t)g.S * n + (size_t)g.S * g.K) * sizeof(float), &g.ws);
     if (rc) return rc;
-    g.dbws = g.ws + (size_t)g.S * PS * n;
+    g.dbws = g.ws + (size_t)g.S * n;
     g.oscale = 1.f / ctx->grad_scale;
-#define C8W_GO(A, B) rc = pool ? c8w_launch<A, B, true>(ctx, g) : c8w_launch<A, B, false>(ctx, g)
+#define C8W_GO(A, B) rc = pool ? c8w_launch_ng<A, B, true>(ctx, g) : c8w_launch_ng<A, B, false>(ctx, g)
     if (NFT == 2 && NCT == 2) C8W_GO(2, 2);
     else if (NFT == 2) C8W_GO(2, 1);
     else if (NCT == 2) C8W_GO(1, 2);
     else C8W_GO(1, 1);
 #undef C8W_GO
     if (rc) return rc;
-    rc = tn_red_push(ctx, g.ws, dW, (uint32_t)n, (uint32_t)(g.S * PS), (uint32_t)n, 0);
+    rc = tn_red_push(ctx, g.ws, dW, (uint32_t)n, (uint32_t)g.S, (uint32_t)n, 0);
     if (rc) return rc;
     rc = tn_red_push(ctx, g.dbws, db, (uint32_t)g.K, (uint32_t)g.S, (uint32_t)g.K, 0);
     if (rc) return rc;
@@ -821,31 +1029,33 @@ int tn_c8_conv_fwd(tn_ctx* ctx, const void* x, const float* W, const float* b, v
     return pool ? c8_run<1>(ctx, g, W, K, C) : c8_run<0>(ctx, g, W, K, C);
 }
 
-// dx (N, C, H, W) = conv^T(dz, W) * act'(prev_a) of the layer below (prev_a NULL: no activation below).
-// pooled != 0: dz is not a tensor: it is gathered from the pooled gradient g (N, K, H/2, W/2), the block's mask and
-// (activations other than leaky-ReLU) its pooled output y, with the block's own (act, prm)
+// dx (N, C, H, W) = conv^T(dz, W) * act'(prev_a) of the layer below (prev_a NULL: no activation below; for a pooled
+// block below prev_a is its POOLED output and dx has its shape -- the gradient a pooled block receives always carries
+// act'(pooled output)).  pooled != 0: dz is not a tensor: the `dz` argument is the pooled gradient (N, K, H/2, W/2) and
+// dz = (bit of the window element in the block's mask) ? pooled gradient : 0, gathered while staging
 int tn_c8_conv_dgrad(tn_ctx* ctx, const void* dz, const float* W, void* dx, int N, int C, int H, int Wd, int K,
-                     const void* prev_a, int prev_act, float prev_prm, int pooled, const uint8_t* mask, const void* y,
-                     int act, float prm) {
+                     const void* prev_a, int prev_act, float prev_prm, int pooled, const uint8_t* mask) {
     TN_REQUIRE((K & 7) == 0, "c8 conv: the number of filters must be a multiple of 8 (got %d)", K);
+    TN_REQUIRE(!pooled || mask != nullptr, "c8 conv dgrad: a pooled block needs its mask");
     C8G g{};
     g.x = static_cast<const _Float16*>(dz); g.out = static_cast<_Float16*>(dx);
     g.prev_a = static_cast<const _Float16*>(prev_a);
     g.N = N; g.C8 = K / 8; g.K8 = (C + 7) / 8; g.H = H; g.W = Wd; g.act = prev_act; g.prm = prev_prm;
-    g.mask_in = mask; g.y_in = static_cast<const _Float16*>(y); g.in_act = act; g.in_prm = prm;
+    g.mask_in = mask;
     // the roles of filters and channels swap: "filters" = the C input channels (rounded up to whole octets: the
     // arranged weights of channels beyond C are zero, so their cells come out zero)
     return pooled ? c8_run<3>(ctx, g, W, C, K) : c8_run<2>(ctx, g, W, C, K);
 }
 
-// dW (K, C, 3, 3), db (K) from x and dz (pooled != 0: from the pooled gradient, the block's mask and pooled output y
-// as in tn_c8_conv_dgrad); dz carries the gradient scale, the results do not
+// dW (K, C, 3, 3), db (K) from x and dz (pooled != 0: dz is gathered from the pooled gradient and the block's mask as in
+// tn_c8_conv_dgrad); dz carries the gradient scale, the results do not
 int tn_c8_conv_wgrad(tn_ctx* ctx, const void* x, const void* dz, float* dW, float* db, int N, int C, int H, int Wd,
-                     int K, int pooled, const uint8_t* mask, const void* y, int act, float prm) {
+                     int K, int pooled, const uint8_t* mask) {
     TN_REQUIRE((K & 7) == 0, "c8 conv: the number of filters must be a multiple of 8 (got %d)", K);
+    TN_REQUIRE(!pooled || mask != nullptr, "c8 conv wgrad: a pooled block needs its mask");
     C8WG g{};
-    g.x = static_cast<const _Float16*>(x); g.dz = static_cast<const _Float16*>(dz);
-    g.mask = mask; g.y = static_cast<const _Float16*>(y); g.act = act; g.prm = prm;
+    g.x = static_cast<const uint4*>(x); g.dz = static_cast<const uint4*>(dz);
+    g.mask = reinterpret_cast<const uint2*>(mask);
     g.N = N; g.C = C; g.C8 = (C + 7) / 8; g.H = H; g.Wd = Wd; g.K = K; g.K8 = K / 8;
     return c8w_run(ctx, g, dW, db, pooled != 0);
 }
@@ -853,7 +1063,9 @@ int tn_c8_conv_wgrad(tn_ctx* ctx, const void* x, const void* dz, float* dW, floa
 int tn_c8_conv_wgrad_supported(int N, int C, int H, int Wd, int K) {
     C8WG g{};
     g.N = N; g.C = C; g.C8 = (C + 7) / 8; g.H = H; g.Wd = Wd; g.K = K; g.K8 = K / 8;
-    if ((K & 7) || !c8w_geometry(g, 256)) return 0;
+    if ((K & 7) || !c8w_geometry(g, 256, true) || c8w_ngx(g) > 5) return 0;
+    if (c8w_lds_bytes(g) > 160 * 1024) return 0;
+    if (!c8w_geometry(g, 256, false) || c8w_ngx(g) > 5) return 0;
     return c8w_lds_bytes(g) <= 160 * 1024;
 }
 

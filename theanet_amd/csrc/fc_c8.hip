@@ -1,0 +1,456 @@
+// DTYPE 'float16', fully-connected products on fp16-RESIDENT activations (BASELINE.json configs[4]).
+// Same products as theanet/layer/hidden.py:30 (a = act(x . W + b)) and their Theano gradients (layer.py:83); the
+// reference is float32-only (weights.py:8), so the arithmetic of this mode is the oracle's stored-fp16 restatement:
+// the layer input x lives in HBM as halfs (the flattened c8 tensor of the conv stack below, or any (B, n) half
+// matrix), master weights W (n_in, n_out), biases, weight gradients and the layer OUTPUT stay fp32; both operands of
+// every product are halfs (W rounded nearest-even while it is loaded, dz as fp16(gs * dz)), products exact, fp32
+// accumulation.
+//
+// The input is consumed in ITS order: column k of x is c8 element ((o * HW + p) * 8 + e) = channel 8 o + e at pixel p,
+// while the reference flattens NCHW (row (8 o + e) * HW + p of W, neuralnet.py:168-173): the kernels walk W through that
+// row map, so neither the activations nor the 64 MB weight matrix are ever re-ordered.  Channels beyond C (zero in a c8
+// tensor) read a clamped row.
+//
+// Shapes here are short and deep (wide6: 128 x 16384 -> 1024): every product streams W once and is bound by that.
+//   forward : wave = 128 rows x 64 outputs x a K range, operands straight from global memory into the MFMA layout
+//             (x: 16-byte loads; W: 8 dword loads of 128 contiguous bytes per 32 lanes, converted in registers);
+//             the block's four K ranges meet in LDS, K slabs in a finishing kernel (bias + act + mask).
+//   dgrad   : C = W_tile . dz^T with the rows of the W tile permuted so that a lane's accumulators are whole c8 cells:
+//             16-byte stores of fp16(acc * act'(y)) -- y = the pooled output below, in the same order.
+//   wgrad   : both operands want 8 consecutive SAMPLES per lane but are stored sample-major: tiles go to LDS as they
+//             are (dz converted on the way) and gfx950's transposing LDS read (ds_read_b64_tr_b16) delivers them.
+#include "common.h"
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4v __attribute__((ext_vector_type(4)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short fc8_short4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ half4v fc8_tr16(const char* l) {
+    return __builtin_bit_cast(half4v, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) fc8_short4*)l));
+}
+__host__ __device__ __forceinline__ int fc8_swap23(int j) { return (j & ~12) | ((j & 4) << 1) | ((j & 8) >> 1); }
+
+struct FC8 {
+    const _Float16* x;      // (M, Kc) halfs, Kc = C8 * HW * 8
+    const float* W;         // (C * HW, N)
+    const float* bias;
+    const float* dz;        // (M, N) fp32
+    const _Float16* ya;     // dgrad: output of the layer below in x's order (act' is taken from it) or NULL
+    const uint8_t* mask;    // forward: dropout mask (M, N) or NULL
+    float* out;             // forward: (M, N) fp32
+    _Float16* dx;           // dgrad: (M, Kc) halfs, carries the gradient scale
+    float* ws;              // forward: K slabs [S][M][N]; wgrad: sample slabs [S][C*HW][N]
+    float* dbws;            // wgrad: [S][N]
+    int M, N, Kc, C, HW, S, krange, act;
+    float prm, gs, oscale;
+};
+
+// c8 column k (a multiple of 8) -> row of W for element e = 0: rows of e are HW apart
+__device__ __forceinline__ int fc8_row0(const FC8& g, int k, int& step) {
+    const int cell = k >> 3, o = cell / g.HW, p = cell - o * g.HW;
+    step = g.HW;
+    return (o * 8) * g.HW + p;
+}
+
+__device__ __forceinline__ half8 fc8_cvt8(const float (&v)[8]) {
+    half8 h;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) h[j] = (_Float16)v[j];
+    return h;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// forward: grid = (N / 64 column groups, S slabs, M / 128 row groups), 4 waves = 4 K ranges of the slab
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void fc8_fwd_kernel(FC8 g) {
+    __shared__ float red[2][8][16][64];                      // two waves' accumulators: [tile][reg][lane] (64 KB: two blocks per CU)
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, hi = lane >> 5;
+    const int n0 = blockIdx.x * 64, m0 = blockIdx.z * 128;
+    const int kbeg = (blockIdx.y * 4 + wave) * g.krange, kend = min(g.Kc, kbeg + g.krange);
+    const int nmax = g.N - 1, rows = g.C * g.HW;
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const _Float16* xrow[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) xrow[i] = g.x + (size_t)min(m0 + 32 * i + l31, g.M - 1) * g.Kc + 8 * hi;
+    const int nc[2] = {min(n0 + l31, nmax), min(n0 + 32 + l31, nmax)};
+    half8 a[2][4];
+    float b[2][2][8];
+    auto load = [&](int slot, int k) __attribute__((always_inline)) {
+        const int kk = min(k, g.Kc - 16);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[slot][i] = *reinterpret_cast<const half8*>(xrow[i] + kk);
+        int step;
+        const int r0 = fc8_row0(g, kk + 8 * hi, step);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float* wr = g.W + (size_t)min(r0 + j * step, rows - 1) * g.N;
+            b[slot][0][j] = wr[nc[0]];
+            b[slot][1][j] = wr[nc[1]];
+        }
+    };
+    load(0, kbeg);
+    for (int k = kbeg; k < kend; k += 32) {
+        load(1, k + 16);
+        {
+            const half8 b0 = fc8_cvt8(b[0][0]), b1 = fc8_cvt8(b[0][1]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][i], b0, acc[i][0], 0, 0, 0);
+                acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][i], b1, acc[i][1], 0, 0, 0);
+            }
+        }
+        if (k + 16 < kend) {
+            load(0, k + 32);
+            const half8 b0 = fc8_cvt8(b[1][0]), b1 = fc8_cvt8(b[1][1]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1][i], b0, acc[i][0], 0, 0, 0);
+                acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1][i], b1, acc[i][1], 0, 0, 0);
+            }
+        }
+    }
+    // the four K ranges of the block meet in LDS, pairwise in a fixed order: (0 + 2), (1 + 3), then (0 + 1)
+#pragma unroll
+    for (int round = 0; round < 2; ++round) {
+        const int h = round == 0 ? 2 : 1;
+        if (wave >= h && wave < 2 * h) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) red[wave - h][i * 2 + j][r][lane] = acc[i][j][r];
+        }
+        __syncthreads();
+        if (wave < h) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] += red[wave][i * 2 + j][r][lane];
+        }
+        __syncthreads();
+    }
+    if (wave > 0) return;
+    float* const wz = g.ws + (size_t)blockIdx.y * g.M * g.N;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + 32 * j + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                if (m < g.M && n < g.N) wz[(size_t)m * g.N + n] = acc[i][j][r];
+            }
+        }
+}
+
+// out = act(sum of the K slabs + bias) (* mask); thread = 4 consecutive outputs of a row
+__global__ __launch_bounds__(256) void fc8_fwd_finish_kernel(const float* __restrict__ ws, int S, size_t MN, int N,
+                                                            const float* __restrict__ bias, const uint8_t* __restrict__ mask,
+                                                            float* __restrict__ out, int act, float prm) {
+    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= MN) return;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int z = 0; z < S; ++z) {
+        const float4 w = *reinterpret_cast<const float4*>(ws + (size_t)z * MN + i);
+        v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+    }
+    const float4 b = *reinterpret_cast<const float4*>(bias + i % N);
+    v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+    tn_act_fwd4(v, act, prm);
+    if (mask) {
+        const uchar4 m = *reinterpret_cast<const uchar4*>(mask + i);
+        v.x = m.x ? v.x : 0.f; v.y = m.y ? v.y : 0.f; v.z = m.z ? v.z : 0.f; v.w = m.w ? v.w : 0.f;
+    }
+    *reinterpret_cast<float4*>(out + i) = v;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// dgrad: dx16[m][k] = fp16(act'(ya[m][k]) * sum_n fp16(gs dz[m][n]) * fp16(W[row(k)][n])); grid = (Kc / 64, M / 128);
+// wave = (32-column tile, 64-row half): C = W_tile . dz^T, MFMA row j <-> column base + swap23(j)
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void fc8_dgrad_kernel(FC8 g) {
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, hi = lane >> 5;
+    const int kbase = blockIdx.x * 64 + (wave & 1) * 32, m0 = blockIdx.y * 128 + (wave >> 1) * 64;
+    const int rows = g.C * g.HW;
+    const int kcol = kbase + fc8_swap23(l31);
+    int wrow;
+    {
+        const int cell = kcol >> 3, o = cell / g.HW, p = cell - o * g.HW;
+        wrow = min((o * 8 + (kcol & 7)) * g.HW + p, rows - 1);
+    }
+    const float* wp = g.W + (size_t)wrow * g.N + 8 * hi;
+    const float* dp[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) dp[i] = g.dz + (size_t)min(m0 + 32 * i + l31, g.M - 1) * g.N + 8 * hi;
+    f32x16 acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    float4 wv[2][2], dv[2][2][2];
+    auto load = [&](int slot, int n) __attribute__((always_inline)) {
+        const int nn = min(n, g.N - 16);
+        wv[slot][0] = *reinterpret_cast<const float4*>(wp + nn);
+        wv[slot][1] = *reinterpret_cast<const float4*>(wp + nn + 4);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            dv[slot][i][0] = *reinterpret_cast<const float4*>(dp[i] + nn);
+            dv[slot][i][1] = *reinterpret_cast<const float4*>(dp[i] + nn + 4);
+        }
+    };
+    auto mm = [&](int slot) __attribute__((always_inline)) {
+        const float wf[8] = {wv[slot][0].x, wv[slot][0].y, wv[slot][0].z, wv[slot][0].w,
+                             wv[slot][1].x, wv[slot][1].y, wv[slot][1].z, wv[slot][1].w};
+        const half8 a = fc8_cvt8(wf);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const float df[8] = {dv[slot][i][0].x * g.gs, dv[slot][i][0].y * g.gs, dv[slot][i][0].z * g.gs, dv[slot][i][0].w * g.gs,
+                                 dv[slot][i][1].x * g.gs, dv[slot][i][1].y * g.gs, dv[slot][i][1].z * g.gs, dv[slot][i][1].w * g.gs};
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, fc8_cvt8(df), acc[i], 0, 0, 0);
+        }
+    };
+    load(0, 0);
+    for (int n = 0; n < g.N; n += 32) {
+        load(1, n + 16);
+        mm(0);
+        if (n + 16 < g.N) {
+            load(0, n + 32);
+            mm(1);
+        }
+    }
+    // lane (sample l31 of tile i): registers 0-7 / 8-15 are the cells 8 (hi) / 8 (2 + hi) of the 32 columns
+    const float tie = g.prm > 0.f ? 1.f + g.prm : 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = m0 + 32 * i + l31;
+        if (m >= g.M) continue;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const size_t o = (size_t)m * g.Kc + kbase + 8 * (2 * h + hi);
+            half8 y8;
+            if (g.ya) y8 = *reinterpret_cast<const half8*>(g.ya + o);
+            half8 o8;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float v = acc[i][h * 8 + e];
+                if (g.ya) {
+                    const float y = (float)y8[e];
+                    v *= g.act == TN_ACT_LEAKY ? (y > 0.f ? 1.f : (y < 0.f ? g.prm : tie)) : tn_act_grad_from_out(y, g.act, g.prm);
+                }
+                o8[e] = (_Float16)v;
+            }
+            *reinterpret_cast<half8*>(g.dx + o) = o8;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// wgrad: dW[row(k)][n] = (1/gs) sum_m x16[m][k] * fp16(gs dz[m][n]); grid = (Kc / 128, N / 128, S sample slabs);
+// block tile 128 x 128, wave = 64 x 64 (2 x 2 MFMA tiles); sample chunks of 64 go through LDS as they are stored
+// ([sample][128 columns] halfs, row stride 320 bytes) and come out transposed.
+// ---------------------------------------------------------------------------------------------------------------
+#define FC8_RS 320          // row stride = 64 (mod 256) bytes: the 4 x 32-byte rows of both 16-lane groups of a half-wave on disjoint banks
+__global__ __launch_bounds__(256) void fc8_wgrad_kernel(FC8 g) {
+    __shared__ __attribute__((aligned(16))) char lds[2][64 * FC8_RS];        // [x | dz][sample][column]
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, hi = lane >> 5;
+    const int k0 = blockIdx.x * 128, n0 = blockIdx.y * 128, z = blockIdx.z;
+    const int mchunk = g.krange;                     // samples per slab (a multiple of 64)
+    const int mbeg = z * mchunk, mend = min(g.M, mbeg + mchunk);
+    const int wk = (wave & 1) * 64, wn = (wave >> 1) * 64;
+    f32x16 acc[2][2], accb[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accb[i][r] = 0.f;
+    }
+    const bool want_db = blockIdx.x == 0 && (wave & 1) == 0;
+    const half8 ones = {(_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f,
+                        (_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f};
+    // staging: thread -> sample row t >> 2 (64 rows), 32-column quarter t & 3
+    const int sr = t >> 2, sq = (t & 3) * 32;
+    // transposing reads: group of 16 lanes = 4 samples x 16 columns; lane supplies sample r4, columns 4 q .. 4 q + 3
+    const int grp = lane >> 4, r4 = (lane >> 2) & 3, q4 = lane & 3;
+    const int rd = (8 * (grp >> 1) + r4) * FC8_RS + (16 * (grp & 1) + 4 * q4) * 2;
+    for (int mc = mbeg; mc < mend; mc += 64) {
+        const int m = mc + sr;
+        const bool ok = m < mend;
+        const int mm_ = min(m, g.M - 1);
+        uint4 xv[4];
+        float4 dv[8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            xv[i] = *reinterpret_cast<const uint4*>(g.x + (size_t)mm_ * g.Kc + min(k0 + sq + 8 * i, g.Kc - 8));
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            dv[i] = *reinterpret_cast<const float4*>(g.dz + (size_t)mm_ * g.N + min(n0 + sq + 4 * i, g.N - 4));
+        __syncthreads();                       // the previous chunk's reads are done
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool in = ok && k0 + sq + 8 * i < g.Kc;
+            *reinterpret_cast<uint4*>(lds[0] + sr * FC8_RS + (sq + 8 * i) * 2) = in ? xv[i] : make_uint4(0u, 0u, 0u, 0u);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; i += 2) {
+            const bool in = ok && n0 + sq + 4 * i < g.N;
+            const float s = in ? g.gs : 0.f;
+            const float f[8] = {dv[i].x * s, dv[i].y * s, dv[i].z * s, dv[i].w * s, dv[i + 1].x * s, dv[i + 1].y * s, dv[i + 1].z * s, dv[i + 1].w * s};
+            *reinterpret_cast<half8*>(lds[1] + sr * FC8_RS + (sq + 4 * i) * 2) = fc8_cvt8(f);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {       // 16 samples per step
+            half8 a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const char* ap = lds[0] + ks * 16 * FC8_RS + rd + (wk + 32 * i) * 2;
+                const half4v a0 = fc8_tr16(ap), a1 = fc8_tr16(ap + 4 * FC8_RS);
+                a[i] = half8{a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+                const char* bp = lds[1] + ks * 16 * FC8_RS + rd + (wn + 32 * i) * 2;
+                const half4v b0 = fc8_tr16(bp), b1 = fc8_tr16(bp + 4 * FC8_RS);
+                b[i] = half8{b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+            if (want_db) {
+                accb[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ones, b[0], accb[0], 0, 0, 0);
+                accb[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ones, b[1], accb[1], 0, 0, 0);
+            }
+        }
+    }
+    const int rows = g.C * g.HW;
+    float* const wz = g.ws + (size_t)z * rows * g.N;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int k = k0 + wk + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            const int cell = k >> 3, o = cell / g.HW, p = cell - o * g.HW, ch = o * 8 + (k & 7);
+            if (k < g.Kc && ch < g.C) {
+                float* wr = wz + (size_t)(ch * g.HW + p) * g.N;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int n = n0 + wn + 32 * j + l31;
+                    if (n < g.N) wr[n] = acc[i][j][r] * g.oscale;
+                }
+            }
+        }
+    if (want_db && hi == 0) {                   // row 0 of the product with ones (every row is the column sum)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wn + 32 * j + l31;
+            if (n < g.N) g.dbws[(size_t)z * g.N + n] = accb[j][0] * g.oscale;
+        }
+    }
+}
+
+static int fc8_check(tn_ctx* ctx, int B, int C, int HW, int n_out, const char* what) {
+    const int Kc = ((C + 7) / 8) * HW * 8;
+    TN_REQUIRE(B > 0 && C > 0 && HW > 0 && n_out > 0, "%s: bad shape", what);
+    TN_REQUIRE(Kc % 64 == 0 && n_out % 32 == 0, "%s: %d inputs (c8) and %d outputs must be multiples of 64 / 32", what, Kc, n_out);
+    return TN_OK;
+}
+
+extern "C" {
+
+// 1 if the fp16-resident FC products take this layer (input = C maps of HW pixels, c8 order; HW = 1: a plain matrix)
+int tn_c8_fc_supported(int B, int C, int HW, int n_out) {
+    const int Kc = ((C + 7) / 8) * HW * 8;
+    return B > 0 && C > 0 && HW > 0 && n_out > 0 && Kc % 64 == 0 && n_out % 32 == 0;
+}
+
+// a (B, n_out) fp32 = act(x16 . W + b) (* mask); x16 (B, C8*HW*8) halfs in c8 order, W (C*HW, n_out) fp32 in the reference's
+// NCHW-flattened row order (hidden.py:30, neuralnet.py:168-173)
+int tn_c8_fc_fwd(tn_ctx* ctx, const void* x, const float* W, const float* b, float* a, int B, int C, int HW, int n_out,
+                 int act, float act_param, const uint8_t* mask) {
+    int rc = fc8_check(ctx, B, C, HW, n_out, "tn_c8_fc_fwd");
+    if (rc) return rc;
+    FC8 g{};
+    g.x = static_cast<const _Float16*>(x); g.W = W; g.M = B; g.N = n_out; g.C = C; g.HW = HW;
+    g.Kc = ((C + 7) / 8) * HW * 8;
+    const int colg = cdiv(n_out, 64), rowg = cdiv(B, 128);
+    // slabs: enough blocks for two waves per SIMD, K ranges of at least 64 per wave
+    int S = cdiv(2 * ctx->num_cus, colg * rowg);
+    if (S > g.Kc / 256) S = g.Kc / 256;
+    if (S < 1) S = 1;
+    g.krange = cdiv(cdiv(g.Kc, 4 * S), 16) * 16;
+    S = cdiv(g.Kc, 4 * g.krange);
+    g.S = S;
+    rc = tn_scratch_get(ctx, (size_t)S * B * n_out * sizeof(float), &g.ws);
+    if (rc) return rc;
+    fc8_fwd_kernel<<<dim3(colg, S, rowg), 256, 0, ctx->stream>>>(g);
+    TN_LAUNCH_CHECK();
+    const size_t MN = (size_t)B * n_out;
+    fc8_fwd_finish_kernel<<<cdiv(MN / 4, 256), 256, 0, ctx->stream>>>(g.ws, S, MN, n_out, b, mask, a, act, act_param);
+    TN_LAUNCH_CHECK();
+    return TN_OK;
+}
+
+// dx16 (B, C8*HW*8) halfs = fp16(gs * dz . W^T * act'(y16)): dz (B, n_out) fp32 = d cost / d z of this layer, y16 = output
+// of the layer below in x's order (NULL: none), (act, prm) its activation.  dx carries the gradient scale.
+int tn_c8_fc_dgrad(tn_ctx* ctx, const float* dz, const float* W, void* dx, int B, int C, int HW, int n_out, const void* y,
+                   int act, float act_param) {
+    int rc = fc8_check(ctx, B, C, HW, n_out, "tn_c8_fc_dgrad");
+    if (rc) return rc;
+    FC8 g{};
+    g.dz = dz; g.W = W; g.dx = static_cast<_Float16*>(dx); g.ya = static_cast<const _Float16*>(y);
+    g.M = B; g.N = n_out; g.C = C; g.HW = HW; g.Kc = ((C + 7) / 8) * HW * 8;
+    g.act = act; g.prm = act_param; g.gs = ctx->grad_scale;
+    fc8_dgrad_kernel<<<dim3(g.Kc / 64, cdiv(B, 128)), 256, 0, ctx->stream>>>(g);
+    TN_LAUNCH_CHECK();
+    return TN_OK;
+}
+
+// dW (C*HW, n_out), db (n_out) fp32 from x16 and dz (fp32, rounded as fp16(gs * dz) while staged)
+int tn_c8_fc_wgrad(tn_ctx* ctx, const void* x, const float* dz, float* dW, float* db, int B, int C, int HW, int n_out) {
+    int rc = fc8_check(ctx, B, C, HW, n_out, "tn_c8_fc_wgrad");
+    if (rc) return rc;
+    FC8 g{};
+    g.x = static_cast<const _Float16*>(x); g.dz = dz; g.M = B; g.N = n_out; g.C = C; g.HW = HW;
+    g.Kc = ((C + 7) / 8) * HW * 8;
+    g.gs = ctx->grad_scale; g.oscale = 1.f / ctx->grad_scale;
+    const int kb = cdiv(g.Kc, 128), nb = cdiv(n_out, 128);
+    int S = cdiv(2 * ctx->num_cus, kb * nb);
+    if (S > cdiv(B, 64)) S = cdiv(B, 64);
+    if (S < 1) S = 1;
+    g.krange = cdiv(cdiv(B, S), 64) * 64;
+    S = cdiv(B, g.krange);
+    g.S = S;
+    const size_t n = (size_t)C * HW * n_out;
+    if (S == 1) {
+        g.ws = dW; g.dbws = db;
+        // (channels beyond C own no row of dW: nothing to clear)
+        fc8_wgrad_kernel<<<dim3(kb, nb, 1), 256, 0, ctx->stream>>>(g);
+        TN_LAUNCH_CHECK();
+        return TN_OK;
+    }
+    rc = tn_scratch_get(ctx, ((size_t)S * n + (size_t)S * n_out) * sizeof(float), &g.ws);
+    if (rc) return rc;
+    g.dbws = g.ws + (size_t)S * n;
+    fc8_wgrad_kernel<<<dim3(kb, nb, S), 256, 0, ctx->stream>>>(g);
+    TN_LAUNCH_CHECK();
+    rc = tn_red_push(ctx, g.ws, dW, (uint32_t)n, (uint32_t)S, (uint32_t)n, 0);
+    if (rc) return rc;
+    rc = tn_red_push(ctx, g.dbws, db, (uint32_t)n_out, (uint32_t)S, (uint32_t)n_out, 0);
+    if (rc) return rc;
+    return tn_red_commit(ctx);
+}
+
+}  // extern "C"

@@ -180,9 +180,16 @@ int tn_c8_conv_wgrad_supported(int, int, int, int, int) { return 0; }
 int tn_c8_conv_fwd(tn_ctx* ctx, const void*, const float*, const float*, void*, uint8_t*, int, int, int, int, int, int,
                    float, int) { NOT_HERE("tn_c8_conv_fwd"); }
 int tn_c8_conv_dgrad(tn_ctx* ctx, const void*, const float*, void*, int, int, int, int, int, const void*, int, float, int,
-                     const uint8_t*, const void*, int, float) { NOT_HERE("tn_c8_conv_dgrad"); }
-int tn_c8_conv_wgrad(tn_ctx* ctx, const void*, const void*, float*, float*, int, int, int, int, int, int, const uint8_t*,
-                     const void*, int, float) { NOT_HERE("tn_c8_conv_wgrad"); }
+                     const uint8_t*) { NOT_HERE("tn_c8_conv_dgrad"); }
+int tn_c8_conv_wgrad(tn_ctx* ctx, const void*, const void*, float*, float*, int, int, int, int, int, int,
+                     const uint8_t*) { NOT_HERE("tn_c8_conv_wgrad"); }
+int tn_c8_fc_supported(int, int, int, int) { return 0; }
+int tn_c8_fc_fwd(tn_ctx* ctx, const void*, const float*, const float*, float*, int, int, int, int, int, float,
+                 const uint8_t*) { NOT_HERE("tn_c8_fc_fwd"); }
+int tn_c8_fc_dgrad(tn_ctx* ctx, const float*, const float*, void*, int, int, int, int, const void*, int, float) {
+    NOT_HERE("tn_c8_fc_dgrad");
+}
+int tn_c8_fc_wgrad(tn_ctx* ctx, const void*, const float*, float*, float*, int, int, int, int) { NOT_HERE("tn_c8_fc_wgrad"); }
 int tn_c8_pack(tn_ctx* ctx, const float*, int64_t, void*, int, int, int, float) { NOT_HERE("tn_c8_pack"); }
 int tn_c8_unpack(tn_ctx* ctx, const void*, float*, int, int, int, float) { NOT_HERE("tn_c8_unpack"); }
 int tn_convpool_f16_supported(int, int, int, int, int, int, int, int, int, int, int, int, int) { return 0; }
