@@ -45,7 +45,12 @@ training trajectory (forward, all gradients, three old-velocity updates) compute
 torch CPU autograd (tests/golden/make_torch_xchk.py -> torch_xchk.npz), which this
 module reproduces to 1e-9 (tests/test_oracle_kat.py).
 
-Beyond the reference (it is float32-only, weights.py:8): ``r16`` and the ``f16=True``
+Beyond the reference (it is float32-only, weights.py:8): DTYPE 'float16' = the STORED-fp16 mode of the fp16-resident
+kernels (OracleNet): every tensor of the conv stack -- activations going up, gradients coming down -- is rounded to IEEE
+half when it is stored (gradients as r16(GRAD_SCALE * g) / GRAD_SCALE), weights when they are used, products exact,
+sums float64 (the device: fp32), bias / activation / pooling / ties on the unrounded sums, activation derivatives from
+the stored output; the dense layer on top of the stack takes the halfs as its input operand and is fp32 from there on.
+``r16`` and the ``f16=True``
 modes of conv2d_fwd / conv2d_bwd specify the build's DTYPE='float16' (fp16-rounded
 operands, exact products, float64 sums).
 """
@@ -98,6 +103,26 @@ def activation(name):
                     (z <= 0).astype(z.dtype) * z.dtype.type(ii / 100))
         return f, df
     raise NotImplementedError("Unknown Activation Specified: " + name)
+
+
+def act_grad_from_out(name, a):
+    """act'(z) expressed through the layer's STORED output a = act(z) -- how the device's backward kernels take it
+    (documented deviation: for slope 0 an exact a == 0 reads as z < 0)."""
+    if name == "linear":
+        return np.ones_like(a)
+    s = leaky_slope(name)
+    if s is not None:
+        tie = 1.0 + s if s > 0 else 0.0
+        return np.where(a > 0, 1.0, np.where(a < 0, s, tie))
+    if name == "tanh":
+        return 1 - a * a
+    if name == "sigmoid":
+        return a * (1 - a)
+    if name == "softplus":
+        return 1 - np.exp(-a)
+    if name == "scaled_tanh":
+        return 1.7 * 2 / 3 * (1 - (a / 1.7) ** 2)
+    raise NotImplementedError(name)
 
 
 def leaky_slope(name):
@@ -966,8 +991,15 @@ class OracleNet:
                 z = conv2d_fwd(h, l.params[0], l.params[1], l.stride, l.mode, f16=self.f16)
                 c["z"] = z
                 h = activation(l.actvn)[0](z)
+                if self.f16:
+                    c["exact"] = h                              # what pooling (ties included) sees
+                    h = r16(h).astype(self.dtype)               # what is stored
             elif l.kind == "Pool":
-                h = pool_fwd(h, l.p, l.ignore_border)
+                if self.f16:
+                    c["in"] = cache[-1]["exact"]                # max and ties on the unrounded activation
+                    h = r16(pool_fwd(c["in"], l.p, l.ignore_border)).astype(self.dtype)
+                else:
+                    h = pool_fwd(h, l.p, l.ignore_border)
             elif l.kind == "Mean":
                 h = mean_fwd(h)
             elif l.kind == "DropOut":
@@ -996,7 +1028,11 @@ class OracleNet:
             elif l.kind in ("Hidden", "Softmax", "ExpLoss", "Hinge", "Centered"):
                 h = h.reshape(h.shape[0], -1)                       # flatten(2), neuralnet.py:169
                 c["in"] = h
-                z = (h @ l.params[0] + l.params[1]).astype(self.dtype)
+                c["c8"] = self.f16 and i > 0 and self.L[i - 1].kind in ("Conv", "Pool")     # fp16 operands: the stack's halfs
+                if c["c8"]:
+                    z = (r16(h) @ r16(l.params[0]) + l.params[1]).astype(self.dtype)
+                else:
+                    z = (h @ l.params[0] + l.params[1]).astype(self.dtype)
                 c["z"] = z
                 if l.kind == "Softmax":
                     h = log_softmax(z)
@@ -1044,7 +1080,13 @@ class OracleNet:
                 if "mask" in c:
                     g = g * c["mask"]
                 dz = (g * activation(l.actvn)[1](c["z"])).astype(self.dtype)
-            if l.kind in ("Softmax", "Hidden", "ExpLoss", "Hinge", "Centered"):
+            if l.kind == "Hidden" and c.get("c8"):
+                # dense layer on the fp16-resident stack: both operands of its three products are halfs
+                dz16 = r16(dz, self.grad_scale)
+                grads[i] = [(r16(c["in"]).T @ dz16).astype(self.dtype) + wtcost_grad(l.params[0], l.reg),
+                            dz16.sum(axis=0).astype(self.dtype) + wtcost_grad(l.params[1], l.reg)]
+                g = self._f16_down(dz16 @ r16(l.params[0]).T, i, cache) if i > first_param else None
+            elif l.kind in ("Softmax", "Hidden", "ExpLoss", "Hinge", "Centered"):
                 xin = c["in"]
                 dW = (xin.T @ dz).astype(self.dtype)
                 db = dz.sum(axis=0, dtype=self.dtype)
@@ -1070,6 +1112,15 @@ class OracleNet:
                 g = mean_bwd(c["in"], g.reshape(c["out"].shape))
             elif l.kind == "Pool":
                 g = pool_bwd(c["in"], g.reshape(c["out"].shape), l.p, l.ignore_border)
+            elif l.kind == "Conv" and self.f16:
+                # what arrives IS dz as stored (halfs, act' applied by its producer from this block's stored output)
+                dz = np.asarray(g, np.float64).reshape(c["z"].shape)
+                g, dW, db = conv2d_bwd(c["in"], l.params[0], dz, l.stride, l.mode,
+                                       need_dx=i > first_param, f16=True, grad_scale=self.grad_scale)
+                grads[i] = [dW + wtcost_grad(l.params[0], l.reg),
+                            db + wtcost_grad(l.params[1], l.reg)]
+                if g is not None:
+                    g = self._f16_down(g, i, cache)
             elif l.kind == "Conv":
                 dz = (g.reshape(c["z"].shape) * activation(l.actvn)[1](c["z"])).astype(self.dtype)
                 g, dW, db = conv2d_bwd(c["in"], l.params[0], dz, l.stride, l.mode,
@@ -1090,6 +1141,19 @@ class OracleNet:
             if g is None:
                 break
         return grads
+
+    def _f16_down(self, g, i, cache):
+        """Stored-fp16 mode: the gradient layer i hands to the layer below, as the device stores it: times act' of the
+        block below taken from ITS stored output (a Pool layer stands for its conv block), rounded to half at the
+        gradient scale."""
+        below = self.L[i - 1]
+        out = np.asarray(cache[i - 1]["out"], np.float64)
+        g = np.asarray(g, np.float64).reshape(out.shape)
+        if below.kind == "Pool":
+            g = g * act_grad_from_out(self.L[i - 2].actvn, out)
+        elif below.kind == "Conv":
+            g = g * act_grad_from_out(below.actvn, out)
+        return r16(g, self.grad_scale)
 
     # -- public steps ---------------------------------------------------------
     def head(self, h, y):

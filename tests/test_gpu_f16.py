@@ -1,6 +1,10 @@
-"""DTYPE='float16' parity (BASELINE.json configs[4]: "fp16 inputs / fp32 accum MFMA"): the conv
-products on v_mfma_f32_32x32x16_f16 against the oracle's fp16-rounded-operand float64 mode
-(oracle.theanet_oracle.r16 / conv2d_fwd(f16=True) / conv2d_bwd(f16=True)).
+"""DTYPE='float16' parity (BASELINE.json configs[4]: "fp16 inputs / fp32 accum MFMA").
+
+Whole nets (NeuralNet with DTYPE float16 = fp16-RESIDENT tensors, tests/test_gpu_c8.py has the ops) against the float64
+oracle in its stored-fp16 mode (oracle.theanet_oracle.OracleNet, DTYPE 'float16').  The first part of this file keeps
+the C-ABI's operand-rounded products (tn_set_matmul_dtype(1) + tn_conv2d_* / tn_convpool_*: fp32 tensors in HBM, both
+operands rounded while staged; theanet_amd/csrc/conv_tile16.hip) against oracle.theanet_oracle.r16 /
+conv2d_fwd(f16=True) / conv2d_bwd(f16=True).
 
 Tolerances.  The device and the oracle multiply the SAME fp16-rounded operands (products of two
 halfs are exact in fp32), so a single product differs only by the fp32 accumulation: 2e-5 relative to
@@ -215,7 +219,7 @@ def _inject_draws(net, ora, B, C, img):
 @pytest.mark.parametrize("name,img,B", [("cifar_like.prms", 32, 16), ("wide6.prms", 64, 4), ("wide6.prms", 32, 6)])
 def test_f16_nets_match_f16_oracle(name, img, B):
     """Two training steps (forward, every gradient, momentum update, maxnorm) in DTYPE float16 against
-    the float64 oracle in its fp16-rounded-operand mode."""
+    the float64 oracle in its stored-fp16 mode."""
     from theanet_amd import NeuralNet
     prms = load_prms(name, img, batch=B)
     tr = dict(prms["training_params"], DTYPE="float16", GRAD_SCALE=GS)

@@ -203,6 +203,28 @@ class DeviceArray:
         return "DeviceArray(shape=%s, dtype=%s, ptr=0x%x)" % (self.shape, self.dtype, self.ptr)
 
 
+class C8Array(DeviceArray):
+    """An fp16-RESIDENT activation / gradient tensor (DTYPE 'float16'): logical (N, C, H, W), stored
+    [N][ceil(C/8)][H][W][8] halfs -- one 16-byte cell = the 8 channels of an octet at one pixel, channels beyond C zero
+    (theanet_amd/csrc/conv_c8.hip).  ``get_value`` returns the logical NCHW float32 array."""
+
+    def __init__(self, ctx, n, c, h, w):
+        self.c8 = (int(c), int(h), int(w))
+        super().__init__(ctx, (n, (c + 7) // 8, h, w, 8), np.uint16)
+
+    def get_value(self, borrow=True):
+        raw = DeviceArray.get_value(self).view(np.float16)
+        n, c8, h, w, _ = raw.shape
+        return raw.transpose(0, 1, 4, 2, 3).reshape(n, c8 * 8, h, w)[:, :self.c8[0]].astype(np.float32)
+
+    def set_value(self, data):
+        data = np.asarray(data, np.float32)
+        n, c, h, w = data.shape
+        buf = np.zeros((n, self.shape[1] * 8, h, w), np.float16)
+        buf[:, :c] = data.astype(np.float16)
+        DeviceArray.set_value(self, np.ascontiguousarray(buf.reshape(n, self.shape[1], 8, h, w).transpose(0, 1, 3, 4, 2)).view(np.uint16))
+
+
 class HostBuffer:
     """Page-locked host memory (tn_host_alloc) viewed as a numpy array: the target of tn_d2h_early copies."""
 

@@ -7,6 +7,7 @@ import os
 import numpy as np
 
 from .. import _lib
+from ..device import C8Array
 from .layer import Layer, activation_by_name
 from .weights import init_wb
 
@@ -48,21 +49,26 @@ class ConvLayer(Layer):
         self.act = activation_by_name(actvn)
         assert self.act.kind is not None, "softmax is not a conv activation"
         self.ctx = self.W.ctx
-        # DTYPE 'float16' (NeuralNet training param): fp16 operands / fp32 accumulation on the matrix
-        # cores.  Every conv product of the net runs that way or construction fails -- no silent fp32.
+        # DTYPE 'float16' (NeuralNet training param; BASELINE configs[4]): activations and gradients live in HBM as
+        # halfs in the c8 layout (device.C8Array), fp16 MFMA operands / fp32 accumulation, fp32 master weights.  Every
+        # conv layer of the net runs that way or construction fails -- no silent fp32 run of an unsupported shape.
         self.f16 = self.ctx.mm_dtype == "float16"
-        if self.f16:
-            bits = self.ctx.lib.tn_conv_f16_supported(batch_sz, num_prev_maps, in_sz, in_sz, num_maps, filter_sz,
-                                                      stride, self.pad_lo, self.out_sz, self.out_sz)
-            assert bits & 5 == 5, (
-                "DTYPE float16 needs 3x3 stride-1 'same' conv layers on power-of-two maps of 8..64 pixels "
-                "(got {}->{} maps, {}x{} {} filter {} stride {}: forward {}, weight gradient {})".format(
-                    num_prev_maps, num_maps, in_sz, in_sz, mode, filter_sz, stride, bool(bits & 1), bool(bits & 4)))
-            self._f16_dgrad = bool(bits & 2)
         self.inpt = inpt
         self.batch_sz, self.num_prev_maps, self.in_sz = batch_sz, num_prev_maps, in_sz
         self.filter_sz, self.stride = filter_sz, stride
-        self.output = self.ctx.empty((batch_sz, num_maps, self.out_sz, self.out_sz))
+        if self.f16:
+            lib = self.ctx.lib
+            ok = lib.tn_c8_conv_supported(batch_sz, num_prev_maps, in_sz, in_sz, num_maps, filter_sz, stride, self.pad_lo) and \
+                lib.tn_c8_conv_wgrad_supported(batch_sz, num_prev_maps, in_sz, in_sz, num_maps)
+            assert ok and mode == 'same', (
+                "DTYPE float16 needs 3x3 stride-1 'same' conv layers with a multiple of 8 filters on maps of 8, 16, 32 "
+                "or 64 pixels a side (got {}->{} maps, {}x{} {} filter {} stride {})".format(
+                    num_prev_maps, num_maps, in_sz, in_sz, mode, filter_sz, stride))
+            # the first conv layer of the net gets NCHW fp32 images: packed into a c8 tensor in front of the kernel
+            self.x16 = None if getattr(inpt, "c8", None) else C8Array(self.ctx, batch_sz, num_prev_maps, in_sz, in_sz)
+            self.output = C8Array(self.ctx, batch_sz, num_maps, self.out_sz, self.out_sz)
+        else:
+            self.output = self.ctx.empty((batch_sz, num_maps, self.out_sz, self.out_sz))
         self.gin = None
         self.fused_pool = None     # set by NeuralNet: conv+act+pool run as ONE kernel
         self._tile_pool = False    # ... on the LDS-tile matrix-core kernels (wide layers)
@@ -101,10 +107,8 @@ class ConvLayer(Layer):
         """conv -> act -> 2x2 max-pool on small channel counts runs as one fused kernel pair
         (tn_convpool_fwd / tn_convpool_bwd): the conv activation never reaches HBM."""
         if self.f16:
-            self._tile_pool = bool(self.ctx.lib.tn_convpool_f16_supported(
-                self.batch_sz, self.num_prev_maps, self.in_sz, self.in_sz, self.num_maps, self.filter_sz,
-                self.stride, self.pad_lo, self.out_sz, self.out_sz, pool.pool_sz, pool.out_sz, pool.out_sz))
-            return self._tile_pool
+            assert pool.pool_sz == 2 and self.out_sz % 2 == 0, "DTYPE float16: pooling layers are 2x2 on even maps"
+            return True
         if self.stride == 1 and self.ctx.lib.tn_convpool_supported(
                 self.num_prev_maps, self.filter_sz, self.stride, pool.pool_sz):
             return True
@@ -131,9 +135,53 @@ class ConvLayer(Layer):
                 self.filter_sz, self.pad_lo, self.out_sz, self.out_sz, pool.pool_sz,
                 pool.out_sz, pool.out_sz, self.act.kind, self.act.prm)
 
+    # -- DTYPE float16: the fp16-resident kernels (include/theanet_hip.h, tn_c8_*) --------------------------------
+    def _c8_input(self, below=None):
+        """The layer's input as a c8 tensor: the layer below's output, or -- first conv layer of the net -- the NCHW
+        fp32 minibatch packed on the way in (straight from the dataset window when the layer below is an InputLayer)."""
+        if self.x16 is None:
+            return self.inpt
+        src, row0 = self.inpt, 0
+        slot = getattr(self, "_pack_from", None)
+        if slot is not None:
+            src, row0 = slot.data, int(slot.row0)
+        self.ctx.call("tn_c8_pack", src.ptr, row0, self.x16.ptr, self.batch_sz, self.num_prev_maps,
+                      self.in_sz * self.in_sz, 1.0)
+        return self.x16
+
+    def _c8_forward(self, out, mask):
+        x = self._c8_input()
+        self.ctx.call("tn_c8_conv_fwd", x.ptr, self.W.ptr, self.b.ptr, out.ptr, mask.ptr if mask is not None else None,
+                      self.batch_sz, self.num_prev_maps, self.in_sz, self.in_sz, self.num_maps, self.act.kind, self.act.prm,
+                      1 if out is not self.output else 0)
+
+    def _c8_backward(self, gout, need_gin, below):
+        """gout: d cost / d z of this layer as a c8 tensor carrying the gradient scale -- or, for a fused block, the
+        gradient w.r.t. the POOLED output (act' already applied by its producer), dz being formed from it and the
+        pooling mask inside the kernels."""
+        pool = self.fused_pool
+        pooled, mask = (1, pool.mask.ptr) if pool is not None else (0, None)
+        x = self.x16 if self.x16 is not None else self.inpt
+        geom = (self.batch_sz, self.num_prev_maps, self.in_sz, self.in_sz, self.num_maps)
+        if self.has_updates():
+            self.ctx.call("tn_c8_conv_wgrad", x.ptr, gout.ptr, self.grads[0].ptr, self.grads[1].ptr, *geom, pooled, mask)
+        if not need_gin:
+            return None
+        assert self.x16 is None, "DTYPE float16: no trainable layer below the first conv layer"
+        if self.gin is None:
+            self.gin = C8Array(self.ctx, self.batch_sz, self.num_prev_maps, self.in_sz, self.in_sz)
+        b_out, b_act, b_prm, b_mask = below.act_info()
+        assert b_mask is None
+        fuse = b_out is not None and b_act != _lib.TN_ACT_LINEAR
+        self.ctx.call("tn_c8_conv_dgrad", gout.ptr, self.W.ptr, self.gin.ptr, *geom, b_out.ptr if fuse else None,
+                      b_act, b_prm, pooled, mask)
+        return self.gin
+
     def forward(self, train=True):
         if self.fused_pool is not None:
             return                       # the pool layer launches the fused kernel
+        if self.f16:
+            return self._c8_forward(self.output, None)
         self.ctx.call("tn_conv2d_fwd", self.inpt.ptr, self.W.ptr, self.b.ptr, self.output.ptr,
                       *self._geom(), self.act.kind, self.act.prm)
 
@@ -202,6 +250,8 @@ class ConvLayer(Layer):
 
     def backward(self, gout, need_gin, below):
         """gout = d cost / d z of this layer (activation gradient already fused in)."""
+        if self.f16:
+            return self._c8_backward(gout, need_gin, below)
         if self.fused_pool is not None:
             gout = self._backward_fused(gout, need_gin, below)
             if not need_gin:
@@ -241,7 +291,11 @@ class PoolLayer(Layer):
         self.args = (num_maps, in_sz, pool_sz, ignore_border)
         self.n_out = num_maps * self.out_sz ** 2
         self.batch_sz = inpt.shape[0]
-        self.output = self.ctx.empty((self.batch_sz, num_maps, self.out_sz, self.out_sz))
+        self.f16 = getattr(inpt, "c8", None) is not None      # DTYPE float16: pooled c8 tensor (only as a fused block)
+        if self.f16:
+            self.output = C8Array(self.ctx, self.batch_sz, num_maps, self.out_sz, self.out_sz)
+        else:
+            self.output = self.ctx.empty((self.batch_sz, num_maps, self.out_sz, self.out_sz))
         self.gin = None
         self.fused_conv = None
         self.mask = None           # uint8 pooling mask of the fused forward (training graphs only)
@@ -255,8 +309,22 @@ class PoolLayer(Layer):
     def TestVersion(self, inpt):
         return PoolLayer(inpt, *self.args)
 
+    def act_info(self):
+        """DTYPE float16: the gradient a pooled block receives carries act'(pooled output) (applied by whichever kernel
+        produces it, from the block's stored output); fp32 blocks take the derivative from the pooling mask's sign
+        bits inside their own backward kernels instead."""
+        if self.f16:
+            act = self.fused_conv.act
+            return self.output, act.kind, act.prm, None
+        return Layer.act_info(self)
+
     def forward(self, train=True):
         conv = self.fused_conv
+        if self.f16:
+            assert conv is not None, "DTYPE float16: a PoolLayer must directly follow a ConvLayer"
+            if train and self.mask is None:
+                self.mask = self.ctx.empty(self.output.shape, np.uint8)
+            return conv._c8_forward(self.output, self.mask if train else None)
         if conv is not None:
             if train and self.mask is None and conv.filter_sz == 3 and self.pool_sz == 2 and \
                     (conv._tile_pool or os.environ.get("TN_POOL_MASK", "1") != "0"):

@@ -5,6 +5,7 @@ output (:31-32); the test version drops the mask and scales by (1 - pdrop)
 (:50-55).  Note the reference's init quirk: fan_in = fan_out = n_in + n_out (:21-27).
 """
 from .. import _lib
+from ..device import C8Array
 from .dropout import drop_output
 from .layer import Layer, activation_by_name
 from .weights import init_wb
@@ -32,8 +33,19 @@ class HiddenLayer(Layer):
         self.ctx = self.w.ctx
 
         self.act = activation_by_name(actvn)
-        self.inpt = inpt.flatten(2)
-        assert self.inpt.shape[1] == n_in, (self.inpt.shape, n_in)
+        # DTYPE float16: the layer above the conv stack consumes the c8 tensor as it is stored (tn_c8_fc_*: fp16
+        # operands through the NCHW row map, fp32 output); further dense layers are fp32 like the reference
+        self.c8 = getattr(inpt, "c8", None)
+        if self.c8 is not None:
+            c, h, wd = self.c8
+            assert c * h * wd == n_in, (self.c8, n_in)
+            assert self.ctx.lib.tn_c8_fc_supported(inpt.shape[0], c, h * wd, n_out), (
+                "DTYPE float16: a dense layer on {} maps of {}x{} needs a multiple of 64 inputs (c8) and of 32 outputs "
+                "(got {})".format(c, h, wd, n_out))
+            self.inpt = inpt
+        else:
+            self.inpt = inpt.flatten(2)
+            assert self.inpt.shape[1] == n_in, (self.inpt.shape, n_in)
         self.batch_sz = self.inpt.shape[0]
         self.output = self.ctx.empty((self.batch_sz, n_out))
         self.drop = None
@@ -71,7 +83,13 @@ class HiddenLayer(Layer):
 
     def forward(self, train=True):
         drop = self.drop
-        if drop is not None and not drop.injected and not drop.ready:
+        if self.c8 is not None:
+            if drop is not None:
+                drop.generate()
+            c, h, wd = self.c8
+            self.ctx.call("tn_c8_fc_fwd", self.inpt.ptr, self.w.ptr, self.b.ptr, self.output.ptr, self.batch_sz, c, h * wd,
+                          self.n_out, self.act.kind, self.act.prm, drop.mask.ptr if drop is not None else None)
+        elif drop is not None and not drop.injected and not drop.ready:
             # the mask is drawn inside the layer's own launch (and kept for the backward pass)
             self.ctx.call("tn_fc_fwd_dropout", self.inpt.ptr, self.w.ptr, self.b.ptr, self.output.ptr,
                           self.batch_sz, self.n_in, self.n_out, self.act.kind, self.act.prm,
@@ -89,6 +107,21 @@ class HiddenLayer(Layer):
 
     def backward(self, gout, need_gin, below):
         """gout = d cost / d z (activation gradient and dropout mask already applied)."""
+        if self.c8 is not None:
+            c, h, wd = self.c8
+            if self.has_updates():
+                self.ctx.call("tn_c8_fc_wgrad", self.inpt.ptr, gout.ptr, self.grads[0].ptr, self.grads[1].ptr,
+                              self.batch_sz, c, h * wd, self.n_out)
+            if not need_gin:
+                return None
+            if self.gin is None:
+                self.gin = C8Array(self.ctx, self.batch_sz, c, h, wd)
+            b_out, b_act, b_prm, b_mask = below.act_info()
+            assert b_mask is None
+            fuse = b_out is not None and b_act != _lib.TN_ACT_LINEAR
+            self.ctx.call("tn_c8_fc_dgrad", gout.ptr, self.w.ptr, self.gin.ptr, self.batch_sz, c, h * wd, self.n_out,
+                          b_out.ptr if fuse else None, b_act, b_prm)
+            return self.gin
         if self.has_updates() and need_gin:
             # weight gradient and input gradient only share dz: one op, one launch
             if self.wgrad_ws is None:

@@ -48,8 +48,13 @@ class InputLayer(Layer):
     def TestVersion(self, inpt):
         return InputLayer(inpt, self.out_sz, self.num_maps)
 
+    _packed_by_conv = False     # DTYPE float16: the first conv layer reads the dataset window itself (tn_c8_pack)
+
     def forward(self, train=True):
         s = self.inpt
+        if self._packed_by_conv:
+            assert s.d_row0 is None
+            return
         self.ctx.call("tn_elastic_apply", s.data.ptr, int(s.row0),
                       s.d_row0.ptr if s.d_row0 is not None else None, self.output.ptr,
                       self.batch_sz, self.num_maps, self.out_sz, self.out_sz, 0, 1,

@@ -449,9 +449,9 @@ class _TestFn:
 class NeuralNet():
     fuse_conv_pool = True     # class-level switch (tests run both the fused and unfused paths)
     # the C-ABI ops that carry a net's conv products (bench.py brackets them for the conv roofline legs)
-    CONV_FWD_OPS = ("tn_conv2d_fwd", "tn_convpool_fwd_mask", "tn_elastic_convpool_fwd_mask")
+    CONV_FWD_OPS = ("tn_conv2d_fwd", "tn_convpool_fwd_mask", "tn_elastic_convpool_fwd_mask", "tn_c8_conv_fwd")
     CONV_BWD_OPS = ("tn_conv2d_wgrad", "tn_conv2d_dgrad", "tn_convpool_bwd_mask_dx", "tn_convpool_bwd_mask",
-                    "tn_convblock_bwd_mask", "tn_convblock_bwd", "tn_convpool_bwd")
+                    "tn_convblock_bwd_mask", "tn_convblock_bwd", "tn_convpool_bwd", "tn_c8_conv_wgrad", "tn_c8_conv_dgrad")
 
     def __init__(self, layers, training_params, allwts=None,
                  test_x=None):
@@ -565,7 +565,11 @@ class NeuralNet():
                 use_tr_layer = prev_tr_layer
             num_prev_maps = use_tr_layer.num_maps
             prev_out_sz = use_tr_layer.out_sz
-            if tr_inpt.ndim != 4:
+            if getattr(tr_inpt, "c8", None) is not None:
+                # DTYPE float16: fp16-resident tensors of the conv stack (device.C8Array) pass from layer to layer as they are
+                assert curr_layer_type in (ConvLayer, PoolLayer), \
+                    "DTYPE float16: only Conv / Pool layers take the conv stack's fp16-resident tensors (got {})".format(layer_type)
+            elif tr_inpt.ndim != 4:
                 tr_inpt = tr_inpt.reshape(self.local_bsz, num_prev_maps, prev_out_sz, prev_out_sz)
                 te_inpt = te_inpt.reshape(self.local_bsz, num_prev_maps, prev_out_sz, prev_out_sz)
 
@@ -613,7 +617,14 @@ class NeuralNet():
                                           prev_tr_layer.n_out,
                                           **layer_args)
 
+        elif curr_layer_type is HiddenLayer and getattr(tr_inpt, "c8", None) is not None:
+            # DTYPE float16: the dense layer above the conv stack reads the fp16-resident tensor in ITS order (the
+            # kernels walk W through the NCHW row map of flatten(2), neuralnet.py:168-173)
+            curr_layer = HiddenLayer(tr_inpt, wts, self.rand_gen, prev_tr_layer.n_out, **layer_args)
+
         elif curr_layer_type in (AuxConcatLayer, HiddenLayer, SoftmaxLayer, SoftAuxLayer, HingeLayer, ExpLossLayer):
+            assert getattr(tr_inpt, "c8", None) is None, \
+                "DTYPE float16: a HiddenLayer must follow the conv stack (got {})".format(layer_type)
             te_inpt = te_inpt.flatten(2)
             curr_layer = curr_layer_type(tr_inpt.flatten(2),
                                          wts,
@@ -637,6 +648,12 @@ class NeuralNet():
             if isinstance(conv, ConvLayer) and isinstance(pool, PoolLayer) \
                     and conv.can_fuse_with(pool):
                 conv.fused_pool, pool.fused_conv = pool, conv
+        for lyr in lyrs:
+            assert not (isinstance(lyr, PoolLayer) and lyr.f16 and lyr.fused_conv is None), \
+                "DTYPE float16: a PoolLayer must directly follow a ConvLayer"
+        # DTYPE float16: the first conv layer packs its c8 input straight from the dataset window
+        if len(lyrs) >= 2 and isinstance(lyrs[0], InputLayer) and isinstance(lyrs[1], ConvLayer) and lyrs[1].f16:
+            lyrs[1]._pack_from, lyrs[0]._packed_by_conv = lyrs[0].inpt, True
         # an active single-channel ElasticLayer feeding such a block: the block's forward resamples
         # the raw images itself (tn_elastic_convpool_fwd_mask)
         if len(lyrs) >= 3 and isinstance(lyrs[0], ElasticLayer) and lyrs[0].active and \
