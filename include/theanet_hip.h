@@ -152,15 +152,27 @@ int tn_convpool_f16_supported(int N, int C, int H, int Wd, int K, int f, int str
  * them on a tie, Theano's MaxPoolGrad), bit 4 / 5 = pooled value > 0 / < 0.                                      */
 int tn_c8_conv_supported(int N, int C, int H, int W, int K, int f, int stride, int pad);
 int tn_c8_conv_wgrad_supported(int N, int C, int H, int W, int K);
+/* wt (tn_c8_conv_fwd / _dgrad): the layer's weights as fp16 MFMA operand tiles, prepared beforehand by
+ * tn_c8_arrange_multi into a buffer of tn_c8_wt_elems halfs -- every conv product of a step in ONE launch -- or NULL:
+ * the op arranges them itself (one small launch per call).  The arrangement is a function of W only: redo it after
+ * every update.                                                                                                    */
+typedef struct tn_c8_wt_seg {
+    const float* W;  /* (K, C, 3, 3) master weights */
+    void* wt;        /* tn_c8_wt_elems(K, C, dgrad) halfs */
+    int K, C, dgrad; /* dgrad != 0: the operand tiles of the input-gradient product */
+    int pad_;
+} tn_c8_wt_seg;
+size_t tn_c8_wt_elems(int K, int C, int dgrad);
+int tn_c8_arrange_multi(tn_ctx* ctx, const tn_c8_wt_seg* segs, int nseg);
 int tn_c8_conv_fwd(tn_ctx* ctx, const void* x, const float* W, const float* b, void* y, uint8_t* mask, int N, int C,
-                   int H, int Wd, int K, int act, float prm, int pool);
+                   int H, int Wd, int K, int act, float prm, int pool, const void* wt);
 /* dx = conv^T(dz, W) * act'(prev_a) (prev_a NULL: none; for a pooled block below, prev_a is its POOLED output and dx
  * has that shape: the gradient a pooled block receives always carries act'(pooled output)).  pooled != 0: dz is not a
  * tensor: the `dz` argument is the pooled gradient (N, K, H/2, W/2) and dz = (bit of the window element in the block's
  * mask) ? pooled gradient : 0 is formed while staging: the conv activation, MaxPoolGrad's output and dz never exist
  * in HBM                                                                                                            */
 int tn_c8_conv_dgrad(tn_ctx* ctx, const void* dz, const float* W, void* dx, int N, int C, int H, int Wd, int K,
-                     const void* prev_a, int prev_act, float prev_prm, int pooled, const uint8_t* mask);
+                     const void* prev_a, int prev_act, float prev_prm, int pooled, const uint8_t* mask, const void* wt);
 int tn_c8_conv_wgrad(tn_ctx* ctx, const void* x, const void* dz, float* dW, float* db, int N, int C, int H, int Wd,
                      int K, int pooled, const uint8_t* mask);
 /* fully-connected products on an fp16-resident input (replaces hidden.py:30 and its gradients, layer.py:83, for the

@@ -59,12 +59,12 @@ def test_c8_conv_ops(case, f16_mode):
     K8, C8, Hp = K // 8, (C + 7) // 8, H // 2
     # forward
     out = empty((N, K8, H, H, 8), np.uint16)
-    call("tn_c8_conv_fwd", xd.ptr, Wd.ptr, bd.ptr, out.ptr, None, N, C, H, H, K, LEAKY, SLOPE, 0)
+    call("tn_c8_conv_fwd", xd.ptr, Wd.ptr, bd.ptr, out.ptr, None, N, C, H, H, K, LEAKY, SLOPE, 0, None)
     assert _rel(U.from_c8(out.get_value().view(np.float16), K), U.r16(a)) < 1e-3
     # forward + 2x2 max-pool + mask (ties: every window element equal to the maximum)
     pm, bits = U.pool2(a)
     outp, mk = empty((N, K8, Hp, Hp, 8), np.uint16), empty((N, K8, Hp, Hp, 8), np.uint8)
-    call("tn_c8_conv_fwd", xd.ptr, Wd.ptr, bd.ptr, outp.ptr, mk.ptr, N, C, H, H, K, LEAKY, SLOPE, 1)
+    call("tn_c8_conv_fwd", xd.ptr, Wd.ptr, bd.ptr, outp.ptr, mk.ptr, N, C, H, H, K, LEAKY, SLOPE, 1, None)
     assert _rel(U.from_c8(outp.get_value().view(np.float16), K), U.r16(pm)) < 1e-3
     gotm = mk.get_value().transpose(0, 1, 4, 2, 3).reshape(N, K, Hp, Hp)
     assert (gotm != bits).mean() < 1e-4              # (a near-tie may resolve differently in fp32 and float64)
@@ -75,13 +75,13 @@ def test_c8_conv_ops(case, f16_mode):
     dxw = U.conv_same_dgrad(dz, W16) * U.leaky_grad_from_out(prev, SLOPE)
     dzd, pd = _c8(dz), _c8(prev)
     dxo = empty((N, C8, H, H, 8), np.uint16)
-    call("tn_c8_conv_dgrad", dzd.ptr, Wd.ptr, dxo.ptr, N, C, H, H, K, pd.ptr, LEAKY, SLOPE, 0, None)
+    call("tn_c8_conv_dgrad", dzd.ptr, Wd.ptr, dxo.ptr, N, C, H, H, K, pd.ptr, LEAKY, SLOPE, 0, None, None)
     assert _rel(U.from_c8(dxo.get_value().view(np.float16), C), U.r16(dxw)) < 1e-3
     # ... of a pooled block: dz = (window bit of the device's own mask) ? pooled gradient : 0
     g = U.r16(GS * rng.randn(N, K, Hp, Hp) * 1e-3)
     gd = _c8(g)
     dzp = U.unpool_dz(g, gotm)
-    call("tn_c8_conv_dgrad", gd.ptr, Wd.ptr, dxo.ptr, N, C, H, H, K, pd.ptr, LEAKY, SLOPE, 1, mk.ptr)
+    call("tn_c8_conv_dgrad", gd.ptr, Wd.ptr, dxo.ptr, N, C, H, H, K, pd.ptr, LEAKY, SLOPE, 1, mk.ptr, None)
     dxw2 = U.conv_same_dgrad(dzp, W16) * U.leaky_grad_from_out(prev, SLOPE)
     assert _rel(U.from_c8(dxo.get_value().view(np.float16), C), U.r16(dxw2)) < 1e-3
     # weight / bias gradient (fp32 results, scale removed), plain and gathered
@@ -102,7 +102,7 @@ def test_c8_generic_activation_and_pack_roundtrip(f16_mode):
     b = (rng.randn(K) * .1).astype(np.float32)
     act = activation_by_name("tanh")
     out = empty((N, K // 8, H, H, 8), np.uint16)
-    call("tn_c8_conv_fwd", _c8(x).ptr, dev(W).ptr, dev(b).ptr, out.ptr, None, N, C, H, H, K, act.kind, act.prm, 0)
+    call("tn_c8_conv_fwd", _c8(x).ptr, dev(W).ptr, dev(b).ptr, out.ptr, None, N, C, H, H, K, act.kind, act.prm, 0, None)
     want = np.tanh(U.conv_same(x, U.r16(W)) + b[None, :, None, None])
     assert _rel(U.from_c8(out.get_value().view(np.float16), K), U.r16(want)) < 1e-3
     # pack rows 2.. of an fp32 NCHW dataset (x scale), unpack back
@@ -170,7 +170,7 @@ def test_c8_unsupported_shapes_are_errors_not_fallbacks(f16_mode):
     assert not lib.tn_c8_fc_supported(4, 10, 1, 32)                        # 16 c8 inputs: not a multiple of 64
     x, W, b = empty((4, 2, 16, 16, 8), np.uint16), dev(np.zeros((20, 16, 3, 3), np.float32)), dev(np.zeros(20, np.float32))
     with pytest.raises(_lib.BackendError, match="multiple of 8"):
-        call("tn_c8_conv_fwd", x.ptr, W.ptr, b.ptr, x.ptr, None, 4, 16, 16, 16, 20, LEAKY, SLOPE, 0)
+        call("tn_c8_conv_fwd", x.ptr, W.ptr, b.ptr, x.ptr, None, 4, 16, 16, 16, 20, LEAKY, SLOPE, 0, None)
     from theanet_amd import NeuralNet
     tp = {"SEED": 1, "BATCH_SZ": 4, "INIT_LEARNING_RATE": .1, "EPOCHS_TO_HALF_RATE": 1, "DTYPE": "float16"}
     with pytest.raises(AssertionError, match="DTYPE float16"):

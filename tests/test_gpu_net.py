@@ -1,6 +1,7 @@
 """End-to-end parity of the NeuralNet drop-in against the oracle / golden fixtures:
 forward activations, logits (1e-4 rel, argmax bit-exact), every gradient, the 3-step
 weight trajectory (catches the v_old subtlety), the test functions and checkpoints."""
+import copy
 import os
 import pickle
 
@@ -268,6 +269,49 @@ def test_checkpoint_roundtrip_and_data_test_model(tmp_path):
     assert all((v.get_value() == 0).all() for l in net.tr_layers for v in (l.accumulated_updates or ()))
     print(net)   # __str__ works
     print(net.get_wts_info(detailed=True))
+
+
+@pytest.mark.parametrize("pipeline", ["1", "0"])
+def test_checkpoint_with_optimizer_state_resumes_the_uninterrupted_run(pipeline, monkeypatch):
+    """the reference's pickle drops the velocities (train.py:181-200, neuralnet.py:298-301), so a
+    resumed run restarts its momentum.  get_init_params(with_opt_state=True) adds them and the RNG step counter under
+    one extra key; a net rebuilt from such a checkpoint continues the weight trajectory of the uninterrupted run --
+    under both schedules (with two steps in flight the device's velocity is one gradient behind and the checkpoint
+    folds the pending gradient in on the host: 1 ulp of the device's fma)."""
+    from theanet_amd import NeuralNet
+    monkeypatch.setenv("TN_PIPELINE", pipeline)
+    prms = load_prms("mnist.prms", 28, batch=16)
+    rng = np.random.RandomState(3)
+    x = rng.rand(96, 1, 28, 28).astype(np.float32)
+    y = rng.randint(0, 10, 96).astype(np.int32)
+    ref = NeuralNet(copy.deepcopy(prms["layers"]), dict(prms["training_params"]))
+    fr = ref.get_trin_model(x, y)
+    costs_ref = [fr(i)[0] for i in range(6)]
+    net = NeuralNet(copy.deepcopy(prms["layers"]), dict(prms["training_params"]))
+    fn = net.get_trin_model(x, y)
+    for i in range(3):
+        fn(i)
+    plain = net.get_init_params()
+    assert set(plain) == {"layers", "training_params", "allwts"}            # default: the reference's pickle
+    ck = pickle.loads(pickle.dumps(net.get_init_params(with_opt_state=True), -1))
+    assert set(ck) == {"layers", "training_params", "allwts", "opt_state"} and ck["opt_state"]["rng_step"] == 3
+    assert any(np.abs(v).max() > 0 for row in ck["opt_state"]["velocities"] for v in row)
+    fn(3)                                                                   # (taking the checkpoint disturbed nothing)
+    net2 = NeuralNet(ck["layers"], ck["training_params"], ck["allwts"])
+    net2.load_opt_state(ck["opt_state"])
+    f2 = net2.get_trin_model(x, y)
+    costs = [f2(i)[0] for i in range(3, 6)]
+    np.testing.assert_allclose(costs, costs_ref[3:], rtol=2e-6)
+    for a, b, c in zip(ref.tr_layers, net2.tr_layers, net.tr_layers):
+        for wa, wb in zip(a.get_wts(), b.get_wts()):
+            np.testing.assert_allclose(wb, wa, rtol=2e-6, atol=1e-8)
+    # without the state the resumed run is measurably elsewhere (momentum .95 restarts from zero)
+    net3 = NeuralNet(ck["layers"], dict(ck["training_params"]), ck["allwts"])
+    f3 = net3.get_trin_model(x, y)
+    for i in range(3, 6):
+        f3(i)
+    d = max(np.abs(wa - wc).max() for a, c in zip(ref.tr_layers, net3.tr_layers) for wa, wc in zip(a.get_wts(), c.get_wts()))
+    assert d > 1e-5
 
 
 def test_take_index_list_mode():

@@ -76,8 +76,10 @@ SIGNATURES = {
     "tn_convpool_f16_supported": (c_int, [c_int] * 13),
     "tn_c8_conv_supported": (c_int, [c_int] * 8),
     "tn_c8_conv_wgrad_supported": (c_int, [c_int] * 5),
-    "tn_c8_conv_fwd": (c_int, [CTX, P, P, P, P, P] + [c_int] * 6 + [c_float, c_int]),
-    "tn_c8_conv_dgrad": (c_int, [CTX, P, P, P] + [c_int] * 5 + [P, c_int, c_float, c_int, P]),
+    "tn_c8_wt_elems": (c_size_t, [c_int] * 3),
+    "tn_c8_arrange_multi": (c_int, [CTX, P, c_int]),
+    "tn_c8_conv_fwd": (c_int, [CTX, P, P, P, P, P] + [c_int] * 6 + [c_float, c_int, P]),
+    "tn_c8_conv_dgrad": (c_int, [CTX, P, P, P] + [c_int] * 5 + [P, c_int, c_float, c_int, P, P]),
     "tn_c8_conv_wgrad": (c_int, [CTX, P, P, P, P] + [c_int] * 5 + [c_int, P]),
     "tn_c8_fc_supported": (c_int, [c_int] * 4),
     "tn_c8_fc_fwd": (c_int, [CTX, P, P, P, P] + [c_int] * 5 + [c_float, P]),

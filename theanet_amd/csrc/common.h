@@ -28,7 +28,7 @@ struct ElField {       // arguments of the field computation (shared by its two 
 };
 
 // one finishing reduction out[i] = sum_{s<S} src[s*stride + i] (reduce.hip)
-#define TN_RED_MAX 12
+#define TN_RED_MAX 32
 struct tn_red_rec {
     const float* src;
     float* out;

@@ -510,23 +510,54 @@ static int c8_launch(tn_ctx* ctx, C8G& g) {
     return TN_OK;
 }
 
+// halfs of the arranged weights of a (K filters, C channels) product
+static size_t c8_wt_elems(int K, int C) {
+    const int KBF = 32 * c8_pick_ft(K);
+    return (size_t)cdiv(K, KBF) * cdiv(C, 16) * 9 * 2 * KBF * 8;
+}
+
 template <int MODE>
-static int c8_run(tn_ctx* ctx, C8G& g, const float* W, int K, int C) {
+static int c8_run(tn_ctx* ctx, C8G& g, const float* W, int K, int C, const void* wt_ready) {
     const int FT = c8_pick_ft(K);
     TN_REQUIRE(c8_geometry(g, FT, K, C) && c8_lds_bytes(g, FT) <= 156 * 1024, "c8 conv: unsupported shape %dx%d", g.H, g.W);
     TN_REQUIRE((long long)g.N * g.C8 * g.H * g.W < (1ll << 28) && (long long)g.N * g.K8 * g.H * g.W < (1ll << 28),
                "c8 conv: tensor too large for 32-bit cell offsets");
-    const int KBF = 32 * FT, total = g.KT * g.nchunk * 9 * 2 * KBF * 8;
-    float* wt;
-    int rc = tn_scratch_get(ctx, (size_t)total * sizeof(_Float16), &wt);
-    if (rc) return rc;
-    c8_wt_kernel<<<cdiv(total, 256), 256, 0, ctx->stream>>>(W, reinterpret_cast<_Float16*>(wt), K, C, KBF, g.nchunk,
-                                                           total, MODE >= 2 ? 1 : 0);
-    TN_LAUNCH_CHECK();
-    g.wt = reinterpret_cast<const _Float16*>(wt);
+    if (wt_ready) {
+        g.wt = static_cast<const _Float16*>(wt_ready);            // arranged beforehand (tn_c8_arrange_multi)
+    } else {
+        const int KBF = 32 * FT, total = (int)c8_wt_elems(K, C);
+        float* wt;
+        int rc = tn_scratch_get(ctx, (size_t)total * sizeof(_Float16), &wt);
+        if (rc) return rc;
+        c8_wt_kernel<<<cdiv(total, 256), 256, 0, ctx->stream>>>(W, reinterpret_cast<_Float16*>(wt), K, C, KBF, g.nchunk,
+                                                               total, MODE >= 2 ? 1 : 0);
+        TN_LAUNCH_CHECK();
+        g.wt = reinterpret_cast<const _Float16*>(wt);
+    }
     return FT == 2 ? c8_launch<2, MODE>(ctx, g) : c8_launch<1, MODE>(ctx, g);
 }
 
+// every conv layer's arranged weights of a step in ONE launch (a net made eleven 5 us launches of c8_wt_kernel per step)
+struct C8WtBatch {
+    struct { const float* W; _Float16* wt; int K, C, KBF, nchunk, total, dgrad; } s[32];
+};
+__global__ __launch_bounds__(256) void c8_wt_multi_kernel(C8WtBatch b) {
+    const auto& q = b.s[blockIdx.y];
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= q.total) return;
+    int r = idx;
+    const int e = r & 7; r >>= 3;
+    const int j = r % q.KBF; r /= q.KBF;
+    const int o = r & 1; r >>= 1;
+    const int tap = r % 9; r /= 9;
+    const int chunk = r % q.nchunk;
+    const int kt = r / q.nchunk;
+    const int filt = kt * q.KBF + (j & ~31) + c8_swap23(j & 31), ch = chunk * 16 + 8 * o + e;
+    float v = 0.f;
+    if (filt < q.K && ch < q.C)
+        v = q.dgrad ? q.W[((size_t)ch * q.K + filt) * 9 + tap] : q.W[((size_t)filt * q.C + ch) * 9 + (8 - tap)];
+    q.wt[idx] = (_Float16)v;
+}
 
 // =================================================================================================
 // Weight gradient of a 3x3 'same' convolution on c8 tensors:
@@ -1020,13 +1051,36 @@ int tn_c8_conv_supported(int N, int C, int H, int W, int K, int f, int stride, i
 
 // y = act(conv(x, W) + b) [pool != 0: followed by a 2x2 max-pool; mask (may be NULL) records the window elements
 // that attained each maximum and the sign of the pooled value]; x, y c8 fp16, W (K, C, 3, 3) and b fp32
+// halfs of the arranged-weight buffer of a layer's forward (dgrad == 0) or input-gradient (dgrad != 0) product
+size_t tn_c8_wt_elems(int K, int C, int dgrad) { return dgrad ? c8_wt_elems(C, K) : c8_wt_elems(K, C); }
+
+// arranged weights of up to 32 products in one launch; segs: host array of tn_c8_wt_seg
+int tn_c8_arrange_multi(tn_ctx* ctx, const tn_c8_wt_seg* segs, int nseg) {
+    TN_REQUIRE(nseg >= 0 && nseg <= 32 && (segs != nullptr || nseg == 0), "tn_c8_arrange_multi: 0..32 segments");
+    if (!nseg) return TN_OK;
+    C8WtBatch b;
+    int mx = 0;
+    for (int i = 0; i < nseg; ++i) {
+        // input gradient: the roles of filters and channels swap ("filters" = the layer's input channels)
+        const int K = segs[i].dgrad ? segs[i].C : segs[i].K, C = segs[i].dgrad ? segs[i].K : segs[i].C;
+        const int KBF = 32 * c8_pick_ft(K);
+        b.s[i].W = segs[i].W; b.s[i].wt = static_cast<_Float16*>(segs[i].wt);
+        b.s[i].K = K; b.s[i].C = C; b.s[i].KBF = KBF; b.s[i].nchunk = cdiv(C, 16);
+        b.s[i].total = (int)c8_wt_elems(K, C); b.s[i].dgrad = segs[i].dgrad;
+        if (b.s[i].total > mx) mx = b.s[i].total;
+    }
+    c8_wt_multi_kernel<<<dim3(cdiv(mx, 256), nseg), 256, 0, ctx->stream>>>(b);
+    TN_LAUNCH_CHECK();
+    return TN_OK;
+}
+
 int tn_c8_conv_fwd(tn_ctx* ctx, const void* x, const float* W, const float* b, void* y, uint8_t* mask, int N, int C,
-                   int H, int Wd, int K, int act, float prm, int pool) {
+                   int H, int Wd, int K, int act, float prm, int pool, const void* wt) {
     TN_REQUIRE((K & 7) == 0, "c8 conv: the number of filters must be a multiple of 8 (got %d)", K);
     C8G g{};
     g.x = static_cast<const _Float16*>(x); g.out = static_cast<_Float16*>(y); g.bias = b; g.mask_out = mask;
     g.N = N; g.C8 = (C + 7) / 8; g.K8 = K / 8; g.H = H; g.W = Wd; g.act = act; g.prm = prm;
-    return pool ? c8_run<1>(ctx, g, W, K, C) : c8_run<0>(ctx, g, W, K, C);
+    return pool ? c8_run<1>(ctx, g, W, K, C, wt) : c8_run<0>(ctx, g, W, K, C, wt);
 }
 
 // dx (N, C, H, W) = conv^T(dz, W) * act'(prev_a) of the layer below (prev_a NULL: no activation below; for a pooled
@@ -1034,7 +1088,7 @@ int tn_c8_conv_fwd(tn_ctx* ctx, const void* x, const float* W, const float* b, v
 // act'(pooled output)).  pooled != 0: dz is not a tensor: the `dz` argument is the pooled gradient (N, K, H/2, W/2) and
 // dz = (bit of the window element in the block's mask) ? pooled gradient : 0, gathered while staging
 int tn_c8_conv_dgrad(tn_ctx* ctx, const void* dz, const float* W, void* dx, int N, int C, int H, int Wd, int K,
-                     const void* prev_a, int prev_act, float prev_prm, int pooled, const uint8_t* mask) {
+                     const void* prev_a, int prev_act, float prev_prm, int pooled, const uint8_t* mask, const void* wt) {
     TN_REQUIRE((K & 7) == 0, "c8 conv: the number of filters must be a multiple of 8 (got %d)", K);
     TN_REQUIRE(!pooled || mask != nullptr, "c8 conv dgrad: a pooled block needs its mask");
     C8G g{};
@@ -1044,7 +1098,7 @@ int tn_c8_conv_dgrad(tn_ctx* ctx, const void* dz, const float* W, void* dx, int 
     g.mask_in = mask;
     // the roles of filters and channels swap: "filters" = the C input channels (rounded up to whole octets: the
     // arranged weights of channels beyond C are zero, so their cells come out zero)
-    return pooled ? c8_run<3>(ctx, g, W, C, K) : c8_run<2>(ctx, g, W, C, K);
+    return pooled ? c8_run<3>(ctx, g, W, C, K, wt) : c8_run<2>(ctx, g, W, C, K, wt);
 }
 
 // dW (K, C, 3, 3), db (K) from x and dz (pooled != 0: dz is gathered from the pooled gradient and the block's mask as in

@@ -133,14 +133,19 @@ int tn_scratch_get(tn_ctx* ctx, size_t bytes, float** out) {
         int rc = tn_red_flush(ctx);            // pending slabs live in the buffer about to go
         if (rc) return rc;
         off = 0;
-        if (bytes > ctx->scratch_bytes) {
+        // inside a deferral window an overflow means the step's slabs do not fit: the forced flush above costs a
+        // reduction launch and a round trip of those gradients through HBM EVERY step (wide6: 231 MB, 46 us), so the
+        // buffer doubles until a whole step fits (a few synchronisations during the first steps, none afterwards)
+        if (bytes > ctx->scratch_bytes || ctx->defer) {
             TN_HIP(hipStreamSynchronize(ctx->streams[0]));
             TN_HIP(hipStreamSynchronize(ctx->streams[1]));
+            const size_t had = ctx->scratch_bytes;
             if (ctx->scratch) TN_HIP(hipFree(ctx->scratch));
             ctx->scratch = nullptr;
             ctx->scratch_bytes = 0;
             // a deferral window needs room for every op of the step: grow generously
-            const size_t nb = ctx->defer ? 4 * bytes + (8u << 20) : bytes + (bytes >> 2);
+            size_t nb = ctx->defer ? 4 * bytes + (8u << 20) : bytes + (bytes >> 2);
+            if (ctx->defer && nb < 2 * had) nb = 2 * had;
             hipError_t e = hipMalloc((void**)&ctx->scratch, nb);
             if (e != hipSuccess) return tn_fail(ctx, TN_E_NOMEM, "scratch hipMalloc(%zu) failed", nb);
             ctx->scratch_bytes = nb;

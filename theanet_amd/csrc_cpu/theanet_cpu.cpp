@@ -177,10 +177,12 @@ int tn_conv_f16_supported(int, int, int, int, int, int, int, int, int, int) { re
 // tn_set_matmul_dtype refuses the mode, so the host never gets here
 int tn_c8_conv_supported(int, int, int, int, int, int, int, int) { return 0; }
 int tn_c8_conv_wgrad_supported(int, int, int, int, int) { return 0; }
+size_t tn_c8_wt_elems(int, int, int) { return 0; }
+int tn_c8_arrange_multi(tn_ctx* ctx, const tn_c8_wt_seg*, int) { NOT_HERE("tn_c8_arrange_multi"); }
 int tn_c8_conv_fwd(tn_ctx* ctx, const void*, const float*, const float*, void*, uint8_t*, int, int, int, int, int, int,
-                   float, int) { NOT_HERE("tn_c8_conv_fwd"); }
+                   float, int, const void*) { NOT_HERE("tn_c8_conv_fwd"); }
 int tn_c8_conv_dgrad(tn_ctx* ctx, const void*, const float*, void*, int, int, int, int, int, const void*, int, float, int,
-                     const uint8_t*) { NOT_HERE("tn_c8_conv_dgrad"); }
+                     const uint8_t*, const void*) { NOT_HERE("tn_c8_conv_dgrad"); }
 int tn_c8_conv_wgrad(tn_ctx* ctx, const void*, const void*, float*, float*, int, int, int, int, int, int,
                      const uint8_t*) { NOT_HERE("tn_c8_conv_wgrad"); }
 int tn_c8_fc_supported(int, int, int, int) { return 0; }

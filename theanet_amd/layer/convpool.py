@@ -67,6 +67,11 @@ class ConvLayer(Layer):
             # the first conv layer of the net gets NCHW fp32 images: packed into a c8 tensor in front of the kernel
             self.x16 = None if getattr(inpt, "c8", None) else C8Array(self.ctx, batch_sz, num_prev_maps, in_sz, in_sz)
             self.output = C8Array(self.ctx, batch_sz, num_maps, self.out_sz, self.out_sz)
+            # the weights as MFMA operand tiles (forward / input gradient): the net arranges every layer's in one launch
+            # per step (NeuralNet._c8_arrange) and marks them valid until the next update; otherwise the ops do it per call
+            self.wt_fwd = self.ctx.empty((lib.tn_c8_wt_elems(num_maps, num_prev_maps, 0),), np.uint16)
+            self.wt_bwd = None
+            self.wt_valid = False
         else:
             self.output = self.ctx.empty((batch_sz, num_maps, self.out_sz, self.out_sz))
         self.gin = None
@@ -153,7 +158,7 @@ class ConvLayer(Layer):
         x = self._c8_input()
         self.ctx.call("tn_c8_conv_fwd", x.ptr, self.W.ptr, self.b.ptr, out.ptr, mask.ptr if mask is not None else None,
                       self.batch_sz, self.num_prev_maps, self.in_sz, self.in_sz, self.num_maps, self.act.kind, self.act.prm,
-                      1 if out is not self.output else 0)
+                      1 if out is not self.output else 0, self.wt_fwd.ptr if self.wt_valid else None)
 
     def _c8_backward(self, gout, need_gin, below):
         """gout: d cost / d z of this layer as a c8 tensor carrying the gradient scale -- or, for a fused block, the
@@ -174,7 +179,7 @@ class ConvLayer(Layer):
         assert b_mask is None
         fuse = b_out is not None and b_act != _lib.TN_ACT_LINEAR
         self.ctx.call("tn_c8_conv_dgrad", gout.ptr, self.W.ptr, self.gin.ptr, *geom, b_out.ptr if fuse else None,
-                      b_act, b_prm, pooled, mask)
+                      b_act, b_prm, pooled, mask, self.wt_bwd.ptr if self.wt_valid and self.wt_bwd is not None else None)
         return self.gin
 
     def forward(self, train=True):

@@ -417,6 +417,8 @@ class _TestFn:
         net, ctx = self.net, self.net.ctx
         net._sync_weights()
         net._apply_dtype()
+        if net.dtype == 'float16':
+            net._c8_arrange(net.te_layers, False)
         slot = net.test_x
         slot.bind(self.x_data)
         slot.row0 = int(i) * net.batch_sz + net.shard_lo
@@ -907,6 +909,8 @@ class NeuralNet():
             self._dp_tune_tick()
         if self._dp_can_delay:
             self._dp_bind(self._dp_cur if self._dp_delayed else 0)
+        if self.dtype == 'float16':
+            self._c8_arrange(self.tr_layers, True)
         for lyr in self.tr_layers[:-1]:
             lyr.forward(True)
         # the weight-gradient ops only record their finishing slab sums; one launch does them all
@@ -1016,6 +1020,8 @@ class NeuralNet():
                     ctx.call("tn_event_record", self._ar_done_ev)
             if ahead:
                 first._cur, first._pre_valid = nxt, True
+            if self.dtype == 'float16':
+                self._c8_stale()
             return
         delayed = self._dp_delayed
         if delayed and tail:
@@ -1071,6 +1077,43 @@ class NeuralNet():
         if ahead:
             first._cur, first._pre_valid = nxt, True
         self._apply_maxnorm_all()
+        if self.dtype == 'float16':
+            self._c8_stale()
+
+    def _c8_arrange(self, lyrs, train):
+        """DTYPE float16: the conv layers' weights as fp16 MFMA operand tiles, all products of the pass in ONE launch
+        (tn_c8_arrange_multi); valid until the next update (_c8_stale)."""
+        key = "_c8_tab_tr" if train else "_c8_tab_te"
+        tab = getattr(self, key, None)
+        if tab is None:
+            dt = np.dtype([('W', 'u8'), ('wt', 'u8'), ('K', 'i4'), ('C', 'i4'), ('dgrad', 'i4'), ('pad', 'i4')])
+            assert dt.itemsize == 32          # tn_c8_wt_seg
+            rows, convs = [], []
+            for idx, lyr in enumerate(lyrs):
+                if isinstance(lyr, ConvLayer) and lyr.f16:
+                    convs.append(lyr)
+                    rows.append((lyr.W.ptr, lyr.wt_fwd.ptr, lyr.num_maps, lyr.num_prev_maps, 0, 0))
+                    if train and self._need_gin[idx]:
+                        if lyr.wt_bwd is None:
+                            n = self.ctx.lib.tn_c8_wt_elems(lyr.num_maps, lyr.num_prev_maps, 1)
+                            lyr.wt_bwd = self.ctx.empty((n,), np.uint16)
+                        rows.append((lyr.W.ptr, lyr.wt_bwd.ptr, lyr.num_maps, lyr.num_prev_maps, 1, 0))
+            tab = (np.array(rows, dtype=dt) if rows else np.zeros((0,), dt), convs)
+            setattr(self, key, tab)
+        segs, convs = tab
+        for i in range(0, len(segs), 32):
+            chunk = segs[i:i + 32]
+            self.ctx.call("tn_c8_arrange_multi", chunk.ctypes.data, len(chunk))
+        for lyr in convs:
+            lyr.wt_valid = True
+
+    def _c8_stale(self):
+        """The weights are about to change: the arranged operand tiles of both graphs are no longer theirs."""
+        for key in ("_c8_tab_tr", "_c8_tab_te"):
+            tab = getattr(self, key, None)
+            if tab is not None:
+                for lyr in tab[1]:
+                    lyr.wt_valid = False
 
     def _apply_maxnorm_all(self):
         """layer.py:88-103 for every parameter of the net in ONE call (tn_maxnorm_multi: the biases and conv kernels
@@ -1164,11 +1207,14 @@ class NeuralNet():
         for index in get_output_of_layers:          # a requested conv map must be materialised
             lyr = self.te_layers[index]
             if isinstance(lyr, ConvLayer) and lyr.fused_pool is not None:
+                assert not lyr.f16, "DTYPE float16: the conv map of a fused conv + pool block is never materialised"
                 lyr.fused_pool.fused_conv, lyr.fused_pool = None, None
 
         def fn(x, aux=None):
             self._sync_weights()
             self._apply_dtype()
+            if self.dtype == 'float16':
+                self._c8_arrange(self.te_layers, False)
             x = np.ascontiguousarray(x, np.float32).reshape(stage.shape)
             stage.set_value(x)
             if self.takes_aux():                           # neuralnet.py:289-290
@@ -1189,10 +1235,65 @@ class NeuralNet():
 
         return fn
 
-    def get_init_params(self):
-        return {"layers": self.layers,
-                "training_params": self.tr_prms,
-                "allwts": [l.get_wts() for l in self.tr_layers]}
+    def get_init_params(self, with_opt_state=None):
+        """neuralnet.py:298-301: {"layers", "training_params", "allwts"} -- what the reference pickles.  With
+        ``with_opt_state`` (default: training param SAVE_OPT_STATE, off) one more key, "opt_state": the velocities
+        (layer.py:77-79; the reference drops them, so a resumed run restarts its momentum), the RNG step counter and the
+        seeds of the dropout / distortion streams; ``load_opt_state`` puts them back.  Readers of the reference's pickles ignore
+        the extra key."""
+        out = {"layers": self.layers,
+               "training_params": self.tr_prms,
+               "allwts": [l.get_wts() for l in self.tr_layers]}
+        if with_opt_state is None:
+            with_opt_state = bool(self.tr_prms.get('SAVE_OPT_STATE', False))
+        if with_opt_state:
+            out["opt_state"] = self._opt_state()
+        return out
+
+    def _opt_state(self):
+        self._prepare_training()
+        assert not (self._dp_delayed and self._dp_pending), \
+            "opt_state: not while a delayed all-reduce is in flight (TN_DP_OVERLAP=2); use another schedule"
+        fn = getattr(self, "_pipe_fn", None)
+        pend, step = None, int(self.d_step.get_value()[0])
+        if fn is not None and fn._seq is None and fn._twin is not None and fn.t > 0:
+            # two steps in flight: the velocity on the device is one gradient behind (that of step t-1, still with the
+            # stream that ran it, and folded in by that stream's next update): fold it in on the host, same expression
+            # as the kernels (common.h tn_vel: fma(m, v, rn((1-m) g)))
+            fn._flush_parked()
+            self.ctx.sync()
+            pend, step = fn.nets[(fn.t - 1) & 1], fn._base + fn.t
+        vel = []
+        for i, lyr in enumerate(self.tr_layers):
+            row = []
+            for j, v in enumerate(lyr.accumulated_updates or ()):
+                a = v.get_value()
+                if pend is not None and lyr.has_updates():
+                    m = np.float32(lyr.reg['momentum'])
+                    g = pend.tr_layers[i].grads[j].get_value()
+                    c = (np.float32(1) - m) * g
+                    a = (np.float64(m) * a.astype(np.float64) + c.astype(np.float64)).astype(np.float32)
+                row.append(a)
+            vel.append(row)
+        seeds = [(getattr(l, "seed", None), l.drop.seed if getattr(l, "drop", None) is not None else None)
+                 for l in self.tr_layers]
+        return {"velocities": vel, "rng_step": step, "stream_seeds": seeds}
+
+    def load_opt_state(self, state):
+        """Velocities and RNG step counter saved by get_init_params(with_opt_state=True); call before training."""
+        self._prepare_training()
+        if getattr(self, "_pipe_fn", None) is not None:
+            self._pipe_fn._fall_back()
+        for lyr, row in zip(self.tr_layers, state["velocities"]):
+            for v, a in zip(lyr.accumulated_updates or (), row):
+                v.set_value(np.asarray(a, np.float32))
+        self.ctx.call("tn_set_u32", self.d_step.ptr, int(state["rng_step"]))
+        # a net rebuilt from weights draws fresh stream seeds (neuralnet.py:63-68: no SEED chain): put the run's back
+        for lyr, (seed, dseed) in zip(self.tr_layers, state.get("stream_seeds", ())):
+            if seed is not None and hasattr(lyr, "seed"):
+                lyr.seed = seed
+            if dseed is not None and getattr(lyr, "drop", None) is not None:
+                lyr.drop.seed = dseed
 
     def set_rate(self):
         self.cur_learn_rate.set_value(np.float32(

@@ -76,14 +76,14 @@ for name, ns, C, H, K in SHAPES:
     px = N * H * H
     cin, cout = 16.0 * C8 * px, 2.0 * K * px            # bytes of the input / output tensors (c8 cells / halfs)
     ops = [
-        ("fwd", lambda: ctx.call("tn_c8_conv_fwd", x.ptr, W.ptr, b.ptr, y.ptr, None, N, C, H, H, K, LEAKY, .1, 0), cin + cout),
-        ("fwd+pool", lambda: ctx.call("tn_c8_conv_fwd", x.ptr, W.ptr, b.ptr, yp.ptr, mk.ptr, N, C, H, H, K, LEAKY, .1, 1),
+        ("fwd", lambda: ctx.call("tn_c8_conv_fwd", x.ptr, W.ptr, b.ptr, y.ptr, None, N, C, H, H, K, LEAKY, .1, 0, None), cin + cout),
+        ("fwd+pool", lambda: ctx.call("tn_c8_conv_fwd", x.ptr, W.ptr, b.ptr, yp.ptr, mk.ptr, N, C, H, H, K, LEAKY, .1, 1, None),
          cin + cout / 4 + cout / 8),
     ]
     if C >= 8:
         ops += [
-            ("dgrad", lambda: ctx.call("tn_c8_conv_dgrad", dz.ptr, W.ptr, dx.ptr, N, C, H, H, K, x.ptr, LEAKY, .1, 0, None), cout + 2 * cin),
-            ("dgrad (g, mask)", lambda: ctx.call("tn_c8_conv_dgrad", gp.ptr, W.ptr, dx.ptr, N, C, H, H, K, x.ptr, LEAKY, .1, 1, mk.ptr), cout / 4 + cout / 8 + 2 * cin),
+            ("dgrad", lambda: ctx.call("tn_c8_conv_dgrad", dz.ptr, W.ptr, dx.ptr, N, C, H, H, K, x.ptr, LEAKY, .1, 0, None, None), cout + 2 * cin),
+            ("dgrad (g, mask)", lambda: ctx.call("tn_c8_conv_dgrad", gp.ptr, W.ptr, dx.ptr, N, C, H, H, K, x.ptr, LEAKY, .1, 1, mk.ptr, None), cout / 4 + cout / 8 + 2 * cin),
         ]
     if lib.tn_c8_conv_wgrad_supported(N, C, H, H, K):
         ops += [

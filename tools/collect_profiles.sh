@@ -5,11 +5,11 @@
 #   FETCH_SIZE / WRITE_SIZE are collected in their own passes (TCC has 4 slots: 3 + 2 do not fit
 #   together) and PMC passes never carry a trace domain other than --kernel-trace, exactly as
 #   /opt/skills/guides/MI355X_MICROARCH.md prescribes.
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-B="python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline"
+B="python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-other-configs"
 run() {   # name, rocprof args..., -- bench args
     local name=$1; shift
     timeout 600 rocprofv3 "$@" > $OUT/$name.log 2>&1 || echo "FAILED $name (see $name.log)"

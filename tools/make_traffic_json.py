@@ -6,7 +6,7 @@ committed evidence under profiles/:
   <tag>_<config>_summary.md         per kernel: calls, average us, share of GPU time, HBM bytes per launch
                                     (PMC), matrix-core utilisation (PMC)
   <tag>_<config>_bench.json         the bench.py line of the profiled run
-  r02_traffic.json                  {config: {kernel: {FETCH_SIZE_KB, WRITE_SIZE_KB, hbm_bytes_corrected,
+  <round>_traffic.json              {config: {kernel: {FETCH_SIZE_KB, WRITE_SIZE_KB, hbm_bytes_corrected,
                                     mfma_busy_frac, mfma_flop_issued}}} -- what bench.py's `roofline.traffic` cites
 
     python tools/make_traffic_json.py r02_a
@@ -34,13 +34,13 @@ CONFIGS = {  # name -> (stats dir, pmc prefix, description)
     "mnist_bs512": ("mnist512_seq", None, "mnist.prms, 512 images/step (one rank of the 8-GPU strong-scaling run), one step at a time"),
     "mnist_bs512_pipelined": ("mnist512_pipe", None, "mnist.prms, 512 images/step, two steps in flight"),
     "cifar_like_f32": ("cifar_like_f32", "cifar_like_f32", "cifar_like.prms, 2048 images/step, fp32, one step at a time (bench.py --sequential)"),
-    "cifar_like_f16": ("cifar_like_f16", "cifar_like_f16", "cifar_like.prms, 2048 images/step, fp16 conv operands, one step at a time"),
+    "cifar_like_f16": ("cifar_like_f16", "cifar_like_f16", "cifar_like.prms, 2048 images/step, DTYPE float16 (fp16-resident tensors), one step at a time"),
     "wide6_f32": ("wide6_f32", "wide6_f32", "wide6.prms 64x64x3, 128 images/step, fp32, one step at a time"),
-    "wide6_f16": ("wide6_f16", "wide6_f16", "wide6.prms 64x64x3, 128 images/step, fp16 conv operands, one step at a time"),
+    "wide6_f16": ("wide6_f16", "wide6_f16", "wide6.prms 64x64x3, 128 images/step, DTYPE float16 (fp16-resident tensors), one step at a time"),
     "cifar_like_f32_pipelined": ("cifar_like_f32_pipe", None, "cifar_like.prms, 2048 images/step, fp32, two steps in flight (default schedule: kernel durations include the other stream's share of the GPU)"),
-    "cifar_like_f16_pipelined": ("cifar_like_f16_pipe", None, "cifar_like.prms, 2048 images/step, fp16 conv operands, two steps in flight"),
+    "cifar_like_f16_pipelined": ("cifar_like_f16_pipe", None, "cifar_like.prms, 2048 images/step, DTYPE float16, two steps in flight"),
     "wide6_f32_pipelined": ("wide6_f32_pipe", None, "wide6.prms 64x64x3, 128 images/step, fp32, two steps in flight"),
-    "wide6_f16_pipelined": ("wide6_f16_pipe", None, "wide6.prms 64x64x3, 128 images/step, fp16 conv operands, two steps in flight"),
+    "wide6_f16_pipelined": ("wide6_f16_pipe", None, "wide6.prms 64x64x3, 128 images/step, DTYPE float16, two steps in flight"),
 }
 
 
@@ -89,7 +89,7 @@ for cfg, (sdir, pmc, desc) in CONFIGS.items():
         md.write("# %s / %s: rocprofv3 --kernel-trace --stats of `python bench.py ...`\n\n%s, 1 MI355X.\n" % (tag, cfg, desc))
         md.write("Durations: averages over all launches of the kernel-trace run (warm-up, timed steps, the\n"
                  "sync-API loop and the roofline leg).  HBM bytes / matrix-core utilisation: separate PMC passes\n"
-                 "(see r02_traffic.json for the method and the gfx950 FETCH_SIZE correction).\n\n")
+                 "(see %s_traffic.json for the method" % tag.split("_")[0] + " and the gfx950 FETCH_SIZE correction).\n\n")
         md.write("| kernel | calls | avg us | % of GPU time | HBM MB / launch (PMC) | MFMA busy (PMC) | MFMA GFLOP issued / launch |\n"
                  "|---|---:|---:|---:|---:|---:|---:|\n")
         for r in rows:
@@ -105,4 +105,4 @@ for cfg, (sdir, pmc, desc) in CONFIGS.items():
         if line:
             md.write("\nbench line of the kernel-trace run:\n\n```\n%s\n```\n" % line[:2500])
     print("wrote", cfg)
-json.dump(traffic, open(os.path.join(dst, "r02_traffic.json"), "w"), indent=1)
+json.dump(traffic, open(os.path.join(dst, "%s_traffic.json" % tag.split("_")[0]), "w"), indent=1)

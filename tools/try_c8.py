@@ -21,14 +21,14 @@ for (N, C, H, K) in [(3, 16, 16, 32), (2, 64, 64, 64), (5, 24, 8, 40), (2, 128, 
     dW_, db_ = ctx.array(W), ctx.array(b)
     K8 = K // 8
     out = ctx.empty((N, K8, H, H, 8), np.uint16)
-    ctx.call("tn_c8_conv_fwd", dx_.ptr, dW_.ptr, db_.ptr, out.ptr, None, N, C, H, H, K, _lib.TN_ACT_LEAKY, .1, 0)
+    ctx.call("tn_c8_conv_fwd", dx_.ptr, dW_.ptr, db_.ptr, out.ptr, None, N, C, H, H, K, _lib.TN_ACT_LEAKY, .1, 0, None)
     got = from_c8(out.get_value().view(np.float16), K)
     err = np.abs(got - r16(a)).max() / np.abs(a).max()
     # pooled
     pm, bits = pool2(a)
     outp = ctx.empty((N, K8, H // 2, H // 2, 8), np.uint16)
     mk = ctx.empty((N, K8, H // 2, H // 2, 8), np.uint8)
-    ctx.call("tn_c8_conv_fwd", dx_.ptr, dW_.ptr, db_.ptr, outp.ptr, mk.ptr, N, C, H, H, K, _lib.TN_ACT_LEAKY, .1, 1)
+    ctx.call("tn_c8_conv_fwd", dx_.ptr, dW_.ptr, db_.ptr, outp.ptr, mk.ptr, N, C, H, H, K, _lib.TN_ACT_LEAKY, .1, 1, None)
     gotp = from_c8(outp.get_value().view(np.float16), K)
     gotm = mk.get_value().transpose(0, 1, 4, 2, 3).reshape(N, K, H // 2, H // 2)
     errp = np.abs(gotp - r16(pm)).max() / np.abs(a).max()
@@ -42,13 +42,13 @@ for (N, C, H, K) in [(3, 16, 16, 32), (2, 64, 64, 64), (5, 24, 8, 40), (2, 128, 
     dprev = ctx.array(to_c8(prev).view(np.uint16))
     C8 = (C + 7) // 8
     dxo = ctx.empty((N, C8, H, H, 8), np.uint16)
-    ctx.call("tn_c8_conv_dgrad", ddz.ptr, dW_.ptr, dxo.ptr, N, C, H, H, K, dprev.ptr, _lib.TN_ACT_LEAKY, .1, 0, None)
+    ctx.call("tn_c8_conv_dgrad", ddz.ptr, dW_.ptr, dxo.ptr, N, C, H, H, K, dprev.ptr, _lib.TN_ACT_LEAKY, .1, 0, None, None)
     gotdx = from_c8(dxo.get_value().view(np.float16), C)
     errd = np.abs(gotdx - r16(dxw)).max() / np.abs(dxw).max()
     # pooled dgrad: dz from (g, mask)
     g = r16(gs * rng.randn(N, K, H // 2, H // 2) * 1e-3)
     dg = ctx.array(to_c8(g).view(np.uint16))
-    ctx.call("tn_c8_conv_dgrad", dg.ptr, dW_.ptr, dxo.ptr, N, C, H, H, K, dprev.ptr, _lib.TN_ACT_LEAKY, .1, 1, mk.ptr)
+    ctx.call("tn_c8_conv_dgrad", dg.ptr, dW_.ptr, dxo.ptr, N, C, H, H, K, dprev.ptr, _lib.TN_ACT_LEAKY, .1, 1, mk.ptr, None)
     gotdx2 = from_c8(dxo.get_value().view(np.float16), C)
     # the device's own mask may differ from numpy's on near-ties: use the device mask for the reference
     dzp_dev = unpool_dz(g, gotm)

@@ -176,6 +176,8 @@ def run(dataset_name, prms_file_name, redirect):
 
         print("\nInitializing the net ... ")
         net = nn.NeuralNet(layers, tr_prms, allwts)
+        if params.get('opt_state') is not None:        # (this build's optional extension of the pickle: momentum + RNG counter)
+            net.load_opt_state(params['opt_state'])
         print(net)
         print(net.get_wts_info(detailed=True).replace("\n\t", ""))
 
