@@ -85,6 +85,22 @@ int tn_set_i64(tn_ctx* ctx, int64_t* d_dst, int64_t value);
 int tn_set_f32(tn_ctx* ctx, float* d_dst, float value);
 int tn_add_u32(tn_ctx* ctx, uint32_t* d_dst, uint32_t inc);          /* *d_dst += inc (step counter) */
 
+/* ---- a whole step as ONE call (the coarse entry point for launch-bound steps) ----
+ * A plan is the flat list of the C-ABI calls a step makes -- entry point + argument block -- built once by the host
+ * (theanet_amd/plan.py records the calls of a few ordinary steps of a NeuralNet function, checks that they repeat and
+ * which integer arguments follow the minibatch index) and replayed by tn_net_step without the interpreter: what the
+ * reference's compiled theano.function does for fn(i) (neuralnet.py:236-241).  tn_net_plan_add: name = an entry point
+ * of this header taking the context first (the context is not in the list); kinds[k] = 0 pointer / integer (vals[k] =
+ * the value as 64 bits, strides[k] added per unit of tn_net_step's index), 1 float (its 32 bits), 2 double (its 64
+ * bits); at most 48 integer and 8 floating-point arguments.  tn_net_step issues the calls in order and stops at the
+ * first error.  The plan holds raw pointers: it lives no longer than the buffers of the net it was recorded from. */
+int tn_net_plan_create(tn_ctx* ctx, void** plan);
+int tn_net_plan_add(tn_ctx* ctx, void* plan, const char* name, int nargs, const uint8_t* kinds, const uint64_t* vals,
+                    const int64_t* strides);
+int tn_net_step(tn_ctx* ctx, void* plan, int64_t index);
+int tn_net_plan_size(tn_ctx* ctx, void* plan);
+int tn_net_plan_destroy(tn_ctx* ctx, void* plan);
+
 /* ---- HIP graph capture of an op sequence issued through this ABI ---- */
 int tn_graph_begin(tn_ctx* ctx);                   /* start stream capture            */
 int tn_graph_end(tn_ctx* ctx, void** graph_exec);  /* stop, instantiate               */

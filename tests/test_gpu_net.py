@@ -314,6 +314,51 @@ def test_checkpoint_with_optimizer_state_resumes_the_uninterrupted_run(pipeline,
     assert d > 1e-5
 
 
+@pytest.mark.parametrize("pipeline", ["1", "0"])
+@pytest.mark.parametrize("prm", ["mnist.prms", "3flat.prms"])
+def test_planned_steps_equal_interpreted_steps(pipeline, prm, monkeypatch):
+    """tn_net_plan_* / tn_net_step (SURVEY 8(b)'s coarse entry point): once a training function has seen its calls
+    repeat, a step is one C call replaying them.  Same calls, same arguments: costs, outputs and weights are
+    bit-identical to the interpreted run, under both schedules, across a learning-rate change, a step that returns
+    outputs and a weight read-back in the middle."""
+    from theanet_amd import NeuralNet
+    monkeypatch.setenv("TN_PIPELINE", pipeline)
+    prms = load_prms(prm, 28, batch=16)
+    rng = np.random.RandomState(5)
+    x = rng.rand(16 * 12, 1, 28, 28).astype(np.float32)
+    y = rng.randint(0, 10, 16 * 12).astype(np.int32)
+
+    def run(plan):
+        monkeypatch.setenv("TN_NET_PLAN", plan)
+        net = NeuralNet(copy.deepcopy(prms["layers"]), dict(prms["training_params"]))
+        fn = net.get_trin_model(x, y)
+        tfn = net.get_test_model(x, y)
+        outs = []
+        for s in range(60):
+            if s in (30, 47):
+                outs.append(fn(s % 12))                 # a step that returns [cost, features, logprob]
+            else:
+                fn.enqueue(s % 12)
+            if s == 36:
+                net.inc_epoch_set_rate()                # the learning rate changes mid-run
+            if s == 41:
+                outs.append(tfn(0))                     # reads the weights back (brings the pipeline up to date)
+        pl = getattr(fn, "_plan", None)
+        replayed = pl is not None and pl.ready
+        if fn.__class__.__name__ == "_PipeTrainFn" and fn._seq is not None:
+            replayed = fn._seq._plan.ready
+        return outs, [w for l in net.tr_layers for w in l.get_wts()], replayed, pl
+
+    o1, w1, r1, pl = run("1")
+    o0, w0, r0, _ = run("0")
+    assert r1 and not r0, (pl.why, pl.off)
+    for a, b in zip(o1, o0):
+        for u, v in zip(a, b):
+            np.testing.assert_array_equal(np.asarray(u), np.asarray(v))
+    for a, b in zip(w1, w0):
+        np.testing.assert_array_equal(a, b)
+
+
 def test_take_index_list_mode():
     from theanet_amd import NeuralNet
     prms = load_prms("mnist.prms", 28, batch=8)

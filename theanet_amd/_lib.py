@@ -57,6 +57,11 @@ SIGNATURES = {
     "tn_set_i64": (c_int, [CTX, P, c_int64]),
     "tn_set_f32": (c_int, [CTX, P, c_float]),
     "tn_add_u32": (c_int, [CTX, P, c_uint32]),
+    "tn_net_plan_create": (c_int, [CTX, POINTER(c_void_p)]),
+    "tn_net_plan_add": (c_int, [CTX, P, c_char_p, c_int, P, P, P]),
+    "tn_net_step": (c_int, [CTX, P, c_int64]),
+    "tn_net_plan_size": (c_int, [CTX, P]),
+    "tn_net_plan_destroy": (c_int, [CTX, P]),
     "tn_graph_begin": (c_int, [CTX]),
     "tn_graph_end": (c_int, [CTX, POINTER(c_void_p)]),
     "tn_graph_launch": (c_int, [CTX, P]),

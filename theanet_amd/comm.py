@@ -295,6 +295,7 @@ class DeviceGroup:
         n = darr.size if count is None else count
         self._note("sum", n)
         if self.ctx.backend == "cpu" and self.world.size > 1:      # "device" memory is host memory there
+            self.ctx.rec_tainted = True                            # (host-side work: not a step tn_net_step can replay)
             self.rdzv.allreduce_host(self._host_view(darr, n), "sum")
         else:
             self.ctx.call("tn_allreduce_sum", darr.ptr, n)

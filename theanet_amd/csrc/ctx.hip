@@ -412,3 +412,5 @@ int tn_gather_rows(tn_ctx* ctx, const void* src, const int32_t* d_index, void* d
 }
 
 }  // extern "C"
+
+#include "net_plan.h"

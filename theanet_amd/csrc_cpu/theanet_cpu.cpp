@@ -1201,3 +1201,8 @@ int tn_maxnorm_multi(tn_ctx* ctx, const tn_mn_seg* h_segs, int nseg) {
 }
 
 }  // extern "C"
+
+// the coarse step entry points (tn_net_plan_*, tn_net_step): the same host code as the HIP library
+#define TN_REQUIRE(cond, ...) REQUIRE(cond, __VA_ARGS__)
+#define tn_fail fail
+#include "../csrc/net_plan.h"

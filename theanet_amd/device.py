@@ -39,8 +39,12 @@ class Context:
         self._fns = {}            # name -> bound ctypes function (the attribute lookup costs per call otherwise)
         self._ev_seen = 0
         self.ev_pairs = []
+        self.rec = None           # list collecting (name, args) of every call while a StepPlan watches a step (plan.py)
+        self.rec_tainted = False  # ... set by host-side work that a replay of the calls would miss
 
     def call(self, name, *args):
+        if self.rec is not None:
+            self.rec.append((name, args))
         hook = self.ev_hook
         if hook is not None and hook[0] == name:
             self._ev_seen += 1

@@ -20,6 +20,7 @@ from operator import mul
 import numpy as np
 
 from . import comm, layer
+from .plan import StepPlan
 from .device import DeviceArray, get_context, share
 from .layer import (AuxConcatLayer, SoftAuxLayer, CenteredOutLayer, ColorLayer, ConvLayer, DropOutLayer, ElasticLayer, ExpLossLayer, HiddenLayer,
                     HingeLayer, InputLayer, InputSlot, MeanLayer, OutputLayer, PoolLayer, SoftmaxLayer)
@@ -106,8 +107,50 @@ class _TrainFn:
             self.row_bytes = row * 4
             if aux_data is not None:
                 self.aux_stage = ctx.empty((net.local_bsz,) + tuple(aux_data.shape[1:]))
+        # the step as one C call once its calls have been seen to repeat (plan.py); index-list batches upload per step
+        self._plan = None if take_index_list else StepPlan(ctx, net.batch_sz, net.shard_lo)
+
+    def _plan_state(self):
+        net = self.net
+        first = net.tr_layers[0]
+        return (getattr(first, "_cur", None), getattr(first, "_pre_valid", None), getattr(net, "_cost_pending", None),
+                net._dp_cur, net._dp_pending)
+
+    def _plan_set_state(self, st):
+        net = self.net
+        first = net.tr_layers[0]
+        if st[0] is not None:
+            first._cur, first._pre_valid = st[0], st[1]
+        if st[2] is not None:
+            net._cost_pending = st[2]
+        net._dp_cur, net._dp_pending = st[3], st[4]
+
+    def _plannable(self):
+        net = self.net
+        return not getattr(net, "_want_outputs", False) and net._dp_tune is None and net.ctx.ev_hook is None and \
+            not net._injecting()
 
     def enqueue(self, i):
+        pl = self._plan
+        if pl is not None and not pl.off:
+            ok = self._plannable()
+            if pl.ready:
+                if ok:                       # (the learning rate is a device scalar here: no argument changes with it)
+                    self.net._apply_dtype()
+                    return self._plan_set_state(pl.step(i))
+            if ok:
+                pl.begin(i)
+            try:
+                self._enqueue(i)
+            except Exception:
+                ok = False
+                raise
+            finally:
+                pl.end(self._plan_state() if ok else None, ok)
+            return
+        self._enqueue(i)
+
+    def _enqueue(self, i):
         net, ctx = self.net, self.net.ctx
         B, lo = net.batch_sz, net.shard_lo
         slot = net.x
@@ -180,6 +223,7 @@ class _PipeTrainFn:
         self._last = net
         net._pipe_fn = self
         self._ctypes = ctypes
+        self._plan = StepPlan(net.ctx, net.batch_sz, net.shard_lo)
 
     # -- set-up of the twin on first use ---------------------------------------------------------
     def _build(self):
@@ -253,14 +297,32 @@ class _PipeTrainFn:
         return float(np.float32(tp['INIT_LEARNING_RATE'] / (1 + tp['CUR_EPOCH'] / tp['EPOCHS_TO_HALF_RATE'])))
 
     def _blocked(self):
-        net = self.net
-        for lyr in net.tr_layers:
-            drop = getattr(lyr, "drop", None)
-            if (drop is not None and drop.injected) or getattr(lyr, "_inj_draws", False) or \
-                    getattr(lyr, "_inj", None) is not None or \
-                    getattr(lyr, "_inj_flip", None) is not None:
-                return True
-        return net.ctx.ev_hook is not None
+        return self.net._injecting() or self.net.ctx.ev_hook is not None
+
+    # -- the step as one C call (plan.py) -----------------------------------------------------------
+    def _plan_state(self):
+        """What a step leaves behind on the host (restored after a replayed step of the same phase)."""
+        per_net = []
+        for X in self.nets:
+            first = X.tr_layers[0]
+            per_net.append((X._cost_pending, getattr(first, "_cur", None), getattr(first, "_pre_valid", None)))
+        return (self.nets.index(self._last), tuple(per_net))
+
+    def _plan_set_state(self, st):
+        self._last = self.nets[st[0]]
+        for X, (cp, cur, pv) in zip(self.nets, st[1]):
+            X._cost_pending = cp
+            if cur is not None:
+                first = X.tr_layers[0]
+                first._cur, first._pre_valid = cur, pv
+        self._updated = False
+        self.t += 1
+
+    def _plannable(self):
+        lr = self._lr_now()
+        return self._seq is None and self._twin is not None and not self._updated and not getattr(self, "_want", False) \
+            and self.t >= 4 and lr == self._lr_prev and self._lr_set[0] == lr and self._lr_set[1] == lr \
+            and not self._blocked()
 
     # -- the start-of-step update -----------------------------------------------------------------
     def _update_for(self, t):
@@ -336,6 +398,25 @@ class _PipeTrainFn:
 
     # -- the step ---------------------------------------------------------------------------------
     def enqueue(self, i):
+        pl = self._plan
+        if pl is None or pl.off:
+            return self._enqueue(i)
+        ok = self._plannable()
+        if pl.ready and ok:
+            self.net._apply_dtype()
+            self._plan_set_state(pl.step(i))
+            return
+        if ok:
+            pl.begin(i)
+        try:
+            self._enqueue(i)
+        except Exception:
+            ok = False
+            raise
+        finally:
+            pl.end(self._plan_state() if ok and self._seq is None else None, ok and self._seq is None)
+
+    def _enqueue(self, i):
         if self._seq is None and self._blocked():
             self._fall_back()
         if self._seq is not None:
@@ -1079,6 +1160,15 @@ class NeuralNet():
         self._apply_maxnorm_all()
         if self.dtype == 'float16':
             self._c8_stale()
+
+    def _injecting(self):
+        """A parity test has injected random draws somewhere (dropout masks, elastic / color draws)."""
+        for lyr in self.tr_layers:
+            drop = getattr(lyr, "drop", None)
+            if (drop is not None and drop.injected) or getattr(lyr, "_inj_draws", False) or \
+                    getattr(lyr, "_inj", None) is not None or getattr(lyr, "_inj_flip", None) is not None:
+                return True
+        return False
 
     def _c8_arrange(self, lyrs, train):
         """DTYPE float16: the conv layers' weights as fp16 MFMA operand tiles, all products of the pass in ONE launch
