@@ -689,33 +689,37 @@ def test_graph_capture_of_abi_ops():
     call("tn_graph_destroy", g)
 
 
-def test_step_tail_equals_separate_launches(monkeypatch):
-    """Building the next minibatch's elastic field beside the update (tn_step_tail) is a pure
-    re-scheduling: costs, log-probabilities and weights must match the plain schedule bit for bit."""
+@pytest.mark.parametrize("name,img,ch,B", [("mnist.prms", 28, 1, 64), ("cifar_like.prms", 32, 3, 16)])
+def test_fused_step_equals_separate_launches(monkeypatch, name, img, ch, B):
+    """The sequential step's fusions -- weight-gradient slab sums and the minibatch cost inside the update launch
+    (tn_sgd_update_multi_lazy), the next minibatch's elastic field riding in the
+    paired GEMM launch or built beside the update (tn_step_tail) -- are pure re-scheduling: against the generic
+    schedule (NeuralNet.fused_step = False: one launch per piece of work) costs, log-probabilities, gradients and
+    weights match bit for bit."""
     from theanet_amd import NeuralNet
     import copy
-    prms = load_prms("mnist.prms", 28, batch=64)
+    prms = load_prms(name, img, batch=B)
     rng = np.random.RandomState(3)
-    x = rng.rand(4 * 64, 1, 28, 28).astype(np.float32)
-    y = rng.randint(0, 10, 4 * 64).astype(np.int32)
+    x = rng.rand(4 * B, ch, img, img).astype(np.float32)
+    y = rng.randint(0, 10, 4 * B).astype(np.int32)
     nets = []
-    # rider in the paired GEMM launch / beside the update (tn_step_tail) / a launch of its own
     monkeypatch.setenv("TN_PIPELINE", "0")        # this test is about the sequential step's launches
-    for tail, rider in (("1", "1"), ("1", "0"), ("0", "0")):
-        monkeypatch.setenv("TN_STEP_TAIL", tail)
-        monkeypatch.setenv("TN_FIELD_RIDER", rider)
+    for fused in (True, False):
+        monkeypatch.setattr(NeuralNet, "fused_step", fused)
         net = NeuralNet(copy.deepcopy(prms["layers"]), dict(prms["training_params"]))
         fn = net.get_trin_model(x, y)
         outs = [fn(s % 4) for s in range(6)]
-        assert net.tr_layers[0]._pre_valid == (tail == "1")
+        first = net.tr_layers[0]
+        if hasattr(first, "_pre_valid") and getattr(first, "has_field", False):
+            assert first._pre_valid == fused      # the field of the next minibatch was built ahead
         nets.append((net, outs))
-    for other in nets[1:]:
-        for (c0, _, l0), (c1, _, l1) in zip(nets[0][1], other[1]):
-            assert c0 == c1
-            np.testing.assert_array_equal(l0, l1)
-        for la, lb in zip(nets[0][0].tr_layers, other[0].tr_layers):
-            for wa, wb in zip(la.get_wts(), lb.get_wts()):
-                np.testing.assert_array_equal(wa, wb)
+    for (c0, _, l0), (c1, _, l1) in zip(nets[0][1], nets[1][1]):
+        assert c0 == c1
+        np.testing.assert_array_equal(l0, l1)
+    np.testing.assert_array_equal(nets[0][0].flat_grads.get_value(), nets[1][0].flat_grads.get_value())
+    for la, lb in zip(nets[0][0].tr_layers, nets[1][0].tr_layers):
+        for wa, wb in zip(la.get_wts(), lb.get_wts()):
+            np.testing.assert_array_equal(wa, wb)
 
 
 @pytest.mark.parametrize("name,img,ch,B", [("mnist.prms", 28, 1, 64), ("cifar_like.prms", 32, 3, 16),
@@ -866,33 +870,6 @@ def test_pipelined_function_handover(monkeypatch, n1, n2):
     np.testing.assert_array_equal(res[0][0][1], res[1][0][1])
     for wa, wb in zip(res[0][1], res[1][1]):
         np.testing.assert_array_equal(wa, wb)
-
-
-@pytest.mark.parametrize("name,img,ch,B", [("mnist.prms", 28, 1, 64), ("cifar_like.prms", 32, 3, 16)])
-def test_lazy_update_equals_reduce_then_update(monkeypatch, name, img, ch, B):
-    """Summing the weight-gradient slabs inside the update launch (tn_sgd_update_multi_lazy) keeps the
-    summation order of the reduction launch: costs, gradients and weights match bit for bit."""
-    from theanet_amd import NeuralNet
-    import copy
-    prms = load_prms(name, img, batch=B)
-    rng = np.random.RandomState(5)
-    x = rng.rand(4 * B, ch, img, img).astype(np.float32)
-    y = rng.randint(0, 10, 4 * B).astype(np.int32)
-    nets = []
-    monkeypatch.setenv("TN_PIPELINE", "0")        # this test is about the sequential step's launches
-    for lazy in ("1", "0"):
-        monkeypatch.setenv("TN_LAZY_UPDATE", lazy)
-        net = NeuralNet(copy.deepcopy(prms["layers"]), dict(prms["training_params"]))
-        fn = net.get_trin_model(x, y)
-        outs = [fn(s % 4) for s in range(5)]
-        nets.append((net, outs))
-    for (c0, _, l0), (c1, _, l1) in zip(nets[0][1], nets[1][1]):
-        assert c0 == c1
-        np.testing.assert_array_equal(l0, l1)
-    np.testing.assert_array_equal(nets[0][0].flat_grads.get_value(), nets[1][0].flat_grads.get_value())
-    for la, lb in zip(nets[0][0].tr_layers, nets[1][0].tr_layers):
-        for wa, wb in zip(la.get_wts(), lb.get_wts()):
-            np.testing.assert_array_equal(wa, wb)
 
 
 @pytest.mark.parametrize("name,img,B", [("cifar_like.prms", 32, 16), ("wide6.prms", 16, 4)])

@@ -652,12 +652,6 @@ static size_t cm_lds_bytes(const CmGeom& q) { return ((size_t)q.tabf + 4 * (size
 // 1 if the matrix-core backward applies to this block shape
 static int cm_supported(int C, int K, int f, int stride, int p, int H, int Wd, int pad_lo, int Ho,
                         int Wo, int Hp, int Wp, bool recompute) {
-    static int enabled = -1;
-    if (enabled < 0) {
-        const char* e = getenv("TN_CB_MFMA");
-        enabled = e ? atoi(e) : 1;
-    }
-    if (recompute && !enabled) return 0;
     if (f != 3 || stride != 1 || p != 2 || C < 1 || C > 4 || K < 1 || K > 32) return 0;
     if (C * H * Wd > 64 * CM_XR || K * Hp * Wp > 64 * CM_XR) return 0;
     if (H + 2 * pad_lo > Ho + 2 || Wd + 2 * pad_lo > Wo + 2) return 0;     // the padded image is the tile

@@ -1215,16 +1215,11 @@ int tn_fc_bwd(tn_ctx* ctx, const float* x, const float* dz, const float* W, floa
               float* dx, int B, int n_in, int n_out, void* ws, const float* prev_a, int prev_act,
               float prev_act_param, const uint8_t* prev_mask) {
     TN_REQUIRE(B > 0 && n_in > 0 && n_out > 0 && ws != nullptr && dx != nullptr, "tn_fc_bwd: bad arguments");
-    static int pair_on = -1;
-    if (pair_on < 0) {
-        const char* e = getenv("TN_FC_PAIR");
-        pair_on = e ? atoi(e) : 1;
-    }
-    if (pair_on && tn_fc_skinny_ok(n_in, n_out, x, nullptr, nullptr) &&
+    if (tn_fc_skinny_ok(n_in, n_out, x, nullptr, nullptr) &&
         tn_fc_skinny_ok(n_in, n_out, dx, prev_a, prev_mask))
         return tn_fc_skinny_bwd(ctx, x, dz, W, dW, db, dx, B, n_in, n_out, (float*)ws, prev_a, prev_act,
                                 prev_act_param, prev_mask);
-    if (pair_on && n_out > SK_MAX && fc_dgrad_splits(ctx, B, n_in, n_out) == 1) {
+    if (n_out > SK_MAX && fc_dgrad_splits(ctx, B, n_in, n_out) == 1) {
         // weight gradient (split-K slabs) and input gradient as ONE launch of interleaved blocks
         const int S = wgrad_splits(B, n_in, n_out);
         float* wsC = (float*)ws;

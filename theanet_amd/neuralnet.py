@@ -58,470 +58,8 @@ def get_training_params_info(training_params):
 _GRAD_ALIGN = 64      # floats: every tensor in the flat gradient buffer starts 256-byte aligned
 
 
-# ###############################################################################
-#                            Compiled step functions
-# ###############################################################################
-
-
-def _features_logprob(out):
-    """[features, logprob] of the output head (neuralnet.py:236-241); for Softmax and Hinge heads features IS
-    logprob (outlayers.py:92-93, :137-139)."""
-    logprob = out.logprob.get_value()
-    feats = logprob if out.features is out.logprob else out.features.get_value()
-    return [feats, logprob]
-
-
-def _step_outputs(net, out):
-    """[cost, features, logprob] of the step ``net`` ran last, on the stream currently selected (the one that
-    holds the launch summing the cost).  When the step sent features / logprob ahead (``NeuralNet._send_outputs``:
-    copies into page-locked memory that ran under the backward pass) the cost follows them through the copy
-    stream and one wait covers all three; otherwise three blocking copies."""
-    early = getattr(net, "_early", None)
-    if early is not None and early["live"]:
-        early["live"] = False
-        if not early["cost_sent"]:
-            net.ctx.call("tn_d2h_early", early["cost"].ptr, net.d_cost.ptr, 4)
-        net.ctx.call("tn_copy_sync")
-        logprob = early["logprob"].array.copy()
-        feats = logprob if out.features is out.logprob else early["features"].array.copy()
-        return [np.float32(early["cost"].array[0]), feats, logprob]
-    cost = net.d_cost.get_value()[0]
-    return [cost] + _features_logprob(out)
-
-
-class _TrainFn:
-    """What ``get_trin_model`` returns: ``fn(i) -> [cost, features, logprob]``
-    (neuralnet.py:236-241).  ``enqueue(i)`` issues the step without reading anything
-    back (the GPU runs ahead of the host); ``fetch()`` copies the last step's outputs."""
-
-    def __init__(self, net, x_data, y_data, take_index_list, aux_data=None):
-        self.net, self.x_data, self.y_data = net, x_data, y_data
-        self.aux_data = aux_data
-        self.take_index_list = take_index_list
-        ctx = net.ctx
-        if take_index_list:
-            row = int(np.prod(x_data.shape[1:]))
-            self.x_stage = ctx.empty((net.local_bsz,) + tuple(x_data.shape[1:]))
-            self.y_stage = ctx.empty((net.local_bsz,), np.int32)
-            self.idx_dev = ctx.empty((net.local_bsz,), np.int32)
-            self.row_bytes = row * 4
-            if aux_data is not None:
-                self.aux_stage = ctx.empty((net.local_bsz,) + tuple(aux_data.shape[1:]))
-        # the step as one C call once its calls have been seen to repeat (plan.py); index-list batches upload per step
-        self._plan = None if take_index_list else StepPlan(ctx, net.batch_sz, net.shard_lo)
-
-    def _plan_state(self):
-        net = self.net
-        first = net.tr_layers[0]
-        return (getattr(first, "_cur", None), getattr(first, "_pre_valid", None), getattr(net, "_cost_pending", None),
-                net._dp_cur, net._dp_pending)
-
-    def _plan_set_state(self, st):
-        net = self.net
-        first = net.tr_layers[0]
-        if st[0] is not None:
-            first._cur, first._pre_valid = st[0], st[1]
-        if st[2] is not None:
-            net._cost_pending = st[2]
-        net._dp_cur, net._dp_pending = st[3], st[4]
-
-    def _plannable(self):
-        net = self.net
-        return not getattr(net, "_want_outputs", False) and net._dp_tune is None and net.ctx.ev_hook is None and \
-            not net._injecting()
-
-    def enqueue(self, i):
-        pl = self._plan
-        if pl is not None and not pl.off:
-            ok = self._plannable()
-            if pl.ready:
-                if ok:                       # (the learning rate is a device scalar here: no argument changes with it)
-                    self.net._apply_dtype()
-                    return self._plan_set_state(pl.step(i))
-            if ok:
-                pl.begin(i)
-            try:
-                self._enqueue(i)
-            except Exception:
-                ok = False
-                raise
-            finally:
-                pl.end(self._plan_state() if ok else None, ok)
-            return
-        self._enqueue(i)
-
-    def _enqueue(self, i):
-        net, ctx = self.net, self.net.ctx
-        B, lo = net.batch_sz, net.shard_lo
-        slot = net.x
-        slot.d_row0 = None
-        if self.take_index_list:
-            idx = np.ascontiguousarray(np.asarray(i, np.int32)[lo:lo + net.local_bsz])
-            self.idx_dev.set_value(idx)
-            ctx.call("tn_gather_rows", self.x_data.ptr, self.idx_dev.ptr, self.x_stage.ptr,
-                     net.local_bsz, self.row_bytes)
-            ctx.call("tn_gather_rows", self.y_data.ptr, self.idx_dev.ptr, self.y_stage.ptr,
-                     net.local_bsz, 4)
-            slot.bind(self.x_stage)
-            slot.row0, y, y_row0 = 0, self.y_stage, 0
-            if self.aux_data is not None:                  # neuralnet.py:233-234
-                ctx.call("tn_gather_rows", self.aux_data.ptr, self.idx_dev.ptr, self.aux_stage.ptr, net.local_bsz,
-                         int(np.prod(self.aux_data.shape[1:])) * 4)
-                net.aux_inpt_tr.bind(self.aux_stage)
-                net.aux_inpt_tr.row0 = 0
-        else:
-            slot.bind(self.x_data)
-            slot.row0 = int(i) * B + lo
-            y, y_row0 = self.y_data, slot.row0
-            if self.aux_data is not None:                  # neuralnet.py:225-226
-                net.aux_inpt_tr.bind(self.aux_data)
-                net.aux_inpt_tr.row0 = slot.row0
-        slot.row_global0 = lo
-        if self.aux_data is not None:
-            net.aux_inpt_tr.row_global0 = int(i) * B + lo if not self.take_index_list else lo
-        net._train_step(y, y_row0)
-
-    def fetch(self):
-        net = self.net
-        out = net.tr_layers[-1]
-        if getattr(net, "_dp_pending", False):
-            net.ctx.sync()                        # the cost travels with the all-reduce on the second stream
-        return _step_outputs(net, out)
-
-    def __call__(self, i):
-        self.net._want_outputs = True       # features / logprob leave right after the forward pass
-        try:
-            self.enqueue(i)
-        finally:
-            self.net._want_outputs = False
-        return self.fetch()
-
-
-class _PipeTrainFn:
-    """``get_trin_model``'s function for single-GPU training with TWO STEPS IN FLIGHT.
-
-    The reference's update applies the OLD velocity (layer.py:82-86: ``v' = m v + (1-m) g``,
-    ``p' = p - rate*lr*v``), so the weights of step t are ``p_{t-1} - s*v_{t-1}`` with ``v_{t-1}`` built
-    from the gradient of step t-2: step t does not depend on the backward pass of step t-1.  Even steps
-    run on the context's first stream with the net itself, odd steps on the second stream with a twin
-    (own weights copy, activations and gradients; the velocities are shared).  Step t starts by waiting
-    for the other stream's update, then ``v <- m v + (1-m) g_{t-2}`` (its own gradient of two steps ago)
-    and ``p_own <- p_other - s*v`` in one launch (tn_sgd_update_multi_pipe), then runs its forward and
-    backward passes while the other stream is still busy with step t-1 -- the two fill each other's
-    launch gaps and lock-step phases (-18 % per step on mnist.prms).  Same weights, costs and outputs as
-    the sequential schedule, bit for bit (tests/test_gpu_net.py::test_pipelined_steps_equal_sequential);
-    reading weights (get_wts, test functions, checkpoints) first brings the net up to date."""
-
-    def __init__(self, net, x_data, y_data):
-        import ctypes
-        self.net, self.x_data, self.y_data = net, x_data, y_data
-        self.take_index_list = False
-        self.t = 0                   # steps enqueued so far
-        self._updated = False        # the update for step self.t has already been applied (weights were read)
-        self._seq = None             # sequential fallback (_TrainFn) once something rules pipelining out
-        self._twin = None
-        self._last = net
-        net._pipe_fn = self
-        self._ctypes = ctypes
-        self._plan = StepPlan(net.ctx, net.batch_sz, net.shard_lo)
-
-    # -- set-up of the twin on first use ---------------------------------------------------------
-    def _build(self):
-        net, ctx = self.net, self.net.ctx
-        import copy
-        twin = NeuralNet.__new__(NeuralNet)
-        twin._is_twin = True
-        twin._main = net
-        tp = dict(net.tr_prms)
-        tp.setdefault('SEED', 0)      # (a net loaded from a checkpoint has none; weights and stream seeds are copied below)
-        twin.__init__(copy.deepcopy(net.layers), tp)
-        if net._dp:
-            twin._dev_group = net._group()                 # ONE communicator; the streams alternate on it
-        twin._prepare_training()
-        if net._dp:
-            net._dp_set_schedule("plain")
-            net._dp_tune = twin._dp_tune = None              # nothing to tune: the all-reduce rides in-stream
-            net.dp_schedule = twin.dp_schedule = "pipelined"
-        for a, b in zip(net.tr_layers, twin.tr_layers):
-            if hasattr(a, "seed"):
-                b.seed = a.seed
-            if getattr(a, "drop", None) is not None:
-                b.drop.seed = a.drop.seed
-            for pa, pb in zip(a.params, b.params):
-                ctx.call("tn_d2d", pb.ptr, pa.ptr, pa.size * 4)
-            if hasattr(a, "centers") and not a.learn_centers:        # fixed class centers: the same on both streams
-                ctx.call("tn_d2d", b.centers.ptr, a.centers.ptr, a.centers.size * 4)
-            if a.params:
-                b.accumulated_updates = a.accumulated_updates        # ONE velocity per tensor
-        # the twin's own velocity buffers are gone with that: its update table must name the shared ones
-        # (it is what _fall_back folds the last gradient through when the twin ran the last step)
-        twin._build_seg_table()
-        if getattr(twin, "_dp_can_delay", False):
-            twin._segs_ab[0] = twin._d_segs
-        self._twin = twin
-        self.nets = (net, twin)
-        seg_dt = np.dtype([('p', 'u8'), ('psrc', 'u8'), ('v', 'u8'), ('g', 'u8'), ('n', 'u8'),
-                           ('momentum', 'f4'), ('rate', 'f4')])
-        self._segs, self._hsegs, self._lr, self._lr_set = [], [], [], [None, None]
-        for X, Y in ((net, twin), (twin, net)):
-            rows = []
-            for lx, ly in zip(X.tr_layers, Y.tr_layers):
-                if lx.has_updates():
-                    for p, ps, v, g in zip(lx.params, ly.params, lx.accumulated_updates, lx.grads):
-                        rows.append((p.ptr, ps.ptr, v.ptr, g.ptr, p.size, lx.reg['momentum'], lx.reg['rate']))
-            host = np.array(rows, dtype=seg_dt)
-            self._hsegs.append(host)             # kept alive: the update matches pending slab sums against it
-            self._segs.append(ctx.array(host.view(np.uint8)))
-            X._cost_pending = False
-            # single-GPU runs leave a step's slab sums and cost to the update that opens the stream's next
-            # step (one launch instead of three); data-parallel steps need both before their all-reduce
-            X._pipe_lazy = not net._dp and os.environ.get("TN_PIPE_LAZY", "1") != "0"
-            self._lr.append(ctx.zeros((1,)))
-            X._cost_rider = False
-        self._nseg, self._max_seg = net._n_segs, net._max_seg
-        self._ev, arev = [], []
-        for _ in range(2):
-            for lst in (self._ev, arev):
-                e = self._ctypes.c_void_p()
-                ctx.call("tn_event_create", self._ctypes.byref(e))
-                lst.append(e)
-        for k, X in enumerate(self.nets):                  # all-reduce k waits for all-reduce k-1
-            X._ar_done_ev, X._ar_wait_ev = arev[k], arev[1 - k]
-        base = int(net.d_step.get_value()[0])            # steps already taken (an earlier training function)
-        self._base = base
-        ctx.call("tn_set_u32", twin.d_step.ptr, base + 1)    # the twin takes every second step
-        self._lr_prev = None
-
-    def _lr_now(self):
-        tp = self.net.tr_prms
-        return float(np.float32(tp['INIT_LEARNING_RATE'] / (1 + tp['CUR_EPOCH'] / tp['EPOCHS_TO_HALF_RATE'])))
-
-    def _blocked(self):
-        return self.net._injecting() or self.net.ctx.ev_hook is not None
-
-    # -- the step as one C call (plan.py) -----------------------------------------------------------
-    def _plan_state(self):
-        """What a step leaves behind on the host (restored after a replayed step of the same phase)."""
-        per_net = []
-        for X in self.nets:
-            first = X.tr_layers[0]
-            per_net.append((X._cost_pending, getattr(first, "_cur", None), getattr(first, "_pre_valid", None)))
-        return (self.nets.index(self._last), tuple(per_net))
-
-    def _plan_set_state(self, st):
-        self._last = self.nets[st[0]]
-        for X, (cp, cur, pv) in zip(self.nets, st[1]):
-            X._cost_pending = cp
-            if cur is not None:
-                first = X.tr_layers[0]
-                first._cur, first._pre_valid = cur, pv
-        self._updated = False
-        self.t += 1
-
-    def _plannable(self):
-        lr = self._lr_now()
-        return self._seq is None and self._twin is not None and not self._updated and not getattr(self, "_want", False) \
-            and self.t >= 4 and lr == self._lr_prev and self._lr_set[0] == lr and self._lr_set[1] == lr \
-            and not self._blocked()
-
-    # -- the start-of-step update -----------------------------------------------------------------
-    def _update_for(self, t):
-        """weights (and velocity) for step t on the stream that will run it"""
-        ctx, k = self.net.ctx, t & 1
-        X = self.nets[k]
-        self.net._apply_dtype()
-        ctx.call("tn_stream_select", k)
-        ctx.call("tn_event_wait", self._ev[1 - k])
-        if self._lr_set[k] != self._lr_prev:              # the rate step t-1 was enqueued under
-            ctx.call("tn_set_f32", self._lr[k].ptr, self._lr_prev)
-            self._lr_set[k] = self._lr_prev
-        out = X.tr_layers[-1]
-        rider = X._cost_pending
-        ctx.call("tn_sgd_update_multi_pipe", self._segs[k].ptr, self._hsegs[k].ctypes.data, self._nseg,
-                 self._max_seg, self._lr[k].ptr, X.d_step.ptr, 2 if t >= 2 else 0, 1 if t >= 2 else 0,
-                 out.rowloss.ptr if rider else None, X.local_bsz, 1.0 / X.batch_sz,
-                 X.d_cost.ptr if rider else None)
-        X._cost_pending = False
-        X._apply_maxnorm_all()
-        ctx.call("tn_event_record", self._ev[k])
-
-    def sync_weights(self):
-        """Bring the net's own weights up to date (p_t after t steps) before anything reads them."""
-        if self._seq is not None or self._twin is None or self.t == 0:
-            return
-        ctx, t = self.net.ctx, self.t
-        if not self._updated:
-            self._update_for(t)
-            self._updated = True
-        if t & 1:                                         # the twin holds p_t: copy into the net
-            ctx.call("tn_stream_select", 0)
-            ctx.call("tn_event_wait", self._ev[1])
-            for a, b in zip(self.net.tr_layers, self._twin.tr_layers):
-                for pa, pb in zip(a.params, b.params):
-                    ctx.call("tn_d2d", pa.ptr, pb.ptr, pa.size * 4)
-        ctx.call("tn_stream_select", 0)
-        ctx.sync()
-
-    def _flush_parked(self):
-        """Finish the slab sums and costs the last steps left parked with their streams (the gradients
-        become ordinary buffers; the next update simply reads them)."""
-        if self._twin is None or self._seq is not None:
-            return
-        ctx = self.net.ctx
-        for k, X in enumerate(self.nets):
-            ctx.call("tn_stream_select", k)
-            ctx.call("tn_defer_reductions", 0)
-            self._finish_cost(X)
-        ctx.call("tn_stream_select", 0)
-
-    def _fall_back(self):
-        """Leave the pipelined schedule for good: bring weights AND velocity to the sequential state."""
-        net, ctx = self.net, self.net.ctx
-        self._flush_parked()
-        if self._twin is not None and self.t > 0:
-            self.sync_weights()
-            # the velocity is one gradient behind (that of step t-1, held by the stream that ran it)
-            Y = self.nets[(self.t - 1) & 1]
-            ctx.call("tn_stream_select", 0)
-            ctx.call("tn_sgd_update_multi_delayed", Y._d_segs.ptr, Y._n_segs, Y._max_seg,
-                     net.cur_learn_rate.ptr, 1.0, None, 3)
-            ctx.call("tn_set_u32", net.d_step.ptr, self._base + self.t)
-            ctx.sync()
-        has_wtcost = any(getattr(l, 'reg', None) and l.params and (l.reg['L1'] or l.reg['L2'])
-                         for l in net.tr_layers)
-        net._cost_rider = (not has_wtcost) and not net._dp and os.environ.get("TN_COST_RIDER", "1") != "0"
-        net._pipe_fn = None
-        first = net.tr_layers[0]
-        if isinstance(first, ElasticLayer):
-            first._pre_valid = False              # a field built ahead was for this stream's step t+2
-        self._seq = _TrainFn(net, self.x_data, self.y_data, False)
-
-    # -- the step ---------------------------------------------------------------------------------
-    def enqueue(self, i):
-        pl = self._plan
-        if pl is None or pl.off:
-            return self._enqueue(i)
-        ok = self._plannable()
-        if pl.ready and ok:
-            self.net._apply_dtype()
-            self._plan_set_state(pl.step(i))
-            return
-        if ok:
-            pl.begin(i)
-        try:
-            self._enqueue(i)
-        except Exception:
-            ok = False
-            raise
-        finally:
-            pl.end(self._plan_state() if ok and self._seq is None else None, ok and self._seq is None)
-
-    def _enqueue(self, i):
-        if self._seq is None and self._blocked():
-            self._fall_back()
-        if self._seq is not None:
-            self.net._want_outputs = getattr(self, "_want", False)
-            try:
-                return self._seq.enqueue(i)
-            finally:
-                self.net._want_outputs = False
-        if self._twin is None:
-            self._build()
-        net, ctx, t = self.net, self.net.ctx, self.t
-        k = t & 1
-        X = self.nets[k]
-        if t >= 1 and not self._updated:
-            self._update_for(t)
-        elif t == 0:
-            ctx.call("tn_stream_select", 0)
-            ctx.call("tn_event_record", self._ev[0])
-        else:
-            ctx.call("tn_stream_select", k)
-        self._updated = False
-        self._lr_prev = self._lr_now()
-        slot = X.x
-        slot.d_row0 = None
-        slot.bind(self.x_data)
-        slot.row0 = int(i) * net.batch_sz + net.shard_lo
-        slot.row_global0 = net.shard_lo
-        X._want_outputs = getattr(self, "_want", False)
-        try:
-            X._train_step(self.y_data, slot.row0, pipe_stride=2)
-        finally:
-            X._want_outputs = False
-            ctx.call("tn_stream_select", 0)
-        self._last = X
-        self.t = t + 1
-
-    def fetch(self):
-        if self._seq is not None:
-            return self._seq.fetch()
-        X = self._last
-        X.ctx.call("tn_stream_select", self.nets.index(X))
-        try:
-            early = getattr(X, "_early", None)
-            sent = early is not None and early["live"]
-            if not (sent and early["cost_sent"]):
-                self._finish_cost(X)
-            if not sent:
-                X.ctx.sync()
-            return _step_outputs(X, X.tr_layers[-1])
-        finally:
-            X.ctx.call("tn_stream_select", 0)
-
-    @staticmethod
-    def _finish_cost(X):
-        """The cost of X's last step, if nothing has summed it yet (on the stream currently selected)."""
-        if getattr(X, "_cost_pending", False):
-            out = X.tr_layers[-1]
-            X.ctx.call("tn_sgd_update_multi_cost", None, 0, 0, X.cur_learn_rate.ptr, 1.0, None,
-                       out.rowloss.ptr, X.local_bsz, 1.0 / X.batch_sz, X.d_cost.ptr)
-            X._cost_pending = False
-
-    def __call__(self, i):
-        self._want = True                   # features / logprob leave right after the forward pass
-        try:
-            self.enqueue(i)
-        finally:
-            self._want = False
-        return self.fetch()
-
-
-class _TestFn:
-    """``get_test_model``'s function: ``fn(i) -> [sym_err, P(MLE)](, features, y_preds)``."""
-
-    def __init__(self, net, x_data, y_data, preds_feats, aux_data=None):
-        self.net, self.x_data, self.y_data, self.preds_feats = net, x_data, y_data, preds_feats
-        self.aux_data = aux_data
-
-    def __call__(self, i):
-        net, ctx = self.net, self.net.ctx
-        net._sync_weights()
-        net._apply_dtype()
-        if net.dtype == 'float16':
-            net._c8_arrange(net.te_layers, False)
-        slot = net.test_x
-        slot.bind(self.x_data)
-        slot.row0 = int(i) * net.batch_sz + net.shard_lo
-        slot.row_global0 = net.shard_lo
-        if self.aux_data is not None:                      # neuralnet.py:266-269
-            net.aux_inpt_te.bind(self.aux_data)
-            net.aux_inpt_te.row0 = slot.row0
-        out = net.te_layers[-1]
-        for lyr in net.te_layers[:-1]:
-            lyr.forward(False)
-        out.forward(False, y=self.y_data, y_row0=slot.row0)
-        ctx.call("tn_error_stats", out.y_preds.ptr, self.y_data.ptr, slot.row0, out.rowp.ptr,
-                 net.local_bsz, out.d_stats.ptr)
-        if net.world.size > 1:
-            net._group().allreduce_sum(out.d_stats)
-        stats = out.d_stats.get_value() / net.world.size
-        if net.world.size > 1:
-            net._group().verify_order()      # the host has synchronised anyway: cheap point to compare
-        res = [stats[0], stats[1]]
-        if self.preds_feats:
-            res += [out.features.get_value(), out.y_preds.get_value().astype(np.int64)]
-        return res
+# The "compiled functions" get_trin_model / get_test_model return live in trainfn.py
+from .trainfn import _PipeTrainFn, _TestFn, _TrainFn  # noqa: E402,F401
 
 
 # ###############################################################################
@@ -531,6 +69,9 @@ class _TestFn:
 
 class NeuralNet():
     fuse_conv_pool = True     # class-level switch (tests run both the fused and unfused paths)
+    # ... and the step-level fusions (slab sums and cost inside the update launch, the next minibatch's elastic field riding in a backward launch or beside the update, two steps in flight):
+    # False = the generic schedule, one launch per piece of work -- what the fused schedules are tested against
+    fused_step = True
     # the C-ABI ops that carry a net's conv products (bench.py brackets them for the conv roofline legs)
     CONV_FWD_OPS = ("tn_conv2d_fwd", "tn_convpool_fwd_mask", "tn_elastic_convpool_fwd_mask", "tn_c8_conv_fwd")
     CONV_BWD_OPS = ("tn_conv2d_wgrad", "tn_conv2d_dgrad", "tn_convpool_bwd_mask_dx", "tn_convpool_bwd_mask",
@@ -545,10 +86,9 @@ class NeuralNet():
             self.rand_gen = None
 
         self.ctx = get_context()             # raises without libtheanet_hip.so / a GPU
-        # the A/B switches a step consults, read once per net: a step makes ~14 C-ABI calls
-        # and every environment lookup in between costs as much host time as a tenth of a launch
-        self._fl = {n: os.environ.get(n, "1") != "0"
-                    for n in ("TN_SOFTMAX_TRAIN", "TN_STEP_TAIL", "TN_FIELD_RIDER", "TN_LAZY_UPDATE")}
+        # the SoftmaxLayer's training step as one kernel (tn_fc_softmax_train) or as its three ops: a choice of kernels
+        # (results agree to rounding, not bit for bit), read once per net
+        self._softmax_train = os.environ.get("TN_SOFTMAX_TRAIN", "1") != "0"
         # DTYPE: 'float32' (default = the reference's floatX, weights.py:8) or 'float16' = fp16 operands /
         # fp32 accumulation for the conv products, fp32 master weights; GRAD_SCALE: power of two applied
         # to dz before it is rounded to fp16 (results are scaled back: exact)
@@ -799,8 +339,7 @@ class NeuralNet():
                          for l in self.tr_layers)
         # data-parallel step (TN_DP_FORCE=1: exercise it with a 1-rank communicator)
         self._dp = self.world.size > 1 or os.environ.get("TN_DP_FORCE") == "1"
-        self._cost_rider = (not has_wtcost) and not self._dp and \
-            os.environ.get("TN_COST_RIDER", "1") != "0"
+        self._cost_rider = self.fused_step and (not has_wtcost) and not self._dp
         self._cost_rider_ok = self._cost_rider
         # which layers must propagate a gradient to their input
         self._need_gin = []
@@ -997,7 +536,7 @@ class NeuralNet():
         # the weight-gradient ops only record their finishing slab sums; one launch does them all
         ctx.call("tn_defer_reductions", 1)
         n_lyr = len(self.tr_layers)
-        fuse_out = n_lyr >= 2 and self._need_gin[n_lyr - 1] and self._fl["TN_SOFTMAX_TRAIN"] \
+        fuse_out = self._softmax_train and n_lyr >= 2 and self._need_gin[n_lyr - 1] \
             and isinstance(out, SoftmaxLayer) and out.loss == "nll"
         try:
             out.forward(True, y=y, y_row0=y_row0, d_row0=d_row0,
@@ -1040,7 +579,7 @@ class NeuralNet():
         # launch build it beside the update instead (tn_step_tail).
         ahead = (isinstance(first, ElasticLayer) and first.active and first.has_field and
                  not first._inj_draws and first.d_step is not None and (self._n_segs or rider) and
-                 self._fl["TN_STEP_TAIL"])
+                 self.fused_step)
         if ahead:
             nxt = 1 - first._cur
             m = first._maps[nxt]
@@ -1048,9 +587,8 @@ class NeuralNet():
             field_args = (hw, hw, float(first.translation), float(first.zoom), float(first.magnitude),
                           int(first.sigma), float(first.angle), int(first.nearest), m[0].ptr, m[1].ptr,
                           m[2].ptr, m[3].ptr)
-            if self._fl["TN_FIELD_RIDER"]:
-                ctx.call("tn_rider_elastic_field", first.draws.ptr, first.seed, pipe_stride or 1,
-                         self.d_step.ptr, *field_args)
+            ctx.call("tn_rider_elastic_field", first.draws.ptr, first.seed, pipe_stride or 1,
+                     self.d_step.ptr, *field_args)
         tail = False
         dp_async = False
         # single-GPU steps leave the finishing slab sums to the update launch (tn_sgd_update_multi_lazy)
@@ -1072,13 +610,12 @@ class NeuralNet():
                     dp_async = True
                 if g is None:
                     break
-            lazy = (not self._dp and 0 < self._n_segs <= 32 and
-                    self._fl["TN_LAZY_UPDATE"])
+            lazy = self.fused_step and not self._dp and 0 < self._n_segs <= 32
         finally:
             waiting = bool(ctx.lib.tn_rider_pending(ctx.h))
             if waiting:
                 ctx.call("tn_rider_cancel")       # nobody carried it: it joins the update launch
-            rode = ahead and not waiting and self._fl["TN_FIELD_RIDER"]
+            rode = ahead and not waiting
             tail = ahead and not rode
             if pipe_stride:                       # pipelined schedule: the update is not part of the step
                 ahead, tail, lazy = rode, False, False
@@ -1250,7 +787,7 @@ class NeuralNet():
 
     def _pipe_ok(self, take_index_list):
         """Two-steps-in-flight schedule (_PipeTrainFn): single GPU, plain momentum-SGD nets."""
-        if getattr(self, "_is_twin", False) or os.environ.get("TN_PIPELINE", "1") == "0":
+        if getattr(self, "_is_twin", False) or not self.fused_step or os.environ.get("TN_PIPELINE", "1") == "0":
             return False
         has_wtcost = any(getattr(l, 'reg', None) and l.params and (l.reg['L1'] or l.reg['L2'])
                          for l in self.tr_layers)
