@@ -148,6 +148,8 @@ def build(prms_name, global_batch, per_gpu, img, dtype):
     tr["BATCH_SZ"] = global_batch
     if dtype == "f16":
         tr["DTYPE"] = "float16"
+    if dtype == "b3":
+        tr["MATMUL"] = "bf16x3"
     net = NeuralNet(copy.deepcopy(prms["layers"]), dict(tr))
     n_batches = max(2, 65536 // global_batch) if per_gpu * img * img * C < (1 << 24) else 2
     x, y = synthetic(n_batches * global_batch, C, img)
@@ -270,7 +272,8 @@ def other_config_leg(ctx, prms_name, dtype, steps):
     return rec
 
 
-DTYPE_LABEL = {"f32": "f32", "f16": "f16 (fp16 tensors and MFMA operands, fp32 accumulate, fp32 master weights)"}
+DTYPE_LABEL = {"f32": "f32", "f16": "f16 (fp16 tensors and MFMA operands, fp32 accumulate, fp32 master weights)",
+               "b3": "f32 tensors; dense products as six bf16 MFMA products of exactly split operands (MATMUL 'bf16x3', opt-in)"}
 
 
 def dry_multi(args):
@@ -519,6 +522,14 @@ def main():
             except Exception as e:          # a leg must never cost the headline its line
                 line["other_configs"].append({"config": {"workload": "params/%s %s" % (name, dt_)},
                                               "error": "%s: %s" % (type(e).__name__, str(e)[-300:])})
+        # the headline workload once more with the opt-in MATMUL 'bf16x3' (NOT the headline: fp32-grade accuracy, other
+        # bits); reported whichever way it compares
+        try:
+            b3 = other_config_leg(ctx, "mnist.prms", "b3", args.steps)
+            line["value_bf16x3"] = b3["value"]
+            line["bf16x3"] = {k: b3[k] for k in ("ms_per_step", "steps", "dtype", "final_cost")}
+        except Exception as e:
+            line["bf16x3"] = {"error": "%s: %s" % (type(e).__name__, str(e)[-300:])}
     if world.size == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(prms, img, C, tr["BATCH_SZ"])
     print(json.dumps(line))

@@ -149,6 +149,11 @@ int tn_conv2d_dgrad(tn_ctx* ctx, const float* dz, const float* W, float* dx,
  * fp32 run: tn_conv_f16_supported says beforehand (bit 0 forward, bit 1 dgrad, bit 2 wgrad).        */
 int tn_set_matmul_dtype(tn_ctx* ctx, int dtype, float grad_scale);
 int tn_get_matmul_dtype(tn_ctx* ctx);
+/* MATMUL 'bf16x3' (opt-in, this build's extension; the reference is float32, weights.py:8): mode 1 runs the products of
+ * tn_fc_fwd / tn_fc_wgrad / tn_fc_dgrad / tn_fc_bwd of layers with more than 16 outputs as six bf16 MFMA products of
+ * exactly split operands (x = x0 + x1 + x2, 8 mantissa bits each) with fp32 accumulation -- fp32-grade accuracy
+ * (the same tolerances hold), not the same bits as mode 0's exact fp32 MFMA.  theanet_amd/csrc/gemm_b3.hip.        */
+int tn_set_fc_matmul(tn_ctx* ctx, int mode);
 int tn_conv_f16_supported(int N, int C, int H, int Wd, int K, int f, int stride, int pad_lo, int Ho, int Wo);
 /* 1 if the conv + act + 2x2 max-pool block runs fused on the fp16-operand tile kernels */
 int tn_convpool_f16_supported(int N, int C, int H, int Wd, int K, int f, int stride, int pad_lo, int Ho, int Wo,

@@ -118,9 +118,9 @@ def test_gold_mnist_three_steps(fname, elastic_on, fuse):
     assert preds.dtype == np.int64
 
 
-def _random_net_case(layers, B, img, C, n_cls, seed=3, steps=2):
+def _random_net_case(layers, B, img, C, n_cls, seed=3, steps=2, **more):
     from theanet_amd import NeuralNet
-    tr = {"SEED": seed, "BATCH_SZ": B, "INIT_LEARNING_RATE": .05, "EPOCHS_TO_HALF_RATE": 1}
+    tr = dict({"SEED": seed, "BATCH_SZ": B, "INIT_LEARNING_RATE": .05, "EPOCHS_TO_HALF_RATE": 1}, **more)
     rng = np.random.RandomState(seed)
     x = rng.rand(steps * B, C, img, img).astype(np.float32)
     y = rng.randint(0, n_cls, steps * B).astype(np.int32)
@@ -203,6 +203,25 @@ def test_mlp_3flat_like_net_matches_oracle():
         ("SoftmaxLayer", {"n_out": 57}),
     ]
     _random_net_case(layers, 48, 12, 1, 57)
+
+
+def test_matmul_bf16x3_dense_products_f16_free_net_matches_oracle():
+    """MATMUL 'bf16x3' (opt-in; gemm_b3.hip): the dense layers' three products as six bf16 MFMA products of exactly split
+    operands -- fp32-grade accuracy, so the float64 oracle is matched at the SAME tolerances as the exact fp32 path
+    (logprob 1e-4 rel, weights after two steps 1e-4), with dropout, a frozen layer, L2 and ragged sizes (K = 144, 100)."""
+    from theanet_amd import _lib
+    layers = [
+        ("InputLayer", {"img_sz": 12, "num_maps": 1}),
+        ("HiddenLayer", {"n_out": 100, "pdrop": .5, "actvn": "relu10", "reg": {"L2": .001}}),
+        ("HiddenLayer", {"n_out": 36, "actvn": "scaled_tanh", "reg": {"rate": 0}}),
+        ("SoftmaxLayer", {"n_out": 57}),
+    ]
+    net, _, _, _ = _random_net_case(layers, 48, 12, 1, 57, MATMUL="bf16x3")
+    assert net.matmul == "bf16x3" and net.ctx._fc_mm == "bf16x3"
+    net2, _, _, _ = _random_net_case(layers, 48, 12, 1, 57)          # the next net puts the context back
+    assert net2.ctx._fc_mm == "float32"
+    with pytest.raises(AssertionError, match="MATMUL"):
+        _random_net_case(layers, 48, 12, 1, 57, MATMUL="fp8")
 
 
 def test_full_batch_size_properties_mnist_4096():

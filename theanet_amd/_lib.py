@@ -77,6 +77,7 @@ SIGNATURES = {
     "tn_conv2d_dgrad": (c_int, [CTX, P, P, P] + [c_int] * 10 + [P, c_int, c_float]),
     "tn_set_matmul_dtype": (c_int, [CTX, c_int, c_float]),
     "tn_get_matmul_dtype": (c_int, [CTX]),
+    "tn_set_fc_matmul": (c_int, [CTX, c_int]),
     "tn_conv_f16_supported": (c_int, [c_int] * 10),
     "tn_convpool_f16_supported": (c_int, [c_int] * 13),
     "tn_c8_conv_supported": (c_int, [c_int] * 8),

@@ -49,6 +49,7 @@ struct tn_ctx {
     // matmul operand precision of the 3x3 conv products (tn_set_matmul_dtype): 0 fp32, 1 fp16 operands /
     // fp32 accumulate; grad_scale: power of two applied to dz before it is rounded to fp16
     int mm_f16 = 0;
+    int fc_b3 = 0;                         // tn_set_fc_matmul: 1 = FC products as bf16 triplets (gemm_b3.hip)
     float grad_scale = 1.f;
     char err[512] = {0};
     // RCCL (loaded lazily, comm.hip)
@@ -86,6 +87,15 @@ int tn_tmp_get(tn_ctx* ctx, size_t bytes, float** out);
 int tn_red_push(tn_ctx* ctx, const float* src, float* out, uint32_t n, uint32_t S, uint32_t stride,
                 uint32_t flip);
 int tn_red_commit(tn_ctx* ctx);
+// MATMUL 'bf16x3' products of a fully-connected layer (gemm_b3.hip); the tn_fc_* entry points dispatch here when
+// tn_set_fc_matmul(ctx, 1) is in force and tn_b3_fc_ok says the shape qualifies
+int tn_b3_fc_ok(const float* x, const float* W, int B, int n_in, int n_out);
+int tn_b3_fc_fwd(tn_ctx* ctx, const float* x, const float* W, const float* b, float* a, int B, int n_in, int n_out, int act,
+                 float prm, const uint8_t* mask);
+int tn_b3_fc_dgrad(tn_ctx* ctx, const float* dz, const float* W, float* dx, int B, int n_in, int n_out, const float* prev_a,
+                   int act, float prm, const uint8_t* mask);
+int tn_b3_fc_wgrad(tn_ctx* ctx, const float* x, const float* dz, float* dW, float* db, int B, int n_in, int n_out, float* ws,
+                   int S);
 int tn_red_flush(tn_ctx* ctx);
 int tn_red_flush_inc(tn_ctx* ctx, uint32_t* inc);
 

@@ -86,6 +86,12 @@ int tn_set_matmul_dtype(tn_ctx* ctx, int dtype, float grad_scale) {
 
 int tn_get_matmul_dtype(tn_ctx* ctx) { return ctx->mm_f16; }
 
+int tn_set_fc_matmul(tn_ctx* ctx, int mode) {
+    TN_REQUIRE(mode == 0 || mode == 1, "tn_set_fc_matmul: mode %d (0 exact fp32 MFMA, 1 bf16 triplets)", mode);
+    ctx->fc_b3 = mode;
+    return TN_OK;
+}
+
 const char* tn_last_error(tn_ctx* ctx) { return ctx ? ctx->err : g_tn_err; }
 
 int tn_sync(tn_ctx* ctx) {

@@ -1096,6 +1096,8 @@ static int fc_dgrad_splits(tn_ctx* ctx, int B, int n_in, int n_out) {
 int tn_fc_fwd(tn_ctx* ctx, const float* x, const float* W, const float* b, float* a, int B, int n_in,
               int n_out, int act, float act_param, const uint8_t* mask) {
     TN_REQUIRE(B > 0 && n_in > 0 && n_out > 0, "tn_fc_fwd: bad shape");
+    if (ctx->fc_b3 && tn_b3_fc_ok(x, W, B, n_in, n_out))
+        return tn_b3_fc_fwd(ctx, x, W, b, a, B, n_in, n_out, act, act_param, mask);
     if (tn_fc_skinny_ok(n_in, n_out, x, nullptr, nullptr))
         return tn_fc_skinny_fwd(ctx, x, W, b, a, B, n_in, n_out, act, act_param, mask);
     const size_t sk_lds = (size_t)n_in * (n_out + 1) * sizeof(float);
@@ -1135,7 +1137,7 @@ int tn_fc_fwd_dropout(tn_ctx* ctx, const float* x, const float* W, const float* 
     g.a_vec = vec_ok(x, n_in); g.b_vec = vec_ok(W, n_out);
     g.drop_out = mask_out; g.pdrop = pdrop; g.dk0 = (uint32_t)seed; g.dk1 = (uint32_t)(seed >> 32);
     g.dstep = step; g.d_step = d_step; g.elem0 = elem0;
-    if (n_out > SK_MAX && fc_fwd_splits(ctx, B, n_in, n_out) == 1 && gemm_fast_ok<true, false>(g) &&
+    if (!(ctx->fc_b3 && tn_b3_fc_ok(x, W, B, n_in, n_out)) && n_out > SK_MAX && fc_fwd_splits(ctx, B, n_in, n_out) == 1 && gemm_fast_ok<true, false>(g) &&
         gemm_cvec_ok(g)) {
         if (gemm_deep_ok<false>(ctx, g))
             launch_deep<false>(ctx, g);
@@ -1163,6 +1165,8 @@ size_t tn_fc_wgrad_ws_bytes(int B, int n_in, int n_out) {
 int tn_fc_wgrad(tn_ctx* ctx, const float* x, const float* dz, float* dW, float* db, int B, int n_in,
                 int n_out, void* ws) {
     TN_REQUIRE(B > 0 && n_in > 0 && n_out > 0 && ws != nullptr, "tn_fc_wgrad: bad arguments");
+    if (ctx->fc_b3 && tn_b3_fc_ok(x, dz, B, n_in, n_out))
+        return tn_b3_fc_wgrad(ctx, x, dz, dW, db, B, n_in, n_out, (float*)ws, wgrad_splits(B, n_in, n_out));
     if (tn_fc_skinny_ok(n_in, n_out, x, nullptr, nullptr))
         return tn_fc_skinny_wgrad(ctx, x, dz, dW, db, B, n_in, n_out, (float*)ws);
     if (n_out <= SK_MAX) {
@@ -1215,6 +1219,11 @@ int tn_fc_bwd(tn_ctx* ctx, const float* x, const float* dz, const float* W, floa
               float* dx, int B, int n_in, int n_out, void* ws, const float* prev_a, int prev_act,
               float prev_act_param, const uint8_t* prev_mask) {
     TN_REQUIRE(B > 0 && n_in > 0 && n_out > 0 && ws != nullptr && dx != nullptr, "tn_fc_bwd: bad arguments");
+    if (ctx->fc_b3 && tn_b3_fc_ok(x, W, B, n_in, n_out) && tn_b3_fc_ok(dz, W, B, n_in, n_out)) {
+        int rc = tn_b3_fc_wgrad(ctx, x, dz, dW, db, B, n_in, n_out, (float*)ws, wgrad_splits(B, n_in, n_out));
+        if (rc) return rc;
+        return tn_b3_fc_dgrad(ctx, dz, W, dx, B, n_in, n_out, prev_a, prev_act, prev_act_param, prev_mask);
+    }
     if (tn_fc_skinny_ok(n_in, n_out, x, nullptr, nullptr) &&
         tn_fc_skinny_ok(n_in, n_out, dx, prev_a, prev_mask))
         return tn_fc_skinny_bwd(ctx, x, dz, W, dW, db, dx, B, n_in, n_out, (float*)ws, prev_a, prev_act,
@@ -1298,6 +1307,8 @@ int tn_fc_bwd(tn_ctx* ctx, const float* x, const float* dz, const float* W, floa
 int tn_fc_dgrad(tn_ctx* ctx, const float* dz, const float* W, float* dx, int B, int n_in, int n_out,
                 const float* prev_a, int prev_act, float prev_act_param, const uint8_t* prev_mask) {
     TN_REQUIRE(B > 0 && n_in > 0 && n_out > 0, "tn_fc_dgrad: bad shape");
+    if (ctx->fc_b3 && tn_b3_fc_ok(dz, W, B, n_in, n_out))
+        return tn_b3_fc_dgrad(ctx, dz, W, dx, B, n_in, n_out, prev_a, prev_act, prev_act_param, prev_mask);
     if (tn_fc_skinny_ok(n_in, n_out, dx, prev_a, prev_mask))
         return tn_fc_skinny_dgrad(ctx, dz, W, dx, B, n_in, n_out, prev_a, prev_act, prev_act_param,
                                   prev_mask);

@@ -172,6 +172,10 @@ int tn_set_matmul_dtype(tn_ctx* ctx, int dtype, float grad_scale) {
     return TN_OK;
 }
 int tn_get_matmul_dtype(tn_ctx*) { return 0; }
+int tn_set_fc_matmul(tn_ctx* ctx, int mode) {
+    REQUIRE(mode == 0, "tn_set_fc_matmul: the CPU backend computes the dense products in float32 only");
+    return TN_OK;
+}
 int tn_conv_f16_supported(int, int, int, int, int, int, int, int, int, int) { return 0; }
 // DTYPE 'float16' on fp16-resident tensors (conv_c8.hip): MI355X only; the capability queries answer 0 and
 // tn_set_matmul_dtype refuses the mode, so the host never gets here

@@ -103,6 +103,12 @@ class Context:
             self._mm_set = want
         self.mm_dtype = dtype
 
+    def set_fc_matmul(self, mode):
+        """'float32' (exact fp32 MFMA) or 'bf16x3' (six bf16 MFMA products of exactly split operands: tn_set_fc_matmul)."""
+        if mode != getattr(self, "_fc_mm", "float32"):
+            self.call("tn_set_fc_matmul", 1 if mode == "bf16x3" else 0)
+            self._fc_mm = mode
+
     def info(self):
         name = ctypes.create_string_buffer(128)
         cus = ctypes.c_int()

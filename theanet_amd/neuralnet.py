@@ -95,6 +95,10 @@ class NeuralNet():
         self.dtype = training_params.get('DTYPE', 'float32')
         assert self.dtype in ('float32', 'float16'), "DTYPE must be 'float32' or 'float16'"
         self.grad_scale = float(training_params.get('GRAD_SCALE', 4096.))
+        # MATMUL: 'float32' (default: exact fp32 MFMA) or 'bf16x3' -- the dense layers' products as six bf16 MFMA
+        # products of exactly split operands (fp32-grade accuracy, not the same bits; gemm_b3.hip)
+        self.matmul = training_params.get('MATMUL', 'float32')
+        assert self.matmul in ('float32', 'bf16x3'), "MATMUL must be 'float32' or 'bf16x3'"
         self._apply_dtype()
         self.world = comm.get_world()
         self._dev_group = None
@@ -297,6 +301,7 @@ class NeuralNet():
         goes onto those streams they are finished (the other net is alive: its buffers exist) or forgotten
         (it has been collected: the recorded outputs are dangling)."""
         self.ctx.set_matmul_dtype(self.dtype, self.grad_scale)
+        self.ctx.set_fc_matmul(self.matmul)
         me = getattr(self, "_main", self)
         ref = NeuralNet._ctx_owner
         prev = ref() if ref is not None else None
