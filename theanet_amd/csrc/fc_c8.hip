@@ -19,6 +19,8 @@
 //             16-byte stores of fp16(acc * act'(y)) -- y = the pooled output below, in the same order.
 //   wgrad   : both operands want 8 consecutive SAMPLES per lane but are stored sample-major: tiles go to LDS as they
 //             are (dz converted on the way) and gfx950's transposing LDS read (ds_read_b64_tr_b16) delivers them.
+#include <cstdlib>
+
 #include "common.h"
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -37,21 +39,24 @@ struct FC8 {
     const float* W;         // (C * HW, N)
     const float* bias;
     const float* dz;        // (M, N) fp32
+    const _Float16* dz16;   // dgrad: fp16(gs dz), (M, Np)
     const _Float16* ya;     // dgrad: output of the layer below in x's order (act' is taken from it) or NULL
     const uint8_t* mask;    // forward: dropout mask (M, N) or NULL
     float* out;             // forward: (M, N) fp32
     _Float16* dx;           // dgrad: (M, Kc) halfs, carries the gradient scale
     float* ws;              // forward: K slabs [S][M][N]; wgrad: sample slabs [S][C*HW][N]
     float* dbws;            // wgrad: [S][N]
-    int M, N, Kc, C, HW, S, krange, act;
+    int M, N, Np, Kc, C, HW, S, krange, act;
+    unsigned magic;         // 2^32 / HW + 1 (0: HW == 1), see fc8_wrow
     float prm, gs, oscale;
 };
 
-// c8 column k (a multiple of 8) -> row of W for element e = 0: rows of e are HW apart
-__device__ __forceinline__ int fc8_row0(const FC8& g, int k, int& step) {
-    const int cell = k >> 3, o = cell / g.HW, p = cell - o * g.HW;
-    step = g.HW;
-    return (o * 8) * g.HW + p;
+// cell (= c8 column >> 3) -> (o, p) = (cell / HW, cell % HW) without an integer division: magic = 2^32 / HW + 1 (exact
+// while cell * HW < 2^32, checked by the host); HW == 1: magic 0
+__device__ __forceinline__ int fc8_wrow(const FC8& g, int cell, int e, int rows) {
+    const int o = g.magic ? (int)__umulhi((unsigned)cell, g.magic) : cell;
+    const int p = cell - o * g.HW;
+    return min((o * 8 + e) * g.HW + p, rows - 1);
 }
 
 __device__ __forceinline__ half8 fc8_cvt8(const float (&v)[8]) {
@@ -61,97 +66,93 @@ __device__ __forceinline__ half8 fc8_cvt8(const float (&v)[8]) {
     return h;
 }
 
+typedef unsigned fc8_u4 __attribute__((ext_vector_type(4)));
+typedef float fc8_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ half4v fc8_cvt4(const fc8_f4 v) {
+    return half4v{(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+}
+
 // ---------------------------------------------------------------------------------------------------------------
-// forward: grid = (N / 64 column groups, S slabs, M / 128 row groups), 4 waves = 4 K ranges of the slab
+// forward: grid = (N / 64 column groups, S K-slabs, M / 128 row groups); block = 128 rows x 64 outputs x one K slab in
+// chunks of 64 c8 columns.  A chunk is FOUR float4 of W and four 16-byte pieces of x per thread; a ring of FC8_NST such
+// register sets keeps NST - 1 chunks (16 KB of W each) of every block in flight -- the op streams the 64 MB matrix
+// once and is bound by that (short batches) -- and one LDS tile at a time feeds the matrix core: x as stored
+// ([row][k], 16-byte reads), W converted to halfs as stored ([k][n]) and read through the transposing LDS read.
 // ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 2) void fc8_fwd_kernel(FC8 g) {
-    __shared__ float red[2][8][16][64];                      // two waves' accumulators: [tile][reg][lane] (64 KB: two blocks per CU)
+#define FC8_NST 4
+#define FC8F_XS 144         // x tile row stride (64 halfs + 16 bytes: 9 x 16 B, every 16-byte read of 32 rows on its own banks)
+#define FC8F_WS 192         // W tile row stride (64 halfs + 64 bytes = 64 (mod 128): the 4 rows of a transposing read on disjoint banks)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void fc8_fwd_kernel(FC8 g) {
+    __shared__ __attribute__((aligned(16))) char xs[128 * FC8F_XS];
+    __shared__ __attribute__((aligned(16))) char wsm[64 * FC8F_WS];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, hi = lane >> 5;
     const int n0 = blockIdx.x * 64, m0 = blockIdx.z * 128;
-    const int kbeg = (blockIdx.y * 4 + wave) * g.krange, kend = min(g.Kc, kbeg + g.krange);
-    const int nmax = g.N - 1, rows = g.C * g.HW;
-    f32x16 acc[4][2];
+    const int kbeg = blockIdx.y * g.krange, kend = min(g.Kc, kbeg + g.krange);
+    const int nch = (kend - kbeg) >> 6, rows = g.C * g.HW;
+    const int wm = wave >> 1, wn = wave & 1;                 // wave = 64 rows x 32 outputs
+    f32x16 acc[2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    // staging roles: x row t >> 1, 32-half part t & 1; W k-rows (t >> 4) + 16 i, columns 4 (t & 15) ..
+    const _Float16* xp = g.x + (size_t)min(m0 + (t >> 1), g.M - 1) * g.Kc + (t & 1) * 32;
+    char* const xdst = xs + (t >> 1) * FC8F_XS + (t & 1) * 64;
+    const float* wcol = g.W + min(n0 + 4 * (t & 15), g.N - 4);
+    char* const wdst = wsm + (t >> 4) * FC8F_WS + 8 * (t & 15);
+    const int we = (t >> 4) & 7, wc0 = (kbeg >> 3) + (t >> 7);
+    fc8_u4 xr[FC8_NST][4];
+    fc8_f4 wr[FC8_NST][4];
+    auto gload = [&](int st, int c) __attribute__((always_inline)) {
+        const int cc = min(c, nch - 1);                      // past the end: the last chunk again (cache hits, never used)
+        const _Float16* xq = xp + kbeg + 64 * cc;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    const _Float16* xrow[4];
+        for (int i = 0; i < 4; ++i) xr[st][i] = *reinterpret_cast<const fc8_u4*>(xq + 8 * i);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) xrow[i] = g.x + (size_t)min(m0 + 32 * i + l31, g.M - 1) * g.Kc + 8 * hi;
-    const int nc[2] = {min(n0 + l31, nmax), min(n0 + 32 + l31, nmax)};
-    half8 a[2][4];
-    float b[2][2][8];
-    auto load = [&](int slot, int k) __attribute__((always_inline)) {
-        const int kk = min(k, g.Kc - 16);
+        for (int i = 0; i < 4; ++i)
+            wr[st][i] = *reinterpret_cast<const fc8_f4*>(wcol + (size_t)fc8_wrow(g, wc0 + 8 * cc + 2 * i, we, rows) * g.N);
+    };
+    auto lstore = [&](int st) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) a[slot][i] = *reinterpret_cast<const half8*>(xrow[i] + kk);
-        int step;
-        const int r0 = fc8_row0(g, kk + 8 * hi, step);
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<fc8_u4*>(xdst + 16 * i) = xr[st][i];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float* wr = g.W + (size_t)min(r0 + j * step, rows - 1) * g.N;
-            b[slot][0][j] = wr[nc[0]];
-            b[slot][1][j] = wr[nc[1]];
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<half4v*>(wdst + 16 * i * FC8F_WS) = fc8_cvt4(wr[st][i]);
+    };
+    const int grp = lane >> 4, r4 = (lane >> 2) & 3, q4 = lane & 3;
+    const char* const ard = xs + (wm * 64 + l31) * FC8F_XS + 16 * hi;
+    const char* const brd = wsm + (8 * (grp >> 1) + r4) * FC8F_WS + (wn * 32 + 16 * (grp & 1) + 4 * q4) * 2;
+    auto compute = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const half4v b0 = fc8_tr16(brd + 16 * ks * FC8F_WS), b1 = fc8_tr16(brd + (16 * ks + 4) * FC8F_WS);
+            const half8 b = half8{b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const half8 a = *reinterpret_cast<const half8*>(ard + 32 * i * FC8F_XS + 32 * ks);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[i], 0, 0, 0);
+            }
         }
     };
-    load(0, kbeg);
-    for (int k = kbeg; k < kend; k += 32) {
-        load(1, k + 16);
-        {
-            const half8 b0 = fc8_cvt8(b[0][0]), b1 = fc8_cvt8(b[0][1]);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][i], b0, acc[i][0], 0, 0, 0);
-                acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][i], b1, acc[i][1], 0, 0, 0);
-            }
-        }
-        if (k + 16 < kend) {
-            load(0, k + 32);
-            const half8 b0 = fc8_cvt8(b[1][0]), b1 = fc8_cvt8(b[1][1]);
+    for (int u = 0; u < FC8_NST; ++u) gload(u, u);
+    for (int c = 0; c < nch; c += FC8_NST) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1][i], b0, acc[i][0], 0, 0, 0);
-                acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1][i], b1, acc[i][1], 0, 0, 0);
-            }
+        for (int u = 0; u < FC8_NST; ++u) {
+            lstore(u);
+            gload(u, c + u + FC8_NST);
+            __syncthreads();
+            if (c + u < nch) compute();
+            __syncthreads();
         }
     }
-    // the four K ranges of the block meet in LDS, pairwise in a fixed order: (0 + 2), (1 + 3), then (0 + 1)
-#pragma unroll
-    for (int round = 0; round < 2; ++round) {
-        const int h = round == 0 ? 2 : 1;
-        if (wave >= h && wave < 2 * h) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) red[wave - h][i * 2 + j][r][lane] = acc[i][j][r];
-        }
-        __syncthreads();
-        if (wave < h) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[i][j][r] += red[wave][i * 2 + j][r][lane];
-        }
-        __syncthreads();
-    }
-    if (wave > 0) return;
     float* const wz = g.ws + (size_t)blockIdx.y * g.M * g.N;
+    const int n = n0 + wn * 32 + l31;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int n = n0 + 32 * j + l31;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                if (m < g.M && n < g.N) wz[(size_t)m * g.N + n] = acc[i][j][r];
-            }
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wm * 64 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            if (m < g.M && n < g.N) wz[(size_t)m * g.N + n] = acc[i][r];
         }
 }
 
@@ -173,64 +174,91 @@ __global__ __launch_bounds__(256) void fc8_fwd_finish_kernel(const float* __rest
 
 // ---------------------------------------------------------------------------------------------------------------
 // dgrad: dx16[m][k] = fp16(act'(ya[m][k]) * sum_n fp16(gs dz[m][n]) * fp16(W[row(k)][n])); grid = (Kc / 64, M / 128);
-// wave = (32-column tile, 64-row half): C = W_tile . dz^T, MFMA row j <-> column base + swap23(j)
+// block = 64 c8 columns x 128 rows, the reduction in chunks of 64 outputs: the block's 64 rows of W (256 contiguous
+// bytes each per chunk) and the dz rows go through a ring of register sets into one LDS tile pair as halfs, [row][n].
+// C = W_tile . dz^T with the rows of the W tile in the order MFMA row j <-> column base + swap23(j): a lane's accumulators
+// are whole c8 cells.  wave = (32-column tile, 64-row half).
 // ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void fc8_dgrad_kernel(FC8 g) {
+// dz16[m][n] = fp16(gs * dz[m][n]), rows padded with zeros to a multiple of 64 outputs: the operand every block of the
+// input-gradient product re-reads (Kc / 64 times) at half the bytes, converted once
+__global__ __launch_bounds__(256) void fc8_dz16_kernel(const float* __restrict__ dz, _Float16* __restrict__ out, int M, int N,
+                                                      int Np, float gs) {
+    const int i = blockIdx.x * 256 + threadIdx.x;            // one 4-column group
+    const int q = Np >> 2, m = i / q, n = 4 * (i - m * q);
+    if (m >= M) return;
+    fc8_f4 v = {0.f, 0.f, 0.f, 0.f};
+    if (n < N) v = *reinterpret_cast<const fc8_f4*>(dz + (size_t)m * N + n) * gs;
+    *reinterpret_cast<half4v*>(out + (size_t)m * Np + n) = fc8_cvt4(v);
+}
+
+template <int NST>                  // ring depth
+__global__ __launch_bounds__(512) void fc8_dgrad_kernel(FC8 g) {
+    constexpr int NC = 64, RS = NC * 2 + 16;                 // outputs per chunk; row stride: an odd number of 16-byte slots
+    __shared__ __attribute__((aligned(16))) char wl[64 * RS];
+    __shared__ __attribute__((aligned(16))) char dl[128 * RS];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, hi = lane >> 5;
-    const int kbase = blockIdx.x * 64 + (wave & 1) * 32, m0 = blockIdx.y * 128 + (wave >> 1) * 64;
-    const int rows = g.C * g.HW;
-    const int kcol = kbase + fc8_swap23(l31);
-    int wrow;
-    {
-        const int cell = kcol >> 3, o = cell / g.HW, p = cell - o * g.HW;
-        wrow = min((o * 8 + (kcol & 7)) * g.HW + p, rows - 1);
+    const int kb0 = blockIdx.x * 64, m0 = blockIdx.y * 128;
+    const int wk = wave & 1, wm = wave >> 1;                 // wave = 32 columns x 32 rows
+    const int rows = g.C * g.HW, nch = g.Np / NC;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    // staging: W row (t >> 4) + 32 i, 4 outputs (t & 15); dz16 row (t >> 3) + 64 i, 8 outputs (t & 7)
+    const int n4 = 4 * (t & 15);
+    const float* wp[2];
+    const _Float16* dp[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int rr = (t >> 4) + 32 * i, kcol = kb0 + (rr & 32) + fc8_swap23(rr & 31);
+        wp[i] = g.W + (size_t)fc8_wrow(g, kcol >> 3, kcol & 7, rows) * g.N;
+        dp[i] = g.dz16 + (size_t)min(m0 + (t >> 3) + 64 * i, g.M - 1) * g.Np + 8 * (t & 7);
     }
-    const float* wp = g.W + (size_t)wrow * g.N + 8 * hi;
-    const float* dp[2];
+    char* const wdst = wl + (t >> 4) * RS + 2 * n4;
+    char* const ddst = dl + (t >> 3) * RS + 16 * (t & 7);
+    fc8_f4 wr[NST][2];
+    fc8_u4 dr[NST][2];
+    auto gload = [&](int st, int c) __attribute__((always_inline)) {
+        const int n = NC * min(c, nch - 1);
+        const int nn = min(n + n4, g.N - 4);                 // W columns past N meet zeros of dz16
 #pragma unroll
-    for (int i = 0; i < 2; ++i) dp[i] = g.dz + (size_t)min(m0 + 32 * i + l31, g.M - 1) * g.N + 8 * hi;
-    f32x16 acc[2];
+        for (int i = 0; i < 2; ++i) wr[st][i] = *reinterpret_cast<const fc8_f4*>(wp[i] + nn);
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i) dr[st][i] = *reinterpret_cast<const fc8_u4*>(dp[i] + n);
+    };
+    auto lstore = [&](int st) __attribute__((always_inline)) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-    float4 wv[2][2], dv[2][2][2];
-    auto load = [&](int slot, int n) __attribute__((always_inline)) {
-        const int nn = min(n, g.N - 16);
-        wv[slot][0] = *reinterpret_cast<const float4*>(wp + nn);
-        wv[slot][1] = *reinterpret_cast<const float4*>(wp + nn + 4);
+        for (int i = 0; i < 2; ++i) *reinterpret_cast<half4v*>(wdst + 32 * i * RS) = fc8_cvt4(wr[st][i]);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            dv[slot][i][0] = *reinterpret_cast<const float4*>(dp[i] + nn);
-            dv[slot][i][1] = *reinterpret_cast<const float4*>(dp[i] + nn + 4);
+        for (int i = 0; i < 2; ++i) *reinterpret_cast<fc8_u4*>(ddst + 64 * i * RS) = dr[st][i];
+    };
+    const char* const ard = wl + (wk * 32 + l31) * RS + 16 * hi;
+    const char* const brd = dl + (wm * 32 + l31) * RS + 16 * hi;
+    auto compute = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int ks = 0; ks < NC / 16; ++ks) {
+            const half8 a = *reinterpret_cast<const half8*>(ard + 32 * ks);
+            const half8 b = *reinterpret_cast<const half8*>(brd + 32 * ks);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc, 0, 0, 0);
         }
     };
-    auto mm = [&](int slot) __attribute__((always_inline)) {
-        const float wf[8] = {wv[slot][0].x, wv[slot][0].y, wv[slot][0].z, wv[slot][0].w,
-                             wv[slot][1].x, wv[slot][1].y, wv[slot][1].z, wv[slot][1].w};
-        const half8 a = fc8_cvt8(wf);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const float df[8] = {dv[slot][i][0].x * g.gs, dv[slot][i][0].y * g.gs, dv[slot][i][0].z * g.gs, dv[slot][i][0].w * g.gs,
-                                 dv[slot][i][1].x * g.gs, dv[slot][i][1].y * g.gs, dv[slot][i][1].z * g.gs, dv[slot][i][1].w * g.gs};
-            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, fc8_cvt8(df), acc[i], 0, 0, 0);
-        }
-    };
-    load(0, 0);
-    for (int n = 0; n < g.N; n += 32) {
-        load(1, n + 16);
-        mm(0);
-        if (n + 16 < g.N) {
-            load(0, n + 32);
-            mm(1);
+    for (int u = 0; u < NST; ++u) gload(u, u);
+    for (int c = 0; c < nch; c += NST) {
+#pragma unroll
+        for (int u = 0; u < NST; ++u) {
+            lstore(u);
+            gload(u, c + u + NST);
+            __syncthreads();
+            if (c + u < nch) compute();
+            __syncthreads();
         }
     }
     // lane (sample l31 of tile i): registers 0-7 / 8-15 are the cells 8 (hi) / 8 (2 + hi) of the 32 columns
+    const int kbase = kb0 + wk * 32;
     const float tie = g.prm > 0.f ? 1.f + g.prm : 0.f;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int m = m0 + 32 * i + l31;
-        if (m >= g.M) continue;
+    {
+        const int m = m0 + wm * 32 + l31;
+        if (m >= g.M) return;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const size_t o = (size_t)m * g.Kc + kbase + 8 * (2 * h + hi);
@@ -239,7 +267,7 @@ __global__ __launch_bounds__(256) void fc8_dgrad_kernel(FC8 g) {
             half8 o8;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                float v = acc[i][h * 8 + e];
+                float v = acc[h * 8 + e];
                 if (g.ya) {
                     const float y = (float)y8[e];
                     v *= g.act == TN_ACT_LEAKY ? (y > 0.f ? 1.f : (y < 0.f ? g.prm : tie)) : tn_act_grad_from_out(y, g.act, g.prm);
@@ -282,18 +310,20 @@ __global__ __launch_bounds__(256) void fc8_wgrad_kernel(FC8 g) {
     // transposing reads: group of 16 lanes = 4 samples x 16 columns; lane supplies sample r4, columns 4 q .. 4 q + 3
     const int grp = lane >> 4, r4 = (lane >> 2) & 3, q4 = lane & 3;
     const int rd = (8 * (grp >> 1) + r4) * FC8_RS + (16 * (grp & 1) + 4 * q4) * 2;
-    for (int mc = mbeg; mc < mend; mc += 64) {
-        const int m = mc + sr;
-        const bool ok = m < mend;
-        const int mm_ = min(m, g.M - 1);
-        uint4 xv[4];
-        float4 dv[8];
+    uint4 xv[4];
+    float4 dv[8];
+    auto gload = [&](int mc) __attribute__((always_inline)) {      // the chunk's rows as stored (clamped: masked when staged)
+        const int mm_ = min(mc + sr, g.M - 1);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             xv[i] = *reinterpret_cast<const uint4*>(g.x + (size_t)mm_ * g.Kc + min(k0 + sq + 8 * i, g.Kc - 8));
 #pragma unroll
         for (int i = 0; i < 8; ++i)
             dv[i] = *reinterpret_cast<const float4*>(g.dz + (size_t)mm_ * g.N + min(n0 + sq + 4 * i, g.N - 4));
+    };
+    gload(mbeg);
+    for (int mc = mbeg; mc < mend; mc += 64) {
+        const bool ok = mc + sr < mend;
         __syncthreads();                       // the previous chunk's reads are done
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -307,6 +337,7 @@ __global__ __launch_bounds__(256) void fc8_wgrad_kernel(FC8 g) {
             const float f[8] = {dv[i].x * s, dv[i].y * s, dv[i].z * s, dv[i].w * s, dv[i + 1].x * s, dv[i + 1].y * s, dv[i + 1].z * s, dv[i + 1].w * s};
             *reinterpret_cast<half8*>(lds[1] + sr * FC8_RS + (sq + 4 * i) * 2) = fc8_cvt8(f);
         }
+        gload(min(mc + 64, mend - 1));         // the next chunk travels during this chunk's products
         __syncthreads();
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {       // 16 samples per step
@@ -356,10 +387,13 @@ __global__ __launch_bounds__(256) void fc8_wgrad_kernel(FC8 g) {
     }
 }
 
+static unsigned fc8_magic(int HW) { return HW == 1 ? 0u : (unsigned)((1ull << 32) / (unsigned)HW + 1u); }
+
 static int fc8_check(tn_ctx* ctx, int B, int C, int HW, int n_out, const char* what) {
     const int Kc = ((C + 7) / 8) * HW * 8;
     TN_REQUIRE(B > 0 && C > 0 && HW > 0 && n_out > 0, "%s: bad shape", what);
     TN_REQUIRE(Kc % 64 == 0 && n_out % 32 == 0, "%s: %d inputs (c8) and %d outputs must be multiples of 64 / 32", what, Kc, n_out);
+    TN_REQUIRE((uint64_t)(Kc / 8) * (uint64_t)HW < (1ull << 32), "%s: %d x %d inputs: too many", what, C, HW);
     return TN_OK;
 }
 
@@ -380,13 +414,15 @@ int tn_c8_fc_fwd(tn_ctx* ctx, const void* x, const float* W, const float* b, flo
     FC8 g{};
     g.x = static_cast<const _Float16*>(x); g.W = W; g.M = B; g.N = n_out; g.C = C; g.HW = HW;
     g.Kc = ((C + 7) / 8) * HW * 8;
+    g.magic = fc8_magic(HW);
     const int colg = cdiv(n_out, 64), rowg = cdiv(B, 128);
-    // slabs: enough blocks for two waves per SIMD, K ranges of at least 64 per wave
-    int S = cdiv(2 * ctx->num_cus, colg * rowg);
+    // K slabs: two blocks per CU, at least four chunks of 64 columns per block
+    static const int per_cu = getenv("TN_FC8_BPC") ? atoi(getenv("TN_FC8_BPC")) : 1;
+    int S = cdiv(per_cu * ctx->num_cus, colg * rowg);
     if (S > g.Kc / 256) S = g.Kc / 256;
     if (S < 1) S = 1;
-    g.krange = cdiv(cdiv(g.Kc, 4 * S), 16) * 16;
-    S = cdiv(g.Kc, 4 * g.krange);
+    g.krange = cdiv(cdiv(g.Kc, S), 64) * 64;
+    S = cdiv(g.Kc, g.krange);
     g.S = S;
     rc = tn_scratch_get(ctx, (size_t)S * B * n_out * sizeof(float), &g.ws);
     if (rc) return rc;
@@ -408,7 +444,15 @@ int tn_c8_fc_dgrad(tn_ctx* ctx, const float* dz, const float* W, void* dx, int B
     g.dz = dz; g.W = W; g.dx = static_cast<_Float16*>(dx); g.ya = static_cast<const _Float16*>(y);
     g.M = B; g.N = n_out; g.C = C; g.HW = HW; g.Kc = ((C + 7) / 8) * HW * 8;
     g.act = act; g.prm = act_param; g.gs = ctx->grad_scale;
-    fc8_dgrad_kernel<<<dim3(g.Kc / 64, cdiv(B, 128)), 256, 0, ctx->stream>>>(g);
+    g.magic = fc8_magic(HW);
+    g.Np = cdiv(n_out, 64) * 64;
+    _Float16* dz16;
+    rc = tn_scratch_get(ctx, (size_t)B * g.Np * sizeof(_Float16), reinterpret_cast<float**>(&dz16));
+    if (rc) return rc;
+    g.dz16 = dz16;
+    fc8_dz16_kernel<<<cdiv((size_t)B * (g.Np / 4), 256), 256, 0, ctx->stream>>>(dz, dz16, B, n_out, g.Np, g.gs);
+    TN_LAUNCH_CHECK();
+    fc8_dgrad_kernel<4><<<dim3(g.Kc / 64, cdiv(B, 128)), 512, 0, ctx->stream>>>(g);
     TN_LAUNCH_CHECK();
     return TN_OK;
 }
