@@ -282,30 +282,34 @@ __global__ __launch_bounds__(256) void fc_skinny_bwd_pair(
 }
 
 // ---- the whole SoftmaxLayer training step in one launch -----------------------------------------
-// block = SKT_RB rows.  (1) logits on the matrix core + the softmax / NLL tail, twice 16 rows, dlogits
+// block = RB rows.  (1) logits on the matrix core + the softmax / NLL tail, twice 16 rows, dlogits
 // kept in LDS; (2) input gradient of the 32 rows (thread = 4 features, 16 rows); (3) the rows'
 // contribution to the weight gradient on the matrix core: wave w owns the 64-feature groups
 // w, w+4, ... and writes them straight into this block's slab.  h is read from HBM once (the two
 // later passes hit L2), dh is written once, and two kernel boundaries disappear.
-#define SKT_RB 16      // rows per block
-template <int NOUT>
+// RB = rows per block: 16, or 4 for short batches (a 512-image shard of the 8-GPU run, wide6's 128 images): the block's
+// time is a chain of latencies that does not shrink with its rows, so short batches are spread over 4x the blocks
+// (rows 4.. of the 16-row logits tile are duplicates and go nowhere).
+__host__ __device__ inline int sk_train_rb(int B) { return B < 2048 ? 4 : 16; }
+template <int NOUT, int RB>
 __global__ __launch_bounds__(256) void fc_skinny_softmax_train(
     const float* __restrict__ x, const float* __restrict__ W, const float* __restrict__ b,
     float* __restrict__ logits, SkSoftmax sm, float* __restrict__ slab, float* __restrict__ dx, int B,
     int n_in, int act, float prm, const uint8_t* __restrict__ mask, int fuse_act) {
     __shared__ float red[4][256];
-    __shared__ __attribute__((aligned(16))) float sdz[SKT_RB][16];
+    __shared__ __attribute__((aligned(16))) float sdz[RB][16];
+    constexpr int NTILE = RB >= 16 ? RB / 16 : 1;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, lo = lane & 15, qd = lane >> 4;
-    const int base = blockIdx.x * SKT_RB;
+    const int base = blockIdx.x * RB;
     const int nch = (n_in + 15) >> 4;
     const int nc = min(lo, NOUT - 1);
     const bool nlive = lo < NOUT;
     const int64_t yoff = sm.y_row0 + (sm.d_row0 ? *sm.d_row0 : 0);
     const float bias = (b && nlive) ? b[nc] : 0.f;
     // ---- (1) forward ---------------------------------------------------------------------------
-    for (int tile = 0; tile < SKT_RB / 16; ++tile) {
+    for (int tile = 0; tile < NTILE; ++tile) {
         const int rb = base + 16 * tile;
-        const float* xr = x + (size_t)min(rb + lo, B - 1) * n_in;
+        const float* xr = x + (size_t)min(rb + min(lo, RB - 1), B - 1) * n_in;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         for (int c0 = w; c0 < nch; c0 += 4 * SKF_CH) {
             float4 xv[SKF_CH];
@@ -333,7 +337,8 @@ __global__ __launch_bounds__(256) void fc_skinny_softmax_train(
             // the four dependent exp / log / row-reduction chains run side by side (1.75 -> 0.6 us of the block)
             {
                 const int r = w;
-                const int rl = 16 * tile + 4 * qd + r, row = base + rl;
+                const int rl = 16 * tile + 4 * qd + r;
+                const int row = rl < RB ? base + rl : B;         // rows of the tile beyond the block's: nothing is stored
                 const int rowc = min(row, B - 1);
                 const float z = ((red[0][r * 64 + lane] + red[1][r * 64 + lane]) + red[2][r * 64 + lane]) +
                                 red[3][r * 64 + lane] + bias;
@@ -344,7 +349,7 @@ __global__ __launch_bounds__(256) void fc_skinny_softmax_train(
                 const float lp = zv - m - logf(se);
                 const int label = sm.y[yoff + rowc];
                 const float d = (nlive && row < B) ? (expf(lp) - (lo == label ? 1.f : 0.f)) * sm.inv_batch : 0.f;
-                sdz[rl][lo] = d;
+                if (rl < RB) sdz[rl][lo] = d;
                 if (nlive && row < B) {
                     const size_t o = (size_t)row * NOUT + lo;
                     if (logits) logits[o] = z;
@@ -363,6 +368,7 @@ __global__ __launch_bounds__(256) void fc_skinny_softmax_train(
     // ---- (2) input gradient: dx = (dz W^T) * act'(x) * mask  (x IS the output of the layer below) ----
     {
         const int nq = n_in >> 2, half = threadIdx.x >> 7;
+        constexpr int GR = RB / 2 < 8 ? RB / 2 : 8, NG = (RB / 2) / GR;     // rows per half in groups of GR
         for (int q0 = 0; q0 < nq; q0 += 128) {
             const int q = q0 + (threadIdx.x & 127);
             const bool live = q < nq;
@@ -374,27 +380,27 @@ __global__ __launch_bounds__(256) void fc_skinny_softmax_train(
                 wf[4 * i] = v.x; wf[4 * i + 1] = v.y; wf[4 * i + 2] = v.z; wf[4 * i + 3] = v.w;
             }
 #pragma unroll
-            for (int g = 0; g < SKT_RB / 16; ++g) {
-                float4 pa[8];
-                uint32_t pm[8];
+            for (int g = 0; g < NG; ++g) {
+                float4 pa[GR];
+                uint32_t pm[GR];
 #pragma unroll
-                for (int r = 0; r < 8; ++r) {
-                    const size_t o = (size_t)min(base + (SKT_RB / 2) * half + 8 * g + r, B - 1) * n_in + k;
+                for (int r = 0; r < GR; ++r) {
+                    const size_t o = (size_t)min(base + (RB / 2) * half + GR * g + r, B - 1) * n_in + k;
                     pa[r] = fuse_act ? *reinterpret_cast<const float4*>(x + o) : make_float4(0.f, 0.f, 0.f, 0.f);
                     pm[r] = mask ? *reinterpret_cast<const uint32_t*>(mask + o) : 0x01010101u;
                 }
                 // act'(x) of the 8 rows behind ONE test of the activation kind (per element the whole switch of
                 // tn_act_grad_from_out was paid 32 times: 401 scalar branches, 5.5 of the block's 12.6 us)
-                float4 gp[8];
+                float4 gp[GR];
 #pragma unroll
-                for (int r = 0; r < 8; ++r) gp[r] = make_float4(1.f, 1.f, 1.f, 1.f);
+                for (int r = 0; r < GR; ++r) gp[r] = make_float4(1.f, 1.f, 1.f, 1.f);
                 if (fuse_act) {
 #pragma unroll
-                    for (int r = 0; r < 8; ++r) tn_act_grad4(gp[r], pa[r], act, prm);
+                    for (int r = 0; r < GR; ++r) tn_act_grad4(gp[r], pa[r], act, prm);
                 }
 #pragma unroll
-                for (int r = 0; r < 8; ++r) {
-                    const int rl = (SKT_RB / 2) * half + 8 * g + r, row = base + rl;
+                for (int r = 0; r < GR; ++r) {
+                    const int rl = (RB / 2) * half + GR * g + r, row = base + rl;
                     float s[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int n = 0; n < NOUT; ++n) {
@@ -423,12 +429,12 @@ __global__ __launch_bounds__(256) void fc_skinny_softmax_train(
             f32x4 acc[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc[e] = f32x4{0.f, 0.f, 0.f, 0.f};
-            float4 xv[SKT_RB / 4];
+            float4 xv[RB / 4];
 #pragma unroll
-            for (int s2 = 0; s2 < SKT_RB / 4; ++s2)
+            for (int s2 = 0; s2 < RB / 4; ++s2)
                 xv[s2] = *reinterpret_cast<const float4*>(x + (size_t)min(base + 4 * s2 + qd, B - 1) * n_in + kc);
 #pragma unroll
-            for (int s2 = 0; s2 < SKT_RB / 4; ++s2) {
+            for (int s2 = 0; s2 < RB / 4; ++s2) {
                 const float dv = sdz[4 * s2 + qd][lo];         // 0 for rows >= B and classes >= NOUT
                 acc[0] = sk_mfma(real ? xv[s2].x : (ones ? 1.f : 0.f), dv, acc[0]);
                 acc[1] = sk_mfma(real ? xv[s2].y : 0.f, dv, acc[1]);
@@ -522,7 +528,7 @@ int tn_fc_skinny_bwd(tn_ctx* ctx, const float* x, const float* dz, const float* 
     return tn_red_commit(ctx);
 }
 
-// ws must hold cdiv(B, 16) slabs of (n_in + 1) * n_out floats (tn_fc_wgrad_ws_bytes provides it)
+// ws must hold cdiv(B, sk_train_rb(B)) slabs of (n_in + 1) * n_out floats (tn_fc_wgrad_ws_bytes provides it)
 int tn_fc_skinny_softmax_train(tn_ctx* ctx, const float* x, const float* W, const float* b, float* logits,
                                int B, int n_in, int n_out, const int32_t* y, int64_t y_row0,
                                const int64_t* d_row0, float* logprob, float* rowloss, int32_t* pred,
@@ -531,11 +537,15 @@ int tn_fc_skinny_softmax_train(tn_ctx* ctx, const float* x, const float* W, cons
     SkSoftmax sm{};
     sm.y = y; sm.y_row0 = y_row0; sm.d_row0 = d_row0; sm.logprob = logprob; sm.rowloss = rowloss;
     sm.pred = pred; sm.rowp = rowp; sm.dz = dz; sm.inv_batch = inv_batch;
-    const int S = cdiv(B, SKT_RB);
+    const int rb = sk_train_rb(B), S = cdiv(B, rb);
 #define SKT_GO(N_)                                                                              \
     case N_:                                                                                    \
-        fc_skinny_softmax_train<N_><<<S, 256, 0, ctx->stream>>>(x, W, b, logits, sm, ws, dx, B, n_in, act, \
-                                                                prm, mask, fuse_act);           \
+        if (rb == 4)                                                                            \
+            fc_skinny_softmax_train<N_, 4><<<S, 256, 0, ctx->stream>>>(x, W, b, logits, sm, ws, dx, B, n_in, act, \
+                                                                       prm, mask, fuse_act);    \
+        else                                                                                    \
+            fc_skinny_softmax_train<N_, 16><<<S, 256, 0, ctx->stream>>>(x, W, b, logits, sm, ws, dx, B, n_in, act, \
+                                                                        prm, mask, fuse_act);   \
         break
     switch (n_out) {
         SKT_GO(1); SKT_GO(2); SKT_GO(3); SKT_GO(4); SKT_GO(5); SKT_GO(6); SKT_GO(7); SKT_GO(8);

@@ -1155,7 +1155,7 @@ size_t tn_fc_wgrad_ws_bytes(int B, int n_in, int n_out) {
     if (n_out <= SK_MAX) {
         const int chunks = cdiv(B, SK_WROWS);
         const size_t a = ((size_t)chunks * n_in * n_out + (size_t)chunks * n_out) * sizeof(float) + 64;
-        const size_t t = (size_t)cdiv(B, 16) * (n_in + 1) * n_out * sizeof(float) + 64;   // softmax_train slabs
+        const size_t t = (size_t)cdiv(B, B < 2048 ? 4 : 16) * (n_in + 1) * n_out * sizeof(float) + 64;   // softmax_train slabs (fc_skinny.hip sk_train_rb)
         return a > t ? a : t;
     }
     const int S = wgrad_splits(B, n_in, n_out);
