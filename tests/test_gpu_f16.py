@@ -286,3 +286,51 @@ def test_full_size_wide6_64x64_b128(dtype):
 def test_full_size_cifar_like_b2048(dtype):
     """BASELINE.json configs[3] at its stated size: 32x32x3, 2048 images, elastic stage on."""
     _full_size("cifar_like.prms", 32, 2048, 32, dtype, 12)
+
+
+def _directional_derivative(name, img, B, dtype, tol):
+    """Every gradient of a full-size step through a size-independent property: along the direction D = the step's own
+    gradient (all parameters), the training cost must change by |g|^2 per unit step -- (cost(W + eps D) - cost(W - eps D))
+    / 2 eps against sum(g^2), with the distortion field and the dropout masks of the step held fixed (same stream
+    seeds, same step counter).  The gradient is read back as the velocity after one step from rest, v = (1 - m) g
+    (layer.py:82-84)."""
+    from theanet_amd import NeuralNet
+    prms = load_prms(name, img, batch=B)
+    tr = dict(prms["training_params"], DTYPE=dtype, GRAD_SCALE=GS)
+    x = np.random.default_rng(3).random((2 * B, 3, img, img), dtype=np.float32)
+    y = np.random.default_rng(4).integers(0, 10, 2 * B).astype(np.int32)
+    base = NeuralNet(copy.deepcopy(prms["layers"]), dict(tr))
+    p0 = base.get_init_params(with_opt_state=True)
+    W0, st0 = p0["allwts"], p0["opt_state"]
+    c0 = float(base.get_trin_model(x, y)(0)[0])
+    vel = base.get_init_params(with_opt_state=True)["opt_state"]["velocities"]
+    g = [[np.asarray(v, np.float64) / (1.0 - lyr.reg['momentum']) for v in row] if lyr.has_updates() else
+         [np.zeros_like(w, np.float64) for w in ws] for lyr, row, ws in zip(base.tr_layers, vel, W0)]
+    gg = sum(float((a * a).sum()) for row in g for a in row)
+    assert np.isfinite(gg) and gg > 0
+    eps = 0.02 / gg                                    # the cost moves by about +-0.02
+
+    def cost_at(sign):
+        W = [[(w.astype(np.float64) + sign * eps * a).astype(np.float32) for w, a in zip(ws, row)] for ws, row in zip(W0, g)]
+        net = NeuralNet(copy.deepcopy(prms["layers"]), dict(tr), allwts=W)
+        net.load_opt_state(st0)
+        return float(net.get_trin_model(x, y)(0)[0])
+
+    assert abs(cost_at(0) - c0) <= 1e-6 * abs(c0), "the rebuilt net does not repeat the step"
+    fd = (cost_at(+1) - cost_at(-1)) / (2 * eps)
+    assert abs(fd - gg) <= tol * gg, "%s %s: directional derivative %.6g, |g|^2 %.6g" % (name, dtype, fd, gg)
+
+
+@pytest.mark.parametrize("dtype,tol", [("float32", 5e-3), ("float16", 1e-2)])
+def test_full_size_gradients_wide6_64x64_b128(dtype, tol):
+    _directional_derivative("wide6.prms", 64, 128, dtype, tol)
+
+
+@pytest.mark.parametrize("dtype,tol", [("float32", 5e-3), ("float16", 1e-2)])
+def test_full_size_gradients_cifar_like_b2048(dtype, tol):
+    _directional_derivative("cifar_like.prms", 32, 2048, dtype, tol)
+
+
+def test_full_size_wide6_64x64_b1024_on_one_gpu():
+    """BASELINE.json configs[4] as stated for the node (bs 1024) on ONE GPU, fp16-resident."""
+    _full_size("wide6.prms", 64, 1024, 4, "float16", 8)

@@ -498,7 +498,9 @@ static int launch_bwd_mask(tn_ctx* ctx, const float* x, const float* g, const fl
                            int K, int pad, int Ho, int Wo, int Hp, int Wp, int act, float prm) {
     const long long total = (long long)N * Hp * Wp;
     TN_REQUIRE(total < (1ll << 31), "tn_convpool_bwd_mask: too many outputs for 32-bit indexing");
-    int nblk = cdiv(total, 256 * tn_tune_mwin());      // windows per thread
+    int mwin = tn_tune_mwin();                          // windows per thread ...
+    while (mwin > 1 && cdiv(total, 256 * mwin) < 2 * ctx->num_cus) mwin >>= 1;   // ... fewer for short batches (a 512-image shard: 85 blocks otherwise)
+    int nblk = cdiv(total, 256 * mwin);
     if (nblk > 2048) nblk = 2048;
     if (nblk < 1) nblk = 1;
     const size_t KCFF = (size_t)K * C * 9;
