@@ -397,7 +397,7 @@ int tn_defer_reductions(tn_ctx* ctx, int on);
 /* tn_defer_reductions(ctx, 0) that also advances a device counter (the RNG step counter) in the same
  * launch, so that everything enqueued afterwards already sees the next step's value.            */
 int tn_defer_flush_step(tn_ctx* ctx, uint32_t* d_step);
-/* A pipelined step may leave its window open (tn_sgd_update_multi_pipe closes it a step later; the window
+/* A pipelined step may leave its window open (tn_sgd_update_net in TN_UPD_PIPE mode closes it a step later; the window
  * travels with its stream across tn_stream_select).  tn_defer_discard forgets the recorded sums of both
  * streams without running them -- for windows whose owner (its gradient buffers) is gone.               */
 int tn_defer_discard(tn_ctx* ctx);
@@ -420,8 +420,32 @@ typedef struct tn_mn_seg {
     float maxnorm;
 } tn_mn_seg;
 int tn_maxnorm_multi(tn_ctx* ctx, const tn_mn_seg* h_segs, int nseg);
-/* The same update for EVERY parameter tensor of the net in one launch.  d_segs = device
- * array of nseg descriptors; max_n = largest n among them (sizes the grid).               */
+/* The update of EVERY parameter tensor of the net in one launch, in the form the step's schedule needs -- ONE entry
+ * point, `mode` selects the form (all of them: Layer.get_updates, layer.py:70-107, bit-identical weight trajectories):
+ *
+ *   TN_UPD_PLAIN    d_segs = device array of nseg tn_sgd_seg; max_n = largest n among them (sizes the grid).
+ *                   g' = g*gscale + L1*sign(p) + 2*L2*p ; v_new = m*v + (1-m)*g' ; p_new = p - rate*lr*v_OLD.
+ *   TN_UPD_LAZY     PLAIN that also ENDS a tn_defer_reductions window: a segment whose gradient is still a stack of
+ *                   deferred partial slabs sums them on the fly (same order as the reduction launch), stores the
+ *                   gradient and applies the update -- one launch less per step.  h_segs = HOST copy of d_segs (matches
+ *                   pending sums to segments; the others are finished by the ordinary reduction launch first).
+ *                   nseg <= 32.
+ *   TN_UPD_DELAYED  data-parallel "delayed" schedule: layer.py:82-86 applies the OLD velocity, so the weights of step
+ *                   t+1 do not depend on the gradient of step t and its all-reduce may overlap the whole next step.
+ *                   seg.g = the REDUCED gradient of the PREVIOUS step; flags 1: v = m v + (1-m) g, then p -= rate*lr*v
+ *                   (steady state); 2: p only (first delayed step); 3: v only (leaving the schedule).  No L1 / L2
+ *                   terms (they need the weights the gradient was taken at), no cost rider.
+ *   TN_UPD_PIPE     pipelined single-GPU schedule: two steps in flight on the context's two streams, each with its own
+ *                   weights / activations / gradients.  d_segs / h_segs = tn_pipe_seg (device array / host copy or
+ *                   NULL): p = the stepping stream's own copy, psrc = the other stream's copy (p_{t-1}, read-only
+ *                   there), g = the stepping stream's gradient of two steps ago, v shared; flags bit 0 = update v (0
+ *                   for the first two steps: no gradient yet).  Also CLOSES the stream's parked tn_defer_reductions
+ *                   window like TN_UPD_LAZY (h_segs != NULL, nseg <= 32).  gscale is not used.
+ *
+ * d_step != NULL: *d_step += step_inc in the same launch (the RNG step counter; step_inc must be 1 outside
+ * TN_UPD_PIPE).  rowloss != NULL: one more block computes *d_cost = cost_scale * sum(rowloss[0:nrow]) in a fixed order
+ * -- the minibatch cost tt.mean(nll) of outlayers.py:50-51 (TN_UPD_PIPE: of the stream's PREVIOUS step) -- instead
+ * of a reduction kernel of its own; with nseg == 0 the launch is that block alone.                                 */
 typedef struct tn_sgd_seg {
     float* p;
     float* v;
@@ -429,30 +453,6 @@ typedef struct tn_sgd_seg {
     uint64_t n;
     float momentum, rate, L1, L2;
 } tn_sgd_seg;
-int tn_sgd_update_multi(tn_ctx* ctx, const tn_sgd_seg* d_segs, int nseg, size_t max_n,
-                        const float* d_lr, float gscale, uint32_t* d_step_inc /* ++ if not NULL */);
-/* ... with a rider: *d_cost = cost_scale * sum(rowloss[0:nrow]) (fixed summation order), the
- * minibatch cost tt.mean(nll) of outlayers.py:50-51, computed by one extra block of the same
- * launch instead of a reduction kernel of its own.  rowloss == NULL: no rider.            */
-int tn_sgd_update_multi_cost(tn_ctx* ctx, const tn_sgd_seg* d_segs, int nseg, size_t max_n,
-                             const float* d_lr, float gscale, uint32_t* d_step_inc,
-                             const float* rowloss, int nrow, float cost_scale, float* d_cost);
-
-/* Update for the data-parallel "delayed" schedule.  layer.py:82-86 applies the OLD velocity
- * (p' = p - rate*lr*v, v' = m v + (1-m) g), so the weights of step t+1 do not depend on the gradient
- * of step t and its all-reduce may overlap the whole next step.  seg.g points at the REDUCED gradient
- * of the PREVIOUS step; mode 1: v = m v + (1-m) g, then p -= rate*lr*v (steady state); mode 2: p only
- * (first delayed step); mode 3: v only (leaving the schedule).  No L1/L2 terms (they need the weights
- * the gradient was taken at).  Same weight trajectory as tn_sgd_update_multi, bit for bit.        */
-int tn_sgd_update_multi_delayed(tn_ctx* ctx, const tn_sgd_seg* d_segs, int nseg, size_t max_n,
-                                const float* d_lr, float gscale, uint32_t* d_step_inc, int mode);
-
-/* Update of the PIPELINED single-GPU schedule: two training steps are in flight on the context's two
- * streams, each with its own weights / activations / gradients.  layer.py:82-86 applies the old
- * velocity, so the weights of step t are p_{t-1} - rate*lr*v_{t-1} with v_{t-1} built from the gradient
- * of step t-2: p = the stepping stream's own copy, psrc = the other stream's copy (p_{t-1}, read-only
- * there), g = the stepping stream's gradient of two steps ago, v shared.  update_v = 0 for the first
- * two steps (no gradient yet).  *d_step += step_inc (the stream's RNG step counter).          */
 typedef struct tn_pipe_seg {
     float* p;
     const float* psrc;
@@ -461,25 +461,13 @@ typedef struct tn_pipe_seg {
     uint64_t n;
     float momentum, rate;
 } tn_pipe_seg;
-int tn_sgd_update_multi_pipe(tn_ctx* ctx, const tn_pipe_seg* d_segs, const tn_pipe_seg* h_segs, int nseg, size_t max_n,
-                             const float* d_lr, uint32_t* d_step, uint32_t step_inc, int update_v,
-                             const float* rowloss, int nrow, float cost_scale, float* d_cost);
-/* ... which also CLOSES the stream's parked tn_defer_reductions window: a pipelined step leaves its weight-
- * gradient slabs pending (no reduction launch at its end); this launch, which opens the same stream's next
- * step, adds them up on the fly (same order as the reduction launch: bit-identical), stores the gradient and
- * applies the update.  h_segs = host copy of d_segs (matches pending sums to segments; NULL: no folding).
- * rowloss != NULL: one more block row computes *d_cost = cost_scale * sum(rowloss[0:nrow]) -- the cost of the
- * stream's PREVIOUS step (outlayers.py:50-51), in the fixed order of tn_sgd_update_multi_cost's rider.     */
-
-/* tn_sgd_update_multi_cost that also ENDS a tn_defer_reductions window: a segment whose gradient is
- * still a stack of deferred partial slabs sums them on the fly (same order as the reduction launch:
- * bit-identical), stores the gradient and applies the update -- one launch less per step.  h_segs is
- * the host copy of d_segs (used to match pending sums to segments); pending sums that belong to no
- * segment are finished by the ordinary reduction launch first.  nseg <= 32 (TN_LAZY_SEGS); the pipelined
- * form takes any nseg and folds nothing in beyond that (the reduction launch finishes those sums).    */
-int tn_sgd_update_multi_lazy(tn_ctx* ctx, const tn_sgd_seg* d_segs, const tn_sgd_seg* h_segs, int nseg,
-                             size_t max_n, const float* d_lr, float gscale, uint32_t* d_step_inc,
-                             const float* rowloss, int nrow, float cost_scale, float* d_cost);
+#define TN_UPD_PLAIN 0
+#define TN_UPD_LAZY 1
+#define TN_UPD_DELAYED 2
+#define TN_UPD_PIPE 3
+int tn_sgd_update_net(tn_ctx* ctx, int mode, const void* d_segs, const void* h_segs, int nseg, size_t max_n,
+                      const float* d_lr, float gscale, uint32_t* d_step, uint32_t step_inc, int flags,
+                      const float* rowloss, int nrow, float cost_scale, float* d_cost);
 
 /* ---- elastic input stage (replaces ElasticLayer's graph; inlayers.py:63-144) ----
  * draws layout (float32, device): [0:2] translation u(-1,1) ; [2:4] origin u(.25,.75) ;
@@ -530,7 +518,7 @@ int tn_rider_elastic_field(tn_ctx* ctx, float* draws_out, uint64_t seed, uint32_
                            float* map_fy, float* map_fx, double* target);
 int tn_rider_pending(tn_ctx* ctx);
 int tn_rider_cancel(tn_ctx* ctx);
-/* The closing launch of a training step: tn_sgd_update_multi_cost (without the counter increment)
+/* The closing launch of a training step: tn_sgd_update_net in TN_UPD_PLAIN mode (without the counter increment)
  * and tn_elastic_field_gen for the NEXT minibatch side by side in one kernel -- the field depends only
  * on *d_step, which the caller has already advanced (tn_defer_flush_step).  Arguments as in the two. */
 int tn_step_tail(tn_ctx* ctx, const tn_sgd_seg* d_segs, int nseg, size_t max_n, const float* d_lr,

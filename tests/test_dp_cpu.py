@@ -73,7 +73,7 @@ def test_world_size_2_gradient_allreduce_equals_full_batch(tmp_path):
 
 
 def test_delayed_update_recurrence_is_the_reference_recurrence():
-    """The data-parallel 'delayed' schedule (NeuralNet._train_step, tn_sgd_update_multi_delayed): the
+    """The data-parallel 'delayed' schedule (NeuralNet._train_step, tn_sgd_update_net in TN_UPD_DELAYED mode): the
     reference's update applies the OLD velocity (layer.py:82-86), so p_{t+1} only needs the gradient of
     step t-1.  Updating at the end of step t with the reduced gradient of step t-1 (mode 2 on the first
     step, mode 1 afterwards, mode 3 when leaving) must reproduce the reference weights exactly."""

@@ -711,7 +711,7 @@ def test_graph_capture_of_abi_ops():
 @pytest.mark.parametrize("name,img,ch,B", [("mnist.prms", 28, 1, 64), ("cifar_like.prms", 32, 3, 16)])
 def test_fused_step_equals_separate_launches(monkeypatch, name, img, ch, B):
     """The sequential step's fusions -- weight-gradient slab sums and the minibatch cost inside the update launch
-    (tn_sgd_update_multi_lazy), the next minibatch's elastic field riding in the
+    (tn_sgd_update_net, TN_UPD_LAZY), the next minibatch's elastic field riding in the
     paired GEMM launch or built beside the update (tn_step_tail) -- are pure re-scheduling: against the generic
     schedule (NeuralNet.fused_step = False: one launch per piece of work) costs, log-probabilities, gradients and
     weights match bit for bit."""

@@ -27,6 +27,7 @@ def backend():
 
 TN_ACT_LINEAR, TN_ACT_LEAKY, TN_ACT_TANH, TN_ACT_SIGMOID, TN_ACT_SOFTPLUS, TN_ACT_SCALED_TANH = range(6)
 TN_UNIQUE_ID_BYTES = 128
+TN_UPD_PLAIN, TN_UPD_LAZY, TN_UPD_DELAYED, TN_UPD_PIPE = range(4)     # modes of tn_sgd_update_net
 
 P = c_void_p          # device or host pointer passed as integer
 CTX = c_void_p
@@ -134,11 +135,7 @@ SIGNATURES = {
     "tn_step_tail": (c_int, [CTX, P, c_int, c_size_t, P, c_float, P, c_int, c_float, P,
                              P, c_uint64, P, c_int, c_int, c_double, c_double, c_double, c_int, c_double,
                              c_int, P, P, P, P]),
-    "tn_sgd_update_multi": (c_int, [CTX, P, c_int, c_size_t, P, c_float, P]),
-    "tn_sgd_update_multi_delayed": (c_int, [CTX, P, c_int, c_size_t, P, c_float, P, c_int]),
-    "tn_sgd_update_multi_pipe": (c_int, [CTX, P, P, c_int, c_size_t, P, P, c_uint32, c_int, P, c_int, c_float, P]),
-    "tn_sgd_update_multi_lazy": (c_int, [CTX, P, P, c_int, c_size_t, P, c_float, P, P, c_int, c_float, P]),
-    "tn_sgd_update_multi_cost": (c_int, [CTX, P, c_int, c_size_t, P, c_float, P, P, c_int, c_float, P]),
+    "tn_sgd_update_net": (c_int, [CTX, c_int, P, P, c_int, c_size_t, P, c_float, P, c_uint32, c_int, P, c_int, c_float, P]),
     "tn_softmax_cost_ws_bytes": (c_size_t, [c_int]),
     "tn_softmax_nll_cost": (c_int, [CTX, P, P, c_int64, P, P, P, P, P, P, c_int, c_int, c_float,
                                     c_float, P, P]),

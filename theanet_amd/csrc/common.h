@@ -64,7 +64,7 @@ struct tn_ctx {
     void* tmp[2] = {nullptr, nullptr};             // per stream: a tensor that lives from one launch to the next (tn_tmp_get)
     size_t tmp_bytes[2] = {0, 0};
     // ... and its parked deferral window: a pipelined step leaves its slab sums pending, the update that
-    // opens the stream's NEXT step folds them in (tn_sgd_update_multi_pipe)
+    // opens the stream's NEXT step folds them in (tn_sgd_update_net, TN_UPD_PIPE)
     bool defer_slot[2] = {false, false};
     size_t scratch_off_slot[2] = {0, 0};
     int npend_slot[2] = {0, 0};

@@ -473,7 +473,7 @@ int tn_step_tail(tn_ctx* ctx, const tn_sgd_seg* d_segs, int nseg, size_t max_n, 
     const int ks = 2 * sigma + 1;
     const size_t lds = ((size_t)ks * ks + tn_elastic_draws_count(h, w) + 16) * sizeof(float);
     if (lds > 48 * 1024) {      // the field does not fit beside the update: two launches
-        int rc = tn_sgd_update_multi_cost(ctx, d_segs, nseg, max_n, d_lr, gscale, nullptr, rowloss, nrow,
+        int rc = tn_sgd_update_net(ctx, TN_UPD_PLAIN, d_segs, nullptr, nseg, max_n, d_lr, gscale, nullptr, 0, 0, rowloss, nrow,
                                           cost_scale, d_cost);
         if (rc) return rc;
         return tn_elastic_field_gen(ctx, draws_out, seed, 0, d_step, h, w, translation, zoom, magnitude,

@@ -496,19 +496,14 @@ int tn_sgd_update(tn_ctx* ctx, float* p, float* v, const float* g, size_t n, flo
     return TN_OK;
 }
 
-int tn_sgd_update_multi(tn_ctx* ctx, const tn_sgd_seg* d_segs, int nseg, size_t max_n,
-                        const float* d_lr, float gscale, uint32_t* d_step_inc) {
-    return tn_sgd_update_multi_cost(ctx, d_segs, nseg, max_n, d_lr, gscale, d_step_inc, nullptr, 0, 0.f,
-                                    nullptr);
-}
 
-int tn_sgd_update_multi_cost(tn_ctx* ctx, const tn_sgd_seg* d_segs, int nseg, size_t max_n,
+static int upd_cost(tn_ctx* ctx, const tn_sgd_seg* d_segs, int nseg, size_t max_n,
                              const float* d_lr, float gscale, uint32_t* d_step_inc,
                              const float* rowloss, int nrow, float cost_scale, float* d_cost) {
     const bool rider = rowloss != nullptr;
     if (nseg <= 0 && !rider) return TN_OK;
-    TN_REQUIRE(nseg <= 0 || (d_segs != nullptr && d_lr != nullptr), "tn_sgd_update_multi: NULL argument");
-    TN_REQUIRE(!rider || (d_cost != nullptr && nrow > 0), "tn_sgd_update_multi_cost: bad cost arguments");
+    TN_REQUIRE(nseg <= 0 || (d_segs != nullptr && d_lr != nullptr), "tn_sgd_update_net: NULL argument");
+    TN_REQUIRE(!rider || (d_cost != nullptr && nrow > 0), "tn_sgd_update_net (cost): bad cost arguments");
     if (nseg < 0) nseg = 0;
     int bx = cdiv(max_n, 1024);
     if (bx > 2048) bx = 2048;
@@ -519,9 +514,9 @@ int tn_sgd_update_multi_cost(tn_ctx* ctx, const tn_sgd_seg* d_segs, int nseg, si
     return TN_OK;
 }
 
-int tn_sgd_update_multi_delayed(tn_ctx* ctx, const tn_sgd_seg* d_segs, int nseg, size_t max_n,
+static int upd_delayed(tn_ctx* ctx, const tn_sgd_seg* d_segs, int nseg, size_t max_n,
                                 const float* d_lr, float gscale, uint32_t* d_step_inc, int mode) {
-    TN_REQUIRE(nseg > 0 && d_segs && d_lr && mode >= 1 && mode <= 3, "tn_sgd_update_multi_delayed: bad arguments");
+    TN_REQUIRE(nseg > 0 && d_segs && d_lr && mode >= 1 && mode <= 3, "tn_sgd_update_net (delayed): bad arguments");
     int bx = cdiv(max_n, 1024);
     if (bx > 2048) bx = 2048;
     if (bx < 1) bx = 1;
@@ -530,12 +525,12 @@ int tn_sgd_update_multi_delayed(tn_ctx* ctx, const tn_sgd_seg* d_segs, int nseg,
     return TN_OK;
 }
 
-int tn_sgd_update_multi_pipe(tn_ctx* ctx, const tn_pipe_seg* d_segs, const tn_pipe_seg* h_segs, int nseg, size_t max_n,
+static int upd_pipe(tn_ctx* ctx, const tn_pipe_seg* d_segs, const tn_pipe_seg* h_segs, int nseg, size_t max_n,
                              const float* d_lr, uint32_t* d_step, uint32_t step_inc, int update_v,
                              const float* rowloss, int nrow, float cost_scale, float* d_cost) {
-    TN_REQUIRE(nseg > 0 && d_segs && d_lr, "tn_sgd_update_multi_pipe: bad arguments");
+    TN_REQUIRE(nseg > 0 && d_segs && d_lr, "tn_sgd_update_net (pipe): bad arguments");
     const bool rider = rowloss != nullptr;
-    TN_REQUIRE(!rider || (d_cost != nullptr && nrow > 0), "tn_sgd_update_multi_pipe: bad cost arguments");
+    TN_REQUIRE(!rider || (d_cost != nullptr && nrow > 0), "tn_sgd_update_net (pipe): bad cost arguments");
     int bx = cdiv(max_n, 1024);
     if (bx > 2048) bx = 2048;
     if (bx < 1) bx = 1;
@@ -572,12 +567,12 @@ int tn_sgd_update_multi_pipe(tn_ctx* ctx, const tn_pipe_seg* d_segs, const tn_pi
     return TN_OK;
 }
 
-int tn_sgd_update_multi_lazy(tn_ctx* ctx, const tn_sgd_seg* d_segs, const tn_sgd_seg* h_segs, int nseg,
+static int upd_lazy(tn_ctx* ctx, const tn_sgd_seg* d_segs, const tn_sgd_seg* h_segs, int nseg,
                              size_t max_n, const float* d_lr, float gscale, uint32_t* d_step_inc,
                              const float* rowloss, int nrow, float cost_scale, float* d_cost) {
-    TN_REQUIRE(nseg > 0 && nseg <= TN_LAZY_SEGS && d_segs && h_segs && d_lr, "tn_sgd_update_multi_lazy: bad arguments");
+    TN_REQUIRE(nseg > 0 && nseg <= TN_LAZY_SEGS && d_segs && h_segs && d_lr, "tn_sgd_update_net (lazy): bad arguments");
     const bool rider = rowloss != nullptr;
-    TN_REQUIRE(!rider || (d_cost != nullptr && nrow > 0), "tn_sgd_update_multi_lazy: bad cost arguments");
+    TN_REQUIRE(!rider || (d_cost != nullptr && nrow > 0), "tn_sgd_update_net (lazy): bad cost arguments");
     // pending slab sums whose output is the gradient of one of the segments are folded into the update;
     // the others (and everything when deferral is off) are finished by the ordinary reduction launch
     LazyBatch lb{};
@@ -600,7 +595,7 @@ int tn_sgd_update_multi_lazy(tn_ctx* ctx, const tn_sgd_seg* d_segs, const tn_sgd
     if (rc) return rc;
     ctx->scratch_off = 0;
     if (nlazy == 0)
-        return tn_sgd_update_multi_cost(ctx, d_segs, nseg, max_n, d_lr, gscale, d_step_inc, rowloss, nrow,
+        return upd_cost(ctx, d_segs, nseg, max_n, d_lr, gscale, d_step_inc, rowloss, nrow,
                                         cost_scale, d_cost);
     int bx = cdiv(max_n, 1024);
     if (bx > 2048) bx = 2048;
@@ -609,6 +604,30 @@ int tn_sgd_update_multi_lazy(tn_ctx* ctx, const tn_sgd_seg* d_segs, const tn_sgd
         d_segs, nseg, d_lr, gscale, d_step_inc, rowloss, nrow, cost_scale, d_cost, lb);
     TN_LAUNCH_CHECK();
     return TN_OK;
+}
+
+// The one update entry point of a step (include/theanet_hip.h): mode selects the schedule's form
+int tn_sgd_update_net(tn_ctx* ctx, int mode, const void* d_segs, const void* h_segs, int nseg, size_t max_n,
+                      const float* d_lr, float gscale, uint32_t* d_step, uint32_t step_inc, int flags,
+                      const float* rowloss, int nrow, float cost_scale, float* d_cost) {
+    TN_REQUIRE(mode == TN_UPD_PIPE || d_step == nullptr || step_inc == 1,
+               "tn_sgd_update_net: the step counter advances by one outside the pipelined schedule");
+    switch (mode) {
+        case TN_UPD_PLAIN:
+            return upd_cost(ctx, static_cast<const tn_sgd_seg*>(d_segs), nseg, max_n, d_lr, gscale, d_step, rowloss, nrow,
+                            cost_scale, d_cost);
+        case TN_UPD_LAZY:
+            return upd_lazy(ctx, static_cast<const tn_sgd_seg*>(d_segs), static_cast<const tn_sgd_seg*>(h_segs), nseg, max_n,
+                            d_lr, gscale, d_step, rowloss, nrow, cost_scale, d_cost);
+        case TN_UPD_DELAYED:
+            TN_REQUIRE(rowloss == nullptr, "tn_sgd_update_net (delayed): no cost rider in this mode");
+            return upd_delayed(ctx, static_cast<const tn_sgd_seg*>(d_segs), nseg, max_n, d_lr, gscale, d_step, flags);
+        case TN_UPD_PIPE:
+            return upd_pipe(ctx, static_cast<const tn_pipe_seg*>(d_segs), static_cast<const tn_pipe_seg*>(h_segs), nseg, max_n,
+                            d_lr, d_step, step_inc, flags & 1, rowloss, nrow, cost_scale, d_cost);
+        default:
+            return tn_fail(ctx, TN_E_ARG, "tn_sgd_update_net: mode %d", mode);
+    }
 }
 
 int tn_maxnorm(tn_ctx* ctx, float* p, int ndim, int d0, int rest, float maxnorm) {

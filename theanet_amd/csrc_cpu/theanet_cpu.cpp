@@ -770,26 +770,17 @@ int tn_maxnorm(tn_ctx* ctx, float* p, int ndim, int d0, int rest, float maxnorm)
     }
     return TN_OK;
 }
-int tn_sgd_update_multi_cost(tn_ctx* ctx, const tn_sgd_seg* segs, int nseg, size_t, const float* d_lr, float gscale,
-                             uint32_t* d_step_inc, const float* rowloss, int nrow, float cost_scale, float* d_cost) {
+static int upd_cost(tn_ctx* ctx, const tn_sgd_seg* segs, int nseg, const float* d_lr, float gscale, uint32_t* d_step_inc,
+                    const float* rowloss, int nrow, float cost_scale, float* d_cost) {
     for (int s = 0; s < nseg; ++s)
         sgd_seg(segs[s].p, segs[s].v, segs[s].g, segs[s].n, segs[s].momentum, segs[s].rate, d_lr[0], segs[s].L1, segs[s].L2, gscale);
     if (d_step_inc) *d_step_inc += 1;
     if (rowloss) return tn_reduce_sum(ctx, rowloss, nrow, cost_scale, d_cost, 0);
     return TN_OK;
 }
-int tn_sgd_update_multi(tn_ctx* ctx, const tn_sgd_seg* segs, int nseg, size_t max_n, const float* d_lr, float gscale,
-                        uint32_t* d_step_inc) {
-    return tn_sgd_update_multi_cost(ctx, segs, nseg, max_n, d_lr, gscale, d_step_inc, nullptr, 0, 0.f, nullptr);
-}
-int tn_sgd_update_multi_lazy(tn_ctx* ctx, const tn_sgd_seg* d_segs, const tn_sgd_seg*, int nseg, size_t max_n,
-                             const float* d_lr, float gscale, uint32_t* d_step_inc, const float* rowloss, int nrow,
-                             float cost_scale, float* d_cost) {
-    return tn_sgd_update_multi_cost(ctx, d_segs, nseg, max_n, d_lr, gscale, d_step_inc, rowloss, nrow, cost_scale, d_cost);
-}
-int tn_sgd_update_multi_delayed(tn_ctx* ctx, const tn_sgd_seg* segs, int nseg, size_t, const float* d_lr, float gscale,
-                                uint32_t* d_step_inc, int mode) {
-    REQUIRE(nseg > 0 && segs && d_lr && mode >= 1 && mode <= 3, "tn_sgd_update_multi_delayed: bad arguments");
+static int upd_delayed(tn_ctx* ctx, const tn_sgd_seg* segs, int nseg, const float* d_lr, float gscale, uint32_t* d_step_inc,
+                       int mode) {
+    REQUIRE(nseg > 0 && segs && d_lr && mode >= 1 && mode <= 3, "tn_sgd_update_net (delayed): bad arguments");
     for (int s = 0; s < nseg; ++s) {
         const tn_sgd_seg& sg = segs[s];
         const float step = sg.rate * d_lr[0], m = sg.momentum;
@@ -803,10 +794,9 @@ int tn_sgd_update_multi_delayed(tn_ctx* ctx, const tn_sgd_seg* segs, int nseg, s
     if (d_step_inc) *d_step_inc += 1;
     return TN_OK;
 }
-int tn_sgd_update_multi_pipe(tn_ctx* ctx, const tn_pipe_seg* segs, const tn_pipe_seg*, int nseg, size_t, const float* d_lr,
-                             uint32_t* d_step, uint32_t step_inc, int update_v, const float* rowloss, int nrow,
-                             float cost_scale, float* d_cost) {
-    REQUIRE(nseg > 0 && segs && d_lr, "tn_sgd_update_multi_pipe: bad arguments");
+static int upd_pipe(tn_ctx* ctx, const tn_pipe_seg* segs, int nseg, const float* d_lr, uint32_t* d_step, uint32_t step_inc,
+                    int update_v, const float* rowloss, int nrow, float cost_scale, float* d_cost) {
+    REQUIRE(nseg > 0 && segs && d_lr, "tn_sgd_update_net (pipe): bad arguments");
     if (rowloss) tn_reduce_sum(ctx, rowloss, nrow, cost_scale, d_cost, 0);      // the previous step's cost
     for (int s = 0; s < nseg; ++s) {
         const tn_pipe_seg& sg = segs[s];
@@ -820,6 +810,28 @@ int tn_sgd_update_multi_pipe(tn_ctx* ctx, const tn_pipe_seg* segs, const tn_pipe
     }
     if (d_step) *d_step += step_inc;
     return TN_OK;
+}
+// one entry point, the schedule's form in `mode` (this library finishes every slab sum where it is produced: LAZY == PLAIN)
+int tn_sgd_update_net(tn_ctx* ctx, int mode, const void* d_segs, const void*, int nseg, size_t, const float* d_lr, float gscale,
+                      uint32_t* d_step, uint32_t step_inc, int flags, const float* rowloss, int nrow, float cost_scale,
+                      float* d_cost) {
+    REQUIRE(mode == TN_UPD_PIPE || d_step == nullptr || step_inc == 1,
+            "tn_sgd_update_net: the step counter advances by one outside the pipelined schedule");
+    switch (mode) {
+        case TN_UPD_PLAIN:
+        case TN_UPD_LAZY:
+            REQUIRE((nseg <= 0 || (d_segs && d_lr)) && (!rowloss || (d_cost && nrow > 0)), "tn_sgd_update_net: bad arguments");
+            return upd_cost(ctx, static_cast<const tn_sgd_seg*>(d_segs), nseg < 0 ? 0 : nseg, d_lr, gscale, d_step, rowloss, nrow,
+                            cost_scale, d_cost);
+        case TN_UPD_DELAYED:
+            REQUIRE(rowloss == nullptr, "tn_sgd_update_net (delayed): no cost rider in this mode");
+            return upd_delayed(ctx, static_cast<const tn_sgd_seg*>(d_segs), nseg, d_lr, gscale, d_step, flags);
+        case TN_UPD_PIPE:
+            return upd_pipe(ctx, static_cast<const tn_pipe_seg*>(d_segs), nseg, d_lr, d_step, step_inc, flags & 1, rowloss, nrow,
+                            cost_scale, d_cost);
+        default:
+            return fail(ctx, TN_E_ARG, "tn_sgd_update_net: mode %d", mode);
+    }
 }
 
 // ================================== elastic input stage (inlayers.py:63-144) ==================================
@@ -951,7 +963,7 @@ int tn_step_tail(tn_ctx* ctx, const tn_sgd_seg* d_segs, int nseg, size_t max_n, 
                  const float* rowloss, int nrow, float cost_scale, float* d_cost, float* draws_out, uint64_t seed,
                  const uint32_t* d_step, int h, int w, double translation, double zoom, double magnitude, int sigma,
                  double angle, int nearest, int32_t* map_idx, float* map_fy, float* map_fx, double* target) {
-    int rc = tn_sgd_update_multi_cost(ctx, d_segs, nseg, max_n, d_lr, gscale, nullptr, rowloss, nrow, cost_scale, d_cost);
+    int rc = tn_sgd_update_net(ctx, TN_UPD_PLAIN, d_segs, nullptr, nseg, max_n, d_lr, gscale, nullptr, 0, 0, rowloss, nrow, cost_scale, d_cost);
     if (rc) return rc;
     return tn_elastic_field_gen(ctx, draws_out, seed, 0, d_step, h, w, translation, zoom, magnitude, sigma, angle, nearest,
                                 map_idx, map_fy, map_fx, target);

@@ -19,7 +19,7 @@ from operator import mul
 
 import numpy as np
 
-from . import comm, layer
+from . import _lib, comm, layer
 from .plan import StepPlan
 from .device import DeviceArray, get_context, share
 from .layer import (AuxConcatLayer, SoftAuxLayer, CenteredOutLayer, ColorLayer, ConvLayer, DropOutLayer, ElasticLayer, ExpLossLayer, HiddenLayer,
@@ -423,7 +423,7 @@ class NeuralNet():
         host = np.array(segs, dtype=seg_dt)
         if segs:
             self._d_segs = self.ctx.array(host.view(np.uint8))
-            self._h_segs = host                       # kept alive: tn_sgd_update_multi_lazy reads it
+            self._h_segs = host                       # kept alive: tn_sgd_update_net (TN_UPD_LAZY) reads it
         return host
 
     _DP_TUNE_PRE, _DP_TUNE_WARM, _DP_TUNE_STEPS = 32, 8, 24      # settle-in steps, per-leg warm-up, timed
@@ -448,8 +448,8 @@ class NeuralNet():
             # leaving the delayed schedule: the velocity is one gradient behind -- catch it up
             prev = 1 - self._dp_cur
             self.ctx.call("tn_stream_wait", 0, 1)
-            self.ctx.call("tn_sgd_update_multi_delayed", self._segs_ab[prev].ptr, self._n_segs, self._max_seg,
-                          self.cur_learn_rate.ptr, 1.0, None, 3)
+            self.ctx.call("tn_sgd_update_net", _lib.TN_UPD_DELAYED, self._segs_ab[prev].ptr, None, self._n_segs, self._max_seg,
+                          self.cur_learn_rate.ptr, 1.0, None, 0, 3, None, 0, 0.0, None)
             self._dp_pending = False
         if name != "delayed":
             self._dp_cur = 0
@@ -555,12 +555,12 @@ class NeuralNet():
             if self._cost_rider_ok and not self._dp:
                 # the caller reads [cost, features, logprob] of this step: the cost is summed now (the cost block
                 # of the update launch on its own: same summation order, same bits) and leaves with the outputs
-                ctx.call("tn_sgd_update_multi_cost", None, 0, 0, self.cur_learn_rate.ptr, 1.0, None,
+                ctx.call("tn_sgd_update_net", _lib.TN_UPD_PLAIN, None, None, 0, 0, self.cur_learn_rate.ptr, 1.0, None, 0, 0,
                          out.rowloss.ptr, self.local_bsz, 1.0 / self.batch_sz, self.d_cost.ptr)
                 cost_sent = True
             self._send_outputs(out, cost_sent)
         # cost = -mean logprob[n, y_n] (this rank's share of the global mean).  Without weight
-        # costs it rides in the update launch at the end of the step (tn_sgd_update_multi_cost);
+        # costs it rides in the update launch at the end of the step (tn_sgd_update_net);
         # with them it must exist before tn_wtcost accumulates onto it: a leaf reduction here.
         rider = self._cost_rider and not pipe_stride
         lazy_pipe = bool(pipe_stride) and getattr(self, "_pipe_lazy", False) and self._cost_rider_ok
@@ -572,7 +572,7 @@ class NeuralNet():
             if pipe_stride and self._cost_rider_ok:
                 # the cost block of the update launch on its own: the same summation order as the
                 # one-step-at-a-time schedule, so the reported cost is bit-identical too
-                ctx.call("tn_sgd_update_multi_cost", None, 0, 0, self.cur_learn_rate.ptr, 1.0, None,
+                ctx.call("tn_sgd_update_net", _lib.TN_UPD_PLAIN, None, None, 0, 0, self.cur_learn_rate.ptr, 1.0, None, 0, 0,
                          out.rowloss.ptr, self.local_bsz, 1.0 / self.batch_sz, self.d_cost.ptr)
             else:
                 ctx.call("tn_reduce_sum", out.rowloss.ptr, self.local_bsz, 1.0 / self.batch_sz,
@@ -596,7 +596,7 @@ class NeuralNet():
                      self.d_step.ptr, *field_args)
         tail = False
         dp_async = False
-        # single-GPU steps leave the finishing slab sums to the update launch (tn_sgd_update_multi_lazy)
+        # single-GPU steps leave the finishing slab sums to the update launch (tn_sgd_update_net, TN_UPD_LAZY)
         lazy = False
         try:
             for idx in range(len(self.tr_layers) - 1, -1, -1):
@@ -658,11 +658,11 @@ class NeuralNet():
             cur = self._dp_cur
             if self._dp_pending:
                 ctx.call("tn_stream_wait", 0, 1)
-                ctx.call("tn_sgd_update_multi_delayed", self._segs_ab[1 - cur].ptr, self._n_segs,
-                         self._max_seg, self.cur_learn_rate.ptr, 1.0, self.d_step.ptr, 1)
+                ctx.call("tn_sgd_update_net", _lib.TN_UPD_DELAYED, self._segs_ab[1 - cur].ptr, None, self._n_segs,
+                         self._max_seg, self.cur_learn_rate.ptr, 1.0, self.d_step.ptr, 1, 1, None, 0, 0.0, None)
             else:
-                ctx.call("tn_sgd_update_multi_delayed", self._segs_ab[cur].ptr, self._n_segs,
-                         self._max_seg, self.cur_learn_rate.ptr, 1.0, self.d_step.ptr, 2)
+                ctx.call("tn_sgd_update_net", _lib.TN_UPD_DELAYED, self._segs_ab[cur].ptr, None, self._n_segs,
+                         self._max_seg, self.cur_learn_rate.ptr, 1.0, self.d_step.ptr, 1, 2, None, 0, 0.0, None)
             ctx.call("tn_stream_wait", 1, 0)
             ctx.call("tn_stream_select", 1)
             self._group().allreduce_sum(self._flat_ab[cur], self.n_flat)
@@ -686,13 +686,13 @@ class NeuralNet():
                      self.d_cost.ptr if rider else None, first.draws.ptr, first.seed, self.d_step.ptr,
                      *field_args)
         elif lazy:
-            ctx.call("tn_sgd_update_multi_lazy", self._d_segs.ptr, self._h_segs.ctypes.data, self._n_segs,
-                     self._max_seg, self.cur_learn_rate.ptr, 1.0, self.d_step.ptr,
+            ctx.call("tn_sgd_update_net", _lib.TN_UPD_LAZY, self._d_segs.ptr, self._h_segs.ctypes.data, self._n_segs,
+                     self._max_seg, self.cur_learn_rate.ptr, 1.0, self.d_step.ptr, 1, 0,
                      out.rowloss.ptr if rider else None, self.local_bsz, 1.0 / self.batch_sz,
                      self.d_cost.ptr if rider else None)
         elif self._n_segs or rider:               # also advances the RNG step counter
-            ctx.call("tn_sgd_update_multi_cost", self._d_segs.ptr if self._n_segs else None,
-                     self._n_segs, self._max_seg, self.cur_learn_rate.ptr, 1.0, self.d_step.ptr,
+            ctx.call("tn_sgd_update_net", _lib.TN_UPD_PLAIN, self._d_segs.ptr if self._n_segs else None, None,
+                     self._n_segs, self._max_seg, self.cur_learn_rate.ptr, 1.0, self.d_step.ptr, 1, 0,
                      out.rowloss.ptr if rider else None, self.local_bsz, 1.0 / self.batch_sz,
                      self.d_cost.ptr if rider else None)
         else:

@@ -7,6 +7,7 @@ import os
 
 import numpy as np
 
+from . import _lib
 from .device import share  # noqa: F401
 from .layer import ElasticLayer
 from .plan import StepPlan
@@ -155,7 +156,7 @@ class _PipeTrainFn:
     run on the context's first stream with the net itself, odd steps on the second stream with a twin
     (own weights copy, activations and gradients; the velocities are shared).  Step t starts by waiting
     for the other stream's update, then ``v <- m v + (1-m) g_{t-2}`` (its own gradient of two steps ago)
-    and ``p_own <- p_other - s*v`` in one launch (tn_sgd_update_multi_pipe), then runs its forward and
+    and ``p_own <- p_other - s*v`` in one launch (tn_sgd_update_net, TN_UPD_PIPE), then runs its forward and
     backward passes while the other stream is still busy with step t-1 -- the two fill each other's
     launch gaps and lock-step phases (-18 % per step on mnist.prms).  Same weights, costs and outputs as
     the sequential schedule, bit for bit (tests/test_gpu_net.py::test_pipelined_steps_equal_sequential);
@@ -287,8 +288,8 @@ class _PipeTrainFn:
             self._lr_set[k] = self._lr_prev
         out = X.tr_layers[-1]
         rider = X._cost_pending
-        ctx.call("tn_sgd_update_multi_pipe", self._segs[k].ptr, self._hsegs[k].ctypes.data, self._nseg,
-                 self._max_seg, self._lr[k].ptr, X.d_step.ptr, 2 if t >= 2 else 0, 1 if t >= 2 else 0,
+        ctx.call("tn_sgd_update_net", _lib.TN_UPD_PIPE, self._segs[k].ptr, self._hsegs[k].ctypes.data, self._nseg,
+                 self._max_seg, self._lr[k].ptr, 1.0, X.d_step.ptr, 2 if t >= 2 else 0, 1 if t >= 2 else 0,
                  out.rowloss.ptr if rider else None, X.local_bsz, 1.0 / X.batch_sz,
                  X.d_cost.ptr if rider else None)
         X._cost_pending = False
@@ -333,8 +334,8 @@ class _PipeTrainFn:
             # the velocity is one gradient behind (that of step t-1, held by the stream that ran it)
             Y = self.nets[(self.t - 1) & 1]
             ctx.call("tn_stream_select", 0)
-            ctx.call("tn_sgd_update_multi_delayed", Y._d_segs.ptr, Y._n_segs, Y._max_seg,
-                     net.cur_learn_rate.ptr, 1.0, None, 3)
+            ctx.call("tn_sgd_update_net", _lib.TN_UPD_DELAYED, Y._d_segs.ptr, None, Y._n_segs, Y._max_seg,
+                     net.cur_learn_rate.ptr, 1.0, None, 0, 3, None, 0, 0.0, None)
             ctx.call("tn_set_u32", net.d_step.ptr, self._base + self.t)
             ctx.sync()
         has_wtcost = any(getattr(l, 'reg', None) and l.params and (l.reg['L1'] or l.reg['L2'])
@@ -424,7 +425,7 @@ class _PipeTrainFn:
         """The cost of X's last step, if nothing has summed it yet (on the stream currently selected)."""
         if getattr(X, "_cost_pending", False):
             out = X.tr_layers[-1]
-            X.ctx.call("tn_sgd_update_multi_cost", None, 0, 0, X.cur_learn_rate.ptr, 1.0, None,
+            X.ctx.call("tn_sgd_update_net", _lib.TN_UPD_PLAIN, None, None, 0, 0, X.cur_learn_rate.ptr, 1.0, None, 0, 0,
                        out.rowloss.ptr, X.local_bsz, 1.0 / X.batch_sz, X.d_cost.ptr)
             X._cost_pending = False
 
