@@ -210,6 +210,12 @@ int tn_c8_fc_dgrad(tn_ctx* ctx, const float* dz, const float* W, void* dx, int B
 int tn_c8_fc_wgrad(tn_ctx* ctx, const void* x, const float* dz, float* dW, float* db, int B, int C, int HW, int n_out);
 /* NCHW fp32 (rows row0.. of a dataset) -> c8 fp16 and back; values are multiplied by scale                        */
 int tn_c8_pack(tn_ctx* ctx, const float* x, int64_t row0, void* out, int N, int C, int HW, float scale);
+/* tn_elastic_apply (below; inlayers.py:126-142) whose output is the c8 tensor the first conv layer consumes: the same
+ * values, rounded to halfs when stored -- the resampled fp32 minibatch is neither written nor re-read by tn_c8_pack.  */
+int tn_c8_elastic_apply(tn_ctx* ctx, const float* x, int64_t x_row0, const int64_t* d_row0, void* out16,
+                        int N, int C, int h, int w, int invert, int nearest, const int32_t* map_idx,
+                        const float* map_fy, const float* map_fx, float pflip, const uint8_t* flipmask,
+                        uint64_t seed, uint32_t step, const uint32_t* d_step, int64_t row_global0);
 int tn_c8_unpack(tn_ctx* ctx, const void* x, float* out, int N, int C, int HW, float scale);
 
 /* 1 if tn_conv2d_* run this shape on the implicit-im2col fp32-MFMA kernels (stride 1, reduction

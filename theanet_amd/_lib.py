@@ -160,6 +160,8 @@ SIGNATURES = {
                                      c_double, c_int, c_double, c_int, P, P, P, P]),
     "tn_elastic_apply": (c_int, [CTX, P, c_int64, P, P, c_int, c_int, c_int, c_int, c_int, c_int,
                                  P, P, P, c_float, P, c_uint64, c_uint32, P, c_int64]),
+    "tn_c8_elastic_apply": (c_int, [CTX, P, c_int64, P, P, c_int, c_int, c_int, c_int, c_int, c_int,
+                                    P, P, P, c_float, P, c_uint64, c_uint32, P, c_int64]),
     "tn_elastic_apply_bwd": (c_int, [CTX, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, c_float, P,
                                      c_uint64, c_uint32, P, c_int64, P, c_int, c_float]),
     "tn_color_factors": (c_int, [CTX, P, c_int, c_int, c_double, c_double, P, c_uint64, c_uint32, P, c_int64]),

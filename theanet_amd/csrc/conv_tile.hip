@@ -270,7 +270,6 @@ template <int FT, bool DGRAD, bool POOL, int NCP = 4>
 static int ct_launch(tn_ctx* ctx, ConvTG& g) {
     static bool attr_set = false;
     size_t lds = ct_lds_bytes(g, FT);
-    if (const char* e = getenv("TN_CT_LDS")) lds = (size_t)atoi(e) > lds ? (size_t)atoi(e) : lds;
     if (!attr_set) {
         TN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_tile_kernel<FT, DGRAD, POOL, NCP>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));

@@ -262,14 +262,7 @@ static bool c16_enabled() {
 }
 
 static int c16_pick_ft(int K) {
-    static int force = -1;
-    if (force < 0) {
-        const char* e = getenv("TN_C16_FT");
-        force = e ? atoi(e) : 0;
-    }
-    const int want = K > 32 ? 2 : 1;
-    if (force == 1 || force == 2 || force == 4) return (force * 32 >= 2 * K && force > 1) ? want : force;
-    return want;
+    return K > 32 ? 2 : 1;
 }
 
 // geometry of the pixel tiling; returns 0 when the shape is outside the kernel's limits
@@ -322,7 +315,6 @@ template <int FT, bool DGRAD, bool POOL>
 static int c16_launch(tn_ctx* ctx, ConvTG& g) {
     static bool attr_set[2] = {false, false};
     size_t lds = c16_lds_bytes(g, FT);
-    if (const char* e = getenv("TN_C16_LDS")) lds = (size_t)atoi(e) > lds ? (size_t)atoi(e) : lds;
     const int ns = g.nx4 > 256 ? 2 : 1;
     const int grid = 8 * cdiv(g.MT, 8) * g.KT;
     if (getenv("TN_CT_DBG")) {

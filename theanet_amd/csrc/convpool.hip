@@ -437,23 +437,9 @@ static int launch_fwd(tn_ctx* ctx, const float* x, const float* W, const float* 
     return TN_OK;
 }
 
-static int tn_tune_kt() {
-    static int kt = -1;
-    if (kt < 0) {
-        const char* e = getenv("TN_CONVPOOL_KT");
-        kt = e ? atoi(e) : 4;
-    }
-    return kt;
-}
+static int tn_tune_kt() { return 4; }          // filters per thread of the recomputing backward
 
-static int tn_tune_ppt() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("TN_CONVPOOL_PPT");
-        v = e ? atoi(e) : 8;
-    }
-    return v;
-}
+static int tn_tune_ppt() { return 8; }         // pixels per thread of the recomputing backward
 
 template <int F, int C, int KT>
 static int launch_bwd(tn_ctx* ctx, const float* x, const float* W, const float* b, const float* g,
@@ -483,14 +469,7 @@ static int launch_bwd(tn_ctx* ctx, const float* x, const float* W, const float* 
     return tn_conv_wgrad_finish(ctx, partial, dbpartial, dW, db, nblk, K, C, F);
 }
 
-static int tn_tune_mwin() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("TN_CONVPOOL_MWIN");
-        v = e ? atoi(e) : 4;
-    }
-    return v;
-}
+static int tn_tune_mwin() { return 4; }        // windows per thread of the mask-driven backward (full batches)
 
 template <int C, int KT>
 static int launch_bwd_mask(tn_ctx* ctx, const float* x, const float* g, const float* y,

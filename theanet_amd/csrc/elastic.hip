@@ -102,20 +102,14 @@ __global__ __launch_bounds__(256) void elastic_apply_kernel(
 
 // The same gather, 4 consecutive output pixels per thread (h*w % 4 == 0): one 16-byte map load,
 // one Philox call (the 4 flip draws of an aligned quad share a counter) and one 16-byte store.
-__global__ __launch_bounds__(256) void elastic_apply4_kernel(
-    const float* __restrict__ x, int64_t x_row0, const int64_t* __restrict__ d_row0,
-    float* __restrict__ out, long long total4, int C, int hw, int w, int invert, int nearest,
-    const int32_t* __restrict__ map_idx, const float* __restrict__ map_fy,
-    const float* __restrict__ map_fx, float pflip, const uint8_t* __restrict__ flipmask, uint32_t k0,
-    uint32_t k1, uint32_t step, const uint32_t* d_step, int64_t row_global0) {
-    const long long t4 = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (t4 >= total4) return;
-    const long long t = t4 * 4;
-    const long long img = t / hw;              // n*C + c
-    const int p = (int)(t - img * hw);
-    const int64_t row_off = x_row0 + (d_row0 ? *d_row0 : 0);
-    const float* xi = x + ((size_t)row_off * C + img) * hw;
-    float v[4];
+// elastic_quad: the four values of pixels p .. p+3 of one (image, channel) plane xi; t = index of the quad's first
+// element in the local (N, C, h, w) batch (flip mask / flip draws)
+__device__ __forceinline__ void elastic_quad(const float* __restrict__ xi, int p, int w, int invert, int nearest,
+                                             const int32_t* __restrict__ map_idx, const float* __restrict__ map_fy,
+                                             const float* __restrict__ map_fx, float pflip,
+                                             const uint8_t* __restrict__ flipmask, uint32_t k0, uint32_t k1, uint32_t step,
+                                             const uint32_t* d_step, int64_t row_global0, int C, int hw, long long t,
+                                             float (&v)[4]) {
     if (!map_idx) {
         const float4 q = *reinterpret_cast<const float4*>(xi + p);
         v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
@@ -163,7 +157,82 @@ __global__ __launch_bounds__(256) void elastic_apply4_kernel(
         if (tn_u01(r.z) < pflip) v[2] = 1.f - v[2];
         if (tn_u01(r.w) < pflip) v[3] = 1.f - v[3];
     }
+}
+
+__global__ __launch_bounds__(256) void elastic_apply4_kernel(
+    const float* __restrict__ x, int64_t x_row0, const int64_t* __restrict__ d_row0,
+    float* __restrict__ out, long long total4, int C, int hw, int w, int invert, int nearest,
+    const int32_t* __restrict__ map_idx, const float* __restrict__ map_fy,
+    const float* __restrict__ map_fx, float pflip, const uint8_t* __restrict__ flipmask, uint32_t k0,
+    uint32_t k1, uint32_t step, const uint32_t* d_step, int64_t row_global0) {
+    const long long t4 = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t4 >= total4) return;
+    const long long t = t4 * 4;
+    const long long img = t / hw;              // n*C + c
+    const int p = (int)(t - img * hw);
+    const int64_t row_off = x_row0 + (d_row0 ? *d_row0 : 0);
+    const float* xi = x + ((size_t)row_off * C + img) * hw;
+    float v[4];
+    elastic_quad(xi, p, w, invert, nearest, map_idx, map_fy, map_fx, pflip, flipmask, k0, k1, step, d_step, row_global0, C,
+                 hw, t, v);
     *reinterpret_cast<float4*>(out + t) = make_float4(v[0], v[1], v[2], v[3]);
+}
+
+// DTYPE float16, the stage feeds the first conv layer: the same values (same expressions as elastic_quad) rounded to
+// halfs and stored as the c8 tensor that layer consumes ([N][C8][pixel][8 channels], channels beyond C zero) -- the fp32
+// image is neither written nor read back by a packing pass.  thread = ONE pixel x the channels of an octet (a quad per
+// thread ran three channels x 16 gathers in sequence on a quarter of the threads: 26 us against 18 + 12 for the two
+// passes it replaces), one 16-byte store.
+typedef _Float16 el_half8 __attribute__((ext_vector_type(8)));
+__global__ __launch_bounds__(256) void elastic_apply_c8_kernel(
+    const float* __restrict__ x, int64_t x_row0, const int64_t* __restrict__ d_row0,
+    _Float16* __restrict__ out, long long total, int C, int C8, int hw, int w, int invert, int nearest,
+    const int32_t* __restrict__ map_idx, const float* __restrict__ map_fy,
+    const float* __restrict__ map_fx, float pflip, const uint8_t* __restrict__ flipmask, uint32_t k0,
+    uint32_t k1, uint32_t step, const uint32_t* d_step, int64_t row_global0) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int p = (int)(i % hw);
+    const long long pl = i / hw;
+    const int o = (int)(pl % C8);
+    const long long n = pl / C8;
+    const int64_t row_off = x_row0 + (d_row0 ? *d_row0 : 0);
+    const int m = map_idx ? map_idx[p] : p;
+    const bool bil = map_idx && !nearest;
+    const float fy = bil ? map_fy[p] : 0.f, fx = bil ? map_fx[p] : 0.f;
+    const uint32_t st = step + (d_step ? *d_step : 0u);
+    el_half8 cell;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int c = 8 * o + e;
+        float v = 0.f;
+        if (c < C) {
+            const long long img = n * C + c;
+            const float* xi = x + ((size_t)row_off * C + img) * hw;
+            if (bil) {
+                float a = xi[m], b = xi[m + 1], cc = xi[m + w], d = xi[m + w + 1];
+                if (invert) {
+                    a = 1.f - a; b = 1.f - b; cc = 1.f - cc; d = 1.f - d;
+                }
+                // same association as inlayers.py:134-137
+                v = a * (1.f - fy) * (1.f - fx) + b * (1.f - fy) * fx + cc * fy * (1.f - fx) + d * fy * fx;
+            } else {
+                v = xi[m];
+                if (invert) v = 1.f - v;
+            }
+            const long long t = img * hw + p;              // element of the local (N, C, h, w) batch
+            if (flipmask) {
+                if (flipmask[t]) v = 1.f - v;
+            } else if (pflip > 0.f) {                      // the four draws of an aligned quad share one Philox call
+                const uint64_t cq = ((uint64_t)row_global0 * C * hw + (uint64_t)t) >> 2;
+                const u32x4 r = philox4x32((uint32_t)cq, (uint32_t)(cq >> 32), st, TN_STREAM_FLIP, k0, k1);
+                const uint32_t rw[4] = {r.x, r.y, r.z, r.w};
+                if (tn_u01(rw[t & 3]) < pflip) v = 1.f - v;
+            }
+        }
+        cell[e] = (_Float16)v;
+    }
+    reinterpret_cast<el_half8*>(out)[(n * C8 + o) * hw + p] = cell;
 }
 
 // ---- ElasticLayer resampling fused into the first conv block's forward --------------------------
@@ -510,6 +579,24 @@ int tn_elastic_apply(tn_ctx* ctx, const float* x, int64_t x_row0, const int64_t*
     elastic_apply_kernel<<<cdiv(total, 256), 256, 0, ctx->stream>>>(
         x, x_row0, d_row0, out, total, C, h * w, w, invert, nearest, map_idx, map_fy, map_fx, pflip,
         flipmask, (uint32_t)seed, (uint32_t)(seed >> 32), step, d_step, row_global0);
+    TN_LAUNCH_CHECK();
+    return TN_OK;
+}
+
+// tn_elastic_apply with the c8 fp16 tensor of the first conv layer as its output (DTYPE float16; include/theanet_hip.h)
+int tn_c8_elastic_apply(tn_ctx* ctx, const float* x, int64_t x_row0, const int64_t* d_row0, void* out16,
+                        int N, int C, int h, int w, int invert, int nearest, const int32_t* map_idx,
+                        const float* map_fy, const float* map_fx, float pflip, const uint8_t* flipmask,
+                        uint64_t seed, uint32_t step, const uint32_t* d_step, int64_t row_global0) {
+    TN_REQUIRE(N > 0 && C > 0 && h > 0 && w > 0 && x && out16, "tn_c8_elastic_apply: bad arguments");
+    const bool al = (((uintptr_t)x | (uintptr_t)out16 | (uintptr_t)map_idx | (uintptr_t)map_fy | (uintptr_t)map_fx) & 15) == 0 &&
+                    ((uintptr_t)flipmask & 3) == 0;
+    TN_REQUIRE((h * w) % 4 == 0 && al, "tn_c8_elastic_apply: maps of %d x %d pixels / unaligned operands", h, w);
+    const int C8 = (C + 7) / 8;
+    const long long total = (long long)N * C8 * (h * w);
+    elastic_apply_c8_kernel<<<cdiv(total, 256), 256, 0, ctx->stream>>>(
+        x, x_row0, d_row0, static_cast<_Float16*>(out16), total, C, C8, h * w, w, invert, nearest, map_idx, map_fy, map_fx,
+        pflip, flipmask, (uint32_t)seed, (uint32_t)(seed >> 32), step, d_step, row_global0);
     TN_LAUNCH_CHECK();
     return TN_OK;
 }

@@ -19,8 +19,6 @@
 //             16-byte stores of fp16(acc * act'(y)) -- y = the pooled output below, in the same order.
 //   wgrad   : both operands want 8 consecutive SAMPLES per lane but are stored sample-major: tiles go to LDS as they
 //             are (dz converted on the way) and gfx950's transposing LDS read (ds_read_b64_tr_b16) delivers them.
-#include <cstdlib>
-
 #include "common.h"
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -416,9 +414,8 @@ int tn_c8_fc_fwd(tn_ctx* ctx, const void* x, const float* W, const float* b, flo
     g.Kc = ((C + 7) / 8) * HW * 8;
     g.magic = fc8_magic(HW);
     const int colg = cdiv(n_out, 64), rowg = cdiv(B, 128);
-    // K slabs: two blocks per CU, at least four chunks of 64 columns per block
-    static const int per_cu = getenv("TN_FC8_BPC") ? atoi(getenv("TN_FC8_BPC")) : 1;
-    int S = cdiv(per_cu * ctx->num_cus, colg * rowg);
+    // K slabs: one block per CU (two measured 15 % slower: twice the slab traffic), at least four chunks of 64 columns per block
+    int S = cdiv(ctx->num_cus, colg * rowg);
     if (S > g.Kc / 256) S = g.Kc / 256;
     if (S < 1) S = 1;
     g.krange = cdiv(cdiv(g.Kc, S), 64) * 64;

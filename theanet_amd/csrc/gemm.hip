@@ -696,23 +696,9 @@ static inline int vec_ok(const void* p, int ld) {
     return ((reinterpret_cast<uintptr_t>(p) & 15) == 0) && (ld % 4 == 0);
 }
 
-static int tn_tune_tile() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("TN_GEMM_TILE");   // 0 auto, 1 force 64x64, 2 force 128x64
-        v = e ? atoi(e) : 0;
-    }
-    return v;
-}
+static int tn_tune_tile() { return 0; }       // 0 auto (1 / 2 would force 64x64 / 128x64: sweeps of rounds 1-2)
 
-static int tn_tune_bk() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("TN_GEMM_BK");
-        v = e ? atoi(e) : 16;
-    }
-    return v;
-}
+static int tn_tune_bk() { return 16; }        // K-tile depth (32 measured slower at the layer shapes of the configs)
 
 // FAST needs aligned operands; row-contiguous operands also need an extent % 4 == 0 so that
 // clamped float4 groups stay inside the matrix
@@ -725,11 +711,7 @@ static bool gemm_fast_ok(const GemmArgs& g) {
 // the 16-byte epilogue (and with it the inline dropout) needs 4-column groups that never straddle
 // the matrix edge and aligned C / side operands
 static bool gemm_cvec_ok(const GemmArgs& g) {
-    static int vec_on = -1;
-    if (vec_on < 0) {
-        const char* e = getenv("TN_GEMM_VEC_EPI");
-        vec_on = e ? atoi(e) : 1;
-    }
+    const bool vec_on = true;
     auto al = [](const void* p, uintptr_t m) { return (reinterpret_cast<uintptr_t>(p) & m) == 0; };
     return vec_on && g.ldc % 4 == 0 && g.N % 4 == 0 && g.N >= 4 && al(g.C, 15) && al(g.prev_a, 15) &&
            al(g.mask, 3) && al(g.drop_out, 3) && (g.elem0 & 3) == 0;

@@ -197,6 +197,10 @@ int tn_c8_fc_dgrad(tn_ctx* ctx, const float*, const float*, void*, int, int, int
 }
 int tn_c8_fc_wgrad(tn_ctx* ctx, const void*, const float*, float*, float*, int, int, int, int) { NOT_HERE("tn_c8_fc_wgrad"); }
 int tn_c8_pack(tn_ctx* ctx, const float*, int64_t, void*, int, int, int, float) { NOT_HERE("tn_c8_pack"); }
+int tn_c8_elastic_apply(tn_ctx* ctx, const float*, int64_t, const int64_t*, void*, int, int, int, int, int, int, const int32_t*,
+                        const float*, const float*, float, const uint8_t*, uint64_t, uint32_t, const uint32_t*, int64_t) {
+    NOT_HERE("tn_c8_elastic_apply");
+}
 int tn_c8_unpack(tn_ctx* ctx, const void*, float*, int, int, int, float) { NOT_HERE("tn_c8_unpack"); }
 int tn_convpool_f16_supported(int, int, int, int, int, int, int, int, int, int, int, int, int) { return 0; }
 

@@ -141,11 +141,15 @@ class ConvLayer(Layer):
                 pool.out_sz, pool.out_sz, self.act.kind, self.act.prm)
 
     # -- DTYPE float16: the fp16-resident kernels (include/theanet_hip.h, tn_c8_*) --------------------------------
+    _c8_prefilled = False
+
     def _c8_input(self, below=None):
         """The layer's input as a c8 tensor: the layer below's output, or -- first conv layer of the net -- the NCHW
         fp32 minibatch packed on the way in (straight from the dataset window when the layer below is an InputLayer)."""
         if self.x16 is None:
             return self.inpt
+        if self._c8_prefilled:
+            return self.x16             # written by the distortion stage below (tn_c8_elastic_apply)
         src, row0 = self.inpt, 0
         slot = getattr(self, "_pack_from", None)
         if slot is not None:

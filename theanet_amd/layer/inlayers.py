@@ -163,6 +163,8 @@ class ElasticLayer(Layer):
             self._inj_flip = self.ctx.array(
                 np.asarray(flipmask).reshape(self.output.shape).astype(np.uint8))
 
+    _c8_consumer = None     # DTYPE float16: the first conv layer, whose c8 input this stage writes (NeuralNet._fuse)
+
     def forward(self, train=True):
         s = self.inpt
         if isinstance(s, InputSlot):
@@ -201,6 +203,11 @@ class ElasticLayer(Layer):
                             self.seed, 0, d_step_ptr, rg0)
         if self.fused_conv is not None and train:
             return                      # the conv block's forward resamples while it loads (PoolLayer)
+        if self._c8_consumer is not None:
+            # DTYPE float16: straight into the c8 tensor of the first conv layer (same values, rounded when stored)
+            a = self._apply_args
+            self.ctx.call("tn_c8_elastic_apply", *(a[:3] + (self._c8_consumer.x16.ptr,) + a[4:]))
+            return
         self.ctx.call("tn_elastic_apply", *self._apply_args)
 
     def backward(self, gout, need_gin, below):

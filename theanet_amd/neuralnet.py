@@ -281,6 +281,10 @@ class NeuralNet():
         # DTYPE float16: the first conv layer packs its c8 input straight from the dataset window
         if len(lyrs) >= 2 and isinstance(lyrs[0], InputLayer) and isinstance(lyrs[1], ConvLayer) and lyrs[1].f16:
             lyrs[1]._pack_from, lyrs[0]._packed_by_conv = lyrs[0].inpt, True
+        # ... or has it written by the distortion stage below it (tn_c8_elastic_apply): no fp32 image, no packing pass
+        if len(lyrs) >= 2 and isinstance(lyrs[0], ElasticLayer) and lyrs[0].active and isinstance(lyrs[1], ConvLayer) \
+                and lyrs[1].f16 and lyrs[1].x16 is not None and (lyrs[0].img_sz * lyrs[0].img_sz) % 4 == 0:
+            lyrs[0]._c8_consumer, lyrs[1]._c8_prefilled = lyrs[1], True
         # an active single-channel ElasticLayer feeding such a block: the block's forward resamples
         # the raw images itself (tn_elastic_convpool_fwd_mask)
         if len(lyrs) >= 3 and isinstance(lyrs[0], ElasticLayer) and lyrs[0].active and \
