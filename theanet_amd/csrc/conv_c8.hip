@@ -619,14 +619,19 @@ __global__ __launch_bounds__(512) void c8_wgrad_kernel(C8WG g) {
     // eight waves = two per SIMD: while one waits for its LDS operands or sits in the issue of an LDS-DMA (~100 cycles
     // each, nothing else of that wave moves meanwhile) the other feeds the matrix pipe.  One wave per SIMD ran this loop
     // at DMA issue + address arithmetic + matrix time, the sum (cycle stamps: 1.4 k + 1.4 k + 3.7 k per tile).
-    constexpr int KP = 4 * NFT, CP = 4 * NCT, KBF = 32 * NFT, CBF = 32 * NCT, PS = 8 / (NFT * NCT), SPW = 8 / PS;
+    // NCT == 0 ("tap-packed"): a first layer, C <= 8 = ONE octet plane.  The 32 columns of an MFMA tile are then 4 taps x
+    // 8 channels instead of 32 channels of one tap (3 of which would be real): three products per step instead of nine,
+    // one x plane in LDS instead of four, and the transposing read picks the tap where it picked the plane.
+    constexpr bool TAPK = NCT == 0;
+    constexpr int NCTe = TAPK ? 1 : NCT, NACC = TAPK ? 3 : 9;
+    constexpr int KP = 4 * NFT, CP = TAPK ? 1 : 4 * NCT, KBF = 32 * NFT, CBF = 32 * NCTe, PS = 8 / (NFT * NCTe), SPW = 8 / PS;
     char* const smem = reinterpret_cast<char*>(ct_smem);
     const int bid = blockIdx.x, per = g.KG * g.CG;
     const int z = ((bid >> 3) / per) * 8 + (bid & 7), rem = (bid >> 3) % per;
     if (z >= g.S) return;
     const int kg = rem / g.CG, cg = rem - kg * g.CG;
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), l31 = lane & 31, hi = lane >> 5;
-    const int ft = wave % NFT, ct = (wave / NFT) % NCT, ps = wave / (NFT * NCT);
+    const int ft = wave % NFT, ct = (wave / NFT) % NCTe, ps = wave / (NFT * NCTe);
     const int tile_beg = z * g.tpb, tile_end = min(g.NTILES, tile_beg + g.tpb);
     const int HW = g.H * g.Wd, Wp = g.Wd >> 1, THm = g.TH - 1, Wm = g.Wd - 1;
     const char* const zero_src = reinterpret_cast<const char*>(&c8_zero_cell_g);
@@ -718,9 +723,9 @@ __global__ __launch_bounds__(512) void c8_wgrad_kernel(C8WG g) {
     using J_0 = std::integral_constant<int, 0>;
     using J_N = std::integral_constant<int, NG>;
 
-    f32x16 acc[9], accb;
+    f32x16 acc[NACC], accb;
 #pragma unroll
-    for (int a_ = 0; a_ < 9; ++a_)
+    for (int a_ = 0; a_ < NACC; ++a_)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[a_][r] = 0.f;
 #pragma unroll
@@ -733,8 +738,14 @@ __global__ __launch_bounds__(512) void c8_wgrad_kernel(C8WG g) {
     // channels 4 q8 .. + 3 of the group's pair of octet planes and receives channel (lane & 15)'s four pixels
     const int grp = lane >> 4, r4 = (lane >> 2) & 3, q8 = lane & 3;
     const int a_off = g.offD + (ft * 4 + 2 * (grp & 1) + (q8 >> 1)) * g.DPS + (q8 & 1) * 8;
-    const int b_off = (ct * 4 + 2 * (grp & 1) + (q8 >> 1)) * g.XPS + (q8 & 1) * 8;
+    const int b_off = TAPK ? (q8 & 1) * 8 : (ct * 4 + 2 * (grp & 1) + (q8 >> 1)) * g.XPS + (q8 & 1) * 8;
     const int RS16 = g.RS * 16;
+    int toff[3];               // TAPK: column tile jt, this lane's 8-channel slot = tap 4 jt + 2 (grp & 1) + (q8 >> 1)
+#pragma unroll
+    for (int jt = 0; jt < 3; ++jt) {
+        const int tap = 4 * jt + 2 * (grp & 1) + (q8 >> 1);
+        toff[jt] = tap < 9 ? (tap / 3) * RS16 + (tap % 3) * 16 : 0;      // taps 9..11: columns that are never stored
+    }
 
     unsigned long long d_wait = 0, d_bar = 0, d_mm = 0, d_t0 = 0, d_w0 = 0;
     if (g.dbg) { d_t0 = __builtin_readcyclecounter(); d_w0 = wall_clock64(); }
@@ -787,17 +798,25 @@ __global__ __launch_bounds__(512) void c8_wgrad_kernel(C8WG g) {
             const char* ap = ab + p * 16;
             const half4v a0 = c8_tr16(ap), a1 = c8_tr16(ap + 64);
             const char* xp = bb + (((p >> g.lgP) * g.THi + ((p >> g.lgW) & THm)) * g.RS + (p & Wm)) * 16;
-            half4v bv[9][2];
+            half4v bv[NACC][2];
+            if (TAPK) {
 #pragma unroll
-            for (int u = 0; u < 3; ++u)
-#pragma unroll
-                for (int v = 0; v < 3; ++v) {
-                    bv[u * 3 + v][0] = c8_tr16(xp + u * RS16 + v * 16);
-                    bv[u * 3 + v][1] = c8_tr16(xp + u * RS16 + v * 16 + 64);
+                for (int jt = 0; jt < 3; ++jt) {
+                    bv[jt][0] = c8_tr16(xp + toff[jt]);
+                    bv[jt][1] = c8_tr16(xp + toff[jt] + 64);
                 }
+            } else {
+#pragma unroll
+                for (int u = 0; u < 3; ++u)
+#pragma unroll
+                    for (int v = 0; v < 3; ++v) {
+                        bv[(u * 3 + v) % NACC][0] = c8_tr16(xp + u * RS16 + v * 16);
+                        bv[(u * 3 + v) % NACC][1] = c8_tr16(xp + u * RS16 + v * 16 + 64);
+                    }
+            }
             const half8 a = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
 #pragma unroll
-            for (int tp = 0; tp < 9; ++tp) {
+            for (int tp = 0; tp < NACC; ++tp) {
                 const half8 b = {bv[tp][0][0], bv[tp][0][1], bv[tp][0][2], bv[tp][0][3],
                                  bv[tp][1][0], bv[tp][1][1], bv[tp][1][2], bv[tp][1][3]};
                 acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[tp], 0, 0, 0);
@@ -820,23 +839,23 @@ __global__ __launch_bounds__(512) void c8_wgrad_kernel(C8WG g) {
     // ---- the PS step subsets of a (filter tile, channel tile) pair are added up through LDS, upper half onto lower
     // half, in a fixed order; subset 0 then holds the block's sums.  At most four waves write in a round:
     // [slot][reg][lane] floats, 36 KB per slot (the bias products take a second, small pass over the same memory)
-    constexpr int NPR = NFT * NCT;
+    constexpr int NPR = NFT * NCTe;
     const int pr = wave % NPR;
 #pragma unroll
     for (int h = PS / 2; h >= 1; h >>= 1) {
         const bool writer = ps >= h && ps < 2 * h, reader = ps < h;
-        float* const slot = ct_smem + (size_t)(((writer ? ps - h : ps) * NPR + pr) * 144) * 64 + lane;
+        float* const slot = ct_smem + (size_t)(((writer ? ps - h : ps) * NPR + pr) * (NACC * 16)) * 64 + lane;
         __syncthreads();
         if (writer) {
 #pragma unroll
-            for (int a_ = 0; a_ < 9; ++a_)
+            for (int a_ = 0; a_ < NACC; ++a_)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) slot[(a_ * 16 + r) * 64] = acc[a_][r];
         }
         __syncthreads();
         if (reader) {
 #pragma unroll
-            for (int a_ = 0; a_ < 9; ++a_)
+            for (int a_ = 0; a_ < NACC; ++a_)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[a_][r] += slot[(a_ * 16 + r) * 64];
         }
@@ -863,6 +882,24 @@ __global__ __launch_bounds__(512) void c8_wgrad_kernel(C8WG g) {
         }
     }
     // slab z: dW layout, tap (u,v) of the correlation is element (2-u, 2-v)
+    if (TAPK) {                                 // column l31 = tap 4 jt + (l31 >> 3), channel l31 & 7
+        const int e = l31 & 7;
+        if (e < g.C) {
+            float* wz = g.ws + (size_t)z * g.K * g.C * 9;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int k = kg * KBF + ft * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                if (k < g.K) {
+#pragma unroll
+                    for (int jt = 0; jt < 3; ++jt) {
+                        const int tap = 4 * jt + (l31 >> 3);
+                        if (tap < 9) wz[((size_t)k * g.C + e) * 9 + 8 - tap] = acc[jt % NACC][r] * os;
+                    }
+                }
+            }
+        }
+        return;
+    }
     const int c = cg * CBF + ct * 32 + l31;
     if (c < g.C) {
         float* wz = g.ws + (size_t)z * g.K * g.C * 9;
@@ -871,7 +908,7 @@ __global__ __launch_bounds__(512) void c8_wgrad_kernel(C8WG g) {
             const int k = kg * KBF + ft * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
             if (k < g.K) {
 #pragma unroll
-                for (int a_ = 0; a_ < 9; ++a_) wz[((size_t)k * g.C + c) * 9 + 8 - a_] = acc[a_][r] * os;
+                for (int a_ = 0; a_ < NACC; ++a_) wz[((size_t)k * g.C + c) * 9 + 8 - a_] = acc[a_][r] * os;
             }
         }
     }
@@ -881,7 +918,7 @@ static int c8w_log2(int v) { int l = 0; while ((1 << l) < v) ++l; return (1 << l
 
 static void c8w_tiles(int K, int C, int& NFT, int& NCT) {
     NFT = K > 32 ? 2 : 1;
-    NCT = C > 32 ? 2 : 1;
+    NCT = C > 32 ? 2 : (C > 8 ? 1 : 0);          // 0: one octet, taps packed into the columns (c8_wgrad_kernel)
 }
 
 static int c8w_geometry(C8WG& g, int num_cus, bool pool) {
@@ -902,7 +939,7 @@ static int c8w_geometry(C8WG& g, int num_cus, bool pool) {
     g.RS = g.Wd + 2;
     int NFT, NCT;
     c8w_tiles(g.K, g.C, NFT, NCT);
-    const int KP = 4 * NFT, CP = 4 * NCT;
+    const int KP = 4 * NFT, CP = NCT ? 4 * NCT : 1;
     g.XC = g.NI * g.THi * g.RS;
     g.XCH = cdiv(g.XC, 64);
     // plane strides = 64 (mod 256) bytes: the four octet planes a transposing read touches sit on disjoint banks
@@ -918,7 +955,7 @@ static int c8w_geometry(C8WG& g, int num_cus, bool pool) {
     g.NQ = g.nQx + g.nQd;
     g.nstage = 3 * g.SB <= 160 * 1024 ? 3 : 2;
     g.KG = cdiv(g.K, 32 * NFT);
-    g.CG = cdiv(g.C, 32 * NCT);
+    g.CG = NCT ? cdiv(g.C, 32 * NCT) : 1;
     g.NTILES = cdiv(g.N, g.NI) * g.RT;
     int S = num_cus / (g.KG * g.CG);
     if (S > g.NTILES) S = g.NTILES;
@@ -970,11 +1007,16 @@ static int c8w_ngx(const C8WG& g) { return cdiv(g.nQx, 8); }
 template <int NFT, int NCT, bool POOL>
 static int c8w_launch_ng(tn_ctx* ctx, C8WG& g) {
     const int ngx = c8w_ngx(g);
-    if (ngx <= 2) return c8w_launch<NFT, NCT, POOL, 2>(ctx, g);
-    if (ngx <= 3) return c8w_launch<NFT, NCT, POOL, 3>(ctx, g);
-    if (ngx <= 4) return c8w_launch<NFT, NCT, POOL, 4>(ctx, g);
-    TN_REQUIRE(ngx <= 5, "c8 conv wgrad: %d LDS-DMA chunks per x stage", g.nQx);
-    return c8w_launch<NFT, NCT, POOL, 5>(ctx, g);
+    if constexpr (NCT == 0) {
+        TN_REQUIRE(ngx <= 2, "c8 conv wgrad: %d LDS-DMA chunks per x stage", g.nQx);
+        return ngx <= 1 ? c8w_launch<NFT, 0, POOL, 1>(ctx, g) : c8w_launch<NFT, 0, POOL, 2>(ctx, g);
+    } else {
+        if (ngx <= 2) return c8w_launch<NFT, NCT, POOL, 2>(ctx, g);
+        if (ngx <= 3) return c8w_launch<NFT, NCT, POOL, 3>(ctx, g);
+        if (ngx <= 4) return c8w_launch<NFT, NCT, POOL, 4>(ctx, g);
+        TN_REQUIRE(ngx <= 5, "c8 conv wgrad: %d LDS-DMA chunks per x stage", g.nQx);
+        return c8w_launch<NFT, NCT, POOL, 5>(ctx, g);
+    }
 }
 
 static int c8w_run(tn_ctx* ctx, C8WG& g, float* dW, float* db, bool pool) {
@@ -989,7 +1031,9 @@ static int c8w_run(tn_ctx* ctx, C8WG& g, float* dW, float* db, bool pool) {
     g.dbws = g.ws + (size_t)g.S * n;
     g.oscale = 1.f / ctx->grad_scale;
 #define C8W_GO(A, B) rc = pool ? c8w_launch_ng<A, B, true>(ctx, g) : c8w_launch_ng<A, B, false>(ctx, g)
-    if (NFT == 2 && NCT == 2) C8W_GO(2, 2);
+    if (NCT == 0 && NFT == 2) C8W_GO(2, 0);
+    else if (NCT == 0) C8W_GO(1, 0);
+    else if (NFT == 2 && NCT == 2) C8W_GO(2, 2);
     else if (NFT == 2) C8W_GO(2, 1);
     else if (NCT == 2) C8W_GO(1, 2);
     else C8W_GO(1, 1);
