@@ -613,7 +613,7 @@ struct C8WG {
     int exp;                   // TN_C8_EXP (experiments): bit 0 no refills inside the loop, bit 1 no matrix steps
 };
 
-template <int NFT, int NCT, bool POOL, int NGX>
+template <int NFT, int NCT, bool POOL, int NGX, int TM = 1>
 __global__ __launch_bounds__(512) void c8_wgrad_kernel(C8WG g) {
     extern __shared__ __attribute__((aligned(16))) float ct_smem[];
     // eight waves = two per SIMD: while one waits for its LDS operands or sits in the issue of an LDS-DMA (~100 cycles
@@ -625,6 +625,9 @@ __global__ __launch_bounds__(512) void c8_wgrad_kernel(C8WG g) {
     constexpr bool TAPK = NCT == 0;
     constexpr int NCTe = TAPK ? 1 : NCT, NACC = TAPK ? 3 : 9;
     constexpr int KP = 4 * NFT, CP = TAPK ? 1 : 4 * NCT, KBF = 32 * NFT, CBF = 32 * NCTe, PS = 8 / (NFT * NCTe), SPW = 8 / PS;
+    // TM: a tile is 128 * TM pixels (a tile costs ~1.5-2 k cycles of barriers, DMA issue and set-up whatever it holds:
+    // layers whose stage is small take four times the pixels per tile), i.e. SPW * TM steps per wave
+    constexpr int NSTEP = SPW * TM, PCP = 32 * TM;            // steps per wave and tile; pooled cells per plane and tile
     char* const smem = reinterpret_cast<char*>(ct_smem);
     const int bid = blockIdx.x, per = g.KG * g.CG;
     const int z = ((bid >> 3) / per) * 8 + (bid & 7), rem = (bid >> 3) % per;
@@ -642,7 +645,8 @@ __global__ __launch_bounds__(512) void c8_wgrad_kernel(C8WG g) {
     // chunk index beyond its kind's count is a filler (zero cell -> the dump KB).  Per chunk (wave-uniform): destination
     // inside the stage; per lane: the source cell relative to the tile's first cell and flags (bit 0 lane in use,
     // 1 always zero, 2 / 3 top / bottom halo row, 4 mask bytes (8-byte cells), 8.. image of the tile)
-    constexpr int NGD = POOL ? 1 : (KP * 2 + 7) / 8, NG = NGX + NGD;
+    constexpr int NQG = KP * TM / 2, NQM = KP * TM / 4;      // POOL: raw pooled-gradient / mask chunks per stage
+    constexpr int NGD = ((POOL ? NQG + NQM : KP * 2 * TM) + 7) / 8, NG = NGX + NGD;
     int gl_rel[NG], gl_fl[NG], gl_dst[NG];
 #pragma unroll
     for (int j = 0; j < NG; ++j) {
@@ -660,21 +664,21 @@ __global__ __launch_bounds__(512) void c8_wgrad_kernel(C8WG g) {
         } else {
             const int qq = 8 * (j - NGX) + wave;
             if (!POOL) {
-                if (qq < 2 * KP) {
-                    const int plane = qq >> 1, pp = (qq & 1) * 64 + lane;
+                if (qq < 2 * KP * TM) {
+                    const int plane = qq / (2 * TM), sub = qq % (2 * TM), pp = sub * 64 + lane;
                     const int ni = pp >> g.lgP, row = (pp >> g.lgW) & THm, col = pp & Wm;
                     rel = (ni * g.K8 + plane) * HW + row * g.Wd + col;
                     fl = 1 | (kg * KP + plane >= g.K8 ? 2 : 0) | (ni << 8);
-                    dst = g.offD + plane * g.DPS + (qq & 1) * 1024;
+                    dst = g.offD + plane * g.DPS + sub * 1024;
                 }
-            } else if (qq < KP / 2) {           // raw pooled gradient: two planes of 32 pooled cells
-                const int plane = 2 * qq + hi, pc = l31;
+            } else if (qq < NQG) {              // raw pooled gradient: [plane][PCP pooled cells] as one run of 16-byte cells
+                const int ci = qq * 64 + lane, plane = ci / PCP, pc = ci % PCP;
                 const int ni = pc >> (g.lgP - 2), prow = (pc >> (g.lgW - 1)) & ((g.TH >> 1) - 1), pcol = pc & (Wp - 1);
                 rel = (ni * g.K8 + plane) * (HW >> 2) + prow * Wp + pcol;
                 fl = 1 | (kg * KP + plane >= g.K8 ? 2 : 0) | (ni << 8);
                 dst = g.offG + qq * 1024;
-            } else if (qq < KP / 2 + KP / 4) {  // mask bytes: four planes per chunk, two pooled cells per lane
-                const int qm = qq - KP / 2, plane = 4 * qm + (lane >> 4), pc = 2 * (lane & 15);
+            } else if (qq < NQG + NQM) {        // mask bytes: [plane][PCP cells of 8 bytes], two pooled cells per lane
+                const int qm = qq - NQG, ci = qm * 128 + 2 * lane, plane = ci / PCP, pc = ci % PCP;
                 const int ni = pc >> (g.lgP - 2), prow = (pc >> (g.lgW - 1)) & ((g.TH >> 1) - 1), pcol = pc & (Wp - 1);
                 rel = (ni * g.K8 + plane) * (HW >> 2) + prow * Wp + pcol;
                 fl = 1 | 16 | (kg * KP + plane >= g.K8 ? 2 : 0) | (ni << 8);
@@ -747,7 +751,7 @@ __global__ __launch_bounds__(512) void c8_wgrad_kernel(C8WG g) {
         toff[jt] = tap < 9 ? (tap / 3) * RS16 + (tap % 3) * 16 : 0;      // taps 9..11: columns that are never stored
     }
 
-    unsigned long long d_wait = 0, d_bar = 0, d_mm = 0, d_t0 = 0, d_w0 = 0;
+    unsigned long long d_wait = 0, d_bar = 0, d_mm = 0, d_t0 = 0, d_w0 = 0, d_exp = 0;     // (d_exp: shown as "prologue" by tools/dbg_c8.py)
     if (g.dbg) { d_t0 = __builtin_readcyclecounter(); d_w0 = wall_clock64(); }
     tile_setup(0);
     issue_range(J_0{}, J_N{});
@@ -770,11 +774,12 @@ __global__ __launch_bounds__(512) void c8_wgrad_kernel(C8WG g) {
         // the refill of the stage two tiles ahead is spread over this tile's matrix steps
         tile_setup((it + g.nstage - 1) % g.nstage);
         if (POOL) {
-            // expand (pooled gradient, mask) -> dz image: thread = one pooled cell of one plane -> its 2 x 2 window
-            const int plane = t >> 5, pc = t & 31;
-            if (plane < KP) {
-                const uint4 gq = *reinterpret_cast<const uint4*>(sb + g.offG + plane * 512 + pc * 16);
-                const uint2 mq = *reinterpret_cast<const uint2*>(sb + g.offM + plane * 256 + pc * 8);
+            // expand (pooled gradient, mask) -> dz image: one pooled cell of one plane -> its 2 x 2 window
+#pragma unroll
+            for (int it = t; it < KP * PCP; it += 512) {
+                const int plane = it / PCP, pc = it % PCP;
+                const uint4 gq = *reinterpret_cast<const uint4*>(sb + g.offG + it * 16);
+                const uint2 mq = *reinterpret_cast<const uint2*>(sb + g.offM + it * 8);
                 const int ni = pc >> (g.lgP - 2), prow = (pc >> (g.lgW - 1)) & ((g.TH >> 1) - 1), pcol = pc & (Wp - 1);
                 char* const d0 = sb + g.offD + plane * g.DPS + ((ni << g.lgP) + ((2 * prow) << g.lgW) + 2 * pcol) * 16;
                 *reinterpret_cast<uint4*>(d0) = c8_pool_cell(gq, mq, 0);
@@ -784,12 +789,13 @@ __global__ __launch_bounds__(512) void c8_wgrad_kernel(C8WG g) {
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
+            if (g.dbg) d_exp += __builtin_readcyclecounter() - s2;
         }
         const char* const ab = sb + a_off;
         const char* const bb = sb + b_off;
         auto step = [&](auto Ic) __attribute__((always_inline)) {
             constexpr int i = decltype(Ic)::value;
-            constexpr int J0 = i * NG / SPW, J1 = (i + 1) * NG / SPW;
+            constexpr int J0 = i * NG / NSTEP, J1 = (i + 1) * NG / NSTEP;
             if (g.exp & 2) {
                 issue_range(std::integral_constant<int, J0>{}, std::integral_constant<int, J1>{});
                 return;
@@ -824,14 +830,17 @@ __global__ __launch_bounds__(512) void c8_wgrad_kernel(C8WG g) {
             if (want_db) accb = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, ones, accb, 0, 0, 0);
             issue_range(std::integral_constant<int, J0>{}, std::integral_constant<int, J1>{});
         };
-        step(std::integral_constant<int, 0>{});
-        if (SPW > 1) step(std::integral_constant<int, 1 % SPW>{});
-        if (SPW > 2) { step(std::integral_constant<int, 2 % SPW>{}); step(std::integral_constant<int, 3 % SPW>{}); }
+#define C8W_ST(I) if (NSTEP > I) step(std::integral_constant<int, (I) % NSTEP>{});
+        C8W_ST(0) C8W_ST(1) C8W_ST(2) C8W_ST(3) C8W_ST(4) C8W_ST(5) C8W_ST(6) C8W_ST(7)
+        C8W_ST(8) C8W_ST(9) C8W_ST(10) C8W_ST(11) C8W_ST(12) C8W_ST(13) C8W_ST(14) C8W_ST(15)
+        C8W_ST(16) C8W_ST(17) C8W_ST(18) C8W_ST(19) C8W_ST(20) C8W_ST(21) C8W_ST(22) C8W_ST(23)
+        C8W_ST(24) C8W_ST(25) C8W_ST(26) C8W_ST(27) C8W_ST(28) C8W_ST(29) C8W_ST(30) C8W_ST(31)
+#undef C8W_ST
         if (g.dbg) d_mm += __builtin_readcyclecounter() - s2;
     }
     if (g.dbg && t == 0) {
         unsigned long long* d = g.dbg + 8 * (size_t)bid;
-        d[0] = d_t0; d[1] = d_t0; d[2] = __builtin_readcyclecounter(); d[3] = d_wait; d[6] = d_bar; d[7] = d_mm;
+        d[0] = d_t0; d[1] = d_t0 + d_exp; d[2] = __builtin_readcyclecounter(); d[3] = d_wait; d[6] = d_bar; d[7] = d_mm;
         d[4] = d_w0; d[5] = wall_clock64();
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the trailing refills (clamped tiles) land before LDS is reused
@@ -921,10 +930,11 @@ static void c8w_tiles(int K, int C, int& NFT, int& NCT) {
     NCT = C > 32 ? 2 : (C > 8 ? 1 : 0);          // 0: one octet, taps packed into the columns (c8_wgrad_kernel)
 }
 
-static int c8w_geometry(C8WG& g, int num_cus, bool pool) {
+static int c8w_geometry(C8WG& g, int num_cus, bool pool, int tm = 1) {
     const int lgW = c8w_log2(g.Wd);
     if (lgW < 3 || lgW > 6) return 0;                  // rows of 8..64 pixels
-    int TH = 128 / g.Wd;
+    const int TP = 128 * tm;                           // pixels per tile
+    int TH = TP / g.Wd;
     g.NI = 1;
     if (TH > g.H) {
         if (TH % g.H) return 0;
@@ -944,14 +954,14 @@ static int c8w_geometry(C8WG& g, int num_cus, bool pool) {
     g.XCH = cdiv(g.XC, 64);
     // plane strides = 64 (mod 256) bytes: the four octet planes a transposing read touches sit on disjoint banks
     g.XPS = (g.XC * 16 + 255) / 256 * 256 + 64;
-    g.DPS = 128 * 16 + 64;
+    g.DPS = TP * 16 + 64;
     g.offD = CP * g.XPS;
     g.offG = g.offD + KP * g.DPS;
-    g.offM = g.offG + (pool ? KP * 512 : 0);
-    g.offDump = (g.offM + (pool ? KP * 256 : 0) + 255) / 256 * 256;      // each stage ends with the fillers' dump KB
+    g.offM = g.offG + (pool ? KP * 512 * tm : 0);
+    g.offDump = (g.offM + (pool ? KP * 256 * tm : 0) + 255) / 256 * 256;      // each stage ends with the fillers' dump KB
     g.SB = g.offDump + 1024;
     g.nQx = CP * g.XCH;
-    g.nQd = pool ? KP / 2 + KP / 4 : KP * 2;
+    g.nQd = pool ? KP * tm / 2 + KP * tm / 4 : KP * 2 * tm;
     g.NQ = g.nQx + g.nQd;
     g.nstage = 3 * g.SB <= 160 * 1024 ? 3 : 2;
     g.KG = cdiv(g.K, 32 * NFT);
@@ -970,11 +980,11 @@ static size_t c8w_lds_bytes(const C8WG& g) {
     return a > red ? a : red;
 }
 
-template <int NFT, int NCT, bool POOL, int NGX>
+template <int NFT, int NCT, bool POOL, int NGX, int TM = 1>
 static int c8w_launch(tn_ctx* ctx, C8WG& g) {
     static bool attr_set = false;
     if (!attr_set) {
-        TN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&c8_wgrad_kernel<NFT, NCT, POOL, NGX>),
+        TN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&c8_wgrad_kernel<NFT, NCT, POOL, NGX, TM>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
@@ -997,7 +1007,7 @@ static int c8w_launch(tn_ctx* ctx, C8WG& g) {
         }
         g.exp = exp_;
     }
-    c8_wgrad_kernel<NFT, NCT, POOL, NGX><<<grid, 512, c8w_lds_bytes(g), ctx->stream>>>(g);
+    c8_wgrad_kernel<NFT, NCT, POOL, NGX, TM><<<grid, 512, c8w_lds_bytes(g), ctx->stream>>>(g);
     TN_LAUNCH_CHECK();
     return TN_OK;
 }
@@ -1005,10 +1015,11 @@ static int c8w_launch(tn_ctx* ctx, C8WG& g) {
 // x chunks per wave and stage: a compile-time count (the waits are counted); shapes land in one of four buckets
 static int c8w_ngx(const C8WG& g) { return cdiv(g.nQx, 8); }
 template <int NFT, int NCT, bool POOL>
-static int c8w_launch_ng(tn_ctx* ctx, C8WG& g) {
+static int c8w_launch_ng(tn_ctx* ctx, C8WG& g, int tm) {
     const int ngx = c8w_ngx(g);
     if constexpr (NCT == 0) {
         TN_REQUIRE(ngx <= 2, "c8 conv wgrad: %d LDS-DMA chunks per x stage", g.nQx);
+        if (tm == 4) return c8w_launch<NFT, 0, POOL, 2, 4>(ctx, g);
         return ngx <= 1 ? c8w_launch<NFT, 0, POOL, 1>(ctx, g) : c8w_launch<NFT, 0, POOL, 2>(ctx, g);
     } else {
         if (ngx <= 2) return c8w_launch<NFT, NCT, POOL, 2>(ctx, g);
@@ -1020,7 +1031,13 @@ static int c8w_launch_ng(tn_ctx* ctx, C8WG& g) {
 }
 
 static int c8w_run(tn_ctx* ctx, C8WG& g, float* dW, float* db, bool pool) {
-    TN_REQUIRE(c8w_geometry(g, ctx->num_cus, pool) && c8w_lds_bytes(g) <= 160 * 1024, "c8 conv wgrad: unsupported shape");
+    // first layers (one octet plane, small stages): 512-pixel tiles when every block still gets four of them
+    int tm = 1;
+    if (g.C <= 8) {
+        C8WG g4 = g;
+        if (c8w_geometry(g4, ctx->num_cus, pool, 4) && g4.nstage == 3 && g4.tpb >= 4 && c8w_ngx(g4) <= 2) tm = 4;
+    }
+    TN_REQUIRE(c8w_geometry(g, ctx->num_cus, pool, tm) && c8w_lds_bytes(g) <= 160 * 1024, "c8 conv wgrad: unsupported shape");
     TN_REQUIRE((long long)g.N * g.C8 * g.H * g.Wd < (1ll << 28) && (long long)g.N * g.K8 * g.H * g.Wd < (1ll << 28),
                "c8 conv wgrad: tensor too large for 32-bit cell offsets");
     int NFT, NCT;
@@ -1030,7 +1047,7 @@ static int c8w_run(tn_ctx* ctx, C8WG& g, float* dW, float* db, bool pool) {
     if (rc) return rc;
     g.dbws = g.ws + (size_t)g.S * n;
     g.oscale = 1.f / ctx->grad_scale;
-#define C8W_GO(A, B) rc = pool ? c8w_launch_ng<A, B, true>(ctx, g) : c8w_launch_ng<A, B, false>(ctx, g)
+#define C8W_GO(A, B) rc = pool ? c8w_launch_ng<A, B, true>(ctx, g, tm) : c8w_launch_ng<A, B, false>(ctx, g, tm)
     if (NCT == 0 && NFT == 2) C8W_GO(2, 0);
     else if (NCT == 0) C8W_GO(1, 0);
     else if (NFT == 2 && NCT == 2) C8W_GO(2, 2);
