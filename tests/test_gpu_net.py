@@ -1149,3 +1149,20 @@ def test_aux_input_layers_match_oracle(take_index_list):
         net2 = NeuralNet(ck["layers"], dict(ck["training_params"]), ck["allwts"])
         np.testing.assert_array_equal(net2.get_data_test_model()(x[:B], aux[:B])[1],
                                       net.get_data_test_model()(x[:B], aux[:B])[1])
+
+
+def test_dataset_of_the_wrong_shape_is_an_assertion_not_a_fault():
+    """A dataset whose images do not have the shape the net was built for (or fewer images than a minibatch) is
+    reported when the functions are made: the kernels index the dataset with the net's shape."""
+    from theanet_amd import NeuralNet
+    prms = load_prms("mnist.prms", 28, batch=8)
+    net = NeuralNet(copy.deepcopy(prms["layers"]), dict(prms["training_params"]))
+    y = np.zeros(16, np.int32)
+    for bad in (np.zeros((16, 3, 28, 28), np.float32), np.zeros((16, 1, 32, 32), np.float32),
+                np.zeros((4, 1, 28, 28), np.float32)):
+        with pytest.raises(AssertionError):
+            net.get_trin_model(bad, y[:bad.shape[0]])
+        with pytest.raises(AssertionError):
+            net.get_test_model(bad, y[:bad.shape[0]])
+    with pytest.raises(AssertionError):
+        net.get_trin_model(np.zeros((16, 1, 28, 28), np.float32), y[:8])

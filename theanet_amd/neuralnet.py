@@ -772,10 +772,24 @@ class NeuralNet():
             self.ctx.call("tn_maxnorm_multi", chunk.ctypes.data, len(chunk))
 
     # ------------------------------------------------------------------------------
+    def _check_images(self, x_data, y_data=None):
+        """The dataset must have the image shape the net was built for (Theano reports the mismatch when the compiled
+        function first runs; here the kernels index the dataset with the net's shape, so it is checked up front) and at
+        least one minibatch."""
+        first = self.tr_layers[0]
+        want = (first.num_maps, first.out_sz, first.out_sz)
+        shape = tuple(x_data.shape)
+        assert len(shape) == 4 and shape[1:] == want, \
+            "image data of shape {} for a net built for (N, {}, {}, {}) images".format(shape, *want)
+        assert shape[0] >= self.batch_sz, "{} images for minibatches of {}".format(shape[0], self.batch_sz)
+        if y_data is not None:
+            assert y_data.shape[0] == shape[0], "{} labels for {} images".format(y_data.shape[0], shape[0])
+
     def get_trin_model(self, x_data, y_data, aux_data=None,
                        take_index_list=False):
         print('Compiling training function...')
         self.tr_layers[-1].cost(None)            # validates the loss name (outlayers.py:12-36)
+        self._check_images(x_data, y_data)
         if hasattr(self, 'aux_inpt_tr'):
             assert aux_data is not None, "Auxillary data not supplied"        # neuralnet.py:216-217
             aux_data = share(aux_data)
@@ -822,6 +836,7 @@ class NeuralNet():
 
     def get_test_model(self, x_data, y_data, aux_data=None, preds_feats=False):
         print('Compiling testing function... ')
+        self._check_images(x_data, y_data)
         if hasattr(self, 'aux_inpt_te'):
             assert aux_data is not None, "Auxillary data not supplied"        # neuralnet.py:266-267
             aux_data = share(aux_data)
