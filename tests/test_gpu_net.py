@@ -1166,3 +1166,27 @@ def test_dataset_of_the_wrong_shape_is_an_assertion_not_a_fault():
             net.get_test_model(bad, y[:bad.shape[0]])
     with pytest.raises(AssertionError):
         net.get_trin_model(np.zeros((16, 1, 28, 28), np.float32), y[:8])
+
+
+@pytest.mark.parametrize("pipelined", [False, True])
+def test_minibatch_outside_the_dataset_is_an_index_error(pipelined, monkeypatch):
+    """fn(i) for a minibatch that is not (entirely) inside the dataset, and index lists with rows that do not exist, raise
+    instead of reading past the arrays."""
+    from theanet_amd import NeuralNet
+    monkeypatch.setenv("TN_PIPELINE", "1" if pipelined else "0")
+    prms = load_prms("mnist.prms", 28, batch=8)
+    net = NeuralNet(copy.deepcopy(prms["layers"]), dict(prms["training_params"]))
+    x = np.random.RandomState(0).rand(20, 1, 28, 28).astype(np.float32)
+    y = np.zeros(20, np.int32)
+    fn, tfn = net.get_trin_model(x, y), net.get_test_model(x, y)
+    assert np.isfinite(fn(1)[0]) and len(tfn(1)) == 2
+    for f in (fn, tfn):
+        for i in (2, 3, -1):                       # 20 rows: minibatches 0 and 1 exist, 2 would be short
+            with pytest.raises(IndexError):
+                f(i)
+    if not pipelined:
+        lfn = net.get_trin_model(x, y, take_index_list=True)
+        assert np.isfinite(lfn(np.arange(8))[0])
+        for idx in (np.arange(8) + 13, np.arange(7), -np.arange(8)):
+            with pytest.raises(IndexError):
+                lfn(idx)

@@ -39,6 +39,14 @@ def _step_outputs(net, out):
     return [cost] + _features_logprob(out)
 
 
+def _batch_in_range(i, n_rows, batch_sz):
+    """Minibatch i must lie inside the dataset (the reference's ``data[i*B:(i+1)*B]`` would come out short and fail in the
+    compiled function; the kernels here would read past the array)."""
+    i = int(i)
+    if i < 0 or (i + 1) * batch_sz > n_rows:
+        raise IndexError("minibatch %d of %d rows each in a dataset of %d rows" % (i, batch_sz, n_rows))
+
+
 class _TrainFn:
     """What ``get_trin_model`` returns: ``fn(i) -> [cost, features, logprob]``
     (neuralnet.py:236-241).  ``enqueue(i)`` issues the step without reading anything
@@ -81,6 +89,13 @@ class _TrainFn:
             not net._injecting()
 
     def enqueue(self, i):
+        if self.take_index_list:
+            idx = np.asarray(i)
+            if idx.shape != (self.net.batch_sz,) or idx.min() < 0 or idx.max() >= self.x_data.shape[0]:
+                raise IndexError("an index list must hold %d row numbers of a dataset of %d rows"
+                                 % (self.net.batch_sz, self.x_data.shape[0]))
+        else:
+            _batch_in_range(i, self.x_data.shape[0], self.net.batch_sz)
         pl = self._plan
         if pl is not None and not pl.off:
             ok = self._plannable()
@@ -349,6 +364,7 @@ class _PipeTrainFn:
 
     # -- the step ---------------------------------------------------------------------------------
     def enqueue(self, i):
+        _batch_in_range(i, self.x_data.shape[0], self.net.batch_sz)
         pl = self._plan
         if pl is None or pl.off:
             return self._enqueue(i)
@@ -447,6 +463,7 @@ class _TestFn:
 
     def __call__(self, i):
         net, ctx = self.net, self.net.ctx
+        _batch_in_range(i, self.x_data.shape[0], net.batch_sz)
         net._sync_weights()
         net._apply_dtype()
         if net.dtype == 'float16':
