@@ -1166,6 +1166,10 @@ def test_dataset_of_the_wrong_shape_is_an_assertion_not_a_fault():
             net.get_test_model(bad, y[:bad.shape[0]])
     with pytest.raises(AssertionError):
         net.get_trin_model(np.zeros((16, 1, 28, 28), np.float32), y[:8])
+    with pytest.raises(IndexError):                 # labels index logprob[arange, y] (outlayers.py:50-51)
+        net.get_trin_model(np.zeros((16, 1, 28, 28), np.float32), y + 10)
+    with pytest.raises(IndexError):
+        net.get_test_model(np.zeros((16, 1, 28, 28), np.float32), y - 1)
 
 
 @pytest.mark.parametrize("pipelined", [False, True])

@@ -784,6 +784,14 @@ class NeuralNet():
         assert shape[0] >= self.batch_sz, "{} images for minibatches of {}".format(shape[0], self.batch_sz)
         if y_data is not None:
             assert y_data.shape[0] == shape[0], "{} labels for {} images".format(y_data.shape[0], shape[0])
+            # labels index the rows of logprob / the class centres (outlayers.py:50-51: logprob[arange, y] -- an IndexError
+            # in the reference)
+            last = self.tr_layers[-1]
+            n_cls = last.centers.shape[0] if getattr(last, "centers", None) is not None else last.n_out
+            yv = y_data.get_value() if hasattr(y_data, "get_value") else np.asarray(y_data)
+            if yv.size and (int(yv.min()) < 0 or int(yv.max()) >= n_cls):
+                raise IndexError("labels in [{}, {}] for an output layer of {} classes".format(
+                    int(yv.min()), int(yv.max()), n_cls))
 
     def get_trin_model(self, x_data, y_data, aux_data=None,
                        take_index_list=False):
