@@ -827,7 +827,10 @@ __global__ __launch_bounds__(512) void c8_wgrad_kernel(C8WG g) {
                                  bv[tp][1][0], bv[tp][1][1], bv[tp][1][2], bv[tp][1][3]};
                 acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[tp], 0, 0, 0);
             }
-            if (want_db) accb = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, ones, accb, 0, 0, 0);
+            // the bias product of a step is taken by ONE of the channel-tile waves that share its pixels, alternating by
+            // step: with it always on channel tile 0 those waves ran 10 MFMAs per step against 9 and the others waited
+            // for them at every tile's barrier
+            if (cg == 0 && (NCTe == 1 || (i & 1) == ct)) accb = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, ones, accb, 0, 0, 0);
             issue_range(std::integral_constant<int, J0>{}, std::integral_constant<int, J1>{});
         };
 #define C8W_ST(I) if (NSTEP > I) step(std::integral_constant<int, (I) % NSTEP>{});
@@ -850,6 +853,19 @@ __global__ __launch_bounds__(512) void c8_wgrad_kernel(C8WG g) {
     // [slot][reg][lane] floats, 36 KB per slot (the bias products take a second, small pass over the same memory)
     constexpr int NPR = NFT * NCTe;
     const int pr = wave % NPR;
+    if (NCTe == 2) {            // the two halves of the bias products meet first: channel tile 1 onto channel tile 0
+        float* const bslot = ct_smem + (size_t)((ps * NFT + ft) * 16) * 64 + lane;
+        __syncthreads();
+        if (ct == 1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) bslot[r * 64] = accb[r];
+        }
+        __syncthreads();
+        if (ct == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accb[r] += bslot[r * 64];
+        }
+    }
 #pragma unroll
     for (int h = PS / 2; h >= 1; h >>= 1) {
         const bool writer = ps >= h && ps < 2 * h, reader = ps < h;
