@@ -1036,6 +1036,7 @@ static int c8w_launch_ng(tn_ctx* ctx, C8WG& g, int tm) {
     if constexpr (NCT == 0) {
         TN_REQUIRE(ngx <= 2, "c8 conv wgrad: %d LDS-DMA chunks per x stage", g.nQx);
         if (tm == 4) return c8w_launch<NFT, 0, POOL, 2, 4>(ctx, g);
+        if (tm == 2) return c8w_launch<NFT, 0, POOL, 1, 2>(ctx, g);
         return ngx <= 1 ? c8w_launch<NFT, 0, POOL, 1>(ctx, g) : c8w_launch<NFT, 0, POOL, 2>(ctx, g);
     } else {
         if (ngx <= 2) return c8w_launch<NFT, NCT, POOL, 2>(ctx, g);
@@ -1047,11 +1048,15 @@ static int c8w_launch_ng(tn_ctx* ctx, C8WG& g, int tm) {
 }
 
 static int c8w_run(tn_ctx* ctx, C8WG& g, float* dW, float* db, bool pool) {
-    // first layers (one octet plane, small stages): 512-pixel tiles when every block still gets four of them
+    // first layers (one octet plane, small stages): 512- or 256-pixel tiles when every block still gets four of them
     int tm = 1;
     if (g.C <= 8) {
         C8WG g4 = g;
         if (c8w_geometry(g4, ctx->num_cus, pool, 4) && g4.nstage == 3 && g4.tpb >= 4 && c8w_ngx(g4) <= 2) tm = 4;
+        if (tm == 1) {          // (the pooled form carries the raw gradient and the mask bytes beside the dz image: 256 pixels)
+            C8WG g2 = g;
+            if (c8w_geometry(g2, ctx->num_cus, pool, 2) && g2.nstage == 3 && g2.tpb >= 4 && c8w_ngx(g2) <= 1) tm = 2;
+        }
     }
     TN_REQUIRE(c8w_geometry(g, ctx->num_cus, pool, tm) && c8w_lds_bytes(g) <= 160 * 1024, "c8 conv wgrad: unsupported shape");
     TN_REQUIRE((long long)g.N * g.C8 * g.H * g.Wd < (1ll << 28) && (long long)g.N * g.K8 * g.H * g.Wd < (1ll << 28),
