@@ -45,24 +45,34 @@ struct C8G {
 __host__ __device__ __forceinline__ int c8_swap23(int j) { return (j & ~12) | ((j & 4) << 1) | ((j & 8) >> 1); }
 
 // wt[kt][chunk][tap][o][j][e] (halfs): MFMA row j of filter tile kt holds filter kt*KBF + (j & ~31) + swap23(j & 31)
-// (so that a lane's accumulators 0-7 / 8-15 are whole octets), channel chunk*16 + 8*o + e, correlation tap
-__global__ __launch_bounds__(256) void c8_wt_kernel(const float* __restrict__ W, _Float16* __restrict__ wt, int K, int C,
-                                                   int KBF, int nchunk, int total, int dgrad) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= total) return;
+// (so that a lane's accumulators 0-7 / 8-15 are whole octets), channel chunk*16 + 8*o + e, correlation tap.
+// Tap-packed form (tk: forward of a first layer, C <= 8 = one octet): wt[kt][tap pair jp < 5][o][j][e] = tap 2 jp + o,
+// channel e -- the 16 reduction indices of an MFMA step are two taps x 8 channels instead of 16 channels of one tap.
+__device__ __forceinline__ float c8_wt_value(const float* __restrict__ W, int K, int C, int KBF, int nchunk, int idx,
+                                             int dgrad, int tk) {
     int r = idx;
     const int e = r & 7; r >>= 3;
     const int j = r % KBF; r /= KBF;
     const int o = r & 1; r >>= 1;
+    if (tk) {
+        const int jp = r % 5, kt = r / 5, tap = 2 * jp + o;
+        const int filt = kt * KBF + (j & ~31) + c8_swap23(j & 31);
+        return (filt < K && e < C && tap < 9) ? W[((size_t)filt * C + e) * 9 + (8 - tap)] : 0.f;
+    }
     const int tap = r % 9; r /= 9;
     const int chunk = r % nchunk;
     const int kt = r / nchunk;
     const int filt = kt * KBF + (j & ~31) + c8_swap23(j & 31), ch = chunk * 16 + 8 * o + e;
-    float v = 0.f;
     if (filt < K && ch < C)
-        v = dgrad ? W[((size_t)ch * K + filt) * 9 + tap]          // W[k = ch][c = filt][u][v]
-                  : W[((size_t)filt * C + ch) * 9 + (8 - tap)];   // true convolution: flipped taps
-    wt[idx] = (_Float16)v;
+        return dgrad ? W[((size_t)ch * K + filt) * 9 + tap]          // W[k = ch][c = filt][u][v]
+                     : W[((size_t)filt * C + ch) * 9 + (8 - tap)];   // true convolution: flipped taps
+    return 0.f;
+}
+__global__ __launch_bounds__(256) void c8_wt_kernel(const float* __restrict__ W, _Float16* __restrict__ wt, int K, int C,
+                                                   int KBF, int nchunk, int total, int dgrad, int tk) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    wt[idx] = (_Float16)c8_wt_value(W, K, C, KBF, nchunk, idx, dgrad, tk);
 }
 
 __device__ __forceinline__ uint4 c8_and4(uint4 v, bool ok) {
@@ -92,15 +102,18 @@ __device__ __forceinline__ uint4 c8_pool_cell(const uint4 g8, const uint2 m8, in
 // ahead whatever tile they belong to, so a tile's epilogue stores and the next tile's first loads overlap the matrix
 // work instead of bracketing it (cycle stamps of the one-tile-per-block form, conv2 of wide6: prologue 5.4 k + main
 // loop 11.5 k + epilogue 5.5 k cycles per block, all blocks of a round in the same phase).
-template <int FT, int MODE, int NS, bool LK>
+template <int FT, int MODE, int NS, bool LK, bool TK = false>
 __global__ __launch_bounds__(256, 2) void c8_conv_kernel(C8G g) {
     extern __shared__ __attribute__((aligned(16))) float ct_smem[];
     constexpr bool DGRAD = MODE >= 2;
     constexpr bool POOLED = MODE == 3;
     constexpr int KBF = 32 * FT;
-    constexpr int WB = 9 * 2 * KBF * 16;              // bytes of one weight chunk
+    // TK ("tap-packed", forward of a first layer: C <= 8 = one octet plane): an MFMA step reduces over 2 taps x 8 channels
+    // instead of 16 channels of one tap -- 5 tap steps instead of 9, one input plane staged instead of two
+    constexpr int NTS = TK ? 5 : 9;
+    constexpr int WB = NTS * 2 * KBF * 16;            // bytes of one weight chunk
     constexpr int WS = (WB / 16 + 255) / 256;         // 16-byte staging slots per thread (3 or 5)
-    const int XB = 2 * g.plane * 16;                  // bytes of one input chunk (two octet planes)
+    const int XB = (TK ? 1 : 2) * g.plane * 16;       // bytes of one input chunk (two octet planes)
     char* const Xs = reinterpret_cast<char*>(ct_smem);            // [2][XB]
     char* const Ws = Xs + 2 * XB;                                 // [2][WB]
     const int bid = blockIdx.x, G = gridDim.x;
@@ -163,7 +176,7 @@ __global__ __launch_bounds__(256, 2) void c8_conv_kernel(C8G g) {
         const int Rc = pin[pt] ? R : 0;
         const int ni = Rc / g.TH, r = Rc - ni * g.TH;
         pni[pt] = ni; prel[pt] = r;
-        boff[pt] = (hi * g.plane + (ni * g.THi + r) * g.RS + pcol) * 16;
+        boff[pt] = ((TK ? 0 : hi * g.plane) + (ni * g.THi + r) * g.RS + pcol) * 16;
     }
     const int aoff = (hi * KBF + l31) * 16;
 
@@ -364,6 +377,12 @@ __global__ __launch_bounds__(256, 2) void c8_conv_kernel(C8G g) {
     __syncthreads();
     if (dbg) dbg[1] = __builtin_readcyclecounter();
     const int RS16 = g.RS * 16;
+    int toff[5];                 // TK: tap step t of this lane = tap 2 t + hi (tap 9 meets zero weights: any cell will do)
+#pragma unroll
+    for (int t_ = 0; t_ < 5; ++t_) {
+        const int tp = min(2 * t_ + hi, 8);
+        toff[t_] = (tp / 3) * RS16 + (tp % 3) * 16;
+    }
     unsigned long long d_ls = 0, d_ep = 0, d_bar = 0;          // TN_C8_DBG: cycles in LDS stores / epilogues / barriers
     auto body = [&](int seq, auto Pc) __attribute__((always_inline)) {
         constexpr int P = decltype(Pc)::value;
@@ -374,24 +393,24 @@ __global__ __launch_bounds__(256, 2) void c8_conv_kernel(C8G g) {
         const char* x0 = Xs + P * XB + boff[0];
         const char* x1 = Xs + P * XB + boff[1];
         const char* Wb = Ws + P * WB + aoff;
-        // nine taps: the LDS operands of tap s+1 (FT A vectors, 2 B vectors of 8 halfs) are requested
+        // nine taps (TK: five tap pairs): the LDS operands of tap s+1 (FT A vectors, 2 B vectors of 8 halfs) are requested
         // before the 2*FT MFMAs of tap s are issued
         half8 a[2][FT], b[2][2];
 #pragma unroll
         for (int f = 0; f < FT; ++f) a[0][f] = *reinterpret_cast<const half8*>(Wb + f * 512);
-        b[0][0] = *reinterpret_cast<const half8*>(x0);
-        b[0][1] = *reinterpret_cast<const half8*>(x1);
+        b[0][0] = *reinterpret_cast<const half8*>(x0 + (TK ? toff[0] : 0));
+        b[0][1] = *reinterpret_cast<const half8*>(x1 + (TK ? toff[0] : 0));
         __builtin_amdgcn_sched_group_barrier(0x100, FT + 2, 0);
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
+        for (int tap = 0; tap < NTS; ++tap) {
             const int cur = tap & 1, nx = cur ^ 1;
-            if (tap + 1 < 9) {
-                const int u = (tap + 1) / 3, v = (tap + 1) % 3;
+            if (tap + 1 < NTS) {
+                const int bo = TK ? toff[(tap + 1) % NTS] : ((tap + 1) / 3) * RS16 + ((tap + 1) % 3) * 16;
 #pragma unroll
                 for (int f = 0; f < FT; ++f)
                     a[nx][f] = *reinterpret_cast<const half8*>(Wb + (tap + 1) * (2 * KBF * 16) + f * 512);
-                b[nx][0] = *reinterpret_cast<const half8*>(x0 + u * RS16 + v * 16);
-                b[nx][1] = *reinterpret_cast<const half8*>(x1 + u * RS16 + v * 16);
+                b[nx][0] = *reinterpret_cast<const half8*>(x0 + bo);
+                b[nx][1] = *reinterpret_cast<const half8*>(x1 + bo);
             }
 #pragma unroll
             for (int f = 0; f < FT; ++f) {
@@ -431,7 +450,7 @@ __global__ __launch_bounds__(256, 2) void c8_conv_kernel(C8G g) {
 }
 
 // geometry of the pixel tiling; 0 when the shape is outside the kernel's limits
-static int c8_geometry(C8G& g, int FT, int K, int C) {
+static int c8_geometry(C8G& g, int FT, int K, int C, bool tk = false) {
     const int W = g.W, H = g.H;
     if (W != 8 && W != 16 && W != 32 && W != 64 && W != 128) return 0;
     if (H & 1) return 0;
@@ -452,7 +471,7 @@ static int c8_geometry(C8G& g, int FT, int K, int C) {
     if (W == 16) g.RS = 24;                 // the two row pairs of a half-wave on distinct bank groups
     if (W == 8) g.RS = 12;
     g.plane = g.NI * g.THi * g.RS + 2;      // cells per octet plane (+ the window overhang)
-    g.nslots = 2 * g.NI * g.THi * W;
+    g.nslots = (tk ? 1 : 2) * g.NI * g.THi * W;
     if (g.nslots > 4 * 256) return 0;
     g.nchunk = cdiv(C, 16);
     g.KT = cdiv(K, 32 * FT);
@@ -471,7 +490,7 @@ extern "C" int tn_c8_dbg_read(tn_ctx* ctx, unsigned long long* host, int nblocks
     return hipMemcpy(host, c8_dbg_buf, (size_t)nblocks * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
 }
 
-template <int FT, int MODE>
+template <int FT, int MODE, bool TK = false>
 static int c8_launch(tn_ctx* ctx, C8G& g) {
     const size_t lds = c8_lds_bytes(g, FT);
     const int ns = cdiv(g.nslots, 256);
@@ -492,11 +511,11 @@ static int c8_launch(tn_ctx* ctx, C8G& g) {
     {                                                                                                         \
         static bool attr_set = false;                                                                         \
         if (!attr_set) {                                                                                      \
-            TN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&c8_conv_kernel<FT, MODE, NS, LK>),      \
+            TN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&c8_conv_kernel<FT, MODE, NS, LK, TK>),  \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));              \
             attr_set = true;                                                                                  \
         }                                                                                                     \
-        c8_conv_kernel<FT, MODE, NS, LK><<<grid, 256, lds, ctx->stream>>>(g);                                 \
+        c8_conv_kernel<FT, MODE, NS, LK, TK><<<grid, 256, lds, ctx->stream>>>(g);                             \
     }
     // the epilogue's activation (forward: the layer's own; gradients: that of the layer below) is a compile-time
     // leaky-ReLU for the reference's defaults; other kinds share one generic instantiation per mode
@@ -516,47 +535,47 @@ static size_t c8_wt_elems(int K, int C) {
     return (size_t)cdiv(K, KBF) * cdiv(C, 16) * 9 * 2 * KBF * 8;
 }
 
+// halfs the arranging kernels write for a (K filters, C channels) product; tk: the tap-packed forward form (C <= 8)
+static bool c8_tap_packed(int C, int dgrad) { return !dgrad && C <= 8; }
+static size_t c8_wt_total(int K, int C, int dgrad) {
+    const int KBF = 32 * c8_pick_ft(K);
+    return c8_tap_packed(C, dgrad) ? (size_t)cdiv(K, KBF) * 5 * 2 * KBF * 8 : c8_wt_elems(K, C);
+}
+
 template <int MODE>
 static int c8_run(tn_ctx* ctx, C8G& g, const float* W, int K, int C, const void* wt_ready) {
     const int FT = c8_pick_ft(K);
-    TN_REQUIRE(c8_geometry(g, FT, K, C) && c8_lds_bytes(g, FT) <= 156 * 1024, "c8 conv: unsupported shape %dx%d", g.H, g.W);
+    const bool tk = MODE < 2 && c8_tap_packed(C, 0);
+    TN_REQUIRE(c8_geometry(g, FT, K, C, tk) && c8_lds_bytes(g, FT) <= 156 * 1024, "c8 conv: unsupported shape %dx%d", g.H, g.W);
     TN_REQUIRE((long long)g.N * g.C8 * g.H * g.W < (1ll << 28) && (long long)g.N * g.K8 * g.H * g.W < (1ll << 28),
                "c8 conv: tensor too large for 32-bit cell offsets");
     if (wt_ready) {
         g.wt = static_cast<const _Float16*>(wt_ready);            // arranged beforehand (tn_c8_arrange_multi)
     } else {
-        const int KBF = 32 * FT, total = (int)c8_wt_elems(K, C);
+        const int KBF = 32 * FT, total = (int)c8_wt_total(K, C, MODE >= 2 ? 1 : 0);
         float* wt;
         int rc = tn_scratch_get(ctx, (size_t)total * sizeof(_Float16), &wt);
         if (rc) return rc;
         c8_wt_kernel<<<cdiv(total, 256), 256, 0, ctx->stream>>>(W, reinterpret_cast<_Float16*>(wt), K, C, KBF, g.nchunk,
-                                                               total, MODE >= 2 ? 1 : 0);
+                                                               total, MODE >= 2 ? 1 : 0, tk ? 1 : 0);
         TN_LAUNCH_CHECK();
         g.wt = reinterpret_cast<const _Float16*>(wt);
+    }
+    if constexpr (MODE < 2) {
+        if (tk) return FT == 2 ? c8_launch<2, MODE, true>(ctx, g) : c8_launch<1, MODE, true>(ctx, g);
     }
     return FT == 2 ? c8_launch<2, MODE>(ctx, g) : c8_launch<1, MODE>(ctx, g);
 }
 
 // every conv layer's arranged weights of a step in ONE launch (a net made eleven 5 us launches of c8_wt_kernel per step)
 struct C8WtBatch {
-    struct { const float* W; _Float16* wt; int K, C, KBF, nchunk, total, dgrad; } s[32];
+    struct { const float* W; _Float16* wt; int K, C, KBF, nchunk, total, dgrad, tk; } s[32];
 };
 __global__ __launch_bounds__(256) void c8_wt_multi_kernel(C8WtBatch b) {
     const auto& q = b.s[blockIdx.y];
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= q.total) return;
-    int r = idx;
-    const int e = r & 7; r >>= 3;
-    const int j = r % q.KBF; r /= q.KBF;
-    const int o = r & 1; r >>= 1;
-    const int tap = r % 9; r /= 9;
-    const int chunk = r % q.nchunk;
-    const int kt = r / q.nchunk;
-    const int filt = kt * q.KBF + (j & ~31) + c8_swap23(j & 31), ch = chunk * 16 + 8 * o + e;
-    float v = 0.f;
-    if (filt < q.K && ch < q.C)
-        v = q.dgrad ? q.W[((size_t)ch * q.K + filt) * 9 + tap] : q.W[((size_t)filt * q.C + ch) * 9 + (8 - tap)];
-    q.wt[idx] = (_Float16)v;
+    q.wt[idx] = (_Float16)c8_wt_value(q.W, q.K, q.C, q.KBF, q.nchunk, idx, q.dgrad, q.tk);
 }
 
 // =================================================================================================
@@ -1148,7 +1167,8 @@ int tn_c8_arrange_multi(tn_ctx* ctx, const tn_c8_wt_seg* segs, int nseg) {
         const int KBF = 32 * c8_pick_ft(K);
         b.s[i].W = segs[i].W; b.s[i].wt = static_cast<_Float16*>(segs[i].wt);
         b.s[i].K = K; b.s[i].C = C; b.s[i].KBF = KBF; b.s[i].nchunk = cdiv(C, 16);
-        b.s[i].total = (int)c8_wt_elems(K, C); b.s[i].dgrad = segs[i].dgrad;
+        b.s[i].total = (int)c8_wt_total(K, C, segs[i].dgrad); b.s[i].dgrad = segs[i].dgrad;
+        b.s[i].tk = c8_tap_packed(C, segs[i].dgrad) ? 1 : 0;
         if (b.s[i].total > mx) mx = b.s[i].total;
     }
     c8_wt_multi_kernel<<<dim3(cdiv(mx, 256), nseg), 256, 0, ctx->stream>>>(b);
