@@ -311,12 +311,32 @@ __global__ __launch_bounds__(256, 2) void c8_conv_kernel(C8G g) {
                     unsigned mb[8];
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
-                        const float a0 = actf(acc[f][0][h * 8 + e]);
-                        const float a1 = actf(acc[f][1][h * 8 + e]);
-                        const float mv = fmaxf(a0, a1);
-                        const float m = fmaxf(mv, __shfl_xor(mv, 1, 64));
-                        unsigned bits = (a0 == m ? (1u << dj) : 0u) | (a1 == m ? (4u << dj) : 0u);
-                        bits |= (unsigned)__shfl_xor((int)bits, 1, 64);
+                        float m;
+                        unsigned bits;
+                        if (LK) {
+                            // leaky-ReLU does not decrease: the maximum of the four activations is the activation of the
+                            // maximum, and (slope > 0) the elements that attain one attain the other; with slope 0 a
+                            // window of negatives marks its largest element instead of all four -- every one of them
+                            // receives g * act'(0) = 0 either way (the derivative is taken from the stored output).
+                            // One activation instead of two per lane; lane ^ 1 through DPP (quad_perm [1,0,3,2]), not
+                            // through the LDS crossbar (__shfl_xor compiled to ds_bpermute: 32 LDS round trips per tile)
+                            const float z0 = acc[f][0][h * 8 + e], z1 = acc[f][1][h * 8 + e];
+                            float zv, zm;
+                            asm("v_max_f32_e32 %0, %1, %2" : "=v"(zv) : "v"(z0), "v"(z1));
+                            const float zp = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(
+                                                 0, __builtin_bit_cast(int, zv), 0xB1, 0xF, 0xF, false));
+                            asm("v_max_f32_e32 %0, %1, %2" : "=v"(zm) : "v"(zv), "v"(zp));
+                            bits = (z0 == zm ? (1u << dj) : 0u) | (z1 == zm ? (4u << dj) : 0u);
+                            bits |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)bits, 0xB1, 0xF, 0xF, false);
+                            m = actf(zm);
+                        } else {
+                            const float a0 = actf(acc[f][0][h * 8 + e]);
+                            const float a1 = actf(acc[f][1][h * 8 + e]);
+                            const float mv = fmaxf(a0, a1);
+                            m = fmaxf(mv, __shfl_xor(mv, 1, 64));
+                            bits = (a0 == m ? (1u << dj) : 0u) | (a1 == m ? (4u << dj) : 0u);
+                            bits |= (unsigned)__shfl_xor((int)bits, 1, 64);
+                        }
                         bits |= (m > 0.f ? 16u : 0u) | (m < 0.f ? 32u : 0u);
                         o8[e] = (_Float16)m;
                         mb[e] = bits;
