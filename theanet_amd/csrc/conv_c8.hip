@@ -333,9 +333,10 @@ __global__ __launch_bounds__(256, 2) void c8_conv_kernel(C8G g) {
                             const float a0 = actf(acc[f][0][h * 8 + e]);
                             const float a1 = actf(acc[f][1][h * 8 + e]);
                             const float mv = fmaxf(a0, a1);
-                            m = fmaxf(mv, __shfl_xor(mv, 1, 64));
+                            m = fmaxf(mv, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(
+                                              0, __builtin_bit_cast(int, mv), 0xB1, 0xF, 0xF, false)));
                             bits = (a0 == m ? (1u << dj) : 0u) | (a1 == m ? (4u << dj) : 0u);
-                            bits |= (unsigned)__shfl_xor((int)bits, 1, 64);
+                            bits |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)bits, 0xB1, 0xF, 0xF, false);
                         }
                         bits |= (m > 0.f ? 16u : 0u) | (m < 0.f ? 32u : 0u);
                         o8[e] = (_Float16)m;
