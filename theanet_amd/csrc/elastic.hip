@@ -100,6 +100,7 @@ __global__ __launch_bounds__(256) void elastic_apply_kernel(
     out[t] = v;
 }
 
+typedef float el_f2u __attribute__((ext_vector_type(2), aligned(4)));     // two neighbouring taps, dword-aligned
 // The same gather, 4 consecutive output pixels per thread (h*w % 4 == 0): one 16-byte map load,
 // one Philox call (the 4 flip draws of an aligned quad share a counter) and one 16-byte store.
 // elastic_quad: the four values of pixels p .. p+3 of one (image, channel) plane xi; t = index of the quad's first
@@ -126,7 +127,9 @@ __device__ __forceinline__ void elastic_quad(const float* __restrict__ xi, int p
             float a[4], b[4], c[4], d[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                a[e] = xi[m[e]]; b[e] = xi[m[e] + 1]; c[e] = xi[m[e] + w]; d[e] = xi[m[e] + w + 1];
+                const el_f2u r0 = *reinterpret_cast<const el_f2u*>(xi + m[e]);              // two taps per 8-byte gather
+                const el_f2u r1 = *reinterpret_cast<const el_f2u*>(xi + m[e] + w);
+                a[e] = r0.x; b[e] = r0.y; c[e] = r1.x; d[e] = r1.y;
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -210,7 +213,10 @@ __global__ __launch_bounds__(256) void elastic_apply_c8_kernel(
             const long long img = n * C + c;
             const float* xi = x + ((size_t)row_off * C + img) * hw;
             if (bil) {
-                float a = xi[m], b = xi[m + 1], cc = xi[m + w], d = xi[m + w + 1];
+                // the two taps of a row are neighbours: one 8-byte load each (dword-aligned: the hardware takes it) --
+                // the kernel is bound by its gather instructions (64 addresses each), 12 of them per pixel before
+                const el_f2u r0 = *reinterpret_cast<const el_f2u*>(xi + m), r1 = *reinterpret_cast<const el_f2u*>(xi + m + w);
+                float a = r0.x, b = r0.y, cc = r1.x, d = r1.y;
                 if (invert) {
                     a = 1.f - a; b = 1.f - b; cc = 1.f - cc; d = 1.f - d;
                 }
@@ -287,7 +293,9 @@ __global__ __launch_bounds__(256) void elastic_convpool_fwd_kernel(
                 const float fy[4] = {fy4.x, fy4.y, fy4.z, fy4.w}, fx[4] = {fx4.x, fx4.y, fx4.z, fx4.w};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    float a = xi[m[e]], bb = xi[m[e] + 1], c = xi[m[e] + w], d = xi[m[e] + w + 1];
+                    const el_f2u r0 = *reinterpret_cast<const el_f2u*>(xi + m[e]);          // two taps per 8-byte gather
+                    const el_f2u r1 = *reinterpret_cast<const el_f2u*>(xi + m[e] + w);
+                    float a = r0.x, bb = r0.y, c = r1.x, d = r1.y;
                     if (invert) {
                         a = 1.f - a; bb = 1.f - bb; c = 1.f - c; d = 1.f - d;
                     }
