@@ -516,7 +516,9 @@ static int c8_launch(tn_ctx* ctx, C8G& g) {
     const size_t lds = c8_lds_bytes(g, FT);
     const int ns = cdiv(g.nslots, 256);
     g.nwork = 8 * cdiv(g.MT, 8) * g.KT;
-    int grid = 8 * (2 * ctx->num_cus / 8);          // two resident blocks per CU, each walking over its work items
+    // two resident blocks per CU, each walking over its work items; three for the 32-filter kernels (their registers and
+    // LDS allow it): another wave per SIMD under their epilogues
+    int grid = 8 * ((FT == 1 && 3 * lds <= 150 * 1024 ? 3 : 2) * ctx->num_cus / 8);
     if (grid > g.nwork) grid = g.nwork;
     static int dbg_on = -1;
     if (dbg_on < 0) {
