@@ -241,3 +241,36 @@ def test_elastic_convpool_fused_equals_separate_ops(hw, nearest, K, mode, act):
     assert np.array_equal(out_a.get_value(), out_b.get_value())
     assert np.array_equal(y_a.get_value(), y_b.get_value())
     assert np.array_equal(m_a.get_value(), m_b.get_value())
+
+
+@pytest.mark.parametrize("C,hw,nearest,invert,mode", [
+    (3, 32, False, 0, "philox"), (3, 32, True, 1, "mask"), (1, 28, False, 1, "none"), (8, 16, False, 0, "philox"),
+    (11, 16, True, 0, "mask"), (4, 64, False, 0, "none"),
+])
+def test_elastic_apply_into_the_c8_tensor_equals_apply_then_pack(C, hw, nearest, invert, mode):
+    """tn_c8_elastic_apply (DTYPE float16: the stage writes the first conv layer's fp16 tensor) stores exactly
+    fp16(tn_elastic_apply's value) -- with sample maps, inversion, an injected flip mask or flips drawn on the device --
+    and zero in the channels beyond C."""
+    N, rng = 5, np.random.RandomState(3)
+    x = rng.rand(N + 2, C, hw, hw).astype(np.float32)
+    idx = dev(rng.randint(0, (hw - 1) * hw - 1, hw * hw).astype(np.int32) // hw * hw + rng.randint(0, hw - 1, hw * hw).astype(np.int32))
+    fy, fx = dev(rng.rand(hw * hw).astype(np.float32)), dev(rng.rand(hw * hw).astype(np.float32))
+    fm = dev((rng.rand(N, C, hw, hw) < .2).astype(np.uint8)) if mode == "mask" else None
+    pflip = .15 if mode == "philox" else 0.0
+    d_step = dev(np.array([7], np.uint32))
+    args = (6, int(nearest), idx.ptr, fy.ptr, fx.ptr, pflip, fm.ptr if fm is not None else None, 12345, 3, d_step.ptr, 40)
+    xd, row0 = dev(x), dev(np.array([1], np.int64))
+    out = empty((N, C, hw, hw))
+    call("tn_elastic_apply", xd.ptr, 1, row0.ptr, out.ptr, N, C, hw, hw, invert, *args[1:])
+    C8 = (C + 7) // 8
+    out16 = empty((N, C8, hw * hw, 8), np.uint16)
+    call("tn_c8_elastic_apply", xd.ptr, 1, row0.ptr, out16.ptr, N, C, hw, hw, invert, *args[1:])
+    want = np.zeros((N, C8 * 8, hw * hw), np.float16)
+    want[:, :C] = out.get_value().reshape(N, C, hw * hw).astype(np.float16)
+    want = want.reshape(N, C8, 8, hw * hw).transpose(0, 1, 3, 2)
+    np.testing.assert_array_equal(out16.get_value().view(np.float16), want)
+    if mode == "philox":                     # and the flips really happened (about pflip of the elements)
+        plain = empty((N, C, hw, hw))
+        call("tn_elastic_apply", xd.ptr, 1, row0.ptr, plain.ptr, N, C, hw, hw, invert, int(nearest), idx.ptr, fy.ptr, fx.ptr,
+             0.0, None, 12345, 3, d_step.ptr, 40)
+        assert 0.10 < np.mean(plain.get_value() != out.get_value()) < 0.20
