@@ -26,7 +26,7 @@ pytestmark = pytest.mark.skipif(not os.path.isfile(CPU_LIB), reason="libtheanet_
 # HIP graphs, RCCL, fp16 MFMA) and BASELINE-size runs that only make sense on the GPU
 NOT_ON_CPU = ("convpool_fused or convblock or convpool_tile or convpool_mask or convpool_tie or "
               "elastic_convpool_fused or graph_capture or rccl or two_gpu or dp_ or 4096 or full_size or "
-              "full_batch or f16 or bf16x3")
+              "full_batch or f16 or bf16x3 or c8")
 
 
 def _env(**kw):
