@@ -68,8 +68,8 @@ class StepPlan:
     def __init__(self, ctx, batch, lo):
         self.ctx, self.batch, self.lo = ctx, int(batch), int(lo)
         self.n = 0                  # steps seen (interpreted or replayed) since the plan object exists
-        self.steps = []             # recorded: (n, i, [(name, args)...], state after the step)
-        self.plans = None           # per phase: (handle, state after)
+        self.steps = []             # recorded: (n, i, [(name, args)...], state after the step, state before it)
+        self.plans = None           # per phase: (handle, state after, state before)
         self.period = 0
         self.off = os.environ.get("TN_NET_PLAN", "1") == "0"
         self.why = "TN_NET_PLAN=0" if self.off else ""
@@ -80,21 +80,23 @@ class StepPlan:
         return self.plans is not None
 
     # -- recording ----------------------------------------------------------------------------------------------
-    def begin(self, i):
+    def begin(self, i, pre=None):
+        """Before an interpreted ordinary step; ``pre`` = the owner's host-side state the step starts from."""
         if self.off or self.ready or self.n < self.WARM:
             return
-        self._cur = (self.n, int(i), [])
+        self._cur = (self.n, int(i), [], pre)
         self.ctx.rec = self._cur[2]
 
     def end(self, state, ok=True):
-        """After an interpreted step (ok False: it was not an ordinary step -- recording starts over)."""
+        """After an interpreted step (ok False: it was not an ordinary step, or it raised -- recording starts
+        over)."""
         self.n += 1
         if self.ctx.rec is not None and self._cur is not None and self.ctx.rec is self._cur[2]:
             self.ctx.rec = None
             tainted = self.ctx.rec_tainted
             self.ctx.rec_tainted = False
             if ok and not tainted:
-                self.steps.append(self._cur[:2] + (self._cur[2], state))
+                self.steps.append(self._cur[:3] + (state, self._cur[3]))
                 if len(self.steps) >= 3 * max(self.PERIODS):
                     self._build()
             else:
@@ -118,10 +120,10 @@ class StepPlan:
 
     def _build(self):
         try:
-            enc = [[(name,) + _encode(name, args) for name, args in calls] for _, _, calls, _ in self.steps]
+            enc = [[(name,) + _encode(name, args) for name, args in calls] for _, _, calls, _, _ in self.steps]
         except PlanError as e:
             return self._give_up(str(e))
-        idx = [i for _, i, _, _ in self.steps]
+        idx = [st[1] for st in self.steps]
         for P in self.PERIODS:
             rows = self._match(enc, idx, P)
             if rows is not None:
@@ -131,7 +133,7 @@ class StepPlan:
         lib, h = self.ctx.lib, self.ctx.h
         plans = [None] * P
         for s in range(len(self.steps) - P, len(self.steps)):
-            n, i, _, state = self.steps[s]
+            n, i, _, state, pre = self.steps[s]
             handle = ctypes.c_void_p()
             self.ctx.call("tn_net_plan_create", ctypes.byref(handle))
             for c, (name, kinds, vals) in enumerate(enc[s]):
@@ -145,7 +147,7 @@ class StepPlan:
                 rc = lib.tn_net_plan_add(h, handle, name.encode(), len(kinds), K, V, S)
                 if rc:
                     _lib.check(h, rc, "tn_net_plan_add")
-            plans[n % P] = (handle, state)
+            plans[n % P] = (handle, state, pre)
         self.plans, self.period, self.steps = plans, P, []
 
     def _match(self, enc, idx, P):
@@ -155,6 +157,8 @@ class StepPlan:
             mine = [s for s in range(len(enc)) if self.steps[s][0] % P == ph]
             if len(mine) < 2:
                 return None
+            if any(self.steps[s][4] != self.steps[mine[0]][4] for s in mine):
+                return None                             # a phase is identified by the state its steps start from
             ref = enc[mine[0]]
             cand = None
             for s in mine:
@@ -176,17 +180,28 @@ class StepPlan:
         return rows
 
     # -- replay -------------------------------------------------------------------------------------------------
-    def step(self, i):
-        handle, state = self.plans[self.n % self.period]
+    def step(self, i, cur=None):
+        """Replay the phase whose recorded step STARTED from the owner's current host-side state ``cur`` and return
+        the state it leaves behind -- or None when no recorded phase starts there (an interpreted step in between
+        left the ping-pong buffers / stream parity elsewhere: the caller interprets this step too).  The baked
+        pointers of a phase are only valid from that state, so the phase is never picked by counting steps."""
+        k = self.n % self.period
+        order = [k] + [j for j in range(self.period) if j != k]
+        for j in order:
+            handle, state, pre = self.plans[j]
+            if pre == cur:
+                break
+        else:
+            return None
         rc = self.ctx.lib.tn_net_step(self.ctx.h, handle, int(i))
         if rc:
             _lib.check(self.ctx.h, rc, "tn_net_step")
-        self.n += 1
+        self.n = j + 1
         return state
 
     def drop(self):
         if self.plans:
-            for handle, _ in self.plans:
+            for handle, _, _ in self.plans:
                 self.ctx.lib.tn_net_plan_destroy(self.ctx.h, handle)
         self.plans = None
 

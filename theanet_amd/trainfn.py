@@ -102,9 +102,11 @@ class _TrainFn:
             if pl.ready:
                 if ok:                       # (the learning rate is a device scalar here: no argument changes with it)
                     self.net._apply_dtype()
-                    return self._plan_set_state(pl.step(i))
+                    st = pl.step(i, self._plan_state())
+                    if st is not None:
+                        return self._plan_set_state(st)
             if ok:
-                pl.begin(i)
+                pl.begin(i, self._plan_state())
             try:
                 self._enqueue(i)
             except Exception:
@@ -272,7 +274,7 @@ class _PipeTrainFn:
         for X in self.nets:
             first = X.tr_layers[0]
             per_net.append((X._cost_pending, getattr(first, "_cur", None), getattr(first, "_pre_valid", None)))
-        return (self.nets.index(self._last), tuple(per_net))
+        return (self.nets.index(self._last), tuple(per_net), self.t & 1)
 
     def _plan_set_state(self, st):
         self._last = self.nets[st[0]]
@@ -371,10 +373,12 @@ class _PipeTrainFn:
         ok = self._plannable()
         if pl.ready and ok:
             self.net._apply_dtype()
-            self._plan_set_state(pl.step(i))
-            return
+            st = pl.step(i, self._plan_state())
+            if st is not None:
+                self._plan_set_state(st)
+                return
         if ok:
-            pl.begin(i)
+            pl.begin(i, self._plan_state())
         try:
             self._enqueue(i)
         except Exception:
