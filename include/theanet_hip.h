@@ -138,15 +138,13 @@ int tn_conv2d_dgrad(tn_ctx* ctx, const float* dz, const float* W, float* dx,
                     int N, int C, int H, int Wd, int K, int f, int stride, int pad_lo,
                     int Ho, int Wo, const float* prev_a, int prev_act, float prev_act_param);
 
-/* ---- fp16-operand / fp32-accumulate products for the 3x3 stride-1 conv layers (BASELINE configs[4];
- * the reference is float32-only, weights.py:8 `floatX`: this is an opt-in DTYPE, default off) ----
- * dtype 0: fp32 operands (reference arithmetic).  dtype 1: tn_conv2d_fwd / _wgrad / _dgrad and the
- * fused conv+pool blocks round BOTH operands of every product to fp16 (round-to-nearest-even) while
- * staging them and accumulate in fp32 on v_mfma_f32_32x32x16_f16; tensors stay fp32 in HBM (fp32
- * master weights).  grad_scale (a power of two, e.g. 4096): products that have dz as an operand round
- * grad_scale*dz and multiply the fp32 result by 1/grad_scale, so small gradients do not fall into
- * fp16's subnormal range.  In dtype 1 an unsupported conv shape is an ERROR (TN_E_ARG), never a silent
- * fp32 run: tn_conv_f16_supported says beforehand (bit 0 forward, bit 1 dgrad, bit 2 wgrad).        */
+/* ---- DTYPE 'float16' (BASELINE configs[4]; the reference is float32-only, weights.py:8 `floatX`: an opt-in
+ * training param of this build, default off) ----
+ * dtype 0: every tensor fp32 (reference arithmetic).  dtype 1: the conv stack of the net lives in HBM as halfs and is
+ * served by the tn_c8_* / tn_fc8_* entry points below; the fp32-tensor conv entry points (tn_conv2d_*, tn_convpool_*)
+ * REFUSE to run in this mode (TN_E_ARG: never a silent fp32 run inside a float16 net).  grad_scale (a power of two,
+ * e.g. 4096): gradient tensors of the stack hold fp16(grad_scale * g) so that small gradients do not fall into
+ * fp16's subnormal range; the fp32 epilogues of the weight gradients remove the factor.                          */
 int tn_set_matmul_dtype(tn_ctx* ctx, int dtype, float grad_scale);
 int tn_get_matmul_dtype(tn_ctx* ctx);
 /* MATMUL 'bf16x3' (opt-in, this build's extension; the reference is float32, weights.py:8): mode 1 runs the products of
@@ -154,10 +152,6 @@ int tn_get_matmul_dtype(tn_ctx* ctx);
  * exactly split operands (x = x0 + x1 + x2, 8 mantissa bits each) with fp32 accumulation -- fp32-grade accuracy
  * (the same tolerances hold), not the same bits as mode 0's exact fp32 MFMA.  theanet_amd/csrc/gemm_b3.hip.        */
 int tn_set_fc_matmul(tn_ctx* ctx, int mode);
-int tn_conv_f16_supported(int N, int C, int H, int Wd, int K, int f, int stride, int pad_lo, int Ho, int Wo);
-/* 1 if the conv + act + 2x2 max-pool block runs fused on the fp16-operand tile kernels */
-int tn_convpool_f16_supported(int N, int C, int H, int Wd, int K, int f, int stride, int pad_lo, int Ho, int Wo,
-                              int p, int Hp, int Wp);
 
 /* ---- DTYPE 'float16' on fp16-RESIDENT tensors (theanet_amd/csrc/conv_c8.hip, fc_c8.hip) --------------------
  * BASELINE.json configs[4]: "fp16 inputs / fp32 accum MFMA".  The reference is float32-only (weights.py:8); these

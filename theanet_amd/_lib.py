@@ -79,8 +79,6 @@ SIGNATURES = {
     "tn_set_matmul_dtype": (c_int, [CTX, c_int, c_float]),
     "tn_get_matmul_dtype": (c_int, [CTX]),
     "tn_set_fc_matmul": (c_int, [CTX, c_int]),
-    "tn_conv_f16_supported": (c_int, [c_int] * 10),
-    "tn_convpool_f16_supported": (c_int, [c_int] * 13),
     "tn_c8_conv_supported": (c_int, [c_int] * 8),
     "tn_c8_conv_wgrad_supported": (c_int, [c_int] * 5),
     "tn_c8_wt_elems": (c_size_t, [c_int] * 3),

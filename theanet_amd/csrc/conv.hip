@@ -388,40 +388,14 @@ int tn_conv_wgrad_finish(tn_ctx* ctx, const float* partial, const float* dbparti
     return tn_red_commit(ctx);
 }
 
-int tn_conv_tile16_ok(const float* x, int N, int C, int H, int Wd, int K, int f, int pad, int Ho, int Wo);
-int tn_conv_tile16_fwd(tn_ctx* ctx, const float* x, const float* W, const float* b, float* a, int N, int C,
-                       int H, int Wd, int K, int pad, int Ho, int Wo, int act, float prm);
-int tn_conv_tile16_dgrad(tn_ctx* ctx, const float* dz, const float* W, float* dx, int N, int C, int H,
-                         int Wd, int K, int pad, int Ho, int Wo, const float* prev_a, int act, float prm);
-int tn_conv_tile16_wgrad_ok(tn_ctx* ctx, const float* x, const float* dz, int N, int C, int H, int Wd, int K,
-                            int f, int pad, int Ho, int Wo);
-int tn_conv_tile16_wgrad(tn_ctx* ctx, const float* x, const float* dz, float* dW, float* db, int N, int C,
-                         int H, int Wd, int K);
-
 extern "C" {
-
-// fp16-operand products (tn_set_matmul_dtype): bit 0 forward, bit 1 input gradient, bit 2 weight gradient
-int tn_conv_f16_supported(int N, int C, int H, int Wd, int K, int f, int stride, int pad_lo, int Ho, int Wo) {
-    if (stride != 1 || f != 3) return 0;
-    int bits = 0;
-    if (tn_conv_tile16_ok(nullptr, N, C, H, Wd, K, f, pad_lo, Ho, Wo)) bits |= 1;
-    if (tn_conv_tile16_ok(nullptr, N, K, Ho, Wo, C, f, f - 1 - pad_lo, H, Wd)) bits |= 2;
-    if (C * 9 <= 32 ? tn_conv_tile_smallc_ok(nullptr, nullptr, N, C, H, Wd, K, f, pad_lo, Ho, Wo)
-                    : tn_conv_tile16_wgrad_ok(nullptr, nullptr, nullptr, N, C, H, Wd, K, f, pad_lo, Ho, Wo))
-        bits |= 4;
-    return bits;
-}
 
 int tn_conv2d_fwd(tn_ctx* ctx, const float* x, const float* W, const float* b, float* a, int N,
                   int C, int H, int Wd, int K, int f, int stride, int pad_lo, int Ho, int Wo,
                   int act, float act_param) {
     TN_REQUIRE(N > 0 && C > 0 && K > 0 && f > 0 && stride > 0 && Ho > 0 && Wo > 0,
                "tn_conv2d_fwd: bad shape");
-    if (ctx->mm_f16) {      // fp16 operands: the LDS-tile kernel or an error, never a silent fp32 run
-        TN_REQUIRE(stride == 1 && tn_conv_tile16_ok(x, N, C, H, Wd, K, f, pad_lo, Ho, Wo),
-                   "tn_conv2d_fwd: no fp16-operand kernel for C=%d K=%d %dx%d f=%d stride=%d", C, K, H, Wd, f, stride);
-        return tn_conv_tile16_fwd(ctx, x, W, b, a, N, C, H, Wd, K, pad_lo, Ho, Wo, act, act_param);
-    }
+    TN_REQUIRE(!ctx->mm_f16, "tn_conv2d_fwd: fp32 tensors in DTYPE float16 mode (the mode's entry points are tn_c8_*)");
     if (tn_conv_mfma_supported(C, K, f, stride))
         return tn_conv_mfma_fwd(ctx, x, W, b, a, N, C, H, Wd, K, f, pad_lo, Ho, Wo, act, act_param);
     // few input channels (first layers): still worth the matrix core when the LDS-tile kernel applies
@@ -448,13 +422,7 @@ int tn_conv2d_fwd(tn_ctx* ctx, const float* x, const float* W, const float* b, f
 int tn_conv2d_wgrad(tn_ctx* ctx, const float* x, const float* dz, float* dW, float* db, int N, int C,
                     int H, int Wd, int K, int f, int stride, int pad_lo, int Ho, int Wo) {
     TN_REQUIRE(N > 0 && C > 0 && K > 0 && f > 0 && stride > 0, "tn_conv2d_wgrad: bad shape");
-    if (ctx->mm_f16) {
-        if (stride == 1 && C * 9 <= 32 && tn_conv_tile_smallc_ok(x, dz, N, C, H, Wd, K, f, pad_lo, Ho, Wo))
-            return tn_conv_tile_smallc_wgrad(ctx, x, dz, dW, db, N, C, H, Wd, K);     // rounds its operands
-        TN_REQUIRE(stride == 1 && tn_conv_tile16_wgrad_ok(ctx, x, dz, N, C, H, Wd, K, f, pad_lo, Ho, Wo),
-                   "tn_conv2d_wgrad: no fp16-operand kernel for C=%d K=%d %dx%d f=%d stride=%d", C, K, H, Wd, f, stride);
-        return tn_conv_tile16_wgrad(ctx, x, dz, dW, db, N, C, H, Wd, K);
-    }
+    TN_REQUIRE(!ctx->mm_f16, "tn_conv2d_wgrad: fp32 tensors in DTYPE float16 mode (the mode's entry points are tn_c8_*)");
     if (tn_conv_mfma_supported(C, K, f, stride))
         return tn_conv_mfma_wgrad(ctx, x, dz, dW, db, N, C, H, Wd, K, f, pad_lo, Ho, Wo);
     if (stride == 1 && tn_conv_tile_smallc_ok(x, dz, N, C, H, Wd, K, f, pad_lo, Ho, Wo))   // first layers
@@ -502,11 +470,7 @@ int tn_conv2d_dgrad(tn_ctx* ctx, const float* dz, const float* W, float* dx, int
                     int Wd, int K, int f, int stride, int pad_lo, int Ho, int Wo, const float* prev_a,
                     int prev_act, float prev_act_param) {
     TN_REQUIRE(N > 0 && C > 0 && K > 0 && f > 0 && stride > 0, "tn_conv2d_dgrad: bad shape");
-    if (ctx->mm_f16) {
-        TN_REQUIRE(stride == 1 && tn_conv_tile16_ok(dz, N, K, Ho, Wo, C, f, f - 1 - pad_lo, H, Wd),
-                   "tn_conv2d_dgrad: no fp16-operand kernel for C=%d K=%d %dx%d f=%d stride=%d", C, K, H, Wd, f, stride);
-        return tn_conv_tile16_dgrad(ctx, dz, W, dx, N, C, H, Wd, K, pad_lo, Ho, Wo, prev_a, prev_act, prev_act_param);
-    }
+    TN_REQUIRE(!ctx->mm_f16, "tn_conv2d_dgrad: fp32 tensors in DTYPE float16 mode (the mode's entry points are tn_c8_*)");
     if (tn_conv_mfma_supported(K, C, f, stride))     // reduction K*f*f, rows = C input maps
         return tn_conv_mfma_dgrad(ctx, dz, W, dx, N, C, H, Wd, K, f, pad_lo, Ho, Wo, prev_a, prev_act,
                                   prev_act_param);

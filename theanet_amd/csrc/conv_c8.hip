@@ -10,7 +10,7 @@
 // Why c8.  The B operand of v_mfma_f32_32x32x16_f16 is "8 consecutive reduction indices per lane"; with lane = pixel
 // and reduction = input channel that is exactly one 16-byte cell, so
 //   * forward / input gradient: the halo tile is COPIED HBM -> LDS (16-byte loads, 16-byte stores, no conversion, no
-//     transposition: conv_tile16.hip spent 32 v_cvt + 8 loads per 4 pixels on that), the im2col is a constant added to
+//     transposition: round 2's operand-rounding kernel spent 32 v_cvt + 8 loads per 4 pixels on that), the im2col is a constant added to
 //     an LDS address, and with the filters of a 32-row MFMA tile permuted (bits 2 and 3 of the row swapped, done once by
 //     the weight-arranging kernel) a lane's accumulators are two complete octets of its pixel: the epilogue stores
 //     16-byte cells straight from registers -- no LDS round trip;
@@ -18,8 +18,8 @@
 //     in-lane max and one lane-pair exchange;
 //   * gradients travel as fp16(gs * g) (gs = GRAD_SCALE, a power of two; |dz| ~ 1e-3/B is fp16-subnormal territory):
 //     scaled ONCE where the first fp16 gradient is produced, unscaled in the fp32 epilogues of the weight gradients.
-// The weight gradient (reduction = pixels) wants the other orientation: its staging pass transposes 4-pixel x 8-channel
-// blocks in registers (16 v_perm_b32 per 64 bytes) into the [channel][pixel] LDS image of conv_tile16.hip's kernel.
+// The weight gradient (reduction = pixels) wants the other orientation: gfx950's transposing LDS read
+// (ds_read_b64_tr_b16) supplies it between LDS and the registers, so its LDS images are plain copies of the c8 tensors.
 #include "conv_tile_common.h"
 
 #include <type_traits>

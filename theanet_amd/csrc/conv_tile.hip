@@ -708,18 +708,10 @@ struct ConvSG {
     int KG, S, ipb;
     int NI, TH, THi, RT, NT;
     int RS, plane, q4, nx4, lgW, lgP;
-    float gscale, oscale;  // F16: dz is rounded as h(gscale*dz), the result multiplied by oscale = 1/gscale
     PoolSrc ps;
 };
 
-// v rounded to fp16 (nearest even) and widened again: products of two such values are exact in fp32, so
-// the fp32 MFMA on rounded operands is the fp16-operand / fp32-accumulate product (tn_set_matmul_dtype)
-__device__ __forceinline__ float cs_r16(float v) { return (float)(_Float16)v; }
-__device__ __forceinline__ float4 cs_r16x4(float4 v, float s) {
-    return make_float4(cs_r16(s * v.x), cs_r16(s * v.y), cs_r16(s * v.z), cs_r16(s * v.w));
-}
-
-template <bool POOL, bool F16>
+template <bool POOL>
 __global__ __launch_bounds__(256) void conv_tile_wgrad_smallc_kernel(ConvSG g) {
     extern __shared__ __attribute__((aligned(16))) float ct_smem[];
     constexpr int DZSZ = 32 * CW_DZS;
@@ -770,7 +762,7 @@ __global__ __launch_bounds__(256) void conv_tile_wgrad_smallc_kernel(ConvSG g) {
     {                                                                                            \
         *reinterpret_cast<float4*>(__builtin_assume_aligned(                                     \
             ct_smem + (so[SL] >= 0 ? (BUF) * BUFSZ + so[SL] : 2 * BUFSZ + 8), 16)) =             \
-            F16 ? cs_r16x4(sv[SL], (SL) < 4 ? g.gscale : 1.f) : sv[SL];                          \
+            sv[SL];                                                                              \
         if ((SL) < 4) dbacc[(SL) < 4 ? (SL) : 0] += dbw_ * ((sv[SL].x + sv[SL].y) + (sv[SL].z + sv[SL].w)); \
     }
     f32x16 acc;
@@ -830,7 +822,7 @@ __global__ __launch_bounds__(256) void conv_tile_wgrad_smallc_kernel(ConvSG g) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int k = kg * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-            if (k < g.K) wz[(size_t)k * CT + cc * 9 + 8 - tap] = F16 ? acc[r] * g.oscale : acc[r];
+            if (k < g.K) wz[(size_t)k * CT + cc * 9 + 8 - tap] = acc[r];
         }
     }
 }
@@ -876,12 +868,8 @@ static int cs_run(tn_ctx* ctx, ConvSG& g, float* dW, float* db, bool pool) {
     const int XSZ = (g.C * g.plane + 3) & ~3;
     const size_t lds = (size_t)(2 * (32 * CW_DZS + XSZ) + 16) * sizeof(float);
     const int grid = 8 * cdiv(g.S, 8) * g.KG;
-    g.gscale = ctx->grad_scale; g.oscale = 1.f / ctx->grad_scale;
-    if (ctx->mm_f16) {
-        if (pool) conv_tile_wgrad_smallc_kernel<true, true><<<grid, 256, lds, ctx->stream>>>(g);
-        else conv_tile_wgrad_smallc_kernel<false, true><<<grid, 256, lds, ctx->stream>>>(g);
-    } else if (pool) conv_tile_wgrad_smallc_kernel<true, false><<<grid, 256, lds, ctx->stream>>>(g);
-    else conv_tile_wgrad_smallc_kernel<false, false><<<grid, 256, lds, ctx->stream>>>(g);
+    if (pool) conv_tile_wgrad_smallc_kernel<true><<<grid, 256, lds, ctx->stream>>>(g);
+    else conv_tile_wgrad_smallc_kernel<false><<<grid, 256, lds, ctx->stream>>>(g);
     TN_LAUNCH_CHECK();
     rc = tn_red_push(ctx, g.ws, dW, (uint32_t)n, (uint32_t)(g.S * 4), (uint32_t)n, 0);
     if (rc) return rc;

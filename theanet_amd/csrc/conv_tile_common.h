@@ -1,5 +1,5 @@
-// Shared pieces of the LDS-tile 3x3 convolution kernels (conv_tile.hip: fp32 MFMA; conv_tile16.hip:
-// fp16 operands / fp32 accumulate MFMA): geometry struct, pooled-gradient expansion, epilogues.
+// Shared pieces of the LDS-tile 3x3 convolution kernels (conv_tile.hip: fp32 MFMA; conv_c8.hip takes the
+// pooled-gradient source from here): geometry struct, pooled-gradient expansion, epilogues.
 #pragma once
 #include "common.h"
 
@@ -52,11 +52,10 @@ struct ConvTG {
     int KT, MT, RT, NI, TH, THi, RS, LP, plane, nchunk, TP, q4, nx4, vec_out;
     PoolSrc ps;                // POOL dgrad: the gathered tensor is formed from (g, mask, y)
     uint8_t* mask_out;         // POOL forward: pooling mask (may be NULL)
-    float iscale, oscale;      // conv_tile16 dgrad: the gathered tensor is scaled before rounding, the result after
     unsigned long long* dbg;   // TN_CT_DBG=1: per block {start, prologue done, loop done, end} (s_memtime) + wall clock
 };
 
-// Epilogue of conv_tile_kernel / conv_tile16_kernel: the block's accumulators (FT filter tiles x 2 pixel tiles per
+// Epilogue of conv_tile_kernel: the block's accumulators (FT filter tiles x 2 pixel tiles per
 // wave, MFMA C/D layout) -> bias + act (+ 2x2 max-pool + mask) or act' of the layer below -> HBM.
 // ACT >= 0: the activation kind is a compile-time constant (leaky-ReLU, the nets' usual one): with a run-time
 // kind every element of the epilogue paid for the whole switch of tn_act_fwd / tn_act_grad_from_out -- 12 k

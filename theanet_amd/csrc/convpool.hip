@@ -26,13 +26,6 @@ extern "C" int tn_convpool_smallc_supported(int N, int C, int H, int Wd, int K, 
                                             int Wo, int p, int Hp, int Wp);
 int tn_conv_tile_smallc_bwd(tn_ctx* ctx, const float* x, const float* g_, const float* y, const uint8_t* mask,
                             float* dW, float* db, int N, int C, int H, int Wd, int K, int act, float prm);
-int tn_convpool_tile16_ok(int N, int C, int H, int Wd, int K, int f, int stride, int pad, int Ho, int Wo,
-                          int p, int Hp, int Wp);
-int tn_conv_tile16_pool_fwd(tn_ctx* ctx, const float* x, const float* W, const float* b, float* y,
-                            uint8_t* mask, int N, int C, int H, int Wd, int K, int act, float prm);
-int tn_conv_tile16_pool_bwd(tn_ctx* ctx, const float* x, const float* W, const float* g_, const float* y,
-                            const uint8_t* mask, float* dx, float* dW, float* db, int N, int C, int H, int Wd,
-                            int K, int act, float prm, const float* prev_a, int prev_act, float prev_prm);
 int tn_conv_tile_pool_fwd(tn_ctx* ctx, const float* x, const float* W, const float* b, float* y,
                           uint8_t* mask, int N, int C, int H, int Wd, int K, int act, float prm);
 int tn_conv_tile_pool_bwd(tn_ctx* ctx, const float* x, const float* W, const float* g_, const float* y,
@@ -540,20 +533,10 @@ int tn_convpool_fwd(tn_ctx* ctx, const float* x, const float* W, const float* b,
                                 act, act_param);
 }
 
-int tn_convpool_f16_supported(int N, int C, int H, int Wd, int K, int f, int stride, int pad_lo, int Ho, int Wo,
-                              int p, int Hp, int Wp) {
-    if (!tn_convpool_tile16_ok(N, C, H, Wd, K, f, stride, pad_lo, Ho, Wo, p, Hp, Wp)) return 0;
-    return C * 9 > 32 || tn_convpool_smallc_supported(N, C, H, Wd, K, f, pad_lo, Ho, Wo, p, Hp, Wp);
-}
-
 int tn_convpool_fwd_mask(tn_ctx* ctx, const float* x, const float* W, const float* b, float* y,
                          uint8_t* mask, int N, int C, int H, int Wd, int K, int f, int pad_lo, int Ho,
                          int Wo, int p, int Hp, int Wp, int act, float act_param) {
-    if (ctx->mm_f16) {      // fp16 operands: the LDS-tile kernel or an error, never a silent fp32 run
-        TN_REQUIRE(tn_convpool_f16_supported(N, C, H, Wd, K, f, 1, pad_lo, Ho, Wo, p, Hp, Wp),
-                   "tn_convpool_fwd_mask: no fp16-operand kernel for C=%d K=%d %dx%d f=%d p=%d", C, K, H, Wd, f, p);
-        return tn_conv_tile16_pool_fwd(ctx, x, W, b, y, mask, N, C, H, Wd, K, act, act_param);
-    }
+    TN_REQUIRE(!ctx->mm_f16, "tn_convpool_fwd_mask: fp32 tensors in DTYPE float16 mode (the mode's entry points are tn_c8_*)");
     if (!tn_convpool_supported(C, f, 1, p) &&
         tn_convpool_tile_supported(N, C, H, Wd, K, f, 1, pad_lo, Ho, Wo, p, Hp, Wp))
         return tn_conv_tile_pool_fwd(ctx, x, W, b, y, mask, N, C, H, Wd, K, act, act_param);   // wide layers
@@ -580,17 +563,7 @@ int tn_convpool_bwd_mask_dx(tn_ctx* ctx, const float* x, const float* W, const f
                             int Wd, int K, int f, int pad_lo, int Ho, int Wo, int p, int Hp, int Wp, int act,
                             float act_param, const float* prev_a, int prev_act, float prev_act_param) {
     TN_REQUIRE(x && W && g && y && mask, "tn_convpool_bwd_mask_dx: null argument");
-    if (ctx->mm_f16) {
-        TN_REQUIRE(tn_convpool_f16_supported(N, C, H, Wd, K, f, 1, pad_lo, Ho, Wo, p, Hp, Wp),
-                   "tn_convpool_bwd_mask_dx: no fp16-operand kernel for C=%d K=%d %dx%d f=%d p=%d", C, K, H, Wd, f, p);
-        if (C * 9 <= 32 && dW) {      // first layers: weight gradient on the small-C kernel (rounds its operands)
-            int rc = tn_conv_tile_smallc_bwd(ctx, x, g, y, mask, dW, db, N, C, H, Wd, K, act, act_param);
-            if (rc) return rc;
-            dW = nullptr; db = nullptr;
-        }
-        return tn_conv_tile16_pool_bwd(ctx, x, W, g, y, mask, dx, dW, db, N, C, H, Wd, K, act, act_param, prev_a,
-                                       prev_act, prev_act_param);
-    }
+    TN_REQUIRE(!ctx->mm_f16, "tn_convpool_bwd_mask_dx: fp32 tensors in DTYPE float16 mode (the mode's entry points are tn_c8_*)");
     TN_REQUIRE(tn_convpool_tile_supported(N, C, H, Wd, K, f, 1, pad_lo, Ho, Wo, p, Hp, Wp),
                "tn_convpool_bwd_mask_dx: unsupported block (C=%d K=%d %dx%d f=%d p=%d)", C, K, H, Wd, f, p);
     return tn_conv_tile_pool_bwd(ctx, x, W, g, y, mask, dx, dW, db, N, C, H, Wd, K, act, act_param, prev_a,

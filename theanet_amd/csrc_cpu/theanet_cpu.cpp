@@ -176,7 +176,6 @@ int tn_set_fc_matmul(tn_ctx* ctx, int mode) {
     REQUIRE(mode == 0, "tn_set_fc_matmul: the CPU backend computes the dense products in float32 only");
     return TN_OK;
 }
-int tn_conv_f16_supported(int, int, int, int, int, int, int, int, int, int) { return 0; }
 // DTYPE 'float16' on fp16-resident tensors (conv_c8.hip): MI355X only; the capability queries answer 0 and
 // tn_set_matmul_dtype refuses the mode, so the host never gets here
 int tn_c8_conv_supported(int, int, int, int, int, int, int, int) { return 0; }
@@ -202,7 +201,6 @@ int tn_c8_elastic_apply(tn_ctx* ctx, const float*, int64_t, const int64_t*, void
     NOT_HERE("tn_c8_elastic_apply");
 }
 int tn_c8_unpack(tn_ctx* ctx, const void*, float*, int, int, int, float) { NOT_HERE("tn_c8_unpack"); }
-int tn_convpool_f16_supported(int, int, int, int, int, int, int, int, int, int, int, int, int) { return 0; }
 
 int tn_alloc(tn_ctx* ctx, size_t bytes, void** dptr) {
     void* p = nullptr;
