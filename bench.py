@@ -135,7 +135,7 @@ def plan_batches(prms_name, batch, scaling, world_size):
     return base * world_size, base, "weak"
 
 
-def build(prms_name, global_batch, per_gpu, img, dtype):
+def build(prms_name, global_batch, per_gpu, img, dtype, group=None):
     from theanet_amd import NeuralNet
     prms = load_prms(prms_name)
     prms["_name"] = prms_name
@@ -151,10 +151,37 @@ def build(prms_name, global_batch, per_gpu, img, dtype):
     if dtype == "b3":
         tr["MATMUL"] = "bf16x3"
     net = NeuralNet(copy.deepcopy(prms["layers"]), dict(tr))
+    if group is not None:
+        net._dev_group = group              # a second net of the same launch: ONE communicator per process
     n_batches = max(2, 65536 // global_batch) if per_gpu * img * img * C < (1 << 24) else 2
     x, y = synthetic(n_batches * global_batch, C, img)
     fn = net.get_trin_model(x, y)
     return prms, tr, net, fn, n_batches, img, C
+
+
+def weak_leg(ctx, args, world, group, per_gpu):
+    """The weak-scaling form of an N-rank run: ``per_gpu`` rows per rank (global batch N * per_gpu), same harness as
+    the headline region (set-up steps, warm-up, exactly --steps enqueued steps between barriers, max over ranks)."""
+    gb = per_gpu * world.size
+    prms, tr, net, fn, n_batches, img, C = build(args.prms, gb, per_gpu, args.img, args.dtype, group=group)
+    n_setup = settle(ctx, fn, n_batches, group)
+    for i in range(args.warmup):
+        fn.enqueue(i % n_batches)
+    ctx.sync()
+    group.barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        fn.enqueue(i % n_batches)
+    ctx.sync()
+    group.barrier()
+    dt = group.rdzv.gather_max(time.perf_counter() - t0)
+    cost = float(fn.fetch()[0])
+    assert np.isfinite(cost), "training diverged (weak leg)"
+    rec = {"value": gb * args.steps / dt, "unit": "images/sec", "scaling": "weak", "global_batch": gb,
+           "rows_per_gpu": per_gpu, "steps": args.steps, "setup_steps": n_setup, "ms_per_step": 1e3 * dt / args.steps,
+           "dp_schedule": getattr(net, "dp_schedule", None), "final_cost": cost}
+    del fn, net
+    return rec
 
 
 def settle(ctx, fn, n_batches, group, min_seconds=0.2):
@@ -296,9 +323,20 @@ def dry_multi(args):
                 for p, g in zip(lyr.params, lyr.grads or ()):
                     tensors.append({"layer": i, "type": type(lyr).__name__, "shape": list(p.shape),
                                     "offset_floats": (g.ptr - net.flat_grads.ptr) // 4})
+            bk = getattr(net, "_dp_bucket", None)
+            buckets = [{"floats": net.n_flat, "offset_floats": 0, "issued": "end of the backward pass",
+                        "holds": "every gradient + the cost"}] if bk is None else \
+                [{"floats": net.n_flat - bk[1], "offset_floats": bk[1],
+                  "issued": "right after the dense layers' backward pass (layer %d down), beside the conv backward" % bk[0],
+                  "holds": "dense-layer gradients + the cost"},
+                 {"floats": bk[1], "offset_floats": 0, "issued": "end of the backward pass",
+                  "holds": "conv-layer gradients"}]
             plan = {"flat_gradient_buffer": {"floats_reduced_per_step": net.n_flat, "bytes": 4 * net.n_flat,
                                              "cost_slot": net.n_flat - 1, "tensors": tensors},
-                    "schedule": "pipelined (two steps in flight, all-reduce in-stream)"
+                    "allreduce_buckets": buckets,
+                    "allreduce_stream": "the context's communication stream (tn_allreduce_sum_async); consumer = the "
+                                        "update that opens the same stream's next step",
+                    "schedule": "pipelined (two steps in flight, all-reduce buckets on the communication stream)"
                     if type(fn).__name__ == "_PipeTrainFn" else
                     "one step at a time; all-reduce schedule autotuned among %s" %
                     (["plain"] + (["overlap"] if net._dp_cand else []) + (["delayed"] if net._dp_can_delay else [])),
@@ -326,6 +364,8 @@ def main():
     ap.add_argument("--img", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true", help="skip the per-kernel roofline leg")
+    ap.add_argument("--no-weak-leg", action="store_true",
+                    help="N > 1, strong scaling: skip the weak-scaling leg (value_weak) the same launch appends")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the cifar_like / wide6 legs the default N=1 mnist run appends (other_configs)")
     ap.add_argument("--dry-multi", type=int, default=0, metavar="N",
@@ -474,8 +514,6 @@ def main():
                                           for k, v in conv.items()}
                 roof["traffic_source"] = "profiles/%s (rocprofv3 --pmc, per launch)" % PMC_FILE
 
-    if world.rank != 0:
-        return
     value = tr["BATCH_SZ"] * args.steps / dt
     step_flops = roofline.net_step_flops(net) * world.size
     first = net.tr_layers[0]
@@ -507,6 +545,22 @@ def main():
         "roofline_others": others,
         "final_cost": float(cost),
     }
+    # N > 1: `value` is STRONG scaling, as BASELINE configs[2] states it (the global batch sharded N ways).  The same
+    # launch then times the WEAK form (the stated batch per GPU, N times the global batch) and reports it beside it:
+    # for mnist.prms the strong figure is bounded by the kernels' fixed costs at 4096/N rows,
+    # the weak one is what the interconnect and the schedule allow.  Every rank takes part (the steps are collectives).
+    if world.size > 1 and scaling == "strong" and not args.no_weak_leg:
+        import gc
+        del fn, net
+        gc.collect()
+        try:
+            wk = weak_leg(ctx, args, world, group, global_batch)
+            line["value_weak"] = wk["value"]
+            line["weak"] = wk
+        except Exception as e:      # (an exception on every rank alike: the headline keeps its line)
+            line["weak"] = {"error": "%s: %s" % (type(e).__name__, str(e)[-300:])}
+    if world.rank != 0:
+        return
     # BASELINE.json's other single-GPU configurations (north_star: images/sec "on synthetic 28x28x1 and 32x32x3
     # batches ... as fraction of the conv roofline"; the >= 50 % fp32-MFMA target on 3x3 convs; configs[4]'s fp16
     # path), timed by THIS run after the headline: the default N = 1 mnist run only.

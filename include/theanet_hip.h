@@ -581,6 +581,14 @@ int tn_comm_init(tn_ctx* ctx, const void* id128, int rank, int world);
 int tn_comm_destroy(tn_ctx* ctx);
 int tn_allreduce_sum(tn_ctx* ctx, float* buf, size_t n);         /* in place, on the ctx stream */
 int tn_allreduce_max(tn_ctx* ctx, float* buf, size_t n);
+/* The same sum on the context's COMMUNICATION stream (a third stream, so that a bucket of gradients can travel while
+ * the compute stream carries on with the backward pass; SURVEY.md 8e "bucket by layer ... to overlap with conv
+ * backward"): ordered behind everything enqueued so far on the current compute stream and behind every earlier
+ * collective of this entry point (one stream = one order of collectives on the communicator, the same on every rank).
+ * done_event (tn_event_create; may be NULL) is recorded on the communication stream behind the collective: the
+ * consumer -- the update that opens the stream's next step -- waits for it with tn_event_wait.  tn_sync also waits
+ * for the communication stream.                                                                                  */
+int tn_allreduce_sum_async(tn_ctx* ctx, float* buf, size_t n, void* done_event);
 int tn_axpby(tn_ctx* ctx, float* y, const float* x, size_t n, float a, float b); /* y = a*x + b*y */
 
 #ifdef __cplusplus

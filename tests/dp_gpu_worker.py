@@ -33,6 +33,8 @@ def main(out_path, prms_name, img, ch, B, steps):
         net._group().verify_order()
     if world.rank == 0:
         np.savez(out_path, costs=np.array(costs), stats=np.array(stats[:2]), schedule=str(getattr(net, "dp_schedule", "")),
+                 n_collectives=net._group().n_issued if world.size > 1 else 0,
+                 bucket=-1 if getattr(net, "_dp_bucket", None) is None else net._dp_bucket[1],
                  **{"w%d" % i: w for i, w in enumerate(wts)})
 
 

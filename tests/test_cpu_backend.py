@@ -134,6 +134,48 @@ def test_product_data_parallel_step_world_size_2(tmp_path, pipe, overlap):
     assert str(two["schedule"]) == want, str(two["schedule"])
 
 
+@pytest.mark.parametrize("world", [2, 4])
+def test_bucketed_allreduce_equals_single_bucket(tmp_path, world):
+    """Two steps in flight, data-parallel: the dense group's gradients (+ cost) leave as a bucket of their own right
+    after the dense layers' backward pass and the conv layers' gradients follow at the end of the step (SURVEY 8e
+    "bucket by layer"; NeuralNet._dp_bucket).  Same sums over the same ranks element by element: costs, statistics and
+    weights are BIT-identical to the one-all-reduce-per-step schedule, with 2 and with 4 ranks, and the bucketed run
+    issues twice the collectives (in the same order on every rank: TN_DP_CHECK_ORDER)."""
+    worker = os.path.join(ROOT, "tests", "dp_gpu_worker.py")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    outs = {}
+    for n, buckets in enumerate(("1", "0")):
+        out = str(tmp_path / ("b%s.npz" % buckets))
+        procs = []
+        for rank in range(world):
+            env = _env(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                       MASTER_PORT=str(port + n), TN_PIPELINE="1", TN_DP_BUCKETS=buckets, TN_DP_CHECK_ORDER="1",
+                       OMP_NUM_THREADS="2")
+            procs.append(subprocess.Popen([sys.executable, worker, out, "cifar_like.prms", "16", "3", "16", "7"],
+                                          env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+        for p in procs:
+            try:
+                o, _ = p.communicate(timeout=600)
+            except subprocess.TimeoutExpired:
+                for q in procs:
+                    q.kill()
+                raise
+            assert p.returncode == 0, o.decode()[-3000:]
+        outs[buckets] = np.load(out)
+    a, b = outs["1"], outs["0"]
+    assert str(a["schedule"]) == "pipelined" and str(b["schedule"]) == "pipelined"
+    assert int(a["bucket"]) > 0 and int(b["bucket"]) == -1
+    assert int(a["n_collectives"]) > int(b["n_collectives"])
+    np.testing.assert_array_equal(a["costs"], b["costs"])
+    np.testing.assert_array_equal(a["stats"], b["stats"])
+    for k in a.files:
+        if k.startswith("w"):
+            np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+
+
 @pytest.mark.parametrize("prms,extra,rows", [("mnist.prms", [], 512), ("wide6.prms", ["--img", "16"], 128)])
 def test_bench_dry_multi_plans_an_8_rank_run_without_a_communicator(prms, extra, rows):
     """bench.py --dry-multi 8: the scaling command line's plan (row shards of the first and last rank, the flat
@@ -155,3 +197,44 @@ def test_bench_dry_multi_plans_an_8_rank_run_without_a_communicator(prms, extra,
     assert flat["cost_slot"] >= last["offset_floats"] + int(np.prod(last["shape"]))
     assert flat["floats_reduced_per_step"] == flat["cost_slot"] + 1
     assert "pipelined" in plan["schedule"]
+    # the collectives of a step: mnist.prms has 780 conv floats (one all-reduce), wide6 a bucket per group
+    bk = plan["allreduce_buckets"]
+    assert len(bk) == (1 if prms == "mnist.prms" else 2)
+    assert sum(b["floats"] for b in bk) == flat["floats_reduced_per_step"]
+    assert bk[0]["offset_floats"] + bk[0]["floats"] == flat["cost_slot"] + 1      # the cost travels in the first bucket
+
+
+def test_bench_two_ranks_reports_strong_and_weak_scaling():
+    """bench.py --gpus 2 as the driver launches it (one process per rank, RANK / WORLD_SIZE / MASTER_* from the
+    environment), on the CPU backend: ONE JSON line from rank 0 whose `value` is the strong-scaling figure (the stated
+    batch sharded over the ranks, BASELINE configs[2]) and whose `value_weak` is the same launch's weak-scaling leg (the
+    stated batch per rank)."""
+    import json
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for rank in range(2):
+        env = _env(RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   OMP_NUM_THREADS="2")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
+                                       "--warmup", "1", "--batch", "64", "--no-cpu-baseline", "--no-roofline"],
+                                      cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        try:
+            o, e = p.communicate(timeout=600)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        assert p.returncode == 0, e[-3000:]
+        outs.append(o)
+    assert outs[1].strip() == ""                                   # only rank 0 prints
+    lines = [l for l in outs[0].splitlines() if l.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["global_batch"] == 64
+    assert d["weak"]["scaling"] == "weak" and d["weak"]["global_batch"] == 128 and d["weak"]["rows_per_gpu"] == 64
+    assert d["value_weak"] == d["weak"]["value"] > 0 and d["value"] > 0

@@ -555,15 +555,20 @@ def test_dp_delayed_allreduce_equals_plain(monkeypatch, name, img, ch, B):
             np.testing.assert_array_equal(wa, wb)
 
 
-@pytest.mark.parametrize("name,img,ch,B", [("mnist.prms", 28, 1, 64), ("cifar_like.prms", 32, 3, 16)])
-def test_dp_pipelined_equals_sequential(monkeypatch, name, img, ch, B):
-    """Data-parallel step (1-rank RCCL communicator) with two steps in flight: the all-reduce follows the
-    backward pass on the step's own stream, the update that consumes it opens that stream's next step.
-    Same costs, outputs and weights as one step at a time with the plain all-reduce schedule."""
+@pytest.mark.parametrize("name,img,ch,B,dtype", [("mnist.prms", 28, 1, 64, "float32"), ("cifar_like.prms", 32, 3, 16, "float32"),
+                                                  ("wide6.prms", 32, 3, 8, "float16_dp")])
+def test_dp_pipelined_equals_sequential(monkeypatch, name, img, ch, B, dtype):
+    """Data-parallel step (1-rank RCCL communicator) with two steps in flight: the collectives of a step -- the dense
+    group's bucket right after the dense layers' backward pass, the conv bucket (or everything, mnist.prms) at the end --
+    travel on the context's communication stream (tn_allreduce_sum_async); the update that consumes them opens that
+    stream's next step behind their event.  Same costs, outputs and weights as one step at a time with the plain
+    all-reduce schedule."""
     from theanet_amd import NeuralNet
     from theanet_amd.neuralnet import _PipeTrainFn
     import copy
     prms = load_prms(name, img, batch=B)
+    if dtype.startswith("float16"):
+        prms["training_params"].update(DTYPE="float16", GRAD_SCALE=4096.0)
     rng = np.random.RandomState(10)
     x = rng.rand(4 * B, ch, img, img).astype(np.float32)
     y = rng.randint(0, 10, 4 * B).astype(np.int32)
@@ -583,6 +588,7 @@ def test_dp_pipelined_equals_sequential(monkeypatch, name, img, ch, B):
                 outs.append(fn.fetch())
         if pipe == "1":
             assert fn._seq is None and net.dp_schedule == "pipelined"
+            assert (net._dp_bucket is not None) == (name != "mnist.prms")
         runs.append((net, outs, [w.copy() for l in net.tr_layers for w in l.get_wts()]))
         net.ctx.call("tn_comm_destroy")
         net._dev_group = None

@@ -223,8 +223,9 @@ class DeviceGroup:
 
     def self_test(self, timeout=None):
         """One-shot check of a fresh communicator, run at creation when there is more than one rank: three
-        all-reduces of rank-stamped vectors in exactly the pattern of the two-steps-in-flight schedule (stream
-        0, stream 1, stream 0 again on ONE communicator, each ordered behind the previous by an event), then the
+        all-reduces of rank-stamped vectors in the patterns the schedules use (stream 0, stream 1, then one issued
+        from stream 0 onto the communication stream, all on ONE communicator, each ordered behind the previous by an
+        event), then the
         sums are verified on every rank.  A watchdog polls the last event (tn_event_query) and RAISES after
         ``timeout`` seconds (TN_COMM_SELFTEST_TIMEOUT, default 60) instead of hanging in a sync: a device-side
         ordering problem of the alternation shows up here, by name, and not as a silent stall of the first
@@ -245,8 +246,11 @@ class DeviceGroup:
                 ctx.call("tn_stream_select", stream)
                 if k:
                     ctx.call("tn_event_wait", evs[k - 1])
-                self.allreduce_sum(bufs[b], n)
-                ctx.call("tn_event_record", evs[k])
+                if k == 2:       # the pipelined schedule's form: on the communication stream, event behind it
+                    self.allreduce_sum_async(bufs[b], n, evs[k])
+                else:
+                    self.allreduce_sum(bufs[b], n)
+                    ctx.call("tn_event_record", evs[k])
             ctx.call("tn_stream_select", 0)
             done, t0 = ctypes.c_int(0), time.time()
             while True:
@@ -299,6 +303,17 @@ class DeviceGroup:
             self.rdzv.allreduce_host(self._host_view(darr, n), "sum")
         else:
             self.ctx.call("tn_allreduce_sum", darr.ptr, n)
+
+    def allreduce_sum_async(self, darr, count=None, done_ev=None):
+        """The sum on the context's communication stream (tn_allreduce_sum_async): behind what the compute stream
+        holds so far, beside what it does next; ``done_ev`` is recorded behind it for the consumer to wait on."""
+        n = darr.size if count is None else count
+        self._note("sum", n)
+        if self.ctx.backend == "cpu" and self.world.size > 1:      # host code is synchronous: nothing to order
+            self.ctx.rec_tainted = True
+            self.rdzv.allreduce_host(self._host_view(darr, n), "sum")
+        else:
+            self.ctx.call("tn_allreduce_sum_async", darr.ptr, n, done_ev)
 
     def allreduce_max(self, darr, count=None):
         n = darr.size if count is None else count

@@ -78,7 +78,9 @@ int tn_comm_init(tn_ctx* ctx, const void* id128, int rank, int world) {
 
 int tn_comm_destroy(tn_ctx* ctx) {
     if (ctx && ctx->comm) {
-        hipStreamSynchronize(ctx->stream);
+        hipStreamSynchronize(ctx->streams[0]);
+        hipStreamSynchronize(ctx->streams[1]);
+        if (ctx->comm_stream) hipStreamSynchronize(ctx->comm_stream);
         g_rccl.CommDestroy((tn_ncclComm_t)ctx->comm);
         ctx->comm = nullptr;
     }
@@ -93,6 +95,17 @@ static int allreduce(tn_ctx* ctx, float* buf, size_t n, int op) {
 }
 
 int tn_allreduce_sum(tn_ctx* ctx, float* buf, size_t n) { return allreduce(ctx, buf, n, TN_NCCL_SUM); }
+
+int tn_allreduce_sum_async(tn_ctx* ctx, float* buf, size_t n, void* done_event) {
+    if (!ctx->comm) return tn_fail(ctx, TN_E_COMM, "all-reduce without tn_comm_init");
+    // behind the producer (the compute stream as enqueued so far) ...
+    TN_HIP(hipEventRecord(ctx->comm_ev, ctx->stream));
+    TN_HIP(hipStreamWaitEvent(ctx->comm_stream, ctx->comm_ev, 0));
+    // ... and, being on ONE stream, behind every earlier collective of this entry point
+    if (n) TN_NCCL(g_rccl.AllReduce(buf, buf, n, TN_NCCL_FLOAT32, TN_NCCL_SUM, (tn_ncclComm_t)ctx->comm, ctx->comm_stream));
+    if (done_event) TN_HIP(hipEventRecord((hipEvent_t)done_event, ctx->comm_stream));
+    return TN_OK;
+}
 int tn_allreduce_max(tn_ctx* ctx, float* buf, size_t n) { return allreduce(ctx, buf, n, TN_NCCL_MAX); }
 
 }  // extern "C"

@@ -42,6 +42,8 @@ struct tn_ctx {
     hipStream_t copy_stream = nullptr;     // device-to-host copies that run under later kernels (tn_d2h_early)
     hipEvent_t copy_ev = nullptr;
     hipEvent_t sync_ev[2] = {nullptr, nullptr};
+    hipStream_t comm_stream = nullptr;     // collectives that travel beside the backward pass (tn_allreduce_sum_async)
+    hipEvent_t comm_ev = nullptr;
     int num_cus = 256;
     // heavy launches since the second stream was last selected: small = two steps in flight share the GPU
     // (tn_fc_bwd then leaves the other stream's kernels a share of the register file), large = this stream has it alone

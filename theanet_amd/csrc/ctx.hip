@@ -32,6 +32,8 @@ int tn_ctx_create(int device, tn_ctx** out) {
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->sync_ev[1], hipEventDisableTiming);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->copy_ev, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->comm_ev, hipEventDisableTiming);
     if (e != hipSuccess) {
         delete c;
         return tn_fail(nullptr, TN_E_HIP, "hipStreamCreate -> %s", hipGetErrorString(e));
@@ -70,6 +72,11 @@ int tn_ctx_destroy(tn_ctx* ctx) {
         hipStreamDestroy(ctx->copy_stream);
     }
     if (ctx->copy_ev) hipEventDestroy(ctx->copy_ev);
+    if (ctx->comm_stream) {
+        hipStreamSynchronize(ctx->comm_stream);
+        hipStreamDestroy(ctx->comm_stream);
+    }
+    if (ctx->comm_ev) hipEventDestroy(ctx->comm_ev);
     delete ctx;
     return TN_OK;
 }
@@ -97,6 +104,7 @@ const char* tn_last_error(tn_ctx* ctx) { return ctx ? ctx->err : g_tn_err; }
 int tn_sync(tn_ctx* ctx) {
     TN_HIP(hipStreamSynchronize(ctx->streams[1]));
     TN_HIP(hipStreamSynchronize(ctx->streams[0]));
+    if (ctx->comm_stream) TN_HIP(hipStreamSynchronize(ctx->comm_stream));
     return TN_OK;
 }
 

@@ -1198,6 +1198,10 @@ int tn_allreduce_sum(tn_ctx* ctx, float*, size_t) {
     REQUIRE(ctx->world == 1, "tn_allreduce_sum: multi-rank reductions of the CPU backend run in theanet_amd.comm (host buffers)");
     return TN_OK;
 }
+int tn_allreduce_sum_async(tn_ctx* ctx, float*, size_t, void*) {     // (host code is synchronous: nothing to order)
+    REQUIRE(ctx->world == 1, "tn_allreduce_sum_async: multi-rank reductions of the CPU backend run in theanet_amd.comm (host buffers)");
+    return TN_OK;
+}
 int tn_allreduce_max(tn_ctx* ctx, float*, size_t) {
     REQUIRE(ctx->world == 1, "tn_allreduce_max: multi-rank reductions of the CPU backend run in theanet_amd.comm (host buffers)");
     return TN_OK;

@@ -373,6 +373,7 @@ class NeuralNet():
         self._dp_cand, self._dp_tune, self.dp_schedule = None, None, "plain"
         self._dp_delayed, self._dp_pending, self._dp_cur, self._dp_can_delay = False, False, 0, False
         self._dp_bound = 0
+        self._dp_bucket = None
         if self._dp:
             j = len(self.tr_layers)
             while j > 0 and isinstance(self.tr_layers[j - 1], HiddenLayer):
@@ -380,6 +381,12 @@ class NeuralNet():
             top = [l for l in self.tr_layers[j:] if l.params]
             if 0 < j < len(self.tr_layers) and top and any(l.has_updates() for l in self.tr_layers[:j]):
                 self._dp_cand = (j, (top[0].grads[0].ptr - self.flat_grads.ptr) // 4)
+                # pipelined schedule: a bucket of its own for the dense group when what is left for the second
+                # collective (the conv layers' gradients) is worth one -- mnist.prms: 780 floats, one all-reduce;
+                # cifar_like: 93 k + 1.05 M, wide6: 1.15 M + 16.8 M floats, two.  TN_DP_BUCKETS=0/1 overrides.
+                want = os.environ.get("TN_DP_BUCKETS", "auto")
+                if want == "1" or (want == "auto" and self._dp_cand[1] * 4 >= (64 << 10)):
+                    self._dp_bucket = self._dp_cand
             # "delayed" schedule: the all-reduce of step t runs under the whole of step t+1 (exact, see
             # _train_step).  It needs a second flat gradient buffer (g_{t+1} is produced while G_t is
             # in flight) and gradients that do not depend on the weights they are applied to (no L1/L2).
@@ -600,6 +607,7 @@ class NeuralNet():
                      self.d_step.ptr, *field_args)
         tail = False
         dp_async = False
+        bucket_sent = False
         # single-GPU steps leave the finishing slab sums to the update launch (tn_sgd_update_net, TN_UPD_LAZY)
         lazy = False
         try:
@@ -617,6 +625,17 @@ class NeuralNet():
                     self._group().allreduce_sum(self.flat_grads.view(self._dp_off, (self.n_flat - self._dp_off,)))
                     ctx.call("tn_stream_select", 0)
                     dp_async = True
+                elif pipe_stride and self._dp and self._dp_bucket is not None and idx == self._dp_bucket[0] \
+                        and g is not None:
+                    # two steps in flight, bucketed (SURVEY 8e "bucket by layer"): the dense group on top of the net
+                    # holds almost all parameters and its gradients exist NOW -- their slab sums are finished and the
+                    # bucket [dense gradients | cost] leaves on the communication stream while this stream carries on
+                    # with the conv blocks' backward kernels; the conv bucket follows at the end of the step
+                    ctx.call("tn_defer_reductions", 0)
+                    ctx.call("tn_defer_reductions", 1)
+                    off = self._dp_bucket[1]
+                    self._group().allreduce_sum_async(self.flat_grads.view(off, (self.n_flat - off,)), None, None)
+                    bucket_sent = True
                 if g is None:
                     break
             lazy = self.fused_step and not self._dp and 0 < self._n_segs <= 32
@@ -638,13 +657,12 @@ class NeuralNet():
             # Data-parallel: the all-reduce simply follows on this stream -- its latency is covered by
             # the other stream's step, and the update that needs it is a whole step away.
             if self._dp:
-                # consecutive collectives of the one communicator alternate between the two streams:
-                # keep them strictly ordered on the device whatever the library does by itself
-                if getattr(self, "_ar_wait_ev", None) is not None:
-                    ctx.call("tn_event_wait", self._ar_wait_ev)
-                self._group().allreduce_sum(self.flat_grads, self.n_flat)
-                if getattr(self, "_ar_done_ev", None) is not None:
-                    ctx.call("tn_event_record", self._ar_done_ev)
+                # every collective of the pipelined schedule goes through the context's ONE communication stream
+                # (tn_allreduce_sum_async): one order of collectives on the communicator whatever stream the step
+                # ran on, and neither compute stream ever waits inside a collective.  The consumer -- the update
+                # that opens this stream's next step -- waits for _ar_done_ev (_PipeTrainFn._update_for).
+                n = self._dp_bucket[1] if bucket_sent else self.n_flat
+                self._group().allreduce_sum_async(self.flat_grads, n, getattr(self, "_ar_done_ev", None))
             if ahead:
                 first._cur, first._pre_valid = nxt, True
             if self.dtype == 'float16':

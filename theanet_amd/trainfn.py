@@ -253,8 +253,8 @@ class _PipeTrainFn:
                 e = self._ctypes.c_void_p()
                 ctx.call("tn_event_create", self._ctypes.byref(e))
                 lst.append(e)
-        for k, X in enumerate(self.nets):                  # all-reduce k waits for all-reduce k-1
-            X._ar_done_ev, X._ar_wait_ev = arev[k], arev[1 - k]
+        for k, X in enumerate(self.nets):                  # recorded behind step's last collective (communication stream)
+            X._ar_done_ev = arev[k]
         base = int(net.d_step.get_value()[0])            # steps already taken (an earlier training function)
         self._base = base
         ctx.call("tn_set_u32", twin.d_step.ptr, base + 1)    # the twin takes every second step
@@ -300,6 +300,8 @@ class _PipeTrainFn:
         self.net._apply_dtype()
         ctx.call("tn_stream_select", k)
         ctx.call("tn_event_wait", self._ev[1 - k])
+        if X._dp and t >= 2:
+            ctx.call("tn_event_wait", X._ar_done_ev)      # this stream's gradient of step t-2, back from the all-reduce
         if self._lr_set[k] != self._lr_prev:              # the rate step t-1 was enqueued under
             ctx.call("tn_set_f32", self._lr[k].ptr, self._lr_prev)
             self._lr_set[k] = self._lr_prev
@@ -429,6 +431,8 @@ class _PipeTrainFn:
             return self._seq.fetch()
         X = self._last
         X.ctx.call("tn_stream_select", self.nets.index(X))
+        if X._dp:
+            X.ctx.call("tn_event_wait", X._ar_done_ev)    # the cost travels with the all-reduce (communication stream)
         try:
             early = getattr(X, "_early", None)
             sent = early is not None and early["live"]
