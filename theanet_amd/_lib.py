@@ -15,6 +15,8 @@ from ctypes import (POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int6
                     c_uint8, c_uint32, c_uint64, c_void_p)
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libtheanet_hip.so")
+if os.environ.get("TN_HIP_LIB"):          # developer A/B of two builds of the HIP library on one box (tools/ab.py)
+    LIB_PATH = os.path.abspath(os.environ["TN_HIP_LIB"])
 CPU_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libtheanet_cpu.so")
 
 
