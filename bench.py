@@ -228,8 +228,12 @@ def conv_roofline(ctx, net, fn, n_batches, nsteps, prms_name, dtype):
     recs = []
     f16 = dtype == "f16"
     peak = roofline.MFMA_F16_PEAK_TFLOPS if f16 else roofline.MFMA_F32_PEAK_TFLOPS
+    # DTYPE float16: one launch per conv layer and direction, in layer order (forward) / reverse order (gradients):
+    # the per-launch HIP-event times give one record per layer and direction (`per_layer`)
+    order = {"tn_c8_conv_fwd": ("forward", convs), "tn_c8_conv_wgrad": ("weight gradient", convs[::-1]),
+             "tn_c8_conv_dgrad": ("input gradient", [l for l in convs[::-1] if l is not first_param])}
     for label, ops, fl in groups:
-        ms, launches = 0.0, 0
+        ms, launches, per_layer = 0.0, 0, []
         for op in ops:
             ctx.time_calls(op, 0)
             for i in range(nsteps):
@@ -239,6 +243,16 @@ def conv_roofline(ctx, net, fn, n_batches, nsteps, prms_name, dtype):
             times = ctx.collect_times_ms()
             ms += float(np.sum(times)) / nsteps
             launches += len(times) // nsteps
+            L = len(times) // nsteps
+            if f16 and op in order and L == len(order[op][1]) and L * nsteps == len(times):
+                avg = np.asarray(times).reshape(nsteps, L).mean(axis=0)
+                for lyr, t_ms in zip(order[op][1], avg):
+                    gf = fl_of(lyr) / 1e9
+                    per_layer.append({"layer": "conv%d %d->%d @%dx%d%s" % (convs.index(lyr) + 1, lyr.num_prev_maps, lyr.num_maps,
+                                                                          lyr.in_sz, lyr.in_sz,
+                                                                          " +pool" if getattr(lyr, "fused_pool", None) else ""),
+                                      "direction": order[op][0], "ms": float(t_ms), "gflop": gf,
+                                      "tflops": gf / float(t_ms), "frac": gf / float(t_ms) / peak})
         if not launches or not fl:
             continue
         ach = fl / (ms * 1e-3) / 1e12
@@ -247,6 +261,8 @@ def conv_roofline(ctx, net, fn, n_batches, nsteps, prms_name, dtype):
                "flops_per_step": fl}
         if f16:
             rec["frac_of_fp32_peak"] = ach / roofline.MFMA_F32_PEAK_TFLOPS
+        if per_layer:
+            rec["per_layer"] = per_layer
         recs.append(rec)
     recs.sort(key=lambda r: -r["ms_per_step"])
     return recs
@@ -443,6 +459,25 @@ def main():
     if group is not None:
         dt_sync = group.rdzv.gather_max(dt_sync)
     value_sync_api = tr["BATCH_SZ"] * n_sync / dt_sync
+    # What THIS build's train.py loop does instead: step_cost(i) -- the step is enqueued and the costs that have arrived
+    # (each step's 4 bytes travel to page-locked memory by themselves) are summed a few calls late; nothing waits.
+    n_loop = int(min(50000, max(args.steps, 0.3 / max(dt / args.steps, 1e-6))))
+    barrier()
+    t1 = time.perf_counter()
+    tot, seen = 0.0, 0
+    for i in range(n_loop):
+        for _, c in fn.step_cost(i % n_batches):
+            tot += float(c)
+            seen += 1
+    for _, c in fn.drain_costs():
+        tot += float(c)
+        seen += 1
+    barrier()
+    dt_loop = time.perf_counter() - t1
+    if group is not None:
+        dt_loop = group.rdzv.gather_max(dt_loop)
+    assert seen == n_loop and np.isfinite(tot), "the cost ring lost a step"
+    value_train_loop = tr["BATCH_SZ"] * n_loop / dt_loop
 
     # ---- per-kernel roofline leg: HIP events (on the stream the kernel runs on) around the
     # heavy kernels of the SAME workload; the dominant one (largest share of the step) is
@@ -529,7 +564,11 @@ def main():
         "data": "synthetic",
         "value_sync_api": value_sync_api,
         "sync_api": {"steps": n_sync, "ms_per_step": 1e3 * dt_sync / n_sync,
-                     "what": "fn(i) returning [cost, features, logprob] every step as train.py:211 does"},
+                     "what": "fn(i) returning [cost, features, logprob] every step as the reference's train.py:211 does"},
+        "value_train_loop": value_train_loop,
+        "train_loop": {"steps": n_loop, "ms_per_step": 1e3 * dt_loop / n_loop,
+                       "what": "this build's train.py loop: fn.step_cost(i) -- every step's cost summed on the host a few "
+                               "calls late (page-locked ring), the NaN guard on it; nothing waits for the GPU"},
         "sustained": sustained,
         "config": {"workload": "params/%s %dx%dx%d synthetic, global batch %d = %d images/GPU/step x %d, %s"
                                % (args.prms, img, img, C, tr["BATCH_SZ"], per_gpu, world.size, stage),

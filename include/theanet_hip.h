@@ -78,6 +78,11 @@ int tn_host_alloc(tn_ctx* ctx, size_t bytes, void** out);
 int tn_host_free(tn_ctx* ctx, void* p);
 int tn_d2h_early(tn_ctx* ctx, void* host_dst, const void* src, size_t bytes);
 int tn_copy_sync(tn_ctx* ctx);
+/* the same copy with an event (tn_event_create) recorded behind it on the copy stream: the host waits for THAT copy
+ * (tn_event_sync) instead of for all of them -- a step's cost picked up a few steps later by train.py's loop
+ * (theanet_amd/trainfn.py _CostRing; polling the destination instead is not an option: a 4-byte copy was observed
+ * half-written from the host) */
+int tn_d2h_early_ev(tn_ctx* ctx, void* host_dst, const void* src, size_t bytes, void* done_event);
 int tn_d2d(tn_ctx* ctx, void* dst, const void* src, size_t bytes);   /* enqueued                */
 int tn_memset(tn_ctx* ctx, void* dst, int byte_value, size_t bytes); /* enqueued                */
 int tn_set_u32(tn_ctx* ctx, uint32_t* d_dst, uint32_t value);        /* enqueued scalar store   */
@@ -116,6 +121,7 @@ int tn_event_destroy(tn_ctx* ctx, void* ev);
 /* non-blocking: *done = 1 once everything recorded in front of the event has finished, else 0 (watchdogs
  * that must raise instead of hanging: the communicator self-test of theanet_amd/comm.py)              */
 int tn_event_query(tn_ctx* ctx, void* ev, int* done);
+int tn_event_sync(tn_ctx* ctx, void* ev);            /* the HOST waits for the event */
 
 /* ---- conv (replaces nnconv.conv2d + tt.grad through it; convpool.py:54-72, layer.py:83) ----
  * True convolution (kernel flipped), W layout (K,C,f,f):

@@ -387,6 +387,58 @@ def test_planned_steps_equal_interpreted_steps(pipeline, prm, monkeypatch):
         np.testing.assert_array_equal(a, b)
 
 
+@pytest.mark.parametrize("pipeline", ["1", "0"])
+def test_step_cost_hands_out_every_cost_in_order(pipeline, monkeypatch):
+    """fn.step_cost(i) / fn.drain_costs() (what train.py's loop uses instead of the reference's synchronous fn(i),
+    train.py:211-226): every step's cost arrives exactly once, in order, bit-identical to fn(i)'s, under both schedules,
+    across the switch to replayed steps (tn_net_step: the ring's slot pointer makes the call sequence repeat every four
+    steps), a drain in the middle, a step with injected draws (falls back to one step at a time) and a second loop; the
+    weights end up the same as well."""
+    from theanet_amd import NeuralNet
+    monkeypatch.setenv("TN_PIPELINE", pipeline)
+    prms = load_prms("mnist.prms", 28, batch=16)
+    rng = np.random.RandomState(5)
+    x = rng.rand(16 * 12, 1, 28, 28).astype(np.float32)
+    y = rng.randint(0, 10, 16 * 12).astype(np.int32)
+    ref_net = NeuralNet(copy.deepcopy(prms["layers"]), dict(prms["training_params"]))
+    ref_fn = ref_net.get_trin_model(x, y)
+    net = NeuralNet(copy.deepcopy(prms["layers"]), dict(prms["training_params"]))
+    fn = net.get_trin_model(x, y)
+    inj = dict(transln=[.5, -.25], noise=np.zeros((2, 28, 28), np.float32), origin_u=[.5, .5], zoom_u=[0, 0], theta_u=0.1)
+
+    def loop(fn_, lo, hi, lagged):
+        costs = {}
+        for s in range(lo, hi):
+            first = fn_.net.tr_layers[0]
+            if s == 77:
+                first.inject(**inj)
+            if lagged:
+                for k, c in fn_.step_cost(s % 12):
+                    assert k not in costs
+                    costs[k] = c
+            else:
+                costs[s - lo] = fn_(s % 12)[0]
+            if s == 77:
+                first.inject()
+        if lagged:
+            for k, c in fn_.drain_costs():
+                assert k not in costs
+                costs[k] = c
+        assert sorted(costs) == list(range(hi - lo))
+        return np.array([costs[k] for k in range(hi - lo)], np.float32)
+
+    replayed = False
+    for lo, hi in ((0, 45), (45, 70), (70, 90)):
+        want = loop(ref_fn, lo, hi, False)
+        got = loop(fn, lo, hi, True)
+        np.testing.assert_array_equal(got, want)
+        pl = fn._plan if getattr(fn, "_seq", None) is None else fn._seq._plan
+        replayed = replayed or (lo == 0 and fn._plan.n > 0)
+    for a, b in zip(ref_net.tr_layers, net.tr_layers):
+        for wa, wb in zip(a.get_wts(), b.get_wts()):
+            np.testing.assert_array_equal(wa, wb)
+
+
 def test_take_index_list_mode():
     from theanet_amd import NeuralNet
     prms = load_prms("mnist.prms", 28, batch=8)

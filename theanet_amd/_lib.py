@@ -54,6 +54,7 @@ SIGNATURES = {
     "tn_host_free": (c_int, [CTX, P]),
     "tn_d2h_early": (c_int, [CTX, P, P, c_size_t]),
     "tn_copy_sync": (c_int, [CTX]),
+    "tn_d2h_early_ev": (c_int, [CTX, P, P, c_size_t, P]),
     "tn_d2d": (c_int, [CTX, P, P, c_size_t]),
     "tn_memset": (c_int, [CTX, P, c_int, c_size_t]),
     "tn_set_u32": (c_int, [CTX, P, c_uint32]),
@@ -75,6 +76,7 @@ SIGNATURES = {
     "tn_event_elapsed_ms": (c_int, [CTX, P, P, POINTER(c_float)]),
     "tn_event_destroy": (c_int, [CTX, P]),
     "tn_event_query": (c_int, [CTX, P, POINTER(c_int)]),
+    "tn_event_sync": (c_int, [CTX, P]),
     "tn_conv2d_fwd": (c_int, [CTX, P, P, P, P] + [c_int] * 10 + [c_int, c_float]),
     "tn_conv2d_wgrad": (c_int, [CTX, P, P, P, P] + [c_int] * 10),
     "tn_conv2d_dgrad": (c_int, [CTX, P, P, P] + [c_int] * 10 + [P, c_int, c_float]),

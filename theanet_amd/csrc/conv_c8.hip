@@ -1239,6 +1239,9 @@ int tn_c8_conv_wgrad(tn_ctx* ctx, const void* x, const void* dz, float* dW, floa
     return c8w_run(ctx, g, dW, db, pooled != 0);
 }
 
+// (the answer does not depend on the device's CU count: in c8w_geometry it only sets the number of slabs S and
+// the tiles per slab, never the tile shape, the LDS stage or the DMA chunk counts the limits below are about -- so the
+// construction-time query and c8w_run, which passes ctx->num_cus, always agree)
 int tn_c8_conv_wgrad_supported(int N, int C, int H, int Wd, int K) {
     C8WG g{};
     g.N = N; g.C = C; g.C8 = (C + 7) / 8; g.H = H; g.Wd = Wd; g.K = K; g.K8 = K / 8;

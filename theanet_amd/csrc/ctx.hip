@@ -199,6 +199,13 @@ int tn_d2h_early(tn_ctx* ctx, void* host_dst, const void* src, size_t bytes) {
     return TN_OK;
 }
 
+int tn_d2h_early_ev(tn_ctx* ctx, void* host_dst, const void* src, size_t bytes, void* done_event) {
+    int rc = tn_d2h_early(ctx, host_dst, src, bytes);
+    if (rc) return rc;
+    if (done_event) TN_HIP(hipEventRecord((hipEvent_t)done_event, ctx->copy_stream));
+    return TN_OK;
+}
+
 int tn_copy_sync(tn_ctx* ctx) {
     TN_HIP(hipStreamSynchronize(ctx->copy_stream));
     return TN_OK;
@@ -299,6 +306,10 @@ int tn_event_elapsed_ms(tn_ctx* ctx, void* a, void* b, float* ms) {
 }
 int tn_event_destroy(tn_ctx* ctx, void* ev) {
     if (ev) TN_HIP(hipEventDestroy((hipEvent_t)ev));
+    return TN_OK;
+}
+int tn_event_sync(tn_ctx* ctx, void* ev) {
+    TN_HIP(hipEventSynchronize((hipEvent_t)ev));
     return TN_OK;
 }
 int tn_event_query(tn_ctx* ctx, void* ev, int* done) {

@@ -16,6 +16,9 @@
 // reaches all of them: unused registers / stack slots are ignored by the callee, a float travels as the low half of
 // its xmm register.
 #pragma once
+#if !defined(__x86_64__)
+#error "net_plan.h: the generic call trampoline relies on the argument classes of the x86-64 SysV ABI (the host of an MI355X node); port tn_plan_invoke before building for another target"
+#endif
 #include <dlfcn.h>
 
 #include <cstdint>

@@ -220,6 +220,7 @@ int tn_host_alloc(tn_ctx* ctx, size_t bytes, void** out) {
 int tn_host_free(tn_ctx*, void* p) { std::free(p); return TN_OK; }
 int tn_d2h_early(tn_ctx*, void* d, const void* s, size_t n) { std::memcpy(d, s, n); return TN_OK; }
 int tn_copy_sync(tn_ctx*) { return TN_OK; }
+int tn_d2h_early_ev(tn_ctx*, void* d, const void* s, size_t n, void*) { std::memcpy(d, s, n); return TN_OK; }
 int tn_d2d(tn_ctx*, void* d, const void* s, size_t n) { std::memmove(d, s, n); return TN_OK; }
 int tn_memset(tn_ctx*, void* d, int v, size_t n) { std::memset(d, v, n); return TN_OK; }
 int tn_set_u32(tn_ctx*, uint32_t* d, uint32_t v) { *d = v; return TN_OK; }
@@ -241,6 +242,7 @@ int tn_event_record(tn_ctx*, void* ev) {
 int tn_event_wait(tn_ctx*, void*) { return TN_OK; }
 int tn_event_elapsed_ms(tn_ctx*, void* a, void* b, float* ms) { *ms = (float)(*static_cast<double*>(b) - *static_cast<double*>(a)); return TN_OK; }
 int tn_event_destroy(tn_ctx*, void* ev) { delete static_cast<double*>(ev); return TN_OK; }
+int tn_event_sync(tn_ctx*, void*) { return TN_OK; }
 int tn_event_query(tn_ctx*, void*, int* done) { *done = 1; return TN_OK; }      // calls are synchronous here
 
 // ================================== conv (im2col + SGEMM) ==================================

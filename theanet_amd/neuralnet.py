@@ -67,6 +67,28 @@ from .trainfn import _PipeTrainFn, _TestFn, _TrainFn  # noqa: E402,F401
 # ###############################################################################
 
 
+def _fma32(m, v, c):
+    """fl32(m * v + c) with ONE rounding, element-wise (the device's __fmaf_rn; numpy has no fma).  m * v is exact in
+    float64 (24 + 24 bits); the float64 sum may round, and rounding that to float32 rounds twice -- wrong only when the
+    float64 sum lands exactly on a float32 midpoint that the exact sum is not on.  The error of the float64 addition
+    (TwoSum) says which side the exact sum lies on."""
+    p = np.float64(m) * np.asarray(v, np.float64)
+    c = np.asarray(c, np.float64)
+    s = p + c
+    bb = s - p
+    err = (p - (s - bb)) + (c - bb)                      # exact: p + c = s + err
+    r = s.astype(np.float32)
+    d = s - r.astype(np.float64)                         # exact (both on the float64 grid near r)
+    up, dn = np.nextafter(r, np.float32(np.inf)), np.nextafter(r, np.float32(-np.inf))
+    half_up = (up.astype(np.float64) - r.astype(np.float64)) / 2
+    half_dn = (r.astype(np.float64) - dn.astype(np.float64)) / 2
+    tie_up, tie_dn = (d == half_up) & (d > 0), (-d == half_dn) & (d < 0)
+    # on a midpoint the float64 -> float32 step went to even; the exact sum is off the midpoint by err
+    r = np.where(tie_up & (err > 0), up, r)              # exact sum above the midpoint: the upper neighbour
+    r = np.where(tie_dn & (err < 0), dn, r)
+    return r.astype(np.float32)
+
+
 class NeuralNet():
     fuse_conv_pool = True     # class-level switch (tests run both the fused and unfused paths)
     # ... and the step-level fusions (slab sums and cost inside the update launch, the next minibatch's elastic field riding in a backward launch or beside the update, two steps in flight):
@@ -929,8 +951,6 @@ class NeuralNet():
 
     def _opt_state(self):
         self._prepare_training()
-        assert not (self._dp_delayed and self._dp_pending), \
-            "opt_state: not while a delayed all-reduce is in flight (TN_DP_OVERLAP=2); use another schedule"
         fn = getattr(self, "_pipe_fn", None)
         pend, step = None, int(self.d_step.get_value()[0])
         if fn is not None and fn._seq is None and fn._twin is not None and fn.t > 0:
@@ -939,17 +959,22 @@ class NeuralNet():
             # as the kernels (common.h tn_vel: fma(m, v, rn((1-m) g)))
             fn._flush_parked()
             self.ctx.sync()
-            pend, step = fn.nets[(fn.t - 1) & 1], fn._base + fn.t
+            X = fn.nets[(fn.t - 1) & 1]
+            pend, step = (lambda i, j: X.tr_layers[i].grads[j].get_value()), fn._base + fn.t
+        elif self._dp_delayed and self._dp_pending:
+            # delayed all-reduce (TN_DP_OVERLAP=2): the same situation -- the reduced gradient of the last step is still
+            # travelling (second stream) and the update that folds it in belongs to the next step.  Read-only here: the
+            # schedule is left alone (a checkpoint is written by one rank; a schedule change must happen on all)
+            self.ctx.sync()
+            prev = self._grads_ab[1 - self._dp_cur]
+            pend = lambda i, j: prev[id(self.tr_layers[i])][j].get_value()
         vel = []
         for i, lyr in enumerate(self.tr_layers):
             row = []
             for j, v in enumerate(lyr.accumulated_updates or ()):
                 a = v.get_value()
                 if pend is not None and lyr.has_updates():
-                    m = np.float32(lyr.reg['momentum'])
-                    g = pend.tr_layers[i].grads[j].get_value()
-                    c = (np.float32(1) - m) * g
-                    a = (np.float64(m) * a.astype(np.float64) + c.astype(np.float64)).astype(np.float32)
+                    a = _fma32(np.float32(lyr.reg['momentum']), a, (np.float32(1) - np.float32(lyr.reg['momentum'])) * pend(i, j))
                 row.append(a)
             vel.append(row)
         seeds = [(getattr(l, "seed", None), l.drop.seed if getattr(l, "drop", None) is not None else None)

@@ -39,6 +39,47 @@ def _step_outputs(net, out):
     return [cost] + _features_logprob(out)
 
 
+class _CostRing:
+    """The costs of enqueued steps, read a few steps LATER so that the loop of train.py (train.py:207-226: it sums the
+    cost of every step and raises on NaN) never waits for the GPU: a step's cost (4 bytes) leaves for one of four
+    page-locked slots as soon as it exists (tn_d2h_early_ev: copy stream, behind the launch that sums it, an event
+    behind the copy) and the host picks it up ``lag`` calls later -- by then it has long arrived; if not, the host
+    waits for that slot's event only."""
+    R = 4
+
+    def __init__(self, ctx, lag):
+        import ctypes
+        from .device import HostBuffer
+        self.ctx, self.lag = ctx, lag
+        self.buf = HostBuffer(ctx, (self.R,), np.float32)
+        self.ev = []
+        for _ in range(self.R):
+            e = ctypes.c_void_p()
+            ctx.call("tn_event_create", ctypes.byref(e))
+            self.ev.append(e)
+        self.next_take = 0          # first step number whose cost the caller has not been handed yet
+        self.sent_upto = 0          # copies have been issued for the steps below
+
+    def send(self, step, d_cost):
+        assert step == self.sent_upto and step - self.next_take < self.R, "cost ring overrun"
+        s = step % self.R
+        self.ctx.call("tn_d2h_early_ev", self.buf.ptr + 4 * s, d_cost.ptr, 4, self.ev[s])
+        self.sent_upto = step + 1
+
+    def take(self, step):
+        s = step % self.R
+        self.ctx.lib.tn_event_sync(self.ctx.h, self.ev[s])
+        self.next_take = step + 1
+        return np.float32(self.buf.array[s])
+
+    def __del__(self):
+        try:
+            for e in self.ev:
+                self.ctx.lib.tn_event_destroy(self.ctx.h, e)
+        except Exception:       # interpreter teardown
+            pass
+
+
 def _batch_in_range(i, n_rows, batch_sz):
     """Minibatch i must lie inside the dataset (the reference's ``data[i*B:(i+1)*B]`` would come out short and fail in the
     compiled function; the kernels here would read past the array)."""
@@ -67,12 +108,13 @@ class _TrainFn:
                 self.aux_stage = ctx.empty((net.local_bsz,) + tuple(aux_data.shape[1:]))
         # the step as one C call once its calls have been seen to repeat (plan.py); index-list batches upload per step
         self._plan = None if take_index_list else StepPlan(ctx, net.batch_sz, net.shard_lo)
+        self._ring, self._n = None, 0          # step_cost(): costs read two calls late; steps enqueued so far
 
     def _plan_state(self):
         net = self.net
         first = net.tr_layers[0]
         return (getattr(first, "_cur", None), getattr(first, "_pre_valid", None), getattr(net, "_cost_pending", None),
-                net._dp_cur, net._dp_pending)
+                net._dp_cur, net._dp_pending, (self._n & 3) if self._ring is not None else -1)
 
     def _plan_set_state(self, st):
         net = self.net
@@ -82,6 +124,9 @@ class _TrainFn:
         if st[2] is not None:
             net._cost_pending = st[2]
         net._dp_cur, net._dp_pending = st[3], st[4]
+        if self._ring is not None:                # (the replayed step has sent its cost like an interpreted one)
+            self._ring.sent_upto = self._n + 1
+        self._n += 1
 
     def _plannable(self):
         net = self.net
@@ -147,6 +192,51 @@ class _TrainFn:
         if self.aux_data is not None:
             net.aux_inpt_tr.row_global0 = int(i) * B + lo if not self.take_index_list else lo
         net._train_step(y, y_row0)
+        if self._ring is not None:                # the step's cost exists behind its last launch: off it goes
+            self._ring.send(self._n, net.d_cost)
+        self._n += 1
+
+    # -- costs a few calls late (what train.py's loop needs of a step; see _CostRing) ----------------------------
+    def step_cost(self, i):
+        """Enqueue step i; return [(step number, cost), ...] of the steps whose cost has become due (step numbers count
+        the step_cost calls since the last drain_costs()).  Do not mix with enqueue() / fn(i) before drain_costs()."""
+        net = self.net
+        if net._dp_delayed or net._dp_tune is not None or self.take_index_list or net._injecting():
+            out = self._ring_rest()                   # (the cost travels on the second stream / per-step host work)
+            out.append((self._sc_n, np.float32(self(i)[0])))
+            self._sc_n += 1
+            return out
+        if self._ring is None:
+            self._ring = _CostRing(net.ctx, 2)
+            self._ring.sent_upto = self._ring.next_take = self._n
+            self._ring_base = self._n - self._sc_n
+            if self._plan is not None:
+                self._plan.restart("cost ring on")
+        r, out = self._ring, []
+        if self._n - r.next_take >= r.lag:
+            out.append((r.next_take - self._ring_base, r.take(r.next_take)))
+        self.enqueue(i)
+        self._sc_n += 1
+        return out
+
+    _sc_n = 0
+
+    def _ring_rest(self):
+        r, out = self._ring, []
+        if r is None:
+            return out
+        while r.next_take < r.sent_upto:
+            out.append((r.next_take - self._ring_base, r.take(r.next_take)))
+        self._ring = None
+        if self._plan is not None:
+            self._plan.restart("cost ring off")
+        return out
+
+    def drain_costs(self):
+        """The costs step_cost() has not handed out yet, in order; afterwards step numbers start from 0 again."""
+        out = self._ring_rest()
+        self._sc_n = 0
+        return out
 
     def fetch(self):
         net = self.net
@@ -191,6 +281,7 @@ class _PipeTrainFn:
         net._pipe_fn = self
         self._ctypes = ctypes
         self._plan = StepPlan(net.ctx, net.batch_sz, net.shard_lo)
+        self._ring = None            # step_cost(): costs read four calls late (_CostRing)
 
     # -- set-up of the twin on first use ---------------------------------------------------------
     def _build(self):
@@ -274,7 +365,7 @@ class _PipeTrainFn:
         for X in self.nets:
             first = X.tr_layers[0]
             per_net.append((X._cost_pending, getattr(first, "_cur", None), getattr(first, "_pre_valid", None)))
-        return (self.nets.index(self._last), tuple(per_net), self.t & 1)
+        return (self.nets.index(self._last), tuple(per_net), (self.t & 3) if self._ring is not None else (self.t & 1))
 
     def _plan_set_state(self, st):
         self._last = self.nets[st[0]]
@@ -284,6 +375,9 @@ class _PipeTrainFn:
                 first = X.tr_layers[0]
                 first._cur, first._pre_valid = cur, pv
         self._updated = False
+        r = self._ring
+        if r is not None and self.t - 2 >= r.sent_upto:
+            r.sent_upto = self.t - 1              # (the replayed step has sent the cost of step t - 2)
         self.t += 1
 
     def _plannable(self):
@@ -347,6 +441,8 @@ class _PipeTrainFn:
     def _fall_back(self):
         """Leave the pipelined schedule for good: bring weights AND velocity to the sequential state."""
         net, ctx = self.net, self.net.ctx
+        if self._ring is not None:                # costs still owed to a step_cost() loop: collect them first
+            self._owed = self._owed + self._leave_ring()
         self._flush_parked()
         if self._twin is not None and self.t > 0:
             self.sync_weights()
@@ -405,6 +501,11 @@ class _PipeTrainFn:
         X = self.nets[k]
         if t >= 1 and not self._updated:
             self._update_for(t)
+            r = self._ring
+            if r is not None and t - 2 >= r.sent_upto:
+                # the launch above has summed the cost of this stream's previous step (t - 2): off it goes
+                r.sent_upto = t - 2
+                r.send(t - 2, X.d_cost)
         elif t == 0:
             ctx.call("tn_stream_select", 0)
             ctx.call("tn_event_record", self._ev[0])
@@ -425,6 +526,63 @@ class _PipeTrainFn:
             ctx.call("tn_stream_select", 0)
         self._last = X
         self.t = t + 1
+
+    # -- costs a few calls late (what train.py's loop needs of a step; see _CostRing) ----------------------------
+    def step_cost(self, i):
+        """Enqueue step i; return [(step number, cost), ...] of the steps whose cost has become due (step numbers count
+        the step_cost calls since the last drain_costs()).  With two steps in flight the cost of step t is summed by
+        the launch that opens step t + 2 and handed out at call t + 4.  Do not mix with enqueue() / fn(i) before
+        drain_costs()."""
+        if self._seq is None and self._blocked():
+            self._fall_back()                     # (collects what the ring owes) one step at a time from here on
+        pre, self._owed = self._owed, []
+        if self._seq is not None:
+            off = self._sc_n - getattr(self._seq, "_sc_n", 0)
+            return pre + [(k + off, c) for k, c in self._seq.step_cost(i)] + self._count()
+        if self._ring is None:
+            self._ring = _CostRing(self.net.ctx, 4)
+            self._ring.sent_upto = self._ring.next_take = self.t
+            self._ring_base = self.t - self._sc_n
+            self._plan.restart("cost ring on")
+        r, out = self._ring, []
+        if self.t - r.next_take >= r.lag:
+            out.append((r.next_take - self._ring_base, r.take(r.next_take)))
+        self.enqueue(i)
+        self._count()
+        return pre + out
+
+    _sc_n, _owed = 0, []
+
+    def _count(self):
+        self._sc_n += 1
+        return []
+
+    def _leave_ring(self):
+        """Everything the ring still owes, in order: the copies already under way, then the last two steps' costs read
+        directly (nothing would ever open the steps that sum them)."""
+        r, out = self._ring, []
+        if r is None:
+            return out
+        assert self._seq is None
+        self._ring = None
+        self._flush_parked()
+        self.net.ctx.sync()
+        while r.next_take < r.sent_upto:
+            out.append((r.next_take - self._ring_base, r.take(r.next_take)))
+        for t in range(r.next_take, self.t):
+            out.append((t - self._ring_base, np.float32(self.nets[t & 1].d_cost.get_value()[0])))
+        self._plan.restart("cost ring off")
+        return out
+
+    def drain_costs(self):
+        out, self._owed = self._owed, []
+        if self._seq is None:
+            out += self._leave_ring()
+        if self._seq is not None:
+            off = self._sc_n - getattr(self._seq, "_sc_n", 0)
+            out += [(k + off, c) for k, c in self._seq.drain_costs()]
+        self._sc_n = 0
+        return out
 
     def fetch(self):
         if self._seq is not None:

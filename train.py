@@ -198,12 +198,31 @@ def run(dataset_name, prms_file_name, redirect):
         np.set_printoptions(precision=2)
         print("Training ...")
         print("Epoch   Cost  Tr_Error Tr_{0}    Te_Error Te_{0}".format(aux))
+        def nan_guard(epoch, ibatch):
+            print("Epoch:{} Iteration:{}".format(epoch, ibatch))
+            print(net.get_wts_info(detailed=True))
+            raise ZeroDivisionError("Nan cost at Epoch:{} Iteration:{}".format(epoch, ibatch))
+
         for epoch in range(tr_prms['NUM_EPOCHS']):
             total_cost, t0 = 0, time.perf_counter()
-            for ibatch in range(n_tr_batches):
+            if not exp_head:
+                # The reference's loop (train.py:211-226) needs ONE number of a step: its cost, for the epoch's total and
+                # the NaN guard.  step_cost(i) enqueues the step and hands back the costs that have ARRIVED (a step's cost
+                # travels to page-locked memory by itself and is picked up a few calls later), so the host keeps running
+                # ahead of the GPU like bench.py's enqueue-only loop; the guard reports the iteration the NaN belongs to.
+                for ibatch in range(n_tr_batches):
+                    for k, cost in training_fn.step_cost(ibatch):
+                        total_cost += cost
+                        if np.isnan(total_cost):
+                            nan_guard(epoch, k)
+                for k, cost in training_fn.drain_costs():
+                    total_cost += cost
+                    if np.isnan(total_cost):
+                        nan_guard(epoch, k)
+            for ibatch in range(n_tr_batches if exp_head else 0):
                 cost, features, _ = training_fn(ibatch)
                 total_cost += cost
-                if exp_head:          # ExpLoss nets: report samples whose true-class feature runs away (train.py:216-222)
+                if True:              # ExpLoss nets: report samples whose true-class feature runs away (train.py:216-222)
                     labels = np.asarray(data.training_y[ibatch * batch_sz:(ibatch + 1) * batch_sz])
                     lo = net.shard_lo                     # a data-parallel rank holds its own rows of the batch
                     own = labels[lo:lo + len(features)]
@@ -214,9 +233,7 @@ def run(dataset_name, prms_file_name, redirect):
                         print(true_features)
                         print(net.get_wts_info(detailed=True))
                 if np.isnan(total_cost):
-                    print("Epoch:{} Iteration:{}".format(epoch, ibatch))
-                    print(net.get_wts_info(detailed=True))
-                    raise ZeroDivisionError("Nan cost at Epoch:{} Iteration:{}".format(epoch, ibatch))
+                    nan_guard(epoch, ibatch)
             rate = n_tr_batches * batch_sz / (time.perf_counter() - t0)
 
             if epoch % tr_prms['EPOCHS_TO_TEST'] == 0:
