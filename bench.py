@@ -365,6 +365,9 @@ def dry_multi(args):
                                 "--master-port P bench.py --gpus %d --steps K --warmup W" % (N, N)}))
 
 
+REAL_STDOUT_FD = None        # the launcher's stdout (set under __main__: fd 1 itself is pointed at stderr for the run)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -590,14 +593,31 @@ def main():
     # the weak one is what the interconnect and the schedule allow.  Every rank takes part (the steps are collectives).
     if world.size > 1 and scaling == "strong" and not args.no_weak_leg:
         import gc
+        import threading
         del fn, net
         gc.collect()
+        # The headline is measured; the extra leg must not be able to cost it its line.  An exception is caught; a HANG
+        # (a rank stuck in a collective) is not an exception: a watchdog thread prints the line as it stands and leaves
+        # (ctypes calls release the interpreter lock, so the thread runs while the main thread sits in the library).
+        limit = float(os.environ.get("TN_BENCH_WEAK_TIMEOUT", 240))
+
+        def give_up():
+            if world.rank == 0:
+                line["weak"] = {"error": "the weak-scaling leg did not finish within %.0f s; skipped" % limit}
+                os.write(REAL_STDOUT_FD if REAL_STDOUT_FD is not None else 1, (json.dumps(line) + "\n").encode())
+            os._exit(0)
+
+        dog = threading.Timer(limit, give_up)
+        dog.daemon = True
+        dog.start()
         try:
             wk = weak_leg(ctx, args, world, group, global_batch)
             line["value_weak"] = wk["value"]
             line["weak"] = wk
         except Exception as e:      # (an exception on every rank alike: the headline keeps its line)
             line["weak"] = {"error": "%s: %s" % (type(e).__name__, str(e)[-300:])}
+        finally:
+            dog.cancel()
     if world.rank != 0:
         return
     # BASELINE.json's other single-GPU configurations (north_star: images/sec "on synthetic 28x28x1 and 32x32x3
@@ -637,7 +657,7 @@ if __name__ == "__main__":
     import io
 
     sys.stdout.flush()
-    _real_fd = os.dup(1)
+    _real_fd = REAL_STDOUT_FD = os.dup(1)
     os.dup2(2, 1)
     _buf = io.StringIO()
     try:
