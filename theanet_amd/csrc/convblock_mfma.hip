@@ -381,7 +381,17 @@ __global__ __launch_bounds__(256, 2) void convblock_bwd_mfma(
 // mask bit r ? g * act'(y) : 0 is formed while the prefetched g / y / mask registers are staged
 // into LDS -- no conv recompute, no epilogue.  The rest is the wgrad and dgrad products above.
 // ---------------------------------------------------------------------------------------------
-template <int C, int KS2, int ACT>
+// W44: the weight-gradient product on v_mfma_f32_4x4x1_16b_f32 with the CBSZ / ABID broadcast (round 4).  20 filters x 37
+// columns sit badly in 16 x 16 tiles (2 x 3 of them: 47 % of the lanes useful).  The 16-block instruction with
+// CBSZ = n shares the A block (group base + ABID) among the 2^n blocks of a group (tools/probe/mfma44_cbsz.hip):
+//   main product (CBSZ 3): the 64 lanes are 2 pixels x 32 columns; lane (g2, a8, r4) supplies dz[filter 4 a8 + r4] of its
+//     pixel as A and x[column 4 a8 + r4] of its pixel as B; instruction ABID = a adds the 4 x 32 outer products of
+//     filters 4a .. 4a+3 for both pixels -- ceil(K / 4) instructions per pixel pair, every lane useful;
+//   remainder (CBSZ 1, only when C*9 + 1 > 32): 8 pixels x 8 columns (taps 32 .. 35, the bias column, 3 idle);
+//     register m supplies filters 8m .. 8m+7, instruction (m, ABID) adds the 4 x 8 outer products of 8 pixels.
+// 25 instructions of 8.6 cycles per 8 pixels for mnist.prms conv2 instead of 12 of 32: 27 cycles per pixel against 48
+// (useful: 25).  The per-lane halves (2 pixels / 8 pixels) meet in the final slab reduction.
+template <int C, int KS2, int ACT, bool W44>
 __global__ __launch_bounds__(256, 2) void convblock_bwd_mask_mfma(
     const float* __restrict__ x, const float* __restrict__ W, const float* __restrict__ g,
     const float* __restrict__ y, const uint8_t* __restrict__ mask, float* __restrict__ dx,
@@ -457,6 +467,24 @@ __global__ __launch_bounds__(256, 2) void convblock_bwd_mask_mfma(
         arow[kt] = k < K ? k * q.npixp : q.dzf;
         amsk[kt] = k < K ? -1 : 0;
     }
+    // W44 operand addresses (see the comment above the kernel)
+    constexpr bool REM = CKK + 1 > 32;
+    constexpr int NM = (KS2 + 1) / 2;
+    const int g2 = lane >> 5, a8 = (lane >> 2) & 7, r4 = lane & 3, g8 = lane >> 3, a2 = (lane >> 2) & 1;
+    const int fM = 4 * a8 + r4, tM = lane & 31, tR = 32 + 4 * a2 + r4;
+    const int arowM = fM < K ? fM * q.npixp : q.dzf, amskM = fM < K ? -1 : 0;
+    const int offM = tM < CKK ? ckk_off(min(tM, CKK - 1)) : (tM == CKK ? ONE : ZERO), mskM = tM < CKK ? -1 : 0;
+    const int offR = tR < CKK ? ckk_off(min(tR, CKK - 1)) : (tR == CKK ? ONE : ZERO), mskR = tR < CKK ? -1 : 0;
+    int arowR[NM], amskR[NM];
+#pragma unroll
+    for (int m = 0; m < NM; ++m) {
+        const int f = 8 * m + 4 * a2 + r4;
+        arowR[m] = f < K ? f * q.npixp : q.dzf;
+        amskR[m] = f < K ? -1 : 0;
+    }
+    f32x4 accM[KS2], accR[KS2];
+#pragma unroll
+    for (int a_ = 0; a_ < KS2; ++a_) accM[a_] = accR[a_] = f32x4{0.f, 0.f, 0.f, 0.f};
     float Aw2[NTD][KS2];       // dgrad product A operand: Wf[k = 4s+qd][c = lo>>2][ab = 4mt + (lo&3)]
 #pragma unroll
     for (int mt = 0; mt < NTD; ++mt)
@@ -517,6 +545,57 @@ __global__ __launch_bounds__(256, 2) void convblock_bwd_mask_mfma(
         if (n + nw < q.N) CM_PREFETCH(n + nw);
         cm_wave_sync();
         CM_STAMP();  // image staged
+        if constexpr (W44) {
+            // ---- wgrad on the 16-block MFMA: step Q = pooling windows 2Q and 2Q + 1 (8 pixels) ----
+            float4 a4c;
+            float b4c[4], arc[NM], brc = 0.f;
+#define CM_W4_LOAD(Q_, A_, B_, AR_, BR_)                                                    \
+            {                                                                               \
+                const int w_ = 2 * (Q_) + g2, wo_ = wtab[w_];                               \
+                A_ = *reinterpret_cast<const float4*>(sdz + arowM + ((4 * w_) & amskM));    \
+                _Pragma("unroll") for (int r = 0; r < 4; ++r)                               \
+                    B_[r] = sx[offM + ((wo_ + (r >> 1) * q.Wx + (r & 1)) & mskM)];          \
+                if (REM) {                                                                  \
+                    const int wr_ = 2 * (Q_) + (g8 >> 2), er_ = g8 & 3;                     \
+                    _Pragma("unroll") for (int m = 0; m < NM; ++m)                          \
+                        AR_[m] = sdz[arowR[m] + ((4 * wr_ + er_) & amskR[m])];              \
+                    BR_ = sx[offR + ((wtab[wr_] + (er_ >> 1) * q.Wx + (er_ & 1)) & mskR)];  \
+                }                                                                           \
+            }
+            CM_W4_LOAD(0, a4c, b4c, arc, brc);
+#pragma unroll 1
+            for (int Q = 0; Q < 2 * q.PT; ++Q) {
+                float4 a4n;
+                float b4n[4], arn[NM], brn = 0.f;
+                const int Qn = min(Q + 1, 2 * q.PT - 1);
+                CM_W4_LOAD(Qn, a4n, b4n, arn, brn);     // next step's operands travel during this step's products
+                if (!(q.dbg & 1)) {
+#define CM_M4(AB) if (AB < KS2) accM[AB < KS2 ? AB : 0] = __builtin_amdgcn_mfma_f32_4x4x1f32(a_, b4c[s_], accM[AB < KS2 ? AB : 0], 3, AB, 0);
+#pragma unroll
+                    for (int s_ = 0; s_ < 4; ++s_) {
+                        const float a_ = s_ == 0 ? a4c.x : s_ == 1 ? a4c.y : s_ == 2 ? a4c.z : a4c.w;
+                        CM_M4(0) CM_M4(1) CM_M4(2) CM_M4(3) CM_M4(4) CM_M4(5) CM_M4(6) CM_M4(7)
+                    }
+#undef CM_M4
+                    if (REM) {
+#pragma unroll
+                        for (int m = 0; m < NM; ++m) {
+                            accR[2 * m] = __builtin_amdgcn_mfma_f32_4x4x1f32(arc[m], brc, accR[2 * m], 1, 0, 0);
+                            if (2 * m + 1 < KS2)
+                                accR[2 * m + 1 < KS2 ? 2 * m + 1 : 0] = __builtin_amdgcn_mfma_f32_4x4x1f32(
+                                    arc[m], brc, accR[2 * m + 1 < KS2 ? 2 * m + 1 : 0], 1, 1, 0);
+                        }
+                    }
+                }
+                a4c = a4n;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) b4c[r] = b4n[r];
+#pragma unroll
+                for (int m = 0; m < NM; ++m) arc[m] = arn[m];
+                brc = brn;
+            }
+#undef CM_W4_LOAD
+        } else {
         // ---- wgrad: dWf[k][ckk] += sum_pix dz[k][pix] * patch[pix][ckk] -------------------------
         float4 ac[NKT];
         float bc[4][NT];
@@ -558,6 +637,7 @@ __global__ __launch_bounds__(256, 2) void convblock_bwd_mask_mfma(
                 for (int nt = 0; nt < NT; ++nt) bc[r][nt] = bn[r][nt];
         }
 #undef CM_WG_LOAD
+        }
         CM_STAMP();  // wgrad done
         if (dx && !(q.dbg & 2)) {
             // ---- dgrad: one dz row per step, see convblock_bwd_mfma --------------------------------
@@ -613,6 +693,38 @@ __global__ __launch_bounds__(256, 2) void convblock_bwd_mask_mfma(
 #undef CM_PREFETCH
     // ---- one partial slab per block: sum the 4 waves' accumulators in wave order ---------------
     __syncthreads();
+    if constexpr (W44) {
+#pragma unroll
+        for (int a_ = 0; a_ < KS2; ++a_)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                wbase[(a_ * 4 + r) * 64 + lane] = accM[a_][r];
+                if (REM) wbase[((KS2 + a_) * 4 + r) * 64 + lane] = accR[a_][r];
+            }
+        __syncthreads();
+        for (int e = threadIdx.x; e < K * (CKK + 1); e += 256) {
+            const int k = e / (CKK + 1), ckk = e - k * (CKK + 1);
+            float s = 0.f;
+            if (!REM || ckk < 32) {       // rows of block k >> 2: lane = pixel parity * 32 + column
+                const float* src = sm + q.tabf + ((k >> 2) * 4 + (k & 3)) * 64 + ckk;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) s += src[w * q.wavef] + src[w * q.wavef + 32];
+            } else {                      // remainder: lane = pixel (0..7) * 8 + column - 32
+                const float* src = sm + q.tabf + ((KS2 + (k >> 2)) * 4 + (k & 3)) * 64 + (ckk - 32);
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    float t = 0.f;
+#pragma unroll
+                    for (int p8 = 0; p8 < 8; ++p8) t += src[w * q.wavef + 8 * p8];
+                    s += t;
+                }
+            }
+            if (ckk < CKK)
+                partial[(size_t)blockIdx.x * K * CKK + k * CKK + ckk] = s;
+            else
+                dbpartial[(size_t)blockIdx.x * K + k] = s;
+        }
+    } else {
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
@@ -630,6 +742,7 @@ __global__ __launch_bounds__(256, 2) void convblock_bwd_mask_mfma(
         else
             dbpartial[(size_t)blockIdx.x * K + k] = s;
     }
+    }
     CM_STAMP();      // slab written
 #undef CM_STAMP
 }
@@ -642,7 +755,8 @@ static void cm_geometry(CmGeom& q, int C, int K) {
     q.npixp = 16 * q.PT + 4;                    // npixp/4 odd: filters land on distinct b128 banks
     q.dzf = 4 * ((K + 3) / 4) * q.npixp;
     q.tabf = (4 * q.PT + 3) & ~3;
-    const int red = 2 * ((C * 9 + 16) / 16) * 4 * 64;     // final accumulator exchange
+    int red = 2 * ((C * 9 + 16) / 16) * 4 * 64;           // final accumulator exchange
+    if (red < 2 * ((K + 3) / 4) * 4 * 64) red = 2 * ((K + 3) / 4) * 4 * 64;      // (W44: main + remainder accumulators)
     q.wavef = 2 * q.xf + q.dzf + 4;          // + one zero float4 behind the dz tile
     if (q.wavef < red) q.wavef = red;
 }
@@ -717,8 +831,21 @@ static int launch_cm_mask(tn_ctx* ctx, const float* x, const float* W, const flo
     if (rc) return rc;
     float* dbpartial = partial + (size_t)nblk * KCFF;
     float* tdbg = (q.dbg & 16) ? db : nullptr;
-    if (act == TN_ACT_LEAKY) {
-        auto kern = convblock_bwd_mask_mfma<C, KS2, TN_ACT_LEAKY>;
+    static int w44 = -1;
+    if (w44 < 0) {
+        const char* e = getenv("TN_CB_W44");
+        w44 = e ? atoi(e) : 1;
+    }
+    if (act == TN_ACT_LEAKY && w44) {
+        auto kern = convblock_bwd_mask_mfma<C, KS2, TN_ACT_LEAKY, true>;
+        static size_t set_for = 0;
+        if (set_for < lds) {
+            TN_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            set_for = lds;
+        }
+        kern<<<nblk, 256, lds, ctx->stream>>>(x, W, g, y, mask, dx, partial, dbpartial, q, act, prm, tdbg);
+    } else if (act == TN_ACT_LEAKY) {
+        auto kern = convblock_bwd_mask_mfma<C, KS2, TN_ACT_LEAKY, false>;
         static size_t set_for = 0;
         if (set_for < lds) {
             TN_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -726,7 +853,7 @@ static int launch_cm_mask(tn_ctx* ctx, const float* x, const float* W, const flo
         }
         kern<<<nblk, 256, lds, ctx->stream>>>(x, W, g, y, mask, dx, partial, dbpartial, q, act, prm, tdbg);
     } else {
-        auto kern = convblock_bwd_mask_mfma<C, KS2, -1>;
+        auto kern = convblock_bwd_mask_mfma<C, KS2, -1, false>;
         static size_t set_for = 0;
         if (set_for < lds) {
             TN_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
