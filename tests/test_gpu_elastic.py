@@ -27,13 +27,16 @@ def _pack(d, h, w):
     return v
 
 
-@pytest.mark.parametrize("prm,nearest,hw,C", [
+CASES = [
     (dict(translation=2, zoom=1.1, magnitude=60, sigma=15, pflip=.03, angle=5), True, 28, 1),
     (dict(translation=2, zoom=1.1, magnitude=30, sigma=4, pflip=0, angle=5), False, 32, 3),
     (dict(translation=3, zoom=1, magnitude=0, sigma=1, pflip=.1, angle=0), False, 17, 2),
     (dict(translation=0, zoom=1.3, magnitude=0, sigma=1, pflip=0, angle=0), True, 20, 1),
     (dict(translation=0, zoom=1, magnitude=12, sigma=3, pflip=0, angle=30), False, 24, 1),
-])
+]
+
+
+@pytest.mark.parametrize("prm,nearest,hw,C", CASES)
 def test_elastic_field_and_apply_match_oracle(prm, nearest, hw, C):
     st = O.ElasticStage(hw, num_maps=C, nearest=nearest, invert_image=True,
                         rand_gen=np.random.RandomState(5), **prm)
@@ -68,6 +71,41 @@ def test_elastic_field_and_apply_match_oracle(prm, nearest, hw, C):
     else:
         assert_close(got, want, atol=2e-3, rtol=0, what="bilinear")
         assert np.abs(got - want).mean() < 2e-5
+
+
+@pytest.mark.parametrize("prm,nearest,hw,C", [c for c in CASES if c[2] % 4 == 0])      # (the c8 stage takes rows of 16 bytes)
+def test_c8_elastic_apply_matches_oracle(prm, nearest, hw, C):
+    """tn_c8_elastic_apply (DTYPE float16: the stage writes the first conv layer's fp16 tensor directly) against the
+    ORACLE's distortion stage with the same injected draws: fp16(oracle value) exactly for nearest-neighbour sampling
+    (away from rounding boundaries of the coordinates), within the bilinear tolerance + half an fp16 ulp otherwise;
+    channels beyond C are zero."""
+    st = O.ElasticStage(hw, num_maps=C, nearest=nearest, invert_image=True,
+                        rand_gen=np.random.RandomState(5), **prm)
+    rng = np.random.RandomState(0)
+    x = rng.rand(10, C, hw, hw).astype(np.float32)
+    d = st.draw((6, C, hw, hw))
+    want, target = st.forward(x[2:8], d)
+    draws = dev(_pack(d, hw, hw))
+    idx, fy, fx = empty((hw * hw,), np.int32), empty((hw * hw,)), empty((hw * hw,))
+    call("tn_elastic_field", draws.ptr, hw, hw, float(prm["translation"]), float(prm["zoom"]),
+         float(prm["magnitude"]), prm["sigma"], float(prm["angle"]), int(nearest), idx.ptr, fy.ptr, fx.ptr, None)
+    fm = dev(d.flipmask.astype(np.uint8)) if prm["pflip"] else None
+    row0 = dev(np.array([1], np.int64))
+    C8 = (C + 7) // 8
+    out16 = empty((6, C8, hw * hw, 8), np.uint16)
+    call("tn_c8_elastic_apply", dev(x).ptr, 1, row0.ptr, out16.ptr, 6, C, hw, hw, 1, int(nearest),
+         idx.ptr, fy.ptr, fx.ptr, 0.0, fm.ptr if fm is not None else None, 0, 0, None, 0)
+    got = out16.get_value().view(np.float16).reshape(6, C8, hw * hw, 8).transpose(0, 1, 3, 2).reshape(6, C8 * 8, hw, hw)
+    assert not got[:, C:].any()
+    got = got[:, :C].astype(np.float32)
+    if nearest:
+        cy = np.clip(target[0], 0, hw - 1.001)
+        cx = np.clip(target[1], 0, hw - 1.001)
+        safe = (np.abs(cy - np.floor(cy) - .5) > 5e-4) & (np.abs(cx - np.floor(cx) - .5) > 5e-4)
+        assert safe.mean() > .99
+        np.testing.assert_array_equal(got[:, :, safe], want.astype(np.float16).astype(np.float32)[:, :, safe])
+    else:
+        assert_close(got, want, atol=2e-3 + 5e-4, rtol=0, what="bilinear, fp16")
 
 
 def test_elastic_identity_and_invert():
