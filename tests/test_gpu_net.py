@@ -775,16 +775,19 @@ def test_graph_capture_of_abi_ops():
     call("tn_graph_destroy", g)
 
 
-@pytest.mark.parametrize("name,img,ch,B", [("mnist.prms", 28, 1, 64), ("cifar_like.prms", 32, 3, 16)])
-def test_fused_step_equals_separate_launches(monkeypatch, name, img, ch, B):
+@pytest.mark.parametrize("name,img,ch,B,dtype", [("mnist.prms", 28, 1, 64, "float32"), ("cifar_like.prms", 32, 3, 16, "float32"),
+                                                  ("cifar_like.prms", 32, 3, 16, "float16_fused")])
+def test_fused_step_equals_separate_launches(monkeypatch, name, img, ch, B, dtype):
     """The sequential step's fusions -- weight-gradient slab sums and the minibatch cost inside the update launch
     (tn_sgd_update_net, TN_UPD_LAZY), the next minibatch's elastic field riding in the
-    paired GEMM launch or built beside the update (tn_step_tail) -- are pure re-scheduling: against the generic
-    schedule (NeuralNet.fused_step = False: one launch per piece of work) costs, log-probabilities, gradients and
-    weights match bit for bit."""
+    paired GEMM launch (DTYPE float16: in the dense layer's weight-gradient launch, fc8_wgrad_kernel) or built beside
+    the update (tn_step_tail) -- are pure re-scheduling: against the generic schedule (NeuralNet.fused_step = False: one
+    launch per piece of work) costs, log-probabilities, gradients and weights match bit for bit."""
     from theanet_amd import NeuralNet
     import copy
     prms = load_prms(name, img, batch=B)
+    if dtype.startswith("float16"):
+        prms["training_params"].update(DTYPE="float16", GRAD_SCALE=4096.0)
     rng = np.random.RandomState(3)
     x = rng.rand(4 * B, ch, img, img).astype(np.float32)
     y = rng.randint(0, 10, 4 * B).astype(np.int32)

@@ -20,6 +20,7 @@
 //   wgrad   : both operands want 8 consecutive SAMPLES per lane but are stored sample-major: tiles go to LDS as they
 //             are (dz converted on the way) and gfx950's transposing LDS read (ds_read_b64_tr_b16) delivers them.
 #include "common.h"
+#include "elastic_field.h"
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4v __attribute__((ext_vector_type(4)));
@@ -283,8 +284,16 @@ __global__ __launch_bounds__(512) void fc8_dgrad_kernel(FC8 g) {
 // ([sample][128 columns] halfs, row stride 320 bytes) and come out transposed.
 // ---------------------------------------------------------------------------------------------------------------
 #define FC8_RS 320          // row stride = 64 (mod 256) bytes: the 4 x 32-byte rows of both 16-lane groups of a half-wave on disjoint banks
-__global__ __launch_bounds__(256) void fc8_wgrad_kernel(FC8 g) {
+// RIDER: grid layers z >= S carry a light independent job of the step -- the elastic field of the NEXT minibatch
+// (tn_rider_elastic_field; inlayers.py:72-125) -- as extra blocks behind the product, like the fp32 nets' paired GEMM
+// launch does: a float16 net has no such launch, and the field cost its stream a 14 us launch of its own per step.
+__global__ __launch_bounds__(256) void fc8_wgrad_kernel(FC8 g, ElField rider, int nrider) {
     __shared__ __attribute__((aligned(16))) char lds[2][64 * FC8_RS];        // [x | dz][sample][column]
+    if ((int)blockIdx.z >= g.S) {
+        const int rb = (((int)blockIdx.z - g.S) * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        if (rb < nrider) elastic_field_block<true>(rider, reinterpret_cast<float*>(&lds[0][0]), rb);
+        return;
+    }
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, hi = lane >> 5;
     const int k0 = blockIdx.x * 128, n0 = blockIdx.y * 128, z = blockIdx.z;
     const int mchunk = g.krange;                     // samples per slab (a multiple of 64)
@@ -470,17 +479,26 @@ int tn_c8_fc_wgrad(tn_ctx* ctx, const void* x, const float* dz, float* dW, float
     S = cdiv(B, g.krange);
     g.S = S;
     const size_t n = (size_t)C * HW * n_out;
+    // a rider waiting in the context travels as extra grid layers behind the product (it works in the tile's LDS)
+    ElField rider{};
+    int nrider = 0, zr = 0;
+    if (ctx->rider_valid && ctx->rider_lds <= sizeof(char) * 2 * 64 * FC8_RS) {
+        rider = ctx->rider;
+        nrider = cdiv(rider.h * rider.w, 4);
+        zr = cdiv(nrider, kb * nb);
+        ctx->rider_valid = false;
+    }
     if (S == 1) {
         g.ws = dW; g.dbws = db;
         // (channels beyond C own no row of dW: nothing to clear)
-        fc8_wgrad_kernel<<<dim3(kb, nb, 1), 256, 0, ctx->stream>>>(g);
+        fc8_wgrad_kernel<<<dim3(kb, nb, 1 + zr), 256, 0, ctx->stream>>>(g, rider, nrider);
         TN_LAUNCH_CHECK();
         return TN_OK;
     }
     rc = tn_scratch_get(ctx, ((size_t)S * n + (size_t)S * n_out) * sizeof(float), &g.ws);
     if (rc) return rc;
     g.dbws = g.ws + (size_t)S * n;
-    fc8_wgrad_kernel<<<dim3(kb, nb, S), 256, 0, ctx->stream>>>(g);
+    fc8_wgrad_kernel<<<dim3(kb, nb, S + zr), 256, 0, ctx->stream>>>(g, rider, nrider);
     TN_LAUNCH_CHECK();
     rc = tn_red_push(ctx, g.ws, dW, (uint32_t)n, (uint32_t)S, (uint32_t)n, 0);
     if (rc) return rc;
