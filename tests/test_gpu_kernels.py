@@ -185,6 +185,8 @@ def test_convblock_lds_backward(case):
     (3, 2, 10, 30, 3, "same", "tanh"),
     (2, 4, 8, 21, 3, "valid", "relu"),
     (5, 1, 14, 7, 3, "valid", "sigmoid"),
+    (4, 1, 12, 5, 3, "valid", "relu10"),        # weight gradient on the 16-block MFMA: one channel, 5 filters (no remainder product)
+    (3, 4, 10, 32, 3, "valid", "relu05"),       # ... the largest filter count (8 filter quads + the remainder columns)
 ])
 def test_convblock_mask_backward(case):
     """tn_convpool_fwd_mask + tn_convblock_bwd_mask (matrix-core backward driven by the forward's
