@@ -776,7 +776,7 @@ def test_graph_capture_of_abi_ops():
 
 
 @pytest.mark.parametrize("name,img,ch,B,dtype", [("mnist.prms", 28, 1, 64, "float32"), ("cifar_like.prms", 32, 3, 16, "float32"),
-                                                  ("cifar_like.prms", 32, 3, 16, "float16_fused")])
+                                                  pytest.param("cifar_like.prms", 32, 3, 16, "float16", id="cifar_like-f16")])
 def test_fused_step_equals_separate_launches(monkeypatch, name, img, ch, B, dtype):
     """The sequential step's fusions -- weight-gradient slab sums and the minibatch cost inside the update launch
     (tn_sgd_update_net, TN_UPD_LAZY), the next minibatch's elastic field riding in the
