@@ -11,7 +11,7 @@ net = NeuralNet(copy.deepcopy(prms["layers"]), dict(prms["training_params"]))
 fn = net.get_trin_model(x, y)
 for i in range(300): fn.enqueue(i % 4)
 for i in range(20): fn(i % 4)
-n = 2000
+n = int(os.environ.get("NSTEPS", 2000))
 seen, tot, ks = 0, 0.0, []
 for i in range(n):
     for k, c in fn.step_cost(i % 4):
@@ -20,4 +20,4 @@ for i in range(n):
 for k, c in fn.drain_costs():
     seen += 1; tot += float(c); ks.append(k)
     if not np.isfinite(c): print("non-finite (drain) at", k, c)
-print("seen", seen, "of", n, "tot", tot, "in order", ks == list(range(len(ks))), "plan", fn._plan.ready, fn._plan.why, type(fn).__name__, fn._seq is None)
+print("seen", seen, "of", n, "tot", tot, "in order", ks == list(range(len(ks))), "plan", fn._plan.ready, fn._plan.why, type(fn).__name__, getattr(fn, "_seq", None) is None)
