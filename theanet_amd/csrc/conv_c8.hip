@@ -650,14 +650,26 @@ struct C8WG {
     int offD, offG, offM, offDump;         // dz planes / raw pooled gradient / raw mask / the fillers' dump KB inside a stage
     int nQx, nQd, NQ;                      // LDS-DMA chunks per stage: x, dz (POOL: pooled gradient), all
     int nstage;
+    int roll, XA;              // ROLL: the x ring (bytes in front of the stages); stages then hold dz (+ raw pooled gradient, mask) only
     float oscale;
     unsigned long long* dbg;   // TN_C8_DBG: per block {life, DMA wait, barrier, matrix steps} cycles
     int exp;                   // TN_C8_EXP (experiments): bit 0 no refills inside the loop, bit 1 no matrix steps
 };
 
-template <int NFT, int NCT, bool POOL, int NGX, int TM = 1>
+// ROLL (round 4; tiles that are bands of TH rows of ONE image, rows of >= 16 pixels): the x rows live in a RING of four
+// regions of TH rows per octet plane instead of a halo tile per stage.  A tile fetches only its own TH rows (2 DMA chunks
+// per plane, no fillers: its 128 cells are contiguous in HBM and in LDS) -- the row above it is the last row of the
+// previous tile's region, the row below it the first row of the next tile's (which therefore lands one tile earlier than
+// the tile's dz), rows outside the image are a zero row behind the ring.  No halo columns either: the cell left of
+// column 0 / right of column W-1 is whatever the ring holds there, and the one k element of the transposed operand
+// that came from it is cleared with a v_and.  At 64-pixel rows a halo tile is 4 x 66 cells for 2 x 64 of content: 5 chunks
+// per plane became 2 (32-pixel rows: 4 -> 2, 16-pixel rows: 3 -> 2); the kernel was bound by the LDS-DMA stream
+// (DMA alone 58 k of a block's 87 k cycles on conv2 of wide6).
+template <int NFT, int NCT, bool POOL, int NGX, int TM = 1, bool ROLL = false>
 __global__ __launch_bounds__(512) void c8_wgrad_kernel(C8WG g) {
     extern __shared__ __attribute__((aligned(16))) float ct_smem[];
+    static_assert(!ROLL || (NCT != 0 && TM == 1), "ROLL: channel-tiled layers, 128-pixel tiles");
+    constexpr int RGB = 2048, ZRO = 4 * RGB;          // ROLL: bytes of a ring region per plane; offset of the zero row
     // eight waves = two per SIMD: while one waits for its LDS operands or sits in the issue of an LDS-DMA (~100 cycles
     // each, nothing else of that wave moves meanwhile) the other feeds the matrix pipe.  One wave per SIMD ran this loop
     // at DMA issue + address arithmetic + matrix time, the sum (cycle stamps: 1.4 k + 1.4 k + 3.7 k per tile).
@@ -693,7 +705,15 @@ __global__ __launch_bounds__(512) void c8_wgrad_kernel(C8WG g) {
 #pragma unroll
     for (int j = 0; j < NG; ++j) {
         int rel = 0, fl = 1 | 2, dst = g.offDump;              // filler by default
-        if (j < NGX) {
+        if (ROLL && j < NGX) {
+            const int q = 8 * j + wave;
+            if (q < g.nQx) {
+                const int plane = q >> 1, sub = q & 1;
+                rel = plane * HW + sub * 64 + lane;
+                fl = 1 | (cg * CP + plane >= g.C8 ? 2 : 0);
+                dst = plane * g.XPS + 16 + sub * 1024;
+            }
+        } else if (j < NGX) {
             const int q = 8 * j + wave;
             if (q < g.nQx) {
                 const int plane = q / g.XCH, c = (q - plane * g.XCH) * 64 + lane;
@@ -736,8 +756,21 @@ __global__ __launch_bounds__(512) void c8_wgrad_kernel(C8WG g) {
     const char* cur_dp = reinterpret_cast<const char*>(g.dz);
     const char* cur_mp = reinterpret_cast<const char*>(g.mask);
     int cur_zmask = 0, cur_nlim = 0;
-    unsigned cur_sb = lds0;
+    unsigned cur_sb = lds0, cur_xr = 0;
     int rf_gi = tile_beg / g.RT, rf_rt = tile_beg - rf_gi * g.RT, rf_tile = tile_beg;      // refill cursor
+    // ROLL: tile number `tile` (clamped into the tensor) -> x region, dz stage
+    auto roll_setup = [&](int tile, int stage, int region) __attribute__((always_inline)) {
+        const int tc = min(max(tile, 0), g.NTILES - 1), n0 = tc / g.RT, r0 = (tc - n0 * g.RT) * g.TH;
+        cur_zmask = 2;
+        cur_nlim = g.N - n0;
+        cur_xp = reinterpret_cast<const char*>(g.x + ((long long)(n0 * g.C8 + cg * CP) * g.H + r0) * g.Wd);
+        const long long db = POOL ? ((long long)(n0 * g.K8 + kg * KP) * (g.H >> 1) + (r0 >> 1)) * Wp
+                                  : ((long long)(n0 * g.K8 + kg * KP) * g.H + r0) * g.Wd;
+        cur_dp = reinterpret_cast<const char*>(g.dz + db);
+        cur_mp = reinterpret_cast<const char*>(g.mask + db);
+        cur_sb = lds0 + g.XA + stage * g.SB;
+        cur_xr = lds0 + region * RGB;
+    };
     auto tile_setup = [&](int stage) __attribute__((always_inline)) {
         // (tiles beyond the slab's end re-read its last tile: the number of DMAs per stage stays constant)
         const int n0 = rf_gi * g.NI, r0 = rf_rt * g.TH;
@@ -763,7 +796,8 @@ __global__ __launch_bounds__(512) void c8_wgrad_kernel(C8WG g) {
             const char* src = j < NGX ? cur_xp + (long long)gl_rel[j] * 16
                             : (POOL && (fl & 16)) ? cur_mp + (long long)gl_rel[j] * 8 : cur_dp + (long long)gl_rel[j] * 16;
             src = zero ? zero_src : src;
-            if ((fl & 1) && !(g.exp & 1)) c8_glds16(src, __builtin_amdgcn_readfirstlane(cur_sb + gl_dst[j]));
+            if ((fl & 1) && !(g.exp & 1))
+                c8_glds16(src, __builtin_amdgcn_readfirstlane(((ROLL && j < NGX) ? cur_xr : cur_sb) + gl_dst[j]));
         }
     };
     using J_0 = std::integral_constant<int, 0>;
@@ -795,26 +829,55 @@ __global__ __launch_bounds__(512) void c8_wgrad_kernel(C8WG g) {
 
     unsigned long long d_wait = 0, d_bar = 0, d_mm = 0, d_t0 = 0, d_w0 = 0, d_exp = 0;     // (d_exp: shown as "prologue" by tools/dbg_c8.py)
     if (g.dbg) { d_t0 = __builtin_readcyclecounter(); d_w0 = wall_clock64(); }
-    tile_setup(0);
-    issue_range(J_0{}, J_N{});
-    if (g.nstage > 2) {
-        tile_setup(1);
+    int c_rt = tile_beg % g.RT;                     // ROLL: row band of the tile being multiplied
+    if ((g.exp & 4) && wave >= 4) __builtin_amdgcn_s_setprio(1);
+    if ((g.exp & 8) && wave < 4) __builtin_amdgcn_s_setprio(1);
+    if (ROLL) {
+        // the zero row of every plane; then: the tile above the slab's first (its last row is that tile's upper halo; unused
+        // when the slab starts at the top of an image) into region 3, tiles 0 and 1 of the slab into regions / stages 0, 1
+        for (int i = t; i < CP * g.Wd; i += 512)
+            *reinterpret_cast<uint4*>(smem + (i >> g.lgW) * g.XPS + 16 + ZRO + (i & Wm) * 16) = make_uint4(0u, 0u, 0u, 0u);
+        roll_setup(tile_beg - 1, 0, 3);
+        issue_range(J_0{}, std::integral_constant<int, NGX>{});
+        roll_setup(tile_beg, 0, 0);
         issue_range(J_0{}, J_N{});
+        roll_setup(tile_beg + 1, 1, 1);
+        issue_range(J_0{}, J_N{});
+    } else {
+        tile_setup(0);
+        issue_range(J_0{}, J_N{});
+        if (g.nstage > 2) {
+            tile_setup(1);
+            issue_range(J_0{}, J_N{});
+        }
     }
     for (int tile = tile_beg, it = 0; tile < tile_end; ++tile, ++it) {
         const int stage = it % g.nstage;
         unsigned long long s0 = 0, s1 = 0, s2 = 0;
         if (g.dbg) s0 = __builtin_readcyclecounter();
         // this wave's DMAs of the stage have landed (the following stage's may still be in flight) ...
-        if (g.nstage > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NG) : "memory");
+        // (ROLL: the x rows of the NEXT tile too -- a tile's x chunks are issued in front of its dz chunks)
+        if (ROLL) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NG - NGX) : "memory");
+        else if (g.nstage > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NG) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (g.dbg) s1 = __builtin_readcyclecounter();
         // ... and everybody's; all waves are also done with the stage that is refilled next
         __builtin_amdgcn_s_barrier();
         if (g.dbg) { s2 = __builtin_readcyclecounter(); d_wait += s1 - s0; d_bar += s2 - s1; }
-        char* const sb = smem + stage * g.SB;
+        char* const sb = smem + (ROLL ? g.XA : 0) + stage * g.SB;
         // the refill of the stage two tiles ahead is spread over this tile's matrix steps
-        tile_setup((it + g.nstage - 1) % g.nstage);
+        // ROLL: rows of this tile's band at reg_off, the row above / below it at top_off / bot_off (ring neighbours or zeros)
+        int reg_off = 0, top_off = 0, bot_off = 0;
+        if (ROLL) {
+            roll_setup(tile + 2, (it + 2) % 3, (it + 2) & 3);
+            const int region = it & 3;
+            reg_off = region * RGB;
+            top_off = c_rt == 0 ? ZRO : ((region + 3) & 3) * RGB + THm * (g.Wd * 16);
+            bot_off = c_rt == g.RT - 1 ? ZRO : ((region + 1) & 3) * RGB;
+            if (++c_rt == g.RT) c_rt = 0;
+        } else {
+            tile_setup((it + g.nstage - 1) % g.nstage);
+        }
         if (POOL) {
             // expand (pooled gradient, mask) -> dz image: one pooled cell of one plane -> its 2 x 2 window
 #pragma unroll
@@ -847,7 +910,30 @@ __global__ __launch_bounds__(512) void c8_wgrad_kernel(C8WG g) {
             const half4v a0 = c8_tr16(ap), a1 = c8_tr16(ap + 64);
             const char* xp = bb + (((p >> g.lgP) * g.THi + ((p >> g.lgW) & THm)) * g.RS + (p & Wm)) * 16;
             half4v bv[NACC][2];
-            if (TAPK) {
+            if (ROLL) {
+                const int g16 = 16 * (ps + PS * i), rl = (g16 >> g.lgW) & THm, W16 = g.Wd * 16;     // wave-uniform
+                const char* const xc = smem + b_off + (p & Wm) * 16;
+                // the k element whose cell lies left of column 0 (tap column 0, first pixel of the lower 8) / right of column
+                // W - 1 (tap column 2, last pixel of the upper 8)
+                const unsigned mL = ((g16 & Wm) == 0 && (grp >> 1) == 0) ? 0xffff0000u : 0xffffffffu;
+                const unsigned mR = (((g16 + 16) & Wm) == 0 && (grp >> 1) == 1) ? 0x0000ffffu : 0xffffffffu;
+#pragma unroll
+                for (int u = 0; u < 3; ++u) {
+                    const int k = rl + u;
+                    const int ro = __builtin_amdgcn_readfirstlane(k == 0 ? top_off : (k == g.TH + 1 ? bot_off : reg_off + (k - 1) * W16));
+#pragma unroll
+                    for (int v = 0; v < 3; ++v) {
+                        bv[(u * 3 + v) % NACC][0] = c8_tr16(xc + ro + v * 16);
+                        bv[(u * 3 + v) % NACC][1] = c8_tr16(xc + ro + v * 16 + 64);
+                    }
+                    uint2 e0 = __builtin_bit_cast(uint2, bv[(u * 3) % NACC][0]);
+                    e0.x &= mL;
+                    bv[(u * 3) % NACC][0] = __builtin_bit_cast(half4v, e0);
+                    uint2 e2 = __builtin_bit_cast(uint2, bv[(u * 3 + 2) % NACC][1]);
+                    e2.y &= mR;
+                    bv[(u * 3 + 2) % NACC][1] = __builtin_bit_cast(half4v, e2);
+                }
+            } else if (TAPK) {
 #pragma unroll
                 for (int jt = 0; jt < 3; ++jt) {
                     bv[jt][0] = c8_tr16(xp + toff[jt]);
@@ -937,11 +1023,9 @@ __global__ __launch_bounds__(512) void c8_wgrad_kernel(C8WG g) {
             for (int r = 0; r < 16; ++r) accb[r] += slot[r * 64];
         }
     }
-    if (ps != 0) return;
-
     // bias gradient partial of the slab: column 0 of the product against ones
     const float os = g.oscale;
-    if (want_db && l31 == 0) {
+    if (ps == 0 && want_db && l31 == 0) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int k = kg * KBF + ft * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
@@ -950,6 +1034,7 @@ __global__ __launch_bounds__(512) void c8_wgrad_kernel(C8WG g) {
     }
     // slab z: dW layout, tap (u,v) of the correlation is element (2-u, 2-v)
     if (TAPK) {                                 // column l31 = tap 4 jt + (l31 >> 3), channel l31 & 7
+        if (ps != 0) return;
         const int e = l31 & 7;
         if (e < g.C) {
             float* wz = g.ws + (size_t)z * g.K * g.C * 9;
@@ -967,6 +1052,31 @@ __global__ __launch_bounds__(512) void c8_wgrad_kernel(C8WG g) {
         }
         return;
     }
+    if (g.K % KBF == 0 && g.C % CBF == 0) {
+        // whole tiles: the block's KBF x (CBF x 9) piece of the slab is KBF runs of CBF * 9 floats.  Straight from the
+        // accumulators a store instruction wrote 4 bytes per lane 36 bytes apart (144 of them per lane, 37.7 MB per
+        // launch as 4-byte pieces: ~15 us of a 50-65 us kernel); through LDS ([k][c * 9 + tap], conflict-free: 9 is odd)
+        // every thread stores 16 bytes next to its neighbour's.
+        constexpr int ROWF = CBF * 9;
+        __syncthreads();                        // the reduction's slots are free
+        if (ps == 0) {
+            float* const T = ct_smem + (size_t)(ft * 32 + 4 * hi) * ROWF + (ct * 32 + l31) * 9;
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+#pragma unroll
+                for (int a_ = 0; a_ < NACC; ++a_) T[((r & 3) + 8 * (r >> 2)) * ROWF + 8 - a_] = acc[a_][r] * os;
+        }
+        __syncthreads();
+        float* const wz = g.ws + (size_t)z * g.K * g.C * 9 + ((size_t)kg * KBF * g.C + (size_t)cg * CBF) * 9;
+        constexpr int Q = ROWF / 4;             // 16-byte pieces per run
+        for (int idx = t; idx < KBF * Q; idx += 512) {
+            const int row = idx / Q, q = idx - row * Q;
+            *reinterpret_cast<float4*>(wz + (size_t)row * g.C * 9 + 4 * q) =
+                *reinterpret_cast<const float4*>(ct_smem + (size_t)row * ROWF + 4 * q);
+        }
+        return;
+    }
+    if (ps != 0) return;
     const int c = cg * CBF + ct * 32 + l31;
     if (c < g.C) {
         float* wz = g.ws + (size_t)z * g.K * g.C * 9;
@@ -988,6 +1098,14 @@ static void c8w_tiles(int K, int C, int& NFT, int& NCT) {
     NCT = C > 32 ? 2 : (C > 8 ? 1 : 0);          // 0: one octet, taps packed into the columns (c8_wgrad_kernel)
 }
 
+static int c8w_roll_on() {           // TN_C8_ROLL=0: the halo-tile form everywhere (A/B)
+    static int on = -1;
+    if (on < 0) {
+        const char* e = getenv("TN_C8_ROLL");
+        on = e ? atoi(e) : 1;
+    }
+    return on;
+}
 static int c8w_geometry(C8WG& g, int num_cus, bool pool, int tm = 1) {
     const int lgW = c8w_log2(g.Wd);
     if (lgW < 3 || lgW > 6) return 0;                  // rows of 8..64 pixels
@@ -1022,6 +1140,20 @@ static int c8w_geometry(C8WG& g, int num_cus, bool pool, int tm = 1) {
     g.nQd = pool ? KP * tm / 2 + KP * tm / 4 : KP * 2 * tm;
     g.NQ = g.nQx + g.nQd;
     g.nstage = 3 * g.SB <= 160 * 1024 ? 3 : 2;
+    g.roll = 0; g.XA = 0;
+    if (NCT && tm == 1 && g.NI == 1 && g.RT >= 2 && lgW >= 5 && c8w_roll_on()) {
+        // ROLL (c8_wgrad_kernel): x ring of four TH-row regions + a zero row per plane, no halo columns; three dz stages
+        const int xps = (16 + 4 * 2048 + g.Wd * 16 + 16 + 255) / 256 * 256 + 64;
+        const int offG = KP * g.DPS, offM = offG + (pool ? KP * 512 : 0);
+        const int offDump = (offM + (pool ? KP * 256 : 0) + 255) / 256 * 256, sb = offDump + 1024;
+        if (CP * xps + 3 * sb <= 160 * 1024) {
+            g.roll = 1;
+            g.XPS = xps; g.XA = CP * xps;
+            g.offD = 0; g.offG = offG; g.offM = offM; g.offDump = offDump; g.SB = sb;
+            g.XCH = 2; g.nQx = CP * 2; g.NQ = g.nQx + g.nQd;
+            g.nstage = 3;
+        }
+    }
     g.KG = cdiv(g.K, 32 * NFT);
     g.CG = NCT ? cdiv(g.C, 32 * NCT) : 1;
     g.NTILES = cdiv(g.N, g.NI) * g.RT;
@@ -1034,15 +1166,15 @@ static int c8w_geometry(C8WG& g, int num_cus, bool pool, int tm = 1) {
 }
 
 static size_t c8w_lds_bytes(const C8WG& g) {
-    const size_t a = (size_t)g.nstage * g.SB, red = (size_t)4 * 144 * 64 * sizeof(float);     // stages; the final reduction
+    const size_t a = (size_t)g.XA + (size_t)g.nstage * g.SB, red = (size_t)4 * 144 * 64 * sizeof(float);     // (ring +) stages; the final reduction
     return a > red ? a : red;
 }
 
-template <int NFT, int NCT, bool POOL, int NGX, int TM = 1>
+template <int NFT, int NCT, bool POOL, int NGX, int TM = 1, bool ROLL = false>
 static int c8w_launch(tn_ctx* ctx, C8WG& g) {
     static bool attr_set = false;
     if (!attr_set) {
-        TN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&c8_wgrad_kernel<NFT, NCT, POOL, NGX, TM>),
+        TN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&c8_wgrad_kernel<NFT, NCT, POOL, NGX, TM, ROLL>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
@@ -1065,7 +1197,7 @@ static int c8w_launch(tn_ctx* ctx, C8WG& g) {
         }
         g.exp = exp_;
     }
-    c8_wgrad_kernel<NFT, NCT, POOL, NGX, TM><<<grid, 512, c8w_lds_bytes(g), ctx->stream>>>(g);
+    c8_wgrad_kernel<NFT, NCT, POOL, NGX, TM, ROLL><<<grid, 512, c8w_lds_bytes(g), ctx->stream>>>(g);
     TN_LAUNCH_CHECK();
     return TN_OK;
 }
@@ -1081,6 +1213,7 @@ static int c8w_launch_ng(tn_ctx* ctx, C8WG& g, int tm) {
         if (tm == 2) return c8w_launch<NFT, 0, POOL, 1, 2>(ctx, g);
         return ngx <= 1 ? c8w_launch<NFT, 0, POOL, 1>(ctx, g) : c8w_launch<NFT, 0, POOL, 2>(ctx, g);
     } else {
+        if (g.roll) return c8w_launch<NFT, NCT, POOL, NCT, 1, true>(ctx, g);      // 2 chunks x 4 NCT planes over 8 waves
         if (ngx <= 2) return c8w_launch<NFT, NCT, POOL, 2>(ctx, g);
         if (ngx <= 3) return c8w_launch<NFT, NCT, POOL, 3>(ctx, g);
         if (ngx <= 4) return c8w_launch<NFT, NCT, POOL, 4>(ctx, g);
