@@ -323,11 +323,14 @@ __global__ __launch_bounds__(256, 2) void c8_conv_kernel(C8G g) {
                             const float z0 = acc[f][0][h * 8 + e], z1 = acc[f][1][h * 8 + e];
                             float zv, zm;
                             asm("v_max_f32_e32 %0, %1, %2" : "=v"(zv) : "v"(z0), "v"(z1));
-                            const float zp = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(
-                                                 0, __builtin_bit_cast(int, zv), 0xB1, 0xF, 0xF, false));
-                            asm("v_max_f32_e32 %0, %1, %2" : "=v"(zm) : "v"(zv), "v"(zp));
-                            bits = (z0 == zm ? (1u << dj) : 0u) | (z1 == zm ? (4u << dj) : 0u);
-                            bits |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)bits, 0xB1, 0xF, 0xF, false);
+                            // the exchange folded into the v_max / v_or themselves (update_dpp compiled to v_mov 0 + v_mov_dpp +
+                            // the operation); the two wait states a DPP read needs after the VALU write of its source are
+                            // part of the statement -- the compiler does not look inside
+                            asm("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"
+                                : "=v"(zm) : "v"(zv));
+                            const unsigned b0 = (z0 == zm ? (1u << dj) : 0u) | (z1 == zm ? (4u << dj) : 0u);
+                            asm("s_nop 1\n\tv_or_b32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"
+                                : "=v"(bits) : "v"(b0));
                             m = actf(zm);
                         } else {
                             const float a0 = actf(acc[f][0][h * 8 + e]);
