@@ -93,6 +93,44 @@ def test_c8_conv_ops(case, f16_mode):
         assert _rel(gb.get_value(), dzz.sum(axis=(0, 2, 3)) / GS) < 2e-5
 
 
+def _wgrad_blas(x, dz):
+    """U.conv_same_wgrad as nine matrix products (float64): the large shapes below in a second instead of a minute."""
+    N, C, H, Wd = x.shape
+    K = dz.shape[1]
+    xp = np.zeros((N, C, H + 2, Wd + 2))
+    xp[:, :, 1:-1, 1:-1] = x
+    d2 = dz.astype(np.float64).transpose(1, 0, 2, 3).reshape(K, -1)
+    dW = np.zeros((K, C, 3, 3))
+    for u in range(3):
+        for v in range(3):
+            dW[:, :, 2 - u, 2 - v] = d2 @ xp[:, :, u:u + H, v:v + Wd].transpose(1, 0, 2, 3).reshape(C, -1).T
+    return dW
+
+
+@pytest.mark.parametrize("case", [(44, 128, 32, 128), (70, 64, 64, 64), (19, 32, 64, 96), (2049, 16, 32, 32)])
+def test_c8_wgrad_rolling_ring_over_many_tiles(case, f16_mode):
+    """The weight gradient's rolling x ring (c8_wgrad_kernel ROLL: rows of >= 32 pixels, one image band per tile) with SEVERAL
+    tiles per slab: the ring wraps (four regions), slabs start in the middle of an image (the row above comes from the
+    tile in front of the slab) and cross image boundaries (zero row), the last slab is short; plain and gathered from a
+    pooled gradient with a random mask.  convpool.py:54-56 (CorrMM_gradWeights); numbers as in test_c8_conv_ops."""
+    N, C, H, K = case
+    rng = np.random.RandomState(11)
+    assert ctx().lib.tn_c8_conv_wgrad_supported(N, C, H, H, K)
+    x = U.r16(rng.randn(N, C, H, H))
+    dz = U.r16(GS * rng.randn(N, K, H, H) * 1e-3)
+    Hp = H // 2
+    g = U.r16(GS * rng.randn(N, K, Hp, Hp) * 1e-3)
+    bits = rng.randint(1, 16, (N, K, Hp, Hp)).astype(np.uint8)
+    mk = dev(np.ascontiguousarray(bits.reshape(N, K // 8, 8, Hp, Hp).transpose(0, 1, 3, 4, 2)))
+    dzp = U.unpool_dz(g, bits)
+    xd, dzd, gd = _c8(x), _c8(dz), _c8(g)
+    gW, gb = empty((K, C, 3, 3)), empty((K,))
+    for pooled, src, dzz in ((0, dzd, dz), (1, gd, dzp)):
+        call("tn_c8_conv_wgrad", xd.ptr, src.ptr, gW.ptr, gb.ptr, N, C, H, H, K, pooled, mk.ptr if pooled else None)
+        assert _rel(gW.get_value(), _wgrad_blas(x, dzz) / GS) < 2e-5
+        assert _rel(gb.get_value(), dzz.sum(axis=(0, 2, 3)) / GS) < 2e-5
+
+
 def test_c8_generic_activation_and_pack_roundtrip(f16_mode):
     """An activation outside the leaky-ReLU family takes the generic epilogue; pack / unpack are exact on halfs."""
     from theanet_amd.layer.layer import activation_by_name
