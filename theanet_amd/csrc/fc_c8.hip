@@ -46,6 +46,7 @@ struct FC8 {
     float* ws;              // forward: K slabs [S][M][N]; wgrad: sample slabs [S][C*HW][N]
     float* dbws;            // wgrad: [S][N]
     int M, N, Np, Kc, C, HW, S, krange, act;
+    int xcd;                // block ids decoded XCD-aware (the host checked the divisibility): see fc8_fwd_kernel / fc8_wgrad_kernel
     unsigned magic;         // 2^32 / HW + 1 (0: HW == 1), see fc8_wrow
     float prm, gs, oscale;
 };
@@ -78,6 +79,14 @@ __device__ __forceinline__ half4v fc8_cvt4(const fc8_f4 v) {
 // once and is bound by that (short batches) -- and one LDS tile at a time feeds the matrix core: x as stored
 // ([row][k], 16-byte reads), W converted to halfs as stored ([k][n]) and read through the transposing LDS read.
 // ---------------------------------------------------------------------------------------------------------------
+static int fc8_xcd_on() {             // TN_FC8_XCD=0: plain block decode (A/B)
+    static int on = -1;
+    if (on < 0) {
+        const char* e = getenv("TN_FC8_XCD");
+        on = e ? atoi(e) : 1;
+    }
+    return on;
+}
 #define FC8_NST 4
 #define FC8F_XS 144         // x tile row stride (64 halfs + 16 bytes: 9 x 16 B, every 16-byte read of 32 rows on its own banks)
 #define FC8F_WS 192         // W tile row stride (64 halfs + 64 bytes = 64 (mod 128): the 4 rows of a transposing read on disjoint banks)
@@ -85,8 +94,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     __shared__ __attribute__((aligned(16))) char xs[128 * FC8F_XS];
     __shared__ __attribute__((aligned(16))) char wsm[64 * FC8F_WS];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, hi = lane >> 5;
-    const int n0 = blockIdx.x * 64, m0 = blockIdx.z * 128;
-    const int kbeg = blockIdx.y * g.krange, kend = min(g.Kc, kbeg + g.krange);
+    // Blocks are handed to the 8 XCDs round robin by linear id and every XCD has its own L2: with the plain decode the
+    // column tiles that share an x tile (same row tile, same K slab) sat on eight XCDs and each fetched it from HBM
+    // (cifar_like: 79.8 MB per launch for 28 algorithmic).  XCD-aware: the column tiles of a (K slab, row tile) pair
+    // are consecutive blocks of ONE XCD (15.3 -> 14.0 us one step at a time on cifar_like, 21.5 -> 20.6 on wide6: the
+    // re-reads were mostly served by the memory-side cache already).
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (g.xcd) {
+        const int L = bx + gridDim.x * (by + gridDim.y * bz), xc = L & 7, j = L >> 3;
+        bx = j % (int)gridDim.x;
+        const int grp = (j / (int)gridDim.x) * 8 + xc;           // (K slab, row tile) pair
+        by = grp % (int)gridDim.y; bz = grp / (int)gridDim.y;
+    }
+    const int n0 = bx * 64, m0 = bz * 128;
+    const int kbeg = by * g.krange, kend = min(g.Kc, kbeg + g.krange);
     const int nch = (kend - kbeg) >> 6, rows = g.C * g.HW;
     const int wm = wave >> 1, wn = wave & 1;                 // wave = 64 rows x 32 outputs
     f32x16 acc[2];
@@ -144,7 +165,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             __syncthreads();
         }
     }
-    float* const wz = g.ws + (size_t)blockIdx.y * g.M * g.N;
+    float* const wz = g.ws + (size_t)by * g.M * g.N;
     const int n = n0 + wn * 32 + l31;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -295,6 +316,8 @@ __global__ __launch_bounds__(256) void fc8_wgrad_kernel(FC8 g, ElField rider, in
         return;
     }
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, hi = lane >> 5;
+    // (an XCD-aware decode -- all blocks of a sample slab on one XCD -- was measured: no change, the re-reads of the
+    // other seven L2s are served by the memory-side cache)
     const int k0 = blockIdx.x * 128, n0 = blockIdx.y * 128, z = blockIdx.z;
     const int mchunk = g.krange;                     // samples per slab (a multiple of 64)
     const int mbeg = z * mchunk, mend = min(g.M, mbeg + mchunk);
@@ -432,6 +455,7 @@ int tn_c8_fc_fwd(tn_ctx* ctx, const void* x, const float* W, const float* b, flo
     g.S = S;
     rc = tn_scratch_get(ctx, (size_t)S * B * n_out * sizeof(float), &g.ws);
     if (rc) return rc;
+    g.xcd = fc8_xcd_on() && (S * rowg) % 8 == 0;
     fc8_fwd_kernel<<<dim3(colg, S, rowg), 256, 0, ctx->stream>>>(g);
     TN_LAUNCH_CHECK();
     const size_t MN = (size_t)B * n_out;
