@@ -76,6 +76,7 @@ struct tn_ctx {
     size_t scratch_off = 0;
     int npend = 0;
     tn_red_rec pend[TN_RED_MAX];
+    unsigned long long scratch_gen = 0;    // bumped by every tn_scratch_get: "nobody has asked for scratch since" checks
     // a light independent job waiting for a heavy launch to ride in (tn_rider_elastic_field)
     bool rider_valid = false;
     ElField rider;

@@ -43,6 +43,7 @@ struct FC8 {
     const uint8_t* mask;    // forward: dropout mask (M, N) or NULL
     float* out;             // forward: (M, N) fp32
     _Float16* dx;           // dgrad: (M, Kc) halfs, carries the gradient scale
+    _Float16* dz16w;        // wgrad: the rounded dz it stages, written out for the input-gradient product that follows (or NULL)
     float* ws;              // forward: K slabs [S][M][N]; wgrad: sample slabs [S][C*HW][N]
     float* dbws;            // wgrad: [S][N]
     int M, N, Np, Kc, C, HW, S, krange, act;
@@ -50,6 +51,15 @@ struct FC8 {
     unsigned magic;         // 2^32 / HW + 1 (0: HW == 1), see fc8_wrow
     float prm, gs, oscale;
 };
+
+// tn_c8_fc_wgrad leaves the rounded dz it wrote for the tn_c8_fc_dgrad call that follows it (same context, stream, dz,
+// shape and gradient scale; consumed or dropped by the next tn_c8_fc_dgrad / any other c8 dense call)
+struct Fc8Dz16Keep {
+    tn_ctx* ctx = nullptr; hipStream_t stream = nullptr; const float* dz = nullptr; _Float16* dz16 = nullptr;
+    int B = 0, n_out = 0; float gs = 0.f;
+    unsigned long long gen = 0;            // ctx->scratch_gen when it was written: nobody has asked for scratch since
+};
+static Fc8Dz16Keep fc8_dz16_keep;
 
 // cell (= c8 column >> 3) -> (o, p) = (cell / HW, cell % HW) without an integer division: magic = 2^32 / HW + 1 (exact
 // while cell * HW < 2^32, checked by the host); HW == 1: magic 0
@@ -365,7 +375,12 @@ __global__ __launch_bounds__(256) void fc8_wgrad_kernel(FC8 g, ElField rider, in
             const bool in = ok && n0 + sq + 4 * i < g.N;
             const float s = in ? g.gs : 0.f;
             const float f[8] = {dv[i].x * s, dv[i].y * s, dv[i].z * s, dv[i].w * s, dv[i + 1].x * s, dv[i + 1].y * s, dv[i + 1].z * s, dv[i + 1].w * s};
-            *reinterpret_cast<half8*>(lds[1] + sr * FC8_RS + (sq + 4 * i) * 2) = fc8_cvt8(f);
+            const half8 h8 = fc8_cvt8(f);
+            *reinterpret_cast<half8*>(lds[1] + sr * FC8_RS + (sq + 4 * i) * 2) = h8;
+            // the blocks of row tile 0 keep what they rounded: fp16(gs dz), (M, Np), zeros beyond N -- exactly what
+            // fc8_dz16_kernel writes for tn_c8_fc_dgrad (which then skips that 5 us launch)
+            if (g.dz16w && blockIdx.x == 0 && ok && n0 + sq + 4 * i < g.Np)
+                *reinterpret_cast<half8*>(g.dz16w + (size_t)(mc + sr) * g.Np + n0 + sq + 4 * i) = h8;
         }
         gload(min(mc + 64, mend - 1));         // the next chunk travels during this chunk's products
         __syncthreads();
@@ -476,12 +491,19 @@ int tn_c8_fc_dgrad(tn_ctx* ctx, const float* dz, const float* W, void* dx, int B
     g.act = act; g.prm = act_param; g.gs = ctx->grad_scale;
     g.magic = fc8_magic(HW);
     g.Np = cdiv(n_out, 64) * 64;
-    _Float16* dz16;
-    rc = tn_scratch_get(ctx, (size_t)B * g.Np * sizeof(_Float16), reinterpret_cast<float**>(&dz16));
-    if (rc) return rc;
-    g.dz16 = dz16;
-    fc8_dz16_kernel<<<cdiv((size_t)B * (g.Np / 4), 256), 256, 0, ctx->stream>>>(dz, dz16, B, n_out, g.Np, g.gs);
-    TN_LAUNCH_CHECK();
+    const Fc8Dz16Keep kp = fc8_dz16_keep;
+    fc8_dz16_keep = Fc8Dz16Keep{};
+    if (kp.ctx == ctx && kp.stream == ctx->stream && kp.dz == dz && kp.B == B && kp.n_out == n_out && kp.gs == g.gs &&
+        kp.gen == ctx->scratch_gen) {
+        g.dz16 = kp.dz16;                    // the weight-gradient launch right in front of this call wrote it
+    } else {
+        _Float16* dz16;
+        rc = tn_scratch_get(ctx, (size_t)B * g.Np * sizeof(_Float16), reinterpret_cast<float**>(&dz16));
+        if (rc) return rc;
+        g.dz16 = dz16;
+        fc8_dz16_kernel<<<cdiv((size_t)B * (g.Np / 4), 256), 256, 0, ctx->stream>>>(dz, dz16, B, n_out, g.Np, g.gs);
+        TN_LAUNCH_CHECK();
+    }
     fc8_dgrad_kernel<4><<<dim3(g.Kc / 64, cdiv(B, 128)), 512, 0, ctx->stream>>>(g);
     TN_LAUNCH_CHECK();
     return TN_OK;
@@ -512,6 +534,21 @@ int tn_c8_fc_wgrad(tn_ctx* ctx, const void* x, const float* dz, float* dW, float
         zr = cdiv(nrider, kb * nb);
         ctx->rider_valid = false;
     }
+    // room for the rounded dz behind the slabs (one request: outside a deferral window every request starts at offset 0)
+    g.Np = cdiv(n_out, 64) * 64;
+    const size_t slabf = S == 1 ? 0 : (size_t)S * n + (size_t)S * n_out, slabf4 = (slabf + 63) & ~(size_t)63;
+    float* scr;
+    rc = tn_scratch_get(ctx, slabf4 * sizeof(float) + (size_t)B * g.Np * sizeof(_Float16), &scr);
+    if (rc) return rc;
+    static int keep_on = -1;               // TN_FC8_DZ16=0: the conversion stays a launch of its own (A/B)
+    if (keep_on < 0) {
+        const char* e = getenv("TN_FC8_DZ16");
+        keep_on = e ? atoi(e) : 1;
+    }
+    if (keep_on) {
+        g.dz16w = reinterpret_cast<_Float16*>(scr + slabf4);
+        fc8_dz16_keep = {ctx, ctx->stream, dz, g.dz16w, B, n_out, ctx->grad_scale, ctx->scratch_gen};
+    }
     if (S == 1) {
         g.ws = dW; g.dbws = db;
         // (channels beyond C own no row of dW: nothing to clear)
@@ -519,8 +556,7 @@ int tn_c8_fc_wgrad(tn_ctx* ctx, const void* x, const float* dz, float* dW, float
         TN_LAUNCH_CHECK();
         return TN_OK;
     }
-    rc = tn_scratch_get(ctx, ((size_t)S * n + (size_t)S * n_out) * sizeof(float), &g.ws);
-    if (rc) return rc;
+    g.ws = scr;
     g.dbws = g.ws + (size_t)S * n;
     fc8_wgrad_kernel<<<dim3(kb, nb, S + zr), 256, 0, ctx->stream>>>(g, rider, nrider);
     TN_LAUNCH_CHECK();

@@ -127,6 +127,7 @@ int tn_red_commit(tn_ctx* ctx) { return ctx->defer ? TN_OK : tn_red_flush(ctx); 
 // bytes of context scratch: the whole buffer outside a deferral window, a fresh 256-byte aligned
 // piece of it inside one (earlier pieces hold slabs that are still to be reduced)
 int tn_scratch_get(tn_ctx* ctx, size_t bytes, float** out) {
+    ++ctx->scratch_gen;
     bytes = (bytes + 255) & ~(size_t)255;
     size_t off = ctx->defer ? ctx->scratch_off : 0;
     if (off + bytes > ctx->scratch_bytes) {
