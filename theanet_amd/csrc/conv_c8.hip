@@ -27,6 +27,7 @@
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 typedef int int4v __attribute__((ext_vector_type(4)));
+typedef int int2v __attribute__((ext_vector_type(2)));
 
 struct C8G {
     const _Float16* x;        // gathered tensor, c8 (N, C8, H, W, 8); MODE 3: the POOLED gradient (N, C8, H/2, W/2, 8)
@@ -702,8 +703,59 @@ __global__ __launch_bounds__(512) void c8_wgrad_kernel(C8WG g) {
     // chunk index beyond its kind's count is a filler (zero cell -> the dump KB).  Per chunk (wave-uniform): destination
     // inside the stage; per lane: the source cell relative to the tile's first cell and flags (bit 0 lane in use,
     // 1 always zero, 2 / 3 top / bottom halo row, 4 mask bytes (8-byte cells), 8.. image of the tile)
-    constexpr int NQG = KP * TM / 2, NQM = KP * TM / 4;      // POOL: raw pooled-gradient / mask chunks per stage
-    constexpr int NGD = ((POOL ? NQG + NQM : KP * 2 * TM) + 7) / 8, NG = NGX + NGD;
+    // POOL (round 4): the pooled gradient and the mask bytes of a tile travel through REGISTERS -- every thread loads
+    // NPC pooled cells (16 + 8 bytes, asm loads counted by hand like the DMAs) while the tile in front of theirs is being
+    // multiplied and expands them into the next stage's dz image (four 16-byte LDS stores) after the last step.  Before,
+    // they went to LDS raw (6 DMA chunks) and a pass over LDS behind a second barrier expanded them: 12 k of a block's 97 k
+    // cycles on conv2 of wide6.
+    constexpr int NGD = POOL ? 0 : (KP * 2 * TM + 7) / 8, NG = NGX + NGD;
+    constexpr int NPC = POOL ? (KP * PCP + 511) / 512 : 1;
+    int pg_rel[NPC], pg_fl[NPC], pg_dst[NPC];
+    if (POOL) {
+#pragma unroll
+        for (int c = 0; c < NPC; ++c) {
+            const int idx = t + 512 * c, live = idx < KP * PCP, ii = live ? idx : 0;
+            const int plane = ii / PCP, pc = ii % PCP;
+            const int ni = pc >> (g.lgP - 2), prow = (pc >> (g.lgW - 1)) & ((g.TH >> 1) - 1), pcol = pc & (Wp - 1);
+            pg_rel[c] = (ni * g.K8 + plane) * (HW >> 2) + prow * Wp + pcol;
+            pg_fl[c] = (live ? 1 : 0) | (kg * KP + plane >= g.K8 ? 2 : 0) | (ni << 8);
+            pg_dst[c] = g.offD + plane * g.DPS + ((ni << g.lgP) + ((2 * prow) << g.lgW) + 2 * pcol) * 16;
+        }
+    }
+    int4v pgv[NPC];                 // (plain vector types: the asm statements below take them as register operands)
+    int2v pmv[NPC];
+    // the pooled cells of tile `tile` (clamped into the tensor) -> registers; untracked by the compiler: waited for by hand
+    auto pool_load = [&](int tile) __attribute__((always_inline)) {
+        const int tc = min(max(tile, 0), g.NTILES - 1), gi_ = tc / g.RT, n0 = gi_ * g.NI, r0 = (tc - gi_ * g.RT) * g.TH;
+        const long long db = ((long long)(n0 * g.K8 + kg * KP) * (g.H >> 1) + (r0 >> 1)) * Wp;
+        const char* const gp = reinterpret_cast<const char*>(g.dz + db);
+        const char* const mp = reinterpret_cast<const char*>(g.mask + db);
+        const int nlim = g.N - n0;
+#pragma unroll
+        for (int c = 0; c < NPC; ++c) {
+            const bool zero = (pg_fl[c] & 3) != 1 || (pg_fl[c] >> 8) >= nlim;
+            const char* sg = zero ? zero_src : gp + (long long)pg_rel[c] * 16;
+            const char* sm = zero ? zero_src : mp + (long long)pg_rel[c] * 8;
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(pgv[c]) : "v"(sg));
+            asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(pmv[c]) : "v"(sm));
+        }
+    };
+    // ... expanded into the dz image of stage `stage` (a zero gradient cell expands to zeros whatever its mask says)
+    auto pool_expand = [&](int stage) __attribute__((always_inline)) {
+        char* const sbn = smem + (ROLL ? g.XA : 0) + stage * g.SB;
+#pragma unroll
+        for (int c = 0; c < NPC; ++c) {
+            if (pg_fl[c] & 1) {
+                char* const d0 = sbn + pg_dst[c];
+                const uint4 gq = __builtin_bit_cast(uint4, pgv[c]);
+                const uint2 mq = __builtin_bit_cast(uint2, pmv[c]);
+                *reinterpret_cast<uint4*>(d0) = c8_pool_cell(gq, mq, 0);
+                *reinterpret_cast<uint4*>(d0 + 16) = c8_pool_cell(gq, mq, 1);
+                *reinterpret_cast<uint4*>(d0 + 16 * g.Wd) = c8_pool_cell(gq, mq, 2);
+                *reinterpret_cast<uint4*>(d0 + 16 * g.Wd + 16) = c8_pool_cell(gq, mq, 3);
+            }
+        }
+    };
     int gl_rel[NG], gl_fl[NG], gl_dst[NG];
 #pragma unroll
     for (int j = 0; j < NG; ++j) {
@@ -736,18 +788,6 @@ __global__ __launch_bounds__(512) void c8_wgrad_kernel(C8WG g) {
                     fl = 1 | (kg * KP + plane >= g.K8 ? 2 : 0) | (ni << 8);
                     dst = g.offD + plane * g.DPS + sub * 1024;
                 }
-            } else if (qq < NQG) {              // raw pooled gradient: [plane][PCP pooled cells] as one run of 16-byte cells
-                const int ci = qq * 64 + lane, plane = ci / PCP, pc = ci % PCP;
-                const int ni = pc >> (g.lgP - 2), prow = (pc >> (g.lgW - 1)) & ((g.TH >> 1) - 1), pcol = pc & (Wp - 1);
-                rel = (ni * g.K8 + plane) * (HW >> 2) + prow * Wp + pcol;
-                fl = 1 | (kg * KP + plane >= g.K8 ? 2 : 0) | (ni << 8);
-                dst = g.offG + qq * 1024;
-            } else if (qq < NQG + NQM) {        // mask bytes: [plane][PCP cells of 8 bytes], two pooled cells per lane
-                const int qm = qq - NQG, ci = qm * 128 + 2 * lane, plane = ci / PCP, pc = ci % PCP;
-                const int ni = pc >> (g.lgP - 2), prow = (pc >> (g.lgW - 1)) & ((g.TH >> 1) - 1), pcol = pc & (Wp - 1);
-                rel = (ni * g.K8 + plane) * (HW >> 2) + prow * Wp + pcol;
-                fl = 1 | 16 | (kg * KP + plane >= g.K8 ? 2 : 0) | (ni << 8);
-                dst = g.offM + qm * 1024;
             }
         }
         gl_rel[j] = rel; gl_fl[j] = fl;
@@ -854,6 +894,12 @@ __global__ __launch_bounds__(512) void c8_wgrad_kernel(C8WG g) {
             issue_range(J_0{}, J_N{});
         }
     }
+    if (POOL) {                                     // the first tile's dz image (the loop's first barrier publishes it)
+        pool_load(tile_beg);
+#pragma unroll
+        for (int c = 0; c < NPC; ++c) asm volatile("s_waitcnt vmcnt(0)" : "+v"(pgv[c]), "+v"(pmv[c]));
+        pool_expand(0);
+    }
     for (int tile = tile_beg, it = 0; tile < tile_end; ++tile, ++it) {
         const int stage = it % g.nstage;
         unsigned long long s0 = 0, s1 = 0, s2 = 0;
@@ -865,6 +911,7 @@ __global__ __launch_bounds__(512) void c8_wgrad_kernel(C8WG g) {
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (g.dbg) s1 = __builtin_readcyclecounter();
         // ... and everybody's; all waves are also done with the stage that is refilled next
+        if (POOL) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // (this wave's stores into the tile's dz image)
         __builtin_amdgcn_s_barrier();
         if (g.dbg) { s2 = __builtin_readcyclecounter(); d_wait += s1 - s0; d_bar += s2 - s1; }
         char* const sb = smem + (ROLL ? g.XA : 0) + stage * g.SB;
@@ -881,24 +928,7 @@ __global__ __launch_bounds__(512) void c8_wgrad_kernel(C8WG g) {
         } else {
             tile_setup((it + g.nstage - 1) % g.nstage);
         }
-        if (POOL) {
-            // expand (pooled gradient, mask) -> dz image: one pooled cell of one plane -> its 2 x 2 window
-#pragma unroll
-            for (int it = t; it < KP * PCP; it += 512) {
-                const int plane = it / PCP, pc = it % PCP;
-                const uint4 gq = *reinterpret_cast<const uint4*>(sb + g.offG + it * 16);
-                const uint2 mq = *reinterpret_cast<const uint2*>(sb + g.offM + it * 8);
-                const int ni = pc >> (g.lgP - 2), prow = (pc >> (g.lgW - 1)) & ((g.TH >> 1) - 1), pcol = pc & (Wp - 1);
-                char* const d0 = sb + g.offD + plane * g.DPS + ((ni << g.lgP) + ((2 * prow) << g.lgW) + 2 * pcol) * 16;
-                *reinterpret_cast<uint4*>(d0) = c8_pool_cell(gq, mq, 0);
-                *reinterpret_cast<uint4*>(d0 + 16) = c8_pool_cell(gq, mq, 1);
-                *reinterpret_cast<uint4*>(d0 + 16 * g.Wd) = c8_pool_cell(gq, mq, 2);
-                *reinterpret_cast<uint4*>(d0 + 16 * g.Wd + 16) = c8_pool_cell(gq, mq, 3);
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            if (g.dbg) d_exp += __builtin_readcyclecounter() - s2;
-        }
+        if (POOL) pool_load(tile + 1);               // lands under this tile's steps, expanded behind them
         const char* const ab = sb + a_off;
         const char* const bb = sb + b_off;
         auto step = [&](auto Ic) __attribute__((always_inline)) {
@@ -970,7 +1000,15 @@ __global__ __launch_bounds__(512) void c8_wgrad_kernel(C8WG g) {
         C8W_ST(16) C8W_ST(17) C8W_ST(18) C8W_ST(19) C8W_ST(20) C8W_ST(21) C8W_ST(22) C8W_ST(23)
         C8W_ST(24) C8W_ST(25) C8W_ST(26) C8W_ST(27) C8W_ST(28) C8W_ST(29) C8W_ST(30) C8W_ST(31)
 #undef C8W_ST
-        if (g.dbg) d_mm += __builtin_readcyclecounter() - s2;
+        unsigned long long s3 = 0;
+        if (g.dbg) { s3 = __builtin_readcyclecounter(); d_mm += s3 - s2; }
+        if (POOL) {
+            // the NGX x chunks of this tile's refill were issued behind the loads: they may still be in flight
+#pragma unroll
+            for (int c = 0; c < NPC; ++c) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(pgv[c]), "+v"(pmv[c]) : "n"(NGX));
+            pool_expand((it + 1) % g.nstage);
+            if (g.dbg) d_exp += __builtin_readcyclecounter() - s3;
+        }
     }
     if (g.dbg && t == 0) {
         unsigned long long* d = g.dbg + 8 * (size_t)bid;
@@ -1136,19 +1174,19 @@ static int c8w_geometry(C8WG& g, int num_cus, bool pool, int tm = 1) {
     g.DPS = TP * 16 + 64;
     g.offD = CP * g.XPS;
     g.offG = g.offD + KP * g.DPS;
-    g.offM = g.offG + (pool ? KP * 512 * tm : 0);
-    g.offDump = (g.offM + (pool ? KP * 256 * tm : 0) + 255) / 256 * 256;      // each stage ends with the fillers' dump KB
+    g.offM = g.offG;                                   // (round 3's raw pooled-gradient / mask areas are gone: registers)
+    g.offDump = (g.offM + 255) / 256 * 256;            // each stage ends with the fillers' dump KB
     g.SB = g.offDump + 1024;
     g.nQx = CP * g.XCH;
-    g.nQd = pool ? KP * tm / 2 + KP * tm / 4 : KP * 2 * tm;
+    g.nQd = pool ? 0 : KP * 2 * tm;
     g.NQ = g.nQx + g.nQd;
     g.nstage = 3 * g.SB <= 160 * 1024 ? 3 : 2;
     g.roll = 0; g.XA = 0;
     if (NCT && tm == 1 && g.NI == 1 && g.RT >= 2 && lgW >= 5 && c8w_roll_on()) {
         // ROLL (c8_wgrad_kernel): x ring of four TH-row regions + a zero row per plane, no halo columns; three dz stages
         const int xps = (16 + 4 * 2048 + g.Wd * 16 + 16 + 255) / 256 * 256 + 64;
-        const int offG = KP * g.DPS, offM = offG + (pool ? KP * 512 : 0);
-        const int offDump = (offM + (pool ? KP * 256 : 0) + 255) / 256 * 256, sb = offDump + 1024;
+        const int offG = KP * g.DPS, offM = offG;
+        const int offDump = (offM + 255) / 256 * 256, sb = offDump + 1024;
         if (CP * xps + 3 * sb <= 160 * 1024) {
             g.roll = 1;
             g.XPS = xps; g.XA = CP * xps;
