@@ -95,6 +95,63 @@ __device__ __forceinline__ uint4 c8_pool_cell(const uint4 g8, const uint2 m8, in
     return make_uint4(g8.x & k0, g8.y & k1, g8.z & k2, g8.w & k3);
 }
 
+// Pooled epilogue of the leaky-ReLU family for FOUR channels of a lane's octet, hand-scheduled (round 4).  z0 / z1: the
+// raw sums of the lane's two pixels (rows 2r, 2r + 1 of its column), partner lane (^ 1) = the other column of the window.
+// Per channel: window maximum (one in-lane v_max, one v_max_f32_dpp), tie bits of the own column (kA / kB = 1 << dj /
+// 4 << dj where z0 / z1 attains it) merged with the partner's (v_or_b32_dpp), ONE activation (the maximum of the
+// activations is the activation of the maximum), sign bits 16 / 32, conversion.  hipcc compiled the C++ statement of the
+// same thing channel by channel through three temporaries and VCC: 22 vector instructions + 7 s_nop per channel; here two
+// channels advance in lockstep (every DPP / SGPR hazard distance is met by the partner channel's instructions): 16.75.
+// o01 / o23: the four activated maxima as halfs; mk: the four mask bytes.
+#define C8_DPPQ "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"
+#define C8_EPI_PAIR(O, ZA0, ZB0, ZA1, ZB1)                                                          \
+    "v_max_f32_e32 %3, " ZA0 ", " ZA1 "\n\t"                                                        \
+    "v_max_f32_e32 %4, " ZB0 ", " ZB1 "\n\t"                                                        \
+    "s_nop 0\n\t"                                                                                   \
+    "v_max_f32_dpp %3, %3, %3 " C8_DPPQ "\n\t"                                                      \
+    "v_max_f32_dpp %4, %4, %4 " C8_DPPQ "\n\t"                                                      \
+    "v_cmp_eq_f32_e64 %11, " ZA0 ", %3\n\t"                                                         \
+    "v_cmp_eq_f32_e64 %12, " ZA1 ", %3\n\t"                                                         \
+    "v_cmp_eq_f32_e64 %13, " ZB0 ", %4\n\t"                                                         \
+    "v_cmp_eq_f32_e64 %14, " ZB1 ", %4\n\t"                                                         \
+    "v_mul_f32_e32 %9, %23, %3\n\t"                                                                 \
+    "v_mul_f32_e32 %10, %23, %4\n\t"                                                                \
+    "v_cndmask_b32_e64 %5, 0, %24, %11\n\t"                                                         \
+    "v_cndmask_b32_e64 %7, 0, %25, %12\n\t"                                                         \
+    "v_cndmask_b32_e64 %6, 0, %24, %13\n\t"                                                         \
+    "v_cndmask_b32_e64 %8, 0, %25, %14\n\t"                                                         \
+    "v_max_f32_e32 %9, %3, %9\n\t"                                                                  \
+    "v_max_f32_e32 %10, %4, %10\n\t"                                                                \
+    "v_or_b32_e32 %5, %5, %7\n\t"                                                                   \
+    "v_or_b32_e32 %6, %6, %8\n\t"                                                                   \
+    "v_cmp_lt_f32_e64 %11, 0, %9\n\t"                                                               \
+    "v_cmp_gt_f32_e64 %12, 0, %9\n\t"                                                               \
+    "v_cmp_lt_f32_e64 %13, 0, %10\n\t"                                                              \
+    "v_cmp_gt_f32_e64 %14, 0, %10\n\t"                                                              \
+    "v_or_b32_dpp %5, %5, %5 " C8_DPPQ "\n\t"                                                       \
+    "v_or_b32_dpp %6, %6, %6 " C8_DPPQ "\n\t"                                                       \
+    "v_cndmask_b32_e64 %7, 0, 16, %11\n\t"                                                          \
+    "v_cndmask_b32_e64 %3, 0, 32, %12\n\t"                                                          \
+    "v_cndmask_b32_e64 %8, 0, 16, %13\n\t"                                                          \
+    "v_cndmask_b32_e64 %4, 0, 32, %14\n\t"                                                          \
+    "v_or3_b32 %5, %5, %7, %3\n\t"                                                                  \
+    "v_or3_b32 %6, %6, %8, %4\n\t"                                                                  \
+    "v_cvt_pk_f16_f32 " O ", %9, %10\n\t"
+__device__ __forceinline__ void c8_pool_epi4(unsigned& o01, unsigned& o23, unsigned& mk, const float (&z0)[4], const float (&z1)[4],
+                                             float prm, unsigned kA, unsigned kB) {
+    unsigned t3, t4, t5, t6, t7, t8, t9, t10;
+    unsigned long long s11, s12, s13, s14;
+    asm volatile(C8_EPI_PAIR("%0", "%15", "%16", "%19", "%20")
+                 "v_lshl_or_b32 %2, %6, 8, %5\n\t"
+                 C8_EPI_PAIR("%1", "%17", "%18", "%21", "%22")
+                 "v_lshl_or_b32 %5, %6, 8, %5\n\t"
+                 "v_lshl_or_b32 %2, %5, 16, %2"
+                 : "=&v"(o01), "=&v"(o23), "=&v"(mk), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7), "=&v"(t8),
+                   "=&v"(t9), "=&v"(t10), "=&s"(s11), "=&s"(s12), "=&s"(s13), "=&s"(s14)
+                 : "v"(z0[0]), "v"(z0[1]), "v"(z0[2]), "v"(z0[3]), "v"(z1[0]), "v"(z1[1]), "v"(z1[2]), "v"(z1[3]), "s"(prm),
+                   "v"(kA), "v"(kB));
+}
+
 // MODE 0: forward (bias + act); 1: forward + 2x2 max-pool + mask; 2: input gradient (x act' of the layer below);
 // 3: input gradient of a pooled block, dz gathered from (g, mask, y).
 // PERSISTENT blocks: a block walks over work items w = blockIdx.x, + gridDim.x, ... (work item = one 256-pixel tile x one
@@ -308,32 +365,38 @@ __global__ __launch_bounds__(256, 2) void c8_conv_kernel(C8G g) {
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     const int oct = kt * (KBF / 8) + f * 4 + h * 2 + hi;
+                    if (LK) {
+                        // (leaky-ReLU does not decrease: the maximum of the four activations is the activation of the maximum,
+                        // and -- slope > 0 -- the elements that attain one attain the other; with slope 0 a window of negatives
+                        // marks its largest element instead of all four: every one of them receives g * act'(0) = 0 either way,
+                        // the derivative is taken from the stored output)
+                        int4v o4;
+                        uint2 m2;
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            const float z0[4] = {acc[f][0][h * 8 + 4 * q], acc[f][0][h * 8 + 4 * q + 1], acc[f][0][h * 8 + 4 * q + 2],
+                                                 acc[f][0][h * 8 + 4 * q + 3]};
+                            const float z1[4] = {acc[f][1][h * 8 + 4 * q], acc[f][1][h * 8 + 4 * q + 1], acc[f][1][h * 8 + 4 * q + 2],
+                                                 acc[f][1][h * 8 + 4 * q + 3]};
+                            unsigned a, b, mk;
+                            c8_pool_epi4(a, b, mk, z0, z1, prm, 1u << dj, 4u << dj);
+                            o4[2 * q] = (int)a; o4[2 * q + 1] = (int)b;
+                            if (q == 0) m2.x = mk; else m2.y = mk;
+                        }
+                        if (ok && dj == 0 && oct < g.K8) {
+                            const size_t o = pbase + (size_t)oct * Hp * Wp;
+                            reinterpret_cast<int4v*>(g.out)[o] = o4;
+                            if (g.mask_out) reinterpret_cast<uint2*>(g.mask_out)[o] = m2;
+                        }
+                        continue;
+                    }
                     half8 o8;
                     unsigned mb[8];
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
                         float m;
                         unsigned bits;
-                        if (LK) {
-                            // leaky-ReLU does not decrease: the maximum of the four activations is the activation of the
-                            // maximum, and (slope > 0) the elements that attain one attain the other; with slope 0 a
-                            // window of negatives marks its largest element instead of all four -- every one of them
-                            // receives g * act'(0) = 0 either way (the derivative is taken from the stored output).
-                            // One activation instead of two per lane; lane ^ 1 through DPP (quad_perm [1,0,3,2]), not
-                            // through the LDS crossbar (__shfl_xor compiled to ds_bpermute: 32 LDS round trips per tile)
-                            const float z0 = acc[f][0][h * 8 + e], z1 = acc[f][1][h * 8 + e];
-                            float zv, zm;
-                            asm("v_max_f32_e32 %0, %1, %2" : "=v"(zv) : "v"(z0), "v"(z1));
-                            // the exchange folded into the v_max / v_or themselves (update_dpp compiled to v_mov 0 + v_mov_dpp +
-                            // the operation); the two wait states a DPP read needs after the VALU write of its source are
-                            // part of the statement -- the compiler does not look inside
-                            asm("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"
-                                : "=v"(zm) : "v"(zv));
-                            const unsigned b0 = (z0 == zm ? (1u << dj) : 0u) | (z1 == zm ? (4u << dj) : 0u);
-                            asm("s_nop 1\n\tv_or_b32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"
-                                : "=v"(bits) : "v"(b0));
-                            m = actf(zm);
-                        } else {
+                        {
                             const float a0 = actf(acc[f][0][h * 8 + e]);
                             const float a1 = actf(acc[f][1][h * 8 + e]);
                             const float mv = fmaxf(a0, a1);
