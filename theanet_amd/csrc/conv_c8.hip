@@ -359,7 +359,8 @@ __global__ __launch_bounds__(256, 2) void c8_conv_kernel(C8G g) {
             const int Hp = Ho >> 1, Wp = Wo >> 1;
             const bool ok = pok[0];
             const int dj = l31 & 1;
-            const size_t pbase = ((size_t)(tl.n0 + pni[0]) * g.K8 * Hp + (prow[0] >> 1)) * Wp + (pcol >> 1);
+            // (cell indices fit 32 bits: c8_run checks N * K8 * H * W < 2^28 -- 64-bit products here were ~12 instructions per cell)
+            const unsigned pbase = ((unsigned)(tl.n0 + pni[0]) * g.K8 * Hp + (prow[0] >> 1)) * Wp + (pcol >> 1);
 #pragma unroll
             for (int f = 0; f < FT; ++f)
 #pragma unroll
@@ -384,7 +385,7 @@ __global__ __launch_bounds__(256, 2) void c8_conv_kernel(C8G g) {
                             if (q == 0) m2.x = mk; else m2.y = mk;
                         }
                         if (ok && dj == 0 && oct < g.K8) {
-                            const size_t o = pbase + (size_t)oct * Hp * Wp;
+                            const unsigned o = pbase + (unsigned)oct * Hp * Wp;
                             reinterpret_cast<int4v*>(g.out)[o] = o4;
                             if (g.mask_out) reinterpret_cast<uint2*>(g.mask_out)[o] = m2;
                         }
@@ -410,7 +411,7 @@ __global__ __launch_bounds__(256, 2) void c8_conv_kernel(C8G g) {
                         mb[e] = bits;
                     }
                     if (ok && dj == 0 && oct < g.K8) {
-                        const size_t o = pbase + (size_t)oct * Hp * Wp;
+                        const unsigned o = pbase + (unsigned)oct * Hp * Wp;
                         reinterpret_cast<half8*>(g.out)[o] = o8;
                         if (g.mask_out) {
                             uint2 m2;
@@ -424,7 +425,7 @@ __global__ __launch_bounds__(256, 2) void c8_conv_kernel(C8G g) {
         }
 #pragma unroll
         for (int pt = 0; pt < 2; ++pt) {
-            const size_t pbase = ((size_t)(tl.n0 + pni[pt]) * g.K8 * Ho + prow[pt]) * Wo + pcol;
+            const unsigned pbase = ((unsigned)(tl.n0 + pni[pt]) * g.K8 * Ho + prow[pt]) * Wo + pcol;
             half8 pa[FT][2];
             if (DGRAD && g.prev_a && pok[pt]) {
 #pragma unroll
@@ -432,7 +433,7 @@ __global__ __launch_bounds__(256, 2) void c8_conv_kernel(C8G g) {
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
                         const int oct = min(kt * (KBF / 8) + f * 4 + h * 2 + hi, g.K8 - 1);
-                        pa[f][h] = reinterpret_cast<const half8*>(g.prev_a)[pbase + (size_t)oct * Ho * Wo];
+                        pa[f][h] = reinterpret_cast<const half8*>(g.prev_a)[pbase + (unsigned)oct * Ho * Wo];
                     }
             }
 #pragma unroll
@@ -452,7 +453,7 @@ __global__ __launch_bounds__(256, 2) void c8_conv_kernel(C8G g) {
 #pragma unroll
                         for (int e = 0; e < 8; ++e) o8[e] = (_Float16)actf(acc[f][pt][h * 8 + e]);
                     }
-                    if (pok[pt] && oct < g.K8) reinterpret_cast<half8*>(g.out)[pbase + (size_t)oct * Ho * Wo] = o8;
+                    if (pok[pt] && oct < g.K8) reinterpret_cast<half8*>(g.out)[pbase + (unsigned)oct * Ho * Wo] = o8;
                 }
         }
     };
