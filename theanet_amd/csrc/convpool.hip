@@ -51,24 +51,29 @@ __device__ __forceinline__ float act_grad_t(float a, int act, float prm) {
 template <int S, int C, bool PADDED>
 struct Window {
     float v[C][S][S];
-    __device__ __forceinline__ void load(const float* __restrict__ xn, int H, int Wd, int y0, int x0) {
-        int roff[S], coff[S];
+    // x: the tensor (block-uniform), base: first element of the thread's image -- unsigned 32-bit BYTE offsets from a uniform
+    // base (the launchers check the input's element count < 2^30) let every load take the scalar-base + 32-bit-offset form; with
+    // a per-thread base pointer each of the S * S * C loads carried its own 64-bit address (v_ashrrev + v_lshl_add_u64)
+    __device__ __forceinline__ void load(const float* __restrict__ x, unsigned base, int H, int Wd, int y0, int x0) {
+        unsigned roff[S], coff[S];
         bool rok[S], cok[S];
 #pragma unroll
         for (int r = 0; r < S; ++r) {
             const int yy = y0 + r, xx = x0 + r;
             rok[r] = (yy >= 0) && (yy < H);
             cok[r] = (xx >= 0) && (xx < Wd);
-            roff[r] = min(max(yy, 0), H - 1) * Wd;
-            coff[r] = min(max(xx, 0), Wd - 1);
+            roff[r] = (unsigned)(min(max(yy, 0), H - 1) * Wd);
+            coff[r] = (unsigned)min(max(xx, 0), Wd - 1);
         }
-        const int HW = H * Wd;
+        const unsigned HW = (unsigned)(H * Wd);
 #pragma unroll
         for (int c = 0; c < C; ++c)
 #pragma unroll
             for (int r = 0; r < S; ++r)
 #pragma unroll
-                for (int q = 0; q < S; ++q) v[c][r][q] = xn[c * HW + roff[r] + coff[q]];
+                for (int q = 0; q < S; ++q)
+                    v[c][r][q] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(x) +
+                                                                 (base + c * HW + roff[r] + coff[q]) * 4u);
         if (PADDED) {
 #pragma unroll
             for (int c = 0; c < C; ++c)
@@ -117,7 +122,7 @@ __global__ __launch_bounds__(256) void convpool_fwd_kernel(
     const int q = (int)(t - (unsigned)n * HpWp);
     const int pi = q / Wp, pj = q - pi * Wp;
     Window<P + F - 1, C, PADDED> pt;
-    pt.load(x + (size_t)n * C * H * Wd, H, Wd, pi * P - pad, pj * P - pad);
+    pt.load(x, (unsigned)n * C * H * Wd, H, Wd, pi * P - pad, pj * P - pad);
     bool valid[P][P];
 #pragma unroll
     for (int di = 0; di < P; ++di)
@@ -220,7 +225,7 @@ __global__ __launch_bounds__(256) void convpool_bwd_kernel(
         const bool valid = live && (i < Ho) && (j < Wo);
         // F x F x C input window of this conv output (all loads in flight together)
         Window<F, C, PADDED> pt;
-        pt.load(x + (size_t)n * C * H * Wd, H, Wd, min(i, Ho - 1) - pad, min(j, Wo - 1) - pad);
+        pt.load(x, (unsigned)n * C * H * Wd, H, Wd, min(i, Ho - 1) - pad, min(j, Wo - 1) - pad);
         float gk[KT];
 #pragma unroll
         for (int kk = 0; kk < KT; ++kk)
@@ -296,6 +301,7 @@ __global__ __launch_bounds__(256) void convpool_bwd_mask_kernel(
     constexpr int F = 3, FF = 9;
     constexpr int NACC = KT * C * FF + KT;
     __shared__ float red[4][NACC];
+    __shared__ __attribute__((aligned(16))) float redx[NACC <= 48 ? NACC : 1][NACC <= 48 ? 256 : 1];
     const int HpWp = Hp * Wp, HoWo = Ho * Wo;
     const unsigned total = (unsigned)N * HpWp;
     const int k0 = blockIdx.y * KT;
@@ -320,7 +326,7 @@ __global__ __launch_bounds__(256) void convpool_bwd_mask_kernel(
         const int q = (int)(tt - (unsigned)n * HpWp);
         const int pi = q / Wp, pj = q - pi * Wp;
         Window<4, C, PADDED> pt;
-        pt.load(x + (size_t)n * C * H * Wd, H, Wd, 2 * pi - pad, 2 * pj - pad);
+        pt.load(x, (unsigned)n * C * H * Wd, H, Wd, 2 * pi - pad, 2 * pj - pad);
         float gy[KT];
         unsigned mk[KT];
 #pragma unroll
@@ -369,6 +375,37 @@ __global__ __launch_bounds__(256) void convpool_bwd_mask_kernel(
         }
     }
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int KCFF = K * C * FF;
+    if constexpr (NACC <= 48) {
+        // (round 4) A wave-wide sum per accumulator -- 4 DPP adds + 4 v_readlane + their wait states, 40 times -- was 600
+        // of the ~1500 instructions a thread executes.  Through LDS: every thread parks its NACC sums ([accumulator]
+        // [thread], conflict-free), then wave w adds up rows w, w + 4, ...: a lane takes 4 neighbours (one 16-byte read),
+        // then one wave-wide sum -- a quarter of the wave-wide sums, in a fixed order.
+        float* const park = &redx[0][0];
+#pragma unroll
+        for (int kk = 0; kk < KT; ++kk) {
+#pragma unroll
+            for (int c = 0; c < C; ++c)
+#pragma unroll
+                for (int s2 = 0; s2 < FF; ++s2) park[((kk * C + c) * FF + s2) * 256 + threadIdx.x] = acc[kk][c][s2];
+            park[(KT * C * FF + kk) * 256 + threadIdx.x] = accb[kk];
+        }
+        __syncthreads();
+        for (int s2 = wave; s2 < NACC; s2 += 4) {
+            const float4 q = *reinterpret_cast<const float4*>(park + s2 * 256 + 4 * lane);
+            const float r = wave_sum_dpp((q.x + q.y) + (q.z + q.w));
+            if (lane == 0) {
+                if (s2 < KT * C * FF) {
+                    const int kk = s2 / (C * FF), rem = s2 - kk * C * FF;
+                    if (k0 + kk < K) partial[(size_t)blockIdx.x * KCFF + (size_t)(k0 + kk) * C * FF + rem] = r;
+                } else {
+                    const int kk = s2 - KT * C * FF;
+                    if (k0 + kk < K) dbpartial[(size_t)blockIdx.x * K + k0 + kk] = r;
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int kk = 0; kk < KT; ++kk) {
 #pragma unroll
@@ -382,7 +419,6 @@ __global__ __launch_bounds__(256) void convpool_bwd_mask_kernel(
         if (lane == 0) red[wave][KT * C * FF + kk] = rb;
     }
     __syncthreads();
-    const int KCFF = K * C * FF;
     for (int s = threadIdx.x; s < NACC; s += 256) {
         const float r = red[0][s] + red[1][s] + red[2][s] + red[3][s];
         if (s < KT * C * FF) {
@@ -405,6 +441,7 @@ static int launch_fwd(tn_ctx* ctx, const float* x, const float* W, const float* 
                       float prm) {
     const long long total = (long long)N * Hp * Wp;
     TN_REQUIRE(total < (1ll << 31), "tn_convpool_fwd: too many outputs for 32-bit indexing");
+    TN_REQUIRE((long long)N * C * H * Wd < (1ll << 30), "tn_convpool_fwd: input too large for 32-bit byte offsets");
     // filter slices (blockIdx.y) until the launch has about two blocks per CU
     int ks = 1;
     while (ks < 8 && ks * 2 <= K && (long long)cdiv(total, 256) * ks < 2 * ctx->num_cus) ks *= 2;
@@ -448,6 +485,7 @@ static int launch_bwd(tn_ctx* ctx, const float* x, const float* W, const float* 
     if (rc) return rc;
     float* dbpartial = partial + (size_t)nblk * KCFF;
     TN_REQUIRE(total < (1ll << 31), "tn_convpool_bwd: too many outputs for 32-bit indexing");
+    TN_REQUIRE((long long)N * C * H * Wd < (1ll << 30), "tn_convpool_bwd: input too large for 32-bit byte offsets");
     const dim3 grid(nblk, cdiv(K, KT));
 #define CP_L(ACT_, PAD_)                                                                          \
     convpool_bwd_kernel<F, C, KT, ACT_, PAD_><<<grid, 256, 0, ctx->stream>>>(                       \
@@ -470,6 +508,7 @@ static int launch_bwd_mask(tn_ctx* ctx, const float* x, const float* g, const fl
                            int K, int pad, int Ho, int Wo, int Hp, int Wp, int act, float prm) {
     const long long total = (long long)N * Hp * Wp;
     TN_REQUIRE(total < (1ll << 31), "tn_convpool_bwd_mask: too many outputs for 32-bit indexing");
+    TN_REQUIRE((long long)N * C * H * Wd < (1ll << 30), "tn_convpool_bwd_mask: input too large for 32-bit byte offsets");
     int mwin = tn_tune_mwin();                          // windows per thread ...
     while (mwin > 1 && cdiv(total, 256 * mwin) < 2 * ctx->num_cus) mwin >>= 1;   // ... fewer for short batches (a 512-image shard: 85 blocks otherwise)
     int nblk = cdiv(total, 256 * mwin);
