@@ -40,6 +40,7 @@ struct C8G {
     int N, C8, K8, H, W, act;
     float prm;
     int KT, MT, RT, NI, TH, THi, RS, plane, nchunk, TP, nslots, nwork;
+    unsigned mKT, mRT;        // 2^32 / KT + 1, 2^32 / RT + 1 (0: divisor 1): the work-item decode without integer divisions
     unsigned long long* dbg;  // TN_C8_DBG=1: per block {start, prologue done, loop done, end} (s_memtime) + wall clock
 };
 
@@ -189,11 +190,15 @@ __global__ __launch_bounds__(256, 2) void c8_conv_kernel(C8G g) {
     struct Tile { int n0, r0, kt, base; bool dead; };
     auto decode = [&](int i) __attribute__((always_inline)) {
         const int w = bid + min(i, nwork - 1) * G, xcd = w & 7, idx = w >> 3;
-        const int mt = (idx / g.KT) * 8 + xcd;
+        // (a body of the loop decodes three work items; as divisions that was ~120 of its ~300 scalar instructions, and the
+        // loop is bound by instruction issue: 670 instructions per 36 products)
+        // x / d = umulhi(x, 2^32 / d + 1), exact while x * d < 2^32 (the host checks the work-item count)
+        const int iq = g.mKT ? (int)__umulhi((unsigned)idx, g.mKT) : idx;
+        const int mt = iq * 8 + xcd;
         Tile tl;
-        tl.kt = idx % g.KT;
+        tl.kt = idx - iq * g.KT;
         tl.dead = mt >= g.MT;                         // (MT not a multiple of 8: computed, never stored)
-        const int mtc = min(mt, g.MT - 1), grp = mtc / g.RT, rt = mtc - grp * g.RT;
+        const int mtc = min(mt, g.MT - 1), grp = g.mRT ? (int)__umulhi((unsigned)mtc, g.mRT) : mtc, rt = mtc - grp * g.RT;
         tl.n0 = grp * g.NI; tl.r0 = rt * g.TH;
         tl.base = POOLED ? tl.n0 * g.C8 * (HW >> 2) + (tl.r0 >> 1) * (g.W >> 1) : tl.n0 * g.C8 * HW + tl.r0 * g.W;
         return tl;
@@ -565,6 +570,9 @@ static int c8_geometry(C8G& g, int FT, int K, int C, bool tk = false) {
     g.nchunk = cdiv(C, 16);
     g.KT = cdiv(K, 32 * FT);
     g.MT = cdiv(g.N, g.NI) * g.RT;
+    g.mKT = g.KT == 1 ? 0u : (unsigned)((1ull << 32) / (unsigned)g.KT + 1u);
+    g.mRT = g.RT == 1 ? 0u : (unsigned)((1ull << 32) / (unsigned)g.RT + 1u);
+    if ((long long)(g.MT + 8) * g.KT * (g.KT > g.RT ? g.KT : g.RT) >= (1ll << 31)) return 0;      // (magic divisions exact)
     return 1;
 }
 
