@@ -223,8 +223,11 @@ __global__ __launch_bounds__(256, 2) void c8_conv_kernel(C8G g) {
                    (o << 5) | (ni << 8);
     }
     auto slot_ok = [&](int s, const Tile& tl) __attribute__((always_inline)) {
+        // bitwise on purpose: the short-circuit form compiled to a chain of exec-mask branches per slot (~25 instructions
+        // each, in a loop that is bound by instruction issue)
         const int fl = sl_fl[s];
-        return (fl & 1) && !((fl & 2) && tl.r0 == 0) && !((fl & 4) && tl.r0 + g.TH >= g.H) && tl.n0 + (fl >> 8) < g.N;
+        const int edge = (tl.r0 == 0 ? 2 : 0) | (tl.r0 + g.TH >= g.H ? 4 : 0);          // wave-uniform
+        return ((fl & 1) != 0) & ((fl & edge) == 0) & (tl.n0 + (fl >> 8) < g.N);
     };
     const uint4* xg = reinterpret_cast<const uint4*>(g.x);
 
