@@ -107,12 +107,12 @@ def _wgrad_blas(x, dz):
     return dW
 
 
-@pytest.mark.parametrize("case", [(44, 128, 32, 128), (70, 64, 64, 64), (19, 32, 64, 96), (2049, 16, 32, 32)])
+@pytest.mark.parametrize("case", [(44, 128, 32, 128), (70, 64, 64, 64), (19, 32, 64, 96), (2049, 16, 32, 32), (21, 40, 32, 72)])
 def test_c8_wgrad_rolling_ring_over_many_tiles(case, f16_mode):
     """The weight gradient's rolling x ring (c8_wgrad_kernel ROLL: rows of >= 32 pixels, one image band per tile) with SEVERAL
     tiles per slab: the ring wraps (four regions), slabs start in the middle of an image (the row above comes from the
-    tile in front of the slab) and cross image boundaries (zero row), the last slab is short; plain and gathered from a
-    pooled gradient with a random mask.  convpool.py:54-56 (CorrMM_gradWeights); numbers as in test_c8_conv_ops."""
+    tile in front of the slab) and cross image boundaries (zero row), the last slab is short, channel / filter planes
+    beyond the tensors (re-read, never stored); plain and gathered from a pooled gradient with a random mask.  convpool.py:54-56 (CorrMM_gradWeights); numbers as in test_c8_conv_ops."""
     N, C, H, K = case
     rng = np.random.RandomState(11)
     assert ctx().lib.tn_c8_conv_wgrad_supported(N, C, H, H, K)

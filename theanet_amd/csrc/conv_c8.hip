@@ -838,9 +838,11 @@ __global__ __launch_bounds__(512) void c8_wgrad_kernel(C8WG g) {
         if (ROLL && j < NGX) {
             const int q = 8 * j + wave;
             if (q < g.nQx) {
-                const int plane = q >> 1, sub = q & 1;
-                rel = plane * HW + sub * 64 + lane;
-                fl = 1 | (cg * CP + plane >= g.C8 ? 2 : 0);
+                // (a plane beyond the tensor re-reads its last plane: it only feeds columns c >= C, which are never stored --
+                // the ring form's DMAs carry no "zero" select at all, ~25 instructions per chunk became ~8)
+                const int plane = q >> 1, sub = q & 1, pc = min(cg * CP + plane, g.C8 - 1) - cg * CP;
+                rel = pc * HW + sub * 64 + lane;
+                fl = 1;
                 dst = plane * g.XPS + 16 + sub * 1024;
             }
         } else if (j < NGX) {
@@ -859,8 +861,10 @@ __global__ __launch_bounds__(512) void c8_wgrad_kernel(C8WG g) {
                 if (qq < 2 * KP * TM) {
                     const int plane = qq / (2 * TM), sub = qq % (2 * TM), pp = sub * 64 + lane;
                     const int ni = pp >> g.lgP, row = (pp >> g.lgW) & THm, col = pp & Wm;
-                    rel = (ni * g.K8 + plane) * HW + row * g.Wd + col;
-                    fl = 1 | (kg * KP + plane >= g.K8 ? 2 : 0) | (ni << 8);
+                    // (ROLL: filter planes beyond the tensor likewise re-read the last one -- rows k >= K are never stored)
+                    const int pk = ROLL ? min(kg * KP + plane, g.K8 - 1) - kg * KP : plane;
+                    rel = (ni * g.K8 + pk) * HW + row * g.Wd + col;
+                    fl = ROLL ? 1 : (1 | (kg * KP + plane >= g.K8 ? 2 : 0) | (ni << 8));
                     dst = g.offD + plane * g.DPS + sub * 1024;
                 }
             }
@@ -909,6 +913,11 @@ __global__ __launch_bounds__(512) void c8_wgrad_kernel(C8WG g) {
         constexpr int J0 = decltype(J0c)::value, J1 = decltype(J1c)::value;
 #pragma unroll
         for (int j = J0; j < J1; ++j) {
+            if (ROLL) {              // every chunk real, every source inside its tensor (clamped planes, clamped tiles)
+                const char* src = (j < NGX ? cur_xp : cur_dp) + (long long)gl_rel[j] * 16;
+                c8_glds16(src, __builtin_amdgcn_readfirstlane((j < NGX ? cur_xr : cur_sb) + gl_dst[j]));
+                continue;
+            }
             const int fl = gl_fl[j];
             const bool zero = (fl & cur_zmask) || (fl >> 8) >= cur_nlim;
             const char* src = j < NGX ? cur_xp + (long long)gl_rel[j] * 16
@@ -948,6 +957,19 @@ __global__ __launch_bounds__(512) void c8_wgrad_kernel(C8WG g) {
     unsigned long long d_wait = 0, d_bar = 0, d_mm = 0, d_t0 = 0, d_w0 = 0, d_exp = 0;     // (d_exp: shown as "prologue" by tools/dbg_c8.py)
     if (g.dbg) { d_t0 = __builtin_readcyclecounter(); d_w0 = wall_clock64(); }
     int c_rt = tile_beg % g.RT;                     // ROLL: row band of the tile being multiplied
+    // ROLL: the band row of step i's 16 pixels does not change from tile to tile: (row - 1) * row bytes and whether the tap
+    // row above / below leaves the band, as scalars (computed per step and tap row they were ~36 instructions per step)
+    int st_ro[NSTEP];
+    bool st_top[NSTEP], st_bot[NSTEP];
+    if (ROLL) {
+#pragma unroll
+        for (int i = 0; i < NSTEP; ++i) {
+            const int rl = __builtin_amdgcn_readfirstlane(((16 * (ps + PS * i)) >> g.lgW) & THm);
+            st_ro[i] = (rl - 1) * (g.Wd * 16);
+            st_top[i] = rl == 0;
+            st_bot[i] = rl == THm;
+        }
+    }
     if ((g.exp & 4) && wave >= 4) __builtin_amdgcn_s_setprio(1);
     if ((g.exp & 8) && wave < 4) __builtin_amdgcn_s_setprio(1);
     if (ROLL) {
@@ -1019,16 +1041,16 @@ __global__ __launch_bounds__(512) void c8_wgrad_kernel(C8WG g) {
             const char* xp = bb + (((p >> g.lgP) * g.THi + ((p >> g.lgW) & THm)) * g.RS + (p & Wm)) * 16;
             half4v bv[NACC][2];
             if (ROLL) {
-                const int g16 = 16 * (ps + PS * i), rl = (g16 >> g.lgW) & THm, W16 = g.Wd * 16;     // wave-uniform
+                const int g16 = 16 * (ps + PS * i), W16 = g.Wd * 16;     // wave-uniform
                 const char* const xc = smem + b_off + (p & Wm) * 16;
+                const int rbase = reg_off + st_ro[i];                    // (row - 1) of the band, in the ring
                 // the k element whose cell lies left of column 0 (tap column 0, first pixel of the lower 8) / right of column
                 // W - 1 (tap column 2, last pixel of the upper 8)
                 const unsigned mL = ((g16 & Wm) == 0 && (grp >> 1) == 0) ? 0xffff0000u : 0xffffffffu;
                 const unsigned mR = (((g16 + 16) & Wm) == 0 && (grp >> 1) == 1) ? 0x0000ffffu : 0xffffffffu;
 #pragma unroll
                 for (int u = 0; u < 3; ++u) {
-                    const int k = rl + u;
-                    const int ro = __builtin_amdgcn_readfirstlane(k == 0 ? top_off : (k == g.TH + 1 ? bot_off : reg_off + (k - 1) * W16));
+                    const int ro = u == 0 ? (st_top[i] ? top_off : rbase) : u == 1 ? rbase + W16 : (st_bot[i] ? bot_off : rbase + 2 * W16);
 #pragma unroll
                     for (int v = 0; v < 3; ++v) {
                         bv[(u * 3 + v) % NACC][0] = c8_tr16(xc + ro + v * 16);
