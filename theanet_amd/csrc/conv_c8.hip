@@ -1279,7 +1279,7 @@ static int c8w_geometry(C8WG& g, int num_cus, bool pool, int tm = 1) {
     g.NQ = g.nQx + g.nQd;
     g.nstage = 3 * g.SB <= 160 * 1024 ? 3 : 2;
     g.roll = 0; g.XA = 0;
-    if (NCT && tm == 1 && g.NI == 1 && g.RT >= 2 && lgW >= 5 && c8w_roll_on()) {
+    if (NCT && tm == 1 && g.NI == 1 && g.RT >= 2 && lgW >= (c8w_roll_on() == 2 ? 4 : 5) && c8w_roll_on()) {
         // ROLL (c8_wgrad_kernel): x ring of four TH-row regions + a zero row per plane, no halo columns; three dz stages
         const int xps = (16 + 4 * 2048 + g.Wd * 16 + 16 + 255) / 256 * 256 + 64;
         const int offG = KP * g.DPS, offM = offG;
