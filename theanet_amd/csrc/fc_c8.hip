@@ -408,6 +408,29 @@ __global__ __launch_bounds__(256) void fc8_wgrad_kernel(FC8 g, ElField rider, in
     }
     const int rows = g.C * g.HW;
     float* const wz = g.ws + (size_t)z * rows * g.N;
+    if (n0 + 128 <= g.N && (g.N & 3) == 0) {
+        // whole column tiles: a wave's 32 x 64 half goes through LDS ([row][64 columns], 8 KB per wave) and leaves as
+        // 16-byte stores, 256 contiguous bytes per row -- straight from the accumulators it was 64 4-byte stores per lane
+        // (the launch writes 67 MB on wide6: the stores are what it does)
+        __syncthreads();                       // the operand tiles are dead
+        float* const T = reinterpret_cast<float*>(&lds[0][0]) + wave * (32 * 64);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) T[((r & 3) + 8 * (r >> 2) + 4 * hi) * 64 + 32 * j + l31] = acc[i][j][r] * g.oscale;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int idx = lane + 64 * q, row = idx >> 4, c4 = idx & 15;
+                const int k = k0 + wk + 32 * i + row;
+                const int cell = k >> 3, o = cell / g.HW, p = cell - o * g.HW, ch = o * 8 + (k & 7);
+                const float4 v = *reinterpret_cast<const float4*>(T + row * 64 + 4 * c4);
+                if (k < g.Kc && ch < g.C)
+                    *reinterpret_cast<float4*>(wz + (size_t)(ch * g.HW + p) * g.N + n0 + wn + 4 * c4) = v;
+            }
+        }
+    } else
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
