@@ -177,6 +177,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     float* const wz = g.ws + (size_t)by * g.M * g.N;
     const int n = n0 + wn * 32 + l31;
+    if (n0 + 64 <= g.N && (g.N & 3) == 0) {
+        // whole column tiles: 16-byte stores through LDS (a wave's 32 x 32 half at a time, 4 KB per wave), as in the weight
+        // gradient below; the operand tiles are dead behind the loop's last barrier
+        float* const T = reinterpret_cast<float*>(xs) + wave * (32 * 32);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) T[((r & 3) + 8 * (r >> 2) + 4 * hi) * 32 + l31] = acc[i][r];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int idx = lane + 64 * q, row = idx >> 3, c4 = idx & 7;
+                const int m = m0 + wm * 64 + 32 * i + row;
+                const float4 v = *reinterpret_cast<const float4*>(T + row * 32 + 4 * c4);
+                if (m < g.M) *reinterpret_cast<float4*>(wz + (size_t)m * g.N + n0 + wn * 32 + 4 * c4) = v;
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
