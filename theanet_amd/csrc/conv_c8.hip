@@ -310,7 +310,12 @@ __global__ __launch_bounds__(256, 2) void c8_conv_kernel(C8G g) {
         okm[P] = m;
         if (++xch == g.nchunk) { xch = 0; tx = decode(++xi); }
     };
+    // one filter tile, one chunk (a first layer; any C <= 16, K <= 32 FT): every step of the block meets the SAME weights
+    // and biases -- both LDS buffers are filled once, the bias registers loaded once (the loop is bound by the instructions
+    // a wave issues, and such a layer runs one body per tile)
+    const bool wconst = g.KT == 1 && g.nchunk == 1;
     auto gloadw = [&]() __attribute__((always_inline)) {
+        if (wconst) return;
         const char* w_ = reinterpret_cast<const char*>(g.wt) + ((size_t)skt * g.nchunk + sch) * WB + 16 * t;
         C8_WL(0, wr0); C8_WL(1, wr1); C8_WL(2, wr2); C8_WL(3, wr3); C8_WL(4, wr4);
     };
@@ -330,7 +335,7 @@ __global__ __launch_bounds__(256, 2) void c8_conv_kernel(C8G g) {
                 *reinterpret_cast<uint4*>(xb + sl_l[s]) = c8_and4(v, (okm[P] >> s) & 1u);
             }
         }
-        C8_WST(0, wr0); C8_WST(1, wr1); C8_WST(2, wr2); C8_WST(3, wr3); C8_WST(4, wr4);
+        if (!wconst) { C8_WST(0, wr0); C8_WST(1, wr1); C8_WST(2, wr2); C8_WST(3, wr3); C8_WST(4, wr4); }
     };
     using P0 = std::integral_constant<int, 0>;
     using P1 = std::integral_constant<int, 1>;
@@ -467,10 +472,21 @@ __global__ __launch_bounds__(256, 2) void c8_conv_kernel(C8G g) {
     };
 
     gloadx(P0{});
-    gloadw();
+    {
+        const char* w_ = reinterpret_cast<const char*>(g.wt) + ((size_t)skt * g.nchunk + sch) * WB + 16 * t;
+        C8_WL(0, wr0); C8_WL(1, wr1); C8_WL(2, wr2); C8_WL(3, wr3); C8_WL(4, wr4);
+    }
     gloadx(P1{});
     __syncthreads();                 // the clearing is done
     lstore(0, P0{});
+    {
+        char* wb = Ws + 16 * t;
+        C8_WST(0, wr0); C8_WST(1, wr1); C8_WST(2, wr2); C8_WST(3, wr3); C8_WST(4, wr4);
+        if (wconst) {
+            wb = Ws + WB + 16 * t;
+            C8_WST(0, wr0); C8_WST(1, wr1); C8_WST(2, wr2); C8_WST(3, wr3); C8_WST(4, wr4);
+        }
+    }
     __syncthreads();
     if (dbg) dbg[1] = __builtin_readcyclecounter();
     const int RS16 = g.RS * 16;
@@ -486,7 +502,7 @@ __global__ __launch_bounds__(256, 2) void c8_conv_kernel(C8G g) {
         sadv();
         gloadw();                    // step seq + 1
         gloadx(Pc);                  // step seq + 2
-        if (!DGRAD && cch + 1 == g.nchunk) bias_load(decode(ci + 1).kt);
+        if (!DGRAD && !wconst && cch + 1 == g.nchunk) bias_load(decode(ci + 1).kt);
         const char* x0 = Xs + P * XB + boff[0];
         const char* x1 = Xs + P * XB + boff[1];
         const char* Wb = Ws + P * WB + aoff;
