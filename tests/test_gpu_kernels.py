@@ -425,7 +425,10 @@ FC_CASES = [(64, 720, 500, "relu01"), (33, 500, 10, "linear"), (5, 7, 3, "tanh")
             (40, 2304, 100, "relu10"),                   # short and deep: split-K forward + finishing kernel
             # few 64 x 64 tiles, moderate reduction: gemm_f32_deep (waves split K, operands straight from global
             # memory): the 512-image shard of the sharded step, a K tail (500 = 31.25 tiles) with ragged M / N
-            (512, 720, 500, "relu01"), (97, 500, 36, "relu10")]
+            (512, 720, 500, "relu01"), (97, 500, 36, "relu10"),
+            # many 64 x 64 tiles: the LDS-DMA kernel (gemm_f32_dma) -- ragged M / N (row and column clamps), K tails on
+            # k-contiguous (n_out = 500) and row-contiguous (B = 1000) operands, 8 split-K slabs with column-sum blocks
+            (2048, 720, 500, "relu01"), (1000, 500, 724, "relu10"), (1100, 96, 260, "tanh")]
 
 
 @pytest.mark.parametrize("B,n_in,n_out,act", FC_CASES)

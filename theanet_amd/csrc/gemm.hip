@@ -23,6 +23,7 @@
 // Skinny layers (n_out <= 16, the 10-way softmax layer) would waste >2/3 of a 32-wide MFMA
 // tile and leave most CUs idle; they run on dedicated VALU kernels at the end of this file.
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 #include "elastic_field.h"
@@ -58,6 +59,7 @@ struct GemmArgs {
     uint32_t dk0, dk1, dstep;
     const uint32_t* d_step;
     uint64_t elem0;    // global index of C[0][0] (multiple of 4)
+    unsigned long long* dbg;   // TN_GEMM_DBG (gemm_f32_dma): per block {life, DMA wait, barrier wait, start} cycles
 };
 
 // ---- guarded tile loaders (edge tiles only) ------------------------------------------------
@@ -461,6 +463,296 @@ __global__ __launch_bounds__(256) void gemm_f32_fast(GemmArgs g) {
     gemm_fast_body<AKC, BKC, BSUM, WM, WN, BKT>(g, smem, (int)blockIdx.x);
 }
 
+// ---- DMA kernel (round 5) --------------------------------------------------------------------
+// Same product, same 64 x 64 x 16 tiles, same fmaf chain per output element as the FAST kernel -- but no operand ever
+// passes through a vector register on its way to LDS and the tile loop holds NO vector-ALU instruction at all.  An fp32
+// MFMA runs at the vector rate and does not overlap vector instructions of its SIMD (profiles/r02_probe_mfma_valu.txt):
+// the FAST kernel's address arithmetic, ds_writes' operand moves and column sums came straight out of the matrix rate
+// (0.57-0.63 of peak on the fc1 products of mnist.prms).  Here:
+//   * both operands are staged by LDS-DMA (global_load_lds_dwordx4: 16 bytes per lane, 1 KB per wave instruction, LDS
+//     destination = M0 + 16 * lane): a wave issues ONE instruction per operand and K-tile.  The global address is
+//     SGPR base (advanced by SALU per tile) + a per-lane 32-bit offset fixed in the prologue;
+//   * a k-contiguous operand lands as [64 rows][16 k] with 64-byte rows; the lane that owns LDS slot (row, j) fetches
+//     source chunk j ^ ((row >> 2) & 3), and the MFMA lanes read chunk c at slot c ^ ((row >> 2) & 3): conflict-free
+//     ds_read_b128 without a pad (the FAST kernel pads rows to 80 bytes, which a DMA cannot write);
+//   * a row-contiguous operand lands as the plain [16 k][64 rows] image: lane (row, half) reads A[k][row] with one
+//     ds_read_b32 per MFMA (immediate offsets; 32 consecutive floats per half-wave);
+//   * a ring of NS = 4 stages (8 KB each), tile j+3 in flight while tile j is multiplied; the fragments of tile j are
+//     read into registers while the MFMAs of tile j-1 issue; one s_waitcnt vmcnt(N) + s_barrier per tile, counted by
+//     hand (hipcc knows nothing of the DMAs);
+//   * the tile loop is unrolled over the ring so that every LDS address is a per-lane base + an immediate.
+// The bias gradient of a weight-gradient product (column sums of dz, which the FAST kernel adds up from its staging
+// registers) moves to gemm_colsum_block: a handful of extra blocks of the same launch, same partition, same order
+// of additions, same bits.
+#define GD_SB 8192                                   // bytes per stage: A tile, then B tile
+template <int NS>
+constexpr int gemm_dma_smem_floats() {
+    return NS * GD_SB / 4 > 64 * 68 ? NS * GD_SB / 4 : 64 * 68;
+}
+
+// 16 bytes per lane, global (sbase + voff) -> LDS (lds_dst + 16 * lane)
+// (the LDS destination is formed inside the statement, base + constant: as a plain operand hipcc keeps one SGPR per
+// stage and operand live across the loop and spills)
+template <int LOFF>
+__device__ __forceinline__ void gd_dma(const void* sbase, unsigned voff, unsigned lds_base) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_add_u32 m0, %3, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_base), "n"(LOFF) : "memory", "scc");
+}
+// this wave's DMAs older than the newest 2 * TILES have landed, its LDS reads have returned; then everybody's
+template <int TILES>
+__device__ __forceinline__ void gd_wait_barrier() {
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(2 * TILES) : "memory");
+}
+// the same with cycle stamps (TN_GEMM_DBG)
+template <int TILES>
+__device__ __forceinline__ void gd_wait_barrier_dbg(unsigned long long& d_wait, unsigned long long& d_bar) {
+    const unsigned long long s0 = __builtin_readcyclecounter();
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * TILES) : "memory");
+    const unsigned long long s1 = __builtin_readcyclecounter();
+    asm volatile("s_barrier" ::: "memory");
+    const unsigned long long s2 = __builtin_readcyclecounter();
+    d_wait += s1 - s0;
+    d_bar += s2 - s1;
+}
+template <int N> using gd_ic = std::integral_constant<int, N>;
+
+// NS = ring stages (even): NS - 1 tiles ahead of the one being multiplied.  2 while many blocks share a CU (the other
+// blocks' waves cover a DMA's latency), 8 for launches of two blocks per CU (a block must cover it by itself once its
+// CU-mate has left: two waves of a SIMD are served oldest first, so the older block finishes well ahead of the younger).
+template <bool AKC, bool BKC, int NS, bool DBG = false>
+__device__ __forceinline__ void gemm_dma_body(const GemmArgs& g, float* __restrict__ smem, int bid) {
+    static_assert(NS >= 2 && NS % 2 == 0 && NS <= 8, "ring stages");
+    int mt, nt, z;
+    if (!gemm_decode(g, bid, mt, nt, z)) return;
+    unsigned long long d_t0 = 0, d_wait = 0, d_bar = 0, d_loop = 0, d_w0 = 0, d_pro = 0;
+    if (DBG) { d_t0 = __builtin_readcyclecounter(); d_w0 = wall_clock64(); }
+    const int t = threadIdx.x, lane = t & 63, r = lane & 31, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = mt * 64, n0 = nt * 64;
+    const int kbeg = z * g.kchunk;
+    const int kend = min(g.K, kbeg + g.kchunk);
+    const int nk = (kend - kbeg) >> 4;                       // full tiles (>= 1: the host checks)
+    const bool tail = ((kend - kbeg) & 15) != 0;
+    char* const sm = reinterpret_cast<char*>(smem);
+
+    // ---- DMA sources: per-lane byte offset (fixed) + wave-uniform base (advances per tile)
+    unsigned offA, offB;
+    if (AKC) {
+        const int row = min(m0 + 16 * wave + (lane >> 2), g.M - 1);
+        offA = ((unsigned)row * (unsigned)g.lda + 4u * ((lane & 3) ^ ((lane >> 4) & 3))) * 4u;
+    } else {
+        const int col = min(m0 + 4 * (lane & 15), g.M - 4);
+        offA = ((unsigned)(4 * wave + (lane >> 4)) * (unsigned)g.lda + (unsigned)col) * 4u;
+    }
+    if (BKC) {
+        const int row = min(n0 + 16 * wave + (lane >> 2), g.N - 1);
+        offB = ((unsigned)row * (unsigned)g.ldb + 4u * ((lane & 3) ^ ((lane >> 4) & 3))) * 4u;
+    } else {
+        const int col = min(n0 + 4 * (lane & 15), g.N - 4);
+        offB = ((unsigned)(4 * wave + (lane >> 4)) * (unsigned)g.ldb + (unsigned)col) * 4u;
+    }
+    const char* const gA = reinterpret_cast<const char*>(AKC ? g.A + kbeg : g.A + (size_t)kbeg * g.lda);
+    const char* const gB = reinterpret_cast<const char*>(BKC ? g.B + kbeg : g.B + (size_t)kbeg * g.ldb);
+    const size_t stepA = AKC ? 64 : (size_t)64 * g.lda;      // bytes per K-tile
+    const size_t stepB = BKC ? 64 : (size_t)64 * g.ldb;
+    const unsigned ldsw = (unsigned)(size_t)(__attribute__((address_space(3))) void*)sm + 1024u * wave;   // this wave's KB of a stage's A tile (B: + 4096)
+
+    // ---- fragment reads: per-lane LDS byte offsets inside a stage
+    const int ra = wm * 32 + r, rb = wn * 32 + r;
+    const int fa0 = AKC ? ra * 64 + (((2 * hi) ^ ((ra >> 2) & 3)) << 4) : (8 * hi) * 256 + ra * 4;
+    const int fb0 = 4096 + (BKC ? rb * 64 + (((2 * hi) ^ ((rb >> 2) & 3)) << 4) : (8 * hi) * 256 + rb * 4);
+    const int fa1 = fa0 ^ 16, fb1 = fb0 ^ 16;                // second 16-byte chunk (k-contiguous operands only)
+
+    f32x16 acc[1][1];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[0][0][i] = 0.f;
+    float av[2][8], bv[2][8];
+
+    // tiles are issued in order: running source pointers
+    const char* pA = gA;
+    const char* pB = gB;
+    auto issue = [&](auto Sc) __attribute__((always_inline)) {
+        constexpr int S = decltype(Sc)::value;
+        gd_dma<S * GD_SB>(pA, offA, ldsw);
+        gd_dma<S * GD_SB + 4096>(pB, offB, ldsw);
+        pA += stepA;
+        pB += stepB;
+    };
+    auto frag = [&](auto Sc) __attribute__((always_inline)) {
+        constexpr int S = decltype(Sc)::value, SET = S & 1;
+        const char* s_ = sm + S * GD_SB;
+        if (AKC) {
+            const float4 u_ = *reinterpret_cast<const float4*>(s_ + fa0);
+            const float4 v_ = *reinterpret_cast<const float4*>(s_ + fa1);
+            av[SET][0] = u_.x; av[SET][1] = u_.y; av[SET][2] = u_.z; av[SET][3] = u_.w;
+            av[SET][4] = v_.x; av[SET][5] = v_.y; av[SET][6] = v_.z; av[SET][7] = v_.w;
+        } else {
+#pragma unroll
+            for (int q_ = 0; q_ < 8; ++q_) av[SET][q_] = *reinterpret_cast<const float*>(s_ + fa0 + 256 * q_);
+        }
+        if (BKC) {
+            const float4 u_ = *reinterpret_cast<const float4*>(s_ + fb0);
+            const float4 v_ = *reinterpret_cast<const float4*>(s_ + fb1);
+            bv[SET][0] = u_.x; bv[SET][1] = u_.y; bv[SET][2] = u_.z; bv[SET][3] = u_.w;
+            bv[SET][4] = v_.x; bv[SET][5] = v_.y; bv[SET][6] = v_.z; bv[SET][7] = v_.w;
+        } else {
+#pragma unroll
+            for (int q_ = 0; q_ < 8; ++q_) bv[SET][q_] = *reinterpret_cast<const float*>(s_ + fb0 + 256 * q_);
+        }
+    };
+    auto mma = [&](auto Sc) __attribute__((always_inline)) {
+        constexpr int SET = decltype(Sc)::value & 1;
+#pragma unroll
+        for (int q_ = 0; q_ < 8; ++q_)
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[SET][q_], bv[SET][q_], acc[0][0], 0, 0, 0);
+    };
+    // wait until at most n (<= NS - 2) of this wave's tiles are in flight, then the barrier
+    auto wait_n = [&](int n) __attribute__((always_inline)) {
+#define GD_WB(N) do { if (DBG) gd_wait_barrier_dbg<(N)>(d_wait, d_bar); else gd_wait_barrier<(N)>(); } while (0)
+        if (n >= NS - 2) GD_WB(NS - 2);
+        else if (NS > 7 && n == 5) GD_WB(NS > 7 ? 5 : 0);
+        else if (NS > 6 && n == 4) GD_WB(NS > 6 ? 4 : 0);
+        else if (NS > 5 && n == 3) GD_WB(NS > 5 ? 3 : 0);
+        else if (NS > 4 && n == 2) GD_WB(NS > 4 ? 2 : 0);
+        else if (NS > 3 && n == 1) GD_WB(NS > 3 ? 1 : 0);
+        else GD_WB(0);
+    };
+    // step j (tile j sits in stage S = j % NS, its fragments go to register set j & 1 = S & 1): wait for tile j -- at
+    // most NS - 2 younger tiles stay in flight --, read its fragments, refill the stage tile j-1 has just left with tile
+    // j + NS - 1, and multiply tile j-1.  sched_barrier: hipcc otherwise moves a step's MFMAs (register-only
+    // instructions) below the NEXT step's wait + barrier, where the wave would park with an idle matrix pipe.
+    // HOT: steps with NS - 1 more tiles behind them (no tests); otherwise the last steps of a block.
+    auto step = [&](auto Sc, auto Hc, int j) __attribute__((always_inline)) {
+        constexpr int S = decltype(Sc)::value;
+        constexpr bool HOT = decltype(Hc)::value != 0;
+        if (HOT) {
+            GD_WB(NS - 2);
+            frag(gd_ic<S>{});
+            issue(gd_ic<(S + NS - 1) % NS>{});
+        } else {
+            wait_n(nk - 1 - j);
+            frag(gd_ic<S>{});
+            if (j + NS - 1 < nk) issue(gd_ic<(S + NS - 1) % NS>{});
+        }
+        mma(gd_ic<(S + 1) & 1>{});
+        __builtin_amdgcn_sched_barrier(0);
+    };
+#undef GD_WB
+    // a trip of NS steps starting at stage 1 (j = 1 (mod NS))
+    auto trip = [&](auto Hc, int j) __attribute__((always_inline)) {
+        step(gd_ic<1 % NS>{}, Hc, j);
+        if (NS > 2) { step(gd_ic<2 % NS>{}, Hc, j + 1); step(gd_ic<3 % NS>{}, Hc, j + 2); }
+        if (NS > 4) { step(gd_ic<4 % NS>{}, Hc, j + 3); step(gd_ic<5 % NS>{}, Hc, j + 4); }
+        if (NS > 6) { step(gd_ic<6 % NS>{}, Hc, j + 5); step(gd_ic<7 % NS>{}, Hc, j + 6); }
+        step(gd_ic<0>{}, Hc, j + NS - 1);
+    };
+
+    issue(gd_ic<0>{});
+    if (NS > 2) { if (1 < nk) issue(gd_ic<1 % NS>{}); if (2 < nk) issue(gd_ic<2 % NS>{}); }
+    if (NS > 4) { if (3 < nk) issue(gd_ic<3 % NS>{}); if (4 < nk) issue(gd_ic<4 % NS>{}); }
+    if (NS > 6) { if (5 < nk) issue(gd_ic<5 % NS>{}); if (6 < nk) issue(gd_ic<6 % NS>{}); }
+    wait_n(min(nk, NS - 1) - 1);
+    if (DBG) d_pro = __builtin_readcyclecounter();
+    frag(gd_ic<0>{});
+    if (NS - 1 < nk) issue(gd_ic<NS - 1>{});
+    __builtin_amdgcn_sched_barrier(0);
+    int j = 1;
+    for (; j + 2 * NS - 1 <= nk; j += NS) trip(gd_ic<1>{}, j);     // (j + NS - 1) + (NS - 1) < nk
+    for (; j + NS <= nk; j += NS) trip(gd_ic<0>{}, j);
+    if (j < nk) { step(gd_ic<1 % NS>{}, gd_ic<0>{}, j); ++j; }
+    if (NS > 2) {
+        if (j < nk) { step(gd_ic<2 % NS>{}, gd_ic<0>{}, j); ++j; }
+        if (j < nk) { step(gd_ic<3 % NS>{}, gd_ic<0>{}, j); ++j; }
+    }
+    if (NS > 4) {
+        if (j < nk) { step(gd_ic<4 % NS>{}, gd_ic<0>{}, j); ++j; }
+        if (j < nk) { step(gd_ic<5 % NS>{}, gd_ic<0>{}, j); ++j; }
+    }
+    if (NS > 6) {
+        if (j < nk) { step(gd_ic<6 % NS>{}, gd_ic<0>{}, j); ++j; }
+        if (j < nk) { step(gd_ic<7 % NS>{}, gd_ic<0>{}, j); ++j; }
+    }
+    if ((nk - 1) & 1) mma(gd_ic<1>{});
+    else mma(gd_ic<0>{});
+    if (DBG) d_loop = __builtin_readcyclecounter();
+
+    if (tail) {
+        // guarded K-tail through registers, written in the DMA's layout (thread t owns the 16 bytes at t * 16 of a tile)
+        const int k0 = kbeg + nk * 16;
+        __syncthreads();
+        float4 ta, tb;
+        if (AKC) ta = load_kc(g.A, g.lda, m0 + (t >> 2), g.M, k0 + 4 * ((t & 3) ^ ((t >> 4) & 3)), kend, g.a_vec);
+        else ta = load_rc(g.A, g.lda, m0 + 4 * (t & 15), g.M, k0 + (t >> 4), kend, g.a_vec);
+        if (BKC) tb = load_kc(g.B, g.ldb, n0 + (t >> 2), g.N, k0 + 4 * ((t & 3) ^ ((t >> 4) & 3)), kend, g.b_vec);
+        else tb = load_rc(g.B, g.ldb, n0 + 4 * (t & 15), g.N, k0 + (t >> 4), kend, g.b_vec);
+        *reinterpret_cast<float4*>(sm + 16 * t) = ta;
+        *reinterpret_cast<float4*>(sm + 4096 + 16 * t) = tb;
+        __syncthreads();
+        frag(gd_ic<0>{});
+        mma(gd_ic<0>{});
+    }
+    if (g.c_vec) {
+        gemm_epilogue_vec<1, 1>(g, acc, smem, m0, n0, z, wm, wn, lane);
+    } else {
+        __syncthreads();
+        gemm_epilogue<1, 1>(g, acc, m0, n0, z, wm, wn, lane);
+    }
+    if (DBG && g.dbg && lane == 0) {
+        unsigned long long* d = g.dbg + 8 * ((size_t)bid * 4 + wave);
+        d[0] = __builtin_readcyclecounter() - d_t0; d[1] = d_wait; d[2] = d_bar; d[3] = d_pro - d_t0; d[4] = d_loop - d_t0;
+        d[5] = wall_clock64(); d[6] = d_w0;
+    }
+}
+
+// column sums of B over a K slab (the bias gradient of a weight-gradient product): block idx = (slab z, column tile
+// nt).  Thread (row lane t >> 4, column group t & 15) adds rows kbeg + (t >> 4) + 16 i in order, the 16 row lanes are
+// added in order -- the partition and the order of the FAST kernel's staging-register sums, hence its bits.
+__device__ __forceinline__ void gemm_colsum_block(const GemmArgs& g, float* __restrict__ smem, int idx) {
+    const int z = idx / g.NT, nt = idx - z * g.NT;
+    const int t = threadIdx.x, rl = t >> 4, cg = t & 15;
+    const int n0 = nt * 64;
+    const int kbeg = z * g.kchunk, kend = min(g.K, kbeg + g.kchunk);
+    const int col = min(n0 + 4 * cg, g.N - 4);
+    const float* p = g.B + (size_t)(kbeg + rl) * g.ldb + col;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    int k = kbeg + rl;
+    for (; k + 16 * 7 < kend; k += 16 * 8) {
+        float4 v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const float4*>(p + (size_t)(16 * i) * g.ldb);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { s.x += v[i].x; s.y += v[i].y; s.z += v[i].z; s.w += v[i].w; }
+        p += (size_t)(16 * 8) * g.ldb;
+    }
+    for (; k < kend; k += 16) {
+        const float4 v = *reinterpret_cast<const float4*>(p);
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        p += (size_t)16 * g.ldb;
+    }
+    *reinterpret_cast<float4*>(&smem[rl * 64 + 4 * cg]) = s;
+    __syncthreads();
+    if (t < 64) {
+        float sum = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) sum += smem[q * 64 + t];
+        if (n0 + t < g.N) g.colsum[(size_t)z * g.N + n0 + t] = sum;
+    }
+}
+
+// blocks [0, nb): the product; [nb, nb + ncs): column sums (BSUM launches)
+template <bool AKC, bool BKC, int NS, bool DBG = false>
+__global__ __launch_bounds__(256) void gemm_f32_dma(GemmArgs g, int nb) {
+    __shared__ __attribute__((aligned(16))) float smem[gemm_dma_smem_floats<NS>()];
+    const int bid = blockIdx.x;
+    if (bid >= nb) {
+        gemm_colsum_block(g, smem, bid - nb);
+        return;
+    }
+    gemm_dma_body<AKC, BKC, NS, DBG>(g, smem, bid);
+}
+
 // Two INDEPENDENT products in one launch (e.g. a layer's weight gradient and its input gradient,
 // which only share dz): groups of 8 blocks alternate between the problems, so blocks of both are
 // co-resident on every CU -- the prologue / epilogue of one product overlaps the main loop of the
@@ -490,6 +782,31 @@ __global__ __launch_bounds__(256, 6) void gemm_f32_pair(GemmArgs g1, GemmArgs g2
         gemm_fast_body<A1, B1, S1, 1, 1, 16>(g1, smem, idx * 8 + l8);
     else
         gemm_fast_body<A2, B2, S2, 1, 1, 16>(g2, smem, idx * 8 + l8);
+}
+
+// the same launch on the DMA bodies; blocks: [n1 + n2 interleaved groups][ncs column-sum blocks of product 1][riders]
+template <bool A1, bool B1, bool A2, bool B2, int NS, int WPS>
+__global__ __launch_bounds__(256, WPS) void gemm_f32_pair_dma(GemmArgs g1, GemmArgs g2, int n1, int n2, int ncs, ElField rider) {
+    __shared__ __attribute__((aligned(16))) float smem[gemm_dma_smem_floats<NS>()];
+    const int bid = blockIdx.x, grp = bid >> 3, l8 = bid & 7;
+    if (bid >= n1 + n2) {
+        if (bid < n1 + n2 + ncs) gemm_colsum_block(g1, smem, bid - n1 - n2);
+        else elastic_field_block<true>(rider, smem, bid - n1 - n2 - ncs);
+        return;
+    }
+    const int G1 = n1 >> 3, G2 = n2 >> 3, Gm = min(G1, G2);
+    int prob, idx;
+    if (grp < 2 * Gm) {
+        prob = grp & 1;
+        idx = grp >> 1;
+    } else {
+        prob = G1 > G2 ? 0 : 1;
+        idx = grp - Gm;
+    }
+    if (prob == 0)
+        gemm_dma_body<A1, B1, NS>(g1, smem, idx * 8 + l8);
+    else
+        gemm_dma_body<A2, B2, NS>(g2, smem, idx * 8 + l8);
 }
 
 // ---- DEEP kernel: few output tiles, a reduction long enough to split ---------------------------------
@@ -748,6 +1065,31 @@ static void launch_deep(tn_ctx* ctx, GemmArgs& g) {
         gemm_f32_deep<BKC, 4><<<grid, 256, 0, ctx->stream>>>(g);
 }
 
+static unsigned long long* gemm_dbg_buf = nullptr;
+extern "C" int tn_gemm_dbg_read(tn_ctx* ctx, unsigned long long* host, int nrec) {
+    if (!gemm_dbg_buf) return -1;
+    (void)hipDeviceSynchronize();
+    return hipMemcpy(host, gemm_dbg_buf, (size_t)nrec * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+}
+// DMA kernel: FAST's preconditions, every K slab holds a full tile, per-lane byte offsets fit 32 bits
+static int tn_tune_dma() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("TN_GEMM_DMA");
+        v = e ? atoi(e) : 1;
+    }
+    return v;
+}
+template <bool AKC, bool BKC>
+static bool gemm_dma_ok(const GemmArgs& g, int S) {
+    if (!tn_tune_dma() || !gemm_fast_ok<AKC, BKC>(g)) return false;
+    const long long lastk = (long long)g.K - (long long)(S - 1) * g.kchunk;
+    if (g.kchunk < 16 || lastk < 16) return false;
+    const long long ea = AKC ? (long long)g.M * g.lda : (long long)g.kchunk * g.lda + g.M;
+    const long long eb = BKC ? (long long)g.N * g.ldb : (long long)g.kchunk * g.ldb + g.N;
+    return ea * 4 < (1ll << 32) && eb * 4 < (1ll << 32);
+}
+
 template <bool AKC, bool BKC, bool BSUM>
 static void launch_gemm(tn_ctx* ctx, GemmArgs& g, int S) {
     const bool fast = gemm_fast_ok<AKC, BKC>(g);
@@ -762,7 +1104,35 @@ static void launch_gemm(tn_ctx* ctx, GemmArgs& g, int S) {
     const int grid = (S == 1) ? 8 * cdiv(g.MT, 8) * g.NT : 8 * cdiv(S, 8) * g.MT * g.NT;
     if (!fast)
         gemm_f32_generic<AKC, BKC, BSUM><<<grid, 256, 0, ctx->stream>>>(g);
-    else if (big)
+    else if ((!big || tn_tune_dma() == 2) && gemm_dma_ok<AKC, BKC>(g, S)) {
+        g.MT = cdiv(g.M, 64);
+        const int nb = (S == 1) ? 8 * cdiv(g.MT, 8) * g.NT : 8 * cdiv(S, 8) * g.MT * g.NT;
+        static int dbg_on = -1, pad = 0, nsf = 0;
+        if (dbg_on < 0) {
+            const char* e = getenv("TN_GEMM_DBG");
+            dbg_on = e ? atoi(e) : 0;
+            e = getenv("TN_GEMM_DMA_PAD");
+            pad = e ? atoi(e) : 0;
+            e = getenv("TN_GEMM_DMA_NS");
+            nsf = e ? atoi(e) : 0;
+        }
+        const int grid = nb + ((BSUM && !BKC) ? S * g.NT : 0);
+        // two blocks per CU or fewer: the deep ring; else four stages
+        const int ns = nsf ? nsf : (nb <= 2 * ctx->num_cus ? 8 : 4);
+        if (dbg_on) {
+            if (!gemm_dbg_buf) (void)hipMalloc(&gemm_dbg_buf, 8 * sizeof(unsigned long long) * 65536);
+            (void)hipMemsetAsync(gemm_dbg_buf, 0, 8 * sizeof(unsigned long long) * 65536, ctx->stream);
+            g.dbg = gemm_dbg_buf;
+            if (ns == 8) gemm_f32_dma<AKC, BKC, 8, true><<<grid, 256, pad, ctx->stream>>>(g, nb);
+            else if (ns == 2) gemm_f32_dma<AKC, BKC, 2, true><<<grid, 256, pad, ctx->stream>>>(g, nb);
+            else gemm_f32_dma<AKC, BKC, 4, true><<<grid, 256, pad, ctx->stream>>>(g, nb);
+        } else if (ns == 8)
+            gemm_f32_dma<AKC, BKC, 8><<<grid, 256, pad, ctx->stream>>>(g, nb);
+        else if (ns == 2)
+            gemm_f32_dma<AKC, BKC, 2><<<grid, 256, pad, ctx->stream>>>(g, nb);
+        else
+            gemm_f32_dma<AKC, BKC, 4><<<grid, 256, pad, ctx->stream>>>(g, nb);
+    } else if (big)
         gemm_f32_fast<AKC, BKC, BSUM, 2, 1, 16><<<grid, 256, 0, ctx->stream>>>(g);
     else if (tn_tune_bk() == 32)
         gemm_f32_fast<AKC, BKC, BSUM, 1, 1, 32><<<grid, 256, 0, ctx->stream>>>(g);
@@ -1267,8 +1637,24 @@ int tn_fc_bwd(tn_ctx* ctx, const float* x, const float* dz, const float* W, floa
                     if (n1 + n2 <= 8 * ctx->num_cus) rlds += 8192;
                 }
             }
-            gemm_f32_pair<false, false, true, true, true, false><<<n1 + n2 + nrider, 256, rlds, ctx->stream>>>(
-                g1, g2, n1, n2, rider);
+            if (gemm_dma_ok<false, false>(g1, Sx) && gemm_dma_ok<true, true>(g2, 1)) {
+                const int ncs = Sx * g1.NT;
+                static int pns = -1;
+                if (pns < 0) {
+                    const char* e = getenv("TN_PAIR_DMA");      // ring stages * 10 + waves per SIMD (experiments)
+                    pns = e ? atoi(e) : 26;
+                }
+                const int grid = n1 + n2 + ncs + nrider;
+#define TN_PAIR_CASE(NS_, W_) case NS_ * 10 + W_: gemm_f32_pair_dma<false, false, true, true, NS_, W_><<<grid, 256, rlds, ctx->stream>>>(g1, g2, n1, n2, ncs, rider); break;
+                switch (pns) {
+                    TN_PAIR_CASE(2, 6) TN_PAIR_CASE(2, 5) TN_PAIR_CASE(2, 4) TN_PAIR_CASE(4, 5) TN_PAIR_CASE(4, 4) TN_PAIR_CASE(4, 3)
+                    TN_PAIR_CASE(8, 2)
+                    default: return tn_fail(ctx, TN_E_ARG, "TN_PAIR_DMA: unknown variant %d", pns);
+                }
+#undef TN_PAIR_CASE
+            } else
+                gemm_f32_pair<false, false, true, true, true, false><<<n1 + n2 + nrider, 256, rlds, ctx->stream>>>(
+                    g1, g2, n1, n2, rider);
             TN_LAUNCH_CHECK();
             if (Sx > 1) {
                 const size_t MN = (size_t)n_in * n_out;
