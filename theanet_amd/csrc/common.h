@@ -174,13 +174,18 @@ __device__ __forceinline__ float tn_act_grad_from_out(float a, int act, float pr
 // per element paid the whole switch every time (fc_skinny_softmax_train's input-gradient phase: 401 scalar branches
 // for 32 elements, 5.5 of the block's 12.6 us); the leaky-ReLU family -- every default of the reference
 // (convpool.py:19, hidden.py:16) -- is straight-line code here, same expressions, same bits.
+// LK (the caller has established act is TN_ACT_LEAKY or TN_ACT_LINEAR): the transcendental kinds are not even compiled in.
+// The GEMM epilogues call these once per unrolled pass; with every kind inlined each time a GEMM kernel was 150-300 KB
+// of code, its leaky-ReLU path a chain of jumps over tanhf / expf bodies -- an epilogue of ~10 k cycles, most of them
+// instruction-cache misses (round 5, tools/dbg_gemm.py).
+template <bool LK = false>
 __device__ __forceinline__ void tn_act_fwd4(float4& v, int act, float prm) {
     if (act == TN_ACT_LEAKY) {
         v.x = fmaxf(0.f, v.x) + fminf(0.f, v.x) * prm;
         v.y = fmaxf(0.f, v.y) + fminf(0.f, v.y) * prm;
         v.z = fmaxf(0.f, v.z) + fminf(0.f, v.z) * prm;
         v.w = fmaxf(0.f, v.w) + fminf(0.f, v.w) * prm;
-    } else if (act != TN_ACT_LINEAR) {
+    } else if (!LK && act != TN_ACT_LINEAR) {
         v.x = tn_act_fwd(v.x, act, prm);
         v.y = tn_act_fwd(v.y, act, prm);
         v.z = tn_act_fwd(v.z, act, prm);
@@ -188,6 +193,7 @@ __device__ __forceinline__ void tn_act_fwd4(float4& v, int act, float prm) {
     }
 }
 // s *= act'(a), a = the layer's OUTPUT
+template <bool LK = false>
 __device__ __forceinline__ void tn_act_grad4(float4& s, const float4& a, int act, float prm) {
     if (act == TN_ACT_LEAKY) {
         const float tie = prm > 0.f ? 1.f + prm : 0.f;
@@ -195,7 +201,7 @@ __device__ __forceinline__ void tn_act_grad4(float4& s, const float4& a, int act
         s.y *= a.y > 0.f ? 1.f : (a.y < 0.f ? prm : tie);
         s.z *= a.z > 0.f ? 1.f : (a.z < 0.f ? prm : tie);
         s.w *= a.w > 0.f ? 1.f : (a.w < 0.f ? prm : tie);
-    } else if (act != TN_ACT_LINEAR) {
+    } else if (!LK && act != TN_ACT_LINEAR) {
         s.x *= tn_act_grad_from_out(a.x, act, prm);
         s.y *= tn_act_grad_from_out(a.y, act, prm);
         s.z *= tn_act_grad_from_out(a.z, act, prm);

@@ -99,9 +99,24 @@ __device__ __forceinline__ float4 load_rc(const float* __restrict__ src, int ld,
 }
 
 // ---- shared epilogue ---------------------------------------------------------------------
-template <int WM, int WN>
-__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[WM][WN], int m0, int n0,
-                                              int z, int wm, int wn, int lane) {
+// leaky-ReLU family / no activation: the only kinds the hot copy of an epilogue contains (see tn_act_fwd4)
+__device__ __forceinline__ bool gemm_act_lk(const GemmArgs& g) {
+    return g.epi == EPI_PLAIN || g.act == TN_ACT_LEAKY || g.act == TN_ACT_LINEAR;
+}
+template <bool LK>
+__device__ __forceinline__ float gemm_act_fwd1(float z, int act, float prm) {
+    if (LK) return act == TN_ACT_LEAKY ? fmaxf(0.f, z) + fminf(0.f, z) * prm : z;
+    return tn_act_fwd(z, act, prm);
+}
+template <bool LK>
+__device__ __forceinline__ float gemm_act_grad1(float a, int act, float prm) {
+    if (LK) return act == TN_ACT_LEAKY ? (a > 0.f ? 1.f : (a < 0.f ? prm : (prm > 0.f ? 1.f + prm : 0.f))) : 1.f;
+    return tn_act_grad_from_out(a, act, prm);
+}
+
+template <bool LK, int WM, int WN>
+__device__ __forceinline__ void gemm_epilogue_impl(const GemmArgs& g, f32x16 (&acc)[WM][WN], int m0, int n0,
+                                                   int z, int wm, int wn, int lane) {
     const int hi = lane >> 5;
     float* Cz = g.C + (size_t)z * ((g.S > 1) ? (size_t)g.M * g.ldc : 0);
 #pragma unroll
@@ -133,10 +148,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[W
                 const int row = rbase + (r & 3) + 8 * (r >> 2);
                 float v = acc[i][j][r];
                 if (g.epi == EPI_FWD) {
-                    v = tn_act_fwd(v + bias, g.act, g.act_prm);
+                    v = gemm_act_fwd1<LK>(v + bias, g.act, g.act_prm);
                     if (g.mask) v *= pm[r];
                 } else if (g.epi == EPI_DGRAD) {
-                    if (g.prev_a) v *= tn_act_grad_from_out(pa[r], g.act, g.act_prm);
+                    if (g.prev_a) v *= gemm_act_grad1<LK>(pa[r], g.act, g.act_prm);
                     if (g.mask) v *= pm[r];
                 }
                 if (cok && row < g.M) Cz[(size_t)row * g.ldc + col] = v;
@@ -145,13 +160,20 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[W
     }
 }
 
+template <int WM, int WN>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[WM][WN], int m0, int n0,
+                                              int z, int wm, int wn, int lane) {
+    if (gemm_act_lk(g)) gemm_epilogue_impl<true, WM, WN>(g, acc, m0, n0, z, wm, wn, lane);
+    else gemm_epilogue_impl<false, WM, WN>(g, acc, m0, n0, z, wm, wn, lane);
+}
+
 // ---- 16-byte epilogue (g.c_vec) ---------------------------------------------------------------
 // The accumulators go through LDS so that every thread owns 4 consecutive columns of a row:
 // one float4 store (plus one float4 / one 32-bit side load) instead of four scattered dwords,
 // and exactly one Philox counter per thread and row for the inline dropout mask.
-template <int WM, int WN>
-__device__ __forceinline__ void gemm_epilogue_vec(const GemmArgs& g, f32x16 (&acc)[WM][WN], float* sC,
-                                                  int m0, int n0, int z, int wm, int wn, int lane) {
+template <bool LK, int WM, int WN>
+__device__ __forceinline__ void gemm_epilogue_vec_impl(const GemmArgs& g, f32x16 (&acc)[WM][WN], float* sC,
+                                                       int m0, int n0, int z, int wm, int wn, int lane) {
     constexpr int BM = 64 * WM, BN = 64 * WN, LDC = BN + 4;
     const int hi = lane >> 5, t = threadIdx.x;
     float* Cz = g.C + (size_t)z * ((g.S > 1) ? (size_t)g.M * g.ldc : 0);
@@ -192,7 +214,7 @@ __device__ __forceinline__ void gemm_epilogue_vec(const GemmArgs& g, f32x16 (&ac
         const size_t o = (size_t)min(row, g.M - 1) * g.ldc + colc;
         if (g.epi == EPI_FWD) {
             v.x += bias.x; v.y += bias.y; v.z += bias.z; v.w += bias.w;
-            tn_act_fwd4(v, g.act, g.act_prm);
+            tn_act_fwd4<LK>(v, g.act, g.act_prm);
             if (g.drop_out) {
                 // element e = elem0 + row*N + col uses word (e & 3) of philox(e >> 2): same
                 // numbers as tn_dropout_mask (dropout_mask_kernel)
@@ -206,7 +228,7 @@ __device__ __forceinline__ void gemm_epilogue_vec(const GemmArgs& g, f32x16 (&ac
                 if (cok && row < g.M) *reinterpret_cast<uint32_t*>(g.drop_out + o) = m;
             }
         } else if (g.epi == EPI_DGRAD && g.prev_a) {
-            tn_act_grad4(v, pa[p], g.act, g.act_prm);
+            tn_act_grad4<LK>(v, pa[p], g.act, g.act_prm);
         }
         if (g.epi != EPI_PLAIN && (g.mask || g.drop_out)) {
             v.x *= (float)(pm[p] & 0xffu);
@@ -216,6 +238,13 @@ __device__ __forceinline__ void gemm_epilogue_vec(const GemmArgs& g, f32x16 (&ac
         }
         if (cok && row < g.M) *reinterpret_cast<float4*>(Cz + (size_t)row * g.ldc + col) = v;
     }
+}
+
+template <int WM, int WN>
+__device__ __forceinline__ void gemm_epilogue_vec(const GemmArgs& g, f32x16 (&acc)[WM][WN], float* sC,
+                                                  int m0, int n0, int z, int wm, int wn, int lane) {
+    if (gemm_act_lk(g)) gemm_epilogue_vec_impl<true, WM, WN>(g, acc, sC, m0, n0, z, wm, wn, lane);
+    else gemm_epilogue_vec_impl<false, WM, WN>(g, acc, sC, m0, n0, z, wm, wn, lane);
 }
 
 // XCD-aware decode of the 1-D block id; returns false for padding blocks
@@ -1075,7 +1104,7 @@ extern "C" int tn_gemm_dbg_read(tn_ctx* ctx, unsigned long long* host, int nrec)
 static int tn_tune_dma() {
     static int v = -1;
     if (v < 0) {
-        const char* e = getenv("TN_GEMM_DMA");
+        const char* e = getenv("TN_GEMM_DMA");    // 0: register-staged tiles (gemm_f32_fast); 2: the DMA kernel also where 128 x 64 tiles would be taken
         v = e ? atoi(e) : 1;
     }
     return v;
@@ -1084,7 +1113,7 @@ template <bool AKC, bool BKC>
 static bool gemm_dma_ok(const GemmArgs& g, int S) {
     if (!tn_tune_dma() || !gemm_fast_ok<AKC, BKC>(g)) return false;
     const long long lastk = (long long)g.K - (long long)(S - 1) * g.kchunk;
-    if (g.kchunk < 16 || lastk < 16) return false;
+    if (g.kchunk < 256 || lastk < 16) return false;      // short reductions (< 16 tiles) gain nothing from the ring: wide6's 128-row weight gradient measured 1.5 % of a step slower
     const long long ea = AKC ? (long long)g.M * g.lda : (long long)g.kchunk * g.lda + g.M;
     const long long eb = BKC ? (long long)g.N * g.ldb : (long long)g.kchunk * g.ldb + g.N;
     return ea * 4 < (1ll << 32) && eb * 4 < (1ll << 32);

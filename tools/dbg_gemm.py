@@ -26,8 +26,8 @@ assert rc == 0, rc
 buf = buf[buf[:, 0] > 0].astype(np.int64)
 print("%s %d x %d x %d: waves stamped %d" % (op, B, n_in, n_out, len(buf)))
 life = buf[:, 0]
-for nm, v in (("wave life", life), ("tile loop", buf[:, 4]), ("DMA wait (vmcnt)", buf[:, 1]), ("barrier wait", buf[:, 2])):
-    print("%-20s cycles: median %8d  p10 %8d  p90 %8d  (%.0f %% of life)" % (nm, np.median(v), np.percentile(v, 10), np.percentile(v, 90), 100.0 * np.median(v) / np.median(life)))
+for nm, v in (("wave life", life), ("tile loop", buf[:, 4]), ("DMA wait (vmcnt)", buf[:, 1]), ("barrier wait", buf[:, 2]), ("prologue", buf[:, 3])):
+    print("%-38s cycles: median %8d  p10 %8d  p90 %8d  (%.0f %% of life)" % (nm, np.median(v), np.percentile(v, 10), np.percentile(v, 90), 100.0 * np.median(v) / np.median(life)))
 w0 = buf[:, 6]; w1 = buf[:, 5]
 print("wall clock (100 MHz ticks): kernel span %d = %.1f us, wave life median %d -> %.2f GHz; start spread p50 %d p90 %d max %d ticks" % (
     w1.max() - w0.min(), (w1.max() - w0.min()) / 100.0, np.median(w1 - w0), np.median(life) / np.median(w1 - w0) / 10.0,
