@@ -500,9 +500,9 @@ def main():
         specs = [("tn_convblock_bwd_mask", 1,
                   "convblock_bwd_mask_mfma (conv2 block backward from the pooling mask: wgrad + dgrad "
                   "on 16x16x4 f32 MFMA, dz in LDS only)", cb_flops, cb_bytes),
-                 ("tn_fc_fwd_dropout", 1, "gemm_f32_fast NN (fc1 forward 4096x720x500, bias + act + "
+                 ("tn_fc_fwd_dropout", 1, "gemm_f32_dma (fc1 forward 4096x720x500, LDS-DMA staged, bias + act + "
                   "inline dropout epilogue)", fl_fc, by_fc + B_ * fc1.n_out),
-                 ("tn_fc_bwd", 1, "gemm_f32_pair (fc1 weight gradient, split-K, + input gradient in one "
+                 ("tn_fc_bwd", 1, "gemm_f32_pair_dma (fc1 weight gradient, split-K, + input gradient in one "
                   "launch)", 2 * fl_fc, 2 * by_fc)]
         if args.time_op:
             op, nth = (args.time_op.split(":") + ["1"])[:2]
@@ -645,6 +645,26 @@ def main():
             line["bf16x3"] = {"error": "%s: %s" % (type(e).__name__, str(e)[-300:])}
     if world.size == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(prms, img, C, tr["BATCH_SZ"])
+    # The compact figures once more, LAST in the line: a reader that keeps only the tail of the output (the round
+    # driver keeps 2000 characters) still sees every configuration's step time.
+    def frac(rec, key):
+        for leg in rec.get("conv_roofline") or []:
+            if key in str(leg.get("kernel", "")) or key in str(leg.get("what", "")):
+                return leg.get("frac")
+        return None
+    legs = [{"cfg": args.prms + (" b%d" % args.batch if args.batch else ""), "dtype": args.dtype,
+             "ms_per_step": round(line["ms_per_step"], 5),
+             "sustained_ms": round(sustained["ms_per_step"], 5) if isinstance(sustained, dict) and sustained.get("ms_per_step") else None}]
+    for rec in line.get("other_configs", []):
+        wl = str(rec.get("config", {}).get("workload", "")).replace("params/", "").split(" ")[0]
+        legs.append({"cfg": wl, "dtype": str(rec.get("dtype", "?"))[:3], "ms_per_step": round(rec["ms_per_step"], 5)
+                     if "ms_per_step" in rec else None, "conv_fwd_frac": frac(rec, "forward"), "conv_bwd_frac": frac(rec, "backward"),
+                     "error": rec.get("error")})
+    line["legs"] = legs
+    line["tail"] = {"ms_per_step": round(line["ms_per_step"], 5), "value": round(line["value"], 1),
+                    "value_train_loop": round(value_train_loop, 1) if value_train_loop else None,
+                    "value_sync_api": round(value_sync_api, 1) if value_sync_api else None,
+                    "roofline_frac": (roof or {}).get("frac") if isinstance(roof, dict) else None}
     print(json.dumps(line))
 
 

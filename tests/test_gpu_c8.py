@@ -8,7 +8,9 @@ oracle.theanet_oracle's DTYPE float16 mode): operands are halfs, products exact,
 device's fp32 accumulation, one rounding to half when a tensor is stored.  Tolerances: a stored fp16 tensor may differ
 by one rounding (half an ulp = 4.9e-4 relative) where the fp32 and the float64 sums fall on different sides of a
 rounding boundary: 1e-3 of the largest entry; fp32 results (weight / bias gradients, dense outputs): 2e-5 of the largest
-entry (accumulation order only); pooling masks bit-exact.  The reference itself is float32-only (weights.py:8)."""
+entry (accumulation order only); pooling masks bit-exact except at provable near-ties (every mismatching byte is
+checked against the fp32 accumulation bound, _assert_masks_equal_up_to_provable_near_ties).  The reference itself is
+float32-only (weights.py:8)."""
 import numpy as np
 import pytest
 
@@ -34,6 +36,33 @@ def _c8(a):
 
 def _rel(got, want):
     return float(np.abs(got - want).max() / np.abs(want).max())
+
+
+def _assert_masks_equal_up_to_provable_near_ties(gotm, bits, a, x, W16, b, C):
+    """Index work is bit-exact: every mask byte equals the specification's -- except where the device's fp32 sums and the
+    specification's float64 sums may PROVABLY order two window elements differently: a window bit may differ only if
+    that element lies within the fp32 accumulation bound of the window maximum, a sign bit only if the maximum lies
+    within it of zero.  Bound per pre-activation: (9 C + 2) u * (sum |x| |w| + |b|), u = 2^-24 (n fp32 additions of exact
+    fp16 x fp16 products); the leaky ReLU is monotone with slope <= 1, so the bound carries over to the activations."""
+    bad = gotm != bits
+    if not bad.any():
+        return
+    assert bad.mean() < 1e-3, "mask mismatches are not rare: %g" % bad.mean()
+    absum = U.conv_same(np.abs(x), np.abs(W16)) + np.abs(b)[None, :, None, None]
+    tol = (9 * C + 2) * 2.0 ** -24 * absum
+    N, K, H, _ = a.shape
+    aw = a.reshape(N, K, H // 2, 2, H // 2, 2)
+    tw = tol.reshape(N, K, H // 2, 2, H // 2, 2)
+    m, tmax = aw.max(axis=(3, 5)), tw.max(axis=(3, 5))
+    for n, k, i, j in zip(*np.nonzero(bad)):
+        diff = int(gotm[n, k, i, j]) ^ int(bits[n, k, i, j])
+        for e in range(4):
+            if (diff >> e) & 1:
+                gap = m[n, k, i, j] - aw[n, k, i, e >> 1, j, e & 1]
+                assert gap <= 2 * tmax[n, k, i, j], ("window bit differs away from a tie", (n, k, i, j, e), gap, tmax[n, k, i, j])
+        if diff & 0x30:
+            assert abs(m[n, k, i, j]) <= tmax[n, k, i, j], ("sign bit differs away from zero", (n, k, i, j), m[n, k, i, j])
+        assert diff & ~0x3f == 0, ("unused mask bits set", (n, k, i, j), gotm[n, k, i, j])
 
 
 C8_CASES = [  # N, C, H, K
@@ -68,7 +97,7 @@ def test_c8_conv_ops(case, f16_mode):
     call("tn_c8_conv_fwd", xd.ptr, Wd.ptr, bd.ptr, outp.ptr, mk.ptr, N, C, H, H, K, LEAKY, SLOPE, 1, None)
     assert _rel(U.from_c8(outp.get_value().view(np.float16), K), U.r16(pm)) < 1e-3
     gotm = mk.get_value().transpose(0, 1, 4, 2, 3).reshape(N, K, Hp, Hp)
-    assert (gotm != bits).mean() < 1e-4              # (a near-tie may resolve differently in fp32 and float64)
+    _assert_masks_equal_up_to_provable_near_ties(gotm, bits, a, x, W16, b, C)
     # input gradient: dz (halfs at the gradient scale) -> dx * act'(output of the layer below), stored as halfs
     dz = U.r16(GS * rng.randn(N, K, H, H) * 1e-3)
     prev = U.r16(rng.randn(N, C, H, H))

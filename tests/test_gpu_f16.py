@@ -100,13 +100,13 @@ def _full_size(name, img, B, rows, dtype, steps):
 @pytest.mark.parametrize("dtype", ["float32", "float16"])
 def test_full_size_wide6_64x64_b128(dtype):
     """BASELINE.json configs[4] at its per-GPU size (1024 / 8 GPUs): 64x64x3, 128 images."""
-    _full_size("wide6.prms", 64, 128, 4, dtype, 8)
+    _full_size("wide6.prms", 64, 128, 16, dtype, 8)
 
 
 @pytest.mark.parametrize("dtype", ["float32", "float16"])
 def test_full_size_cifar_like_b2048(dtype):
     """BASELINE.json configs[3] at its stated size: 32x32x3, 2048 images, elastic stage on."""
-    _full_size("cifar_like.prms", 32, 2048, 32, dtype, 12)
+    _full_size("cifar_like.prms", 32, 2048, 256, dtype, 12)
 
 
 def _directional_derivative(name, img, B, dtype, tol):

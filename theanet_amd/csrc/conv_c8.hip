@@ -1529,12 +1529,24 @@ int tn_c8_conv_wgrad(tn_ctx* ctx, const void* x, const void* dz, float* dW, floa
 // (the answer does not depend on the device's CU count: in c8w_geometry it only sets the number of slabs S and
 // the tiles per slab, never the tile shape, the LDS stage or the DMA chunk counts the limits below are about -- so the
 // construction-time query and c8w_run, which passes ctx->num_cus, always agree)
+// The query has no context argument; it asks the current device for its CU count (what tn_ctx_create stores in
+// ctx->num_cus and c8w_run passes), 256 = MI355X where no device answers (GPU-less construction checks).
+static int c8_current_cus() {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        return 256;
+    }
+    return n;
+}
 int tn_c8_conv_wgrad_supported(int N, int C, int H, int Wd, int K) {
+    static const int cus = c8_current_cus();
     C8WG g{};
     g.N = N; g.C = C; g.C8 = (C + 7) / 8; g.H = H; g.Wd = Wd; g.K = K; g.K8 = K / 8;
-    if ((K & 7) || !c8w_geometry(g, 256, true) || c8w_ngx(g) > 5) return 0;
+    if ((K & 7) || !c8w_geometry(g, cus, true) || c8w_ngx(g) > 5) return 0;
     if (c8w_lds_bytes(g) > 160 * 1024) return 0;
-    if (!c8w_geometry(g, 256, false) || c8w_ngx(g) > 5) return 0;
+    if (!c8w_geometry(g, cus, false) || c8w_ngx(g) > 5) return 0;
     return c8w_lds_bytes(g) <= 160 * 1024;
 }
 

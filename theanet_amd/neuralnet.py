@@ -588,6 +588,7 @@ class NeuralNet():
             if self._cost_rider_ok and not self._dp:
                 # the caller reads [cost, features, logprob] of this step: the cost is summed now (the cost block
                 # of the update launch on its own: same summation order, same bits) and leaves with the outputs
+                self._guard_cost()
                 ctx.call("tn_sgd_update_net", _lib.TN_UPD_PLAIN, None, None, 0, 0, self.cur_learn_rate.ptr, 1.0, None, 0, 0,
                          out.rowloss.ptr, self.local_bsz, 1.0 / self.batch_sz, self.d_cost.ptr)
                 cost_sent = True
@@ -602,6 +603,7 @@ class NeuralNet():
         if lazy_pipe and not cost_sent:
             self._cost_pending = True             # summed by the launch that opens this stream's next step
         elif not rider and not cost_sent:
+            self._guard_cost()
             if pipe_stride and self._cost_rider_ok:
                 # the cost block of the update launch on its own: the same summation order as the
                 # one-step-at-a-time schedule, so the reported cost is bit-identical too
@@ -721,6 +723,8 @@ class NeuralNet():
                 self._group().allreduce_sum(self.flat_grads, self.n_flat)
         for lyr in self.tr_layers:
             lyr.get_wtcost(self.d_cost)
+        if rider:
+            self._guard_cost()
         if delayed:
             pass
         elif tail:
@@ -746,6 +750,14 @@ class NeuralNet():
         self._apply_maxnorm_all()
         if self.dtype == 'float16':
             self._c8_stale()
+
+    def _guard_cost(self):
+        """In front of a launch that writes ``d_cost``: a step_cost() loop may still owe the host the previous value (a
+        4-byte copy on the copy stream, _CostRing.send) -- the stream waits for that copy's event."""
+        ev = getattr(self, "_cost_guard_ev", None)
+        if ev is not None:
+            self.ctx.call("tn_event_wait", ev)
+            self._cost_guard_ev = None
 
     def _injecting(self):
         """A parity test has injected random draws somewhere (dropout masks, elastic / color draws)."""

@@ -60,10 +60,17 @@ class _CostRing:
         self.next_take = 0          # first step number whose cost the caller has not been handed yet
         self.sent_upto = 0          # copies have been issued for the steps below
 
-    def send(self, step, d_cost):
+    def send(self, step, d_cost, net=None):
+        """The copy is ordered behind the launch that summed the cost, on the copy stream; nothing else holds the
+        compute stream back, so the NEXT launch that writes ``d_cost`` must wait for the slot's event first:
+        ``net._guard_cost()`` (NeuralNet) does, in front of every such launch -- a step or two later in the lazy
+        schedules (the copy has long run), a few tens of microseconds later where the cost is summed mid-step
+        (data-parallel pipelined steps, weight-cost nets)."""
         assert step == self.sent_upto and step - self.next_take < self.R, "cost ring overrun"
         s = step % self.R
         self.ctx.call("tn_d2h_early_ev", self.buf.ptr + 4 * s, d_cost.ptr, 4, self.ev[s])
+        if net is not None:
+            net._cost_guard_ev = self.ev[s]
         self.sent_upto = step + 1
 
     def take(self, step):
@@ -109,6 +116,7 @@ class _TrainFn:
         # the step as one C call once its calls have been seen to repeat (plan.py); index-list batches upload per step
         self._plan = None if take_index_list else StepPlan(ctx, net.batch_sz, net.shard_lo)
         self._ring, self._n = None, 0          # step_cost(): costs read two calls late; steps enqueued so far
+        self._sc_n = 0
 
     def _plan_state(self):
         net = self.net
@@ -126,6 +134,7 @@ class _TrainFn:
         net._dp_cur, net._dp_pending = st[3], st[4]
         if self._ring is not None:                # (the replayed step has sent its cost like an interpreted one)
             self._ring.sent_upto = self._n + 1
+            net._cost_guard_ev = self._ring.ev[self._n % self._ring.R]
         self._n += 1
 
     def _plannable(self):
@@ -193,7 +202,7 @@ class _TrainFn:
             net.aux_inpt_tr.row_global0 = int(i) * B + lo if not self.take_index_list else lo
         net._train_step(y, y_row0)
         if self._ring is not None:                # the step's cost exists behind its last launch: off it goes
-            self._ring.send(self._n, net.d_cost)
+            self._ring.send(self._n, net.d_cost, net)
         self._n += 1
 
     # -- costs a few calls late (what train.py's loop needs of a step; see _CostRing) ----------------------------
@@ -219,23 +228,29 @@ class _TrainFn:
         self._sc_n += 1
         return out
 
-    _sc_n = 0
-
-    def _ring_rest(self):
+    def _ring_rest(self, keep=False):
+        """Everything the ring still owes, in order.  ``keep``: the ring (and with it the recorded steps, whose baked
+        slot and event pointers follow the step number modulo 4) stays for the next loop."""
         r, out = self._ring, []
         if r is None:
             return out
         while r.next_take < r.sent_upto:
             out.append((r.next_take - self._ring_base, r.take(r.next_take)))
+        if keep:
+            return out
         self._ring = None
         if self._plan is not None:
             self._plan.restart("cost ring off")
         return out
 
     def drain_costs(self):
-        """The costs step_cost() has not handed out yet, in order; afterwards step numbers start from 0 again."""
-        out = self._ring_rest()
+        """The costs step_cost() has not handed out yet, in order; afterwards step numbers start from 0 again.  train.py
+        calls this at the end of every epoch: ring and plan survive it (an epoch of mnist.prms at batch 4096 is 12
+        steps -- fewer than it takes to watch and record a step)."""
+        out = self._ring_rest(keep=True)
         self._sc_n = 0
+        if self._ring is not None:
+            self._ring_base = self._n
         return out
 
     def fetch(self):
@@ -282,6 +297,7 @@ class _PipeTrainFn:
         self._ctypes = ctypes
         self._plan = StepPlan(net.ctx, net.batch_sz, net.shard_lo)
         self._ring = None            # step_cost(): costs read four calls late (_CostRing)
+        self._sc_n, self._owed = 0, []
 
     # -- set-up of the twin on first use ---------------------------------------------------------
     def _build(self):
@@ -378,6 +394,7 @@ class _PipeTrainFn:
         r = self._ring
         if r is not None and self.t - 2 >= r.sent_upto:
             r.sent_upto = self.t - 1              # (the replayed step has sent the cost of step t - 2)
+            self.nets[self.t & 1]._cost_guard_ev = r.ev[(self.t - 2) % r.R]
         self.t += 1
 
     def _plannable(self):
@@ -401,6 +418,8 @@ class _PipeTrainFn:
             self._lr_set[k] = self._lr_prev
         out = X.tr_layers[-1]
         rider = X._cost_pending
+        if rider:
+            X._guard_cost()
         ctx.call("tn_sgd_update_net", _lib.TN_UPD_PIPE, self._segs[k].ptr, self._hsegs[k].ctypes.data, self._nseg,
                  self._max_seg, self._lr[k].ptr, 1.0, X.d_step.ptr, 2 if t >= 2 else 0, 1 if t >= 2 else 0,
                  out.rowloss.ptr if rider else None, X.local_bsz, 1.0 / X.batch_sz,
@@ -501,16 +520,17 @@ class _PipeTrainFn:
         X = self.nets[k]
         if t >= 1 and not self._updated:
             self._update_for(t)
-            r = self._ring
-            if r is not None and t - 2 >= r.sent_upto:
-                # the launch above has summed the cost of this stream's previous step (t - 2): off it goes
-                r.sent_upto = t - 2
-                r.send(t - 2, X.d_cost)
         elif t == 0:
             ctx.call("tn_stream_select", 0)
             ctx.call("tn_event_record", self._ev[0])
         else:
             ctx.call("tn_stream_select", k)
+        r = self._ring
+        if r is not None and t >= 2 and t - 2 >= r.sent_upto:
+            # the update that opens step t has summed the cost of this stream's previous step (t - 2): off it goes
+            # -- also when that update already ran because something read the weights in between (sync_weights)
+            r.sent_upto = t - 2
+            r.send(t - 2, X.d_cost, X)
         self._updated = False
         self._lr_prev = self._lr_now()
         slot = X.x
@@ -551,33 +571,38 @@ class _PipeTrainFn:
         self._count()
         return pre + out
 
-    _sc_n, _owed = 0, []
-
     def _count(self):
         self._sc_n += 1
         return []
 
-    def _leave_ring(self):
+    def _leave_ring(self, keep=False):
         """Everything the ring still owes, in order: the copies already under way, then the last two steps' costs read
-        directly (nothing would ever open the steps that sum them)."""
+        directly (nothing would ever open the steps that sum them).  ``keep`` (drain_costs at the end of an epoch): ring
+        and recorded steps stay -- the next steps go through the interpreter until both streams have a cost pending
+        again (two steps), then the recorded phases match and replay resumes."""
         r, out = self._ring, []
         if r is None:
             return out
         assert self._seq is None
-        self._ring = None
+        if not keep:
+            self._ring = None
         self._flush_parked()
         self.net.ctx.sync()
         while r.next_take < r.sent_upto:
             out.append((r.next_take - self._ring_base, r.take(r.next_take)))
         for t in range(r.next_take, self.t):
             out.append((t - self._ring_base, np.float32(self.nets[t & 1].d_cost.get_value()[0])))
-        self._plan.restart("cost ring off")
+        if keep:
+            r.next_take = r.sent_upto = self.t
+            self._ring_base = self.t
+        else:
+            self._plan.restart("cost ring off")
         return out
 
     def drain_costs(self):
         out, self._owed = self._owed, []
         if self._seq is None:
-            out += self._leave_ring()
+            out += self._leave_ring(keep=True)
         if self._seq is not None:
             off = self._sc_n - getattr(self._seq, "_sc_n", 0)
             out += [(k + off, c) for k, c in self._seq.drain_costs()]
@@ -607,6 +632,7 @@ class _PipeTrainFn:
         """The cost of X's last step, if nothing has summed it yet (on the stream currently selected)."""
         if getattr(X, "_cost_pending", False):
             out = X.tr_layers[-1]
+            X._guard_cost()
             X.ctx.call("tn_sgd_update_net", _lib.TN_UPD_PLAIN, None, None, 0, 0, X.cur_learn_rate.ptr, 1.0, None, 0, 0,
                        out.rowloss.ptr, X.local_bsz, 1.0 / X.batch_sz, X.d_cost.ptr)
             X._cost_pending = False

@@ -222,16 +222,16 @@ def run(dataset_name, prms_file_name, redirect):
             for ibatch in range(n_tr_batches if exp_head else 0):
                 cost, features, _ = training_fn(ibatch)
                 total_cost += cost
-                if True:              # ExpLoss nets: report samples whose true-class feature runs away (train.py:216-222)
-                    labels = np.asarray(data.training_y[ibatch * batch_sz:(ibatch + 1) * batch_sz])
-                    lo = net.shard_lo                     # a data-parallel rank holds its own rows of the batch
-                    own = labels[lo:lo + len(features)]
-                    true_features = features[np.arange(len(own)), own]
-                    if np.min(true_features) < -6:
-                        print("Epoch:{} Iteration:{}".format(epoch, ibatch))
-                        print(own)
-                        print(true_features)
-                        print(net.get_wts_info(detailed=True))
+                # ExpLoss nets: report samples whose true-class feature runs away (train.py:216-222)
+                labels = np.asarray(data.training_y[ibatch * batch_sz:(ibatch + 1) * batch_sz])
+                lo = net.shard_lo                         # a data-parallel rank holds its own rows of the batch
+                own = labels[lo:lo + len(features)]
+                true_features = features[np.arange(len(own)), own]
+                if np.min(true_features) < -6:
+                    print("Epoch:{} Iteration:{}".format(epoch, ibatch))
+                    print(own)
+                    print(true_features)
+                    print(net.get_wts_info(detailed=True))
                 if np.isnan(total_cost):
                     nan_guard(epoch, ibatch)
             rate = n_tr_batches * batch_sz / (time.perf_counter() - t0)
