@@ -347,11 +347,19 @@ def dry_multi(args):
                   "holds": "dense-layer gradients + the cost"},
                  {"floats": bk[1], "offset_floats": 0, "issued": "end of the backward pass",
                   "holds": "conv-layer gradients"}]
+            for b_ in buckets:
+                b_["bytes"] = 4 * b_["floats"]
+                b_["algorithm"] = {"rsag": "direct reduce-scatter + all-gather (tn_allreduce_sum_rsag: ncclReduceScatter + "
+                                           "ncclAllGather in place, every element summed once at its owner)",
+                                   "allreduce": "one ncclAllReduce (latency-bound bucket: the library's own algorithm)"
+                                   }[comm.collective_algo(b_["floats"], N)]
             plan = {"flat_gradient_buffer": {"floats_reduced_per_step": net.n_flat, "bytes": 4 * net.n_flat,
                                              "cost_slot": net.n_flat - 1, "tensors": tensors},
                     "allreduce_buckets": buckets,
-                    "allreduce_stream": "the context's communication stream (tn_allreduce_sum_async); consumer = the "
-                                        "update that opens the same stream's next step",
+                    "allreduce_stream": "the context's communication stream (tn_allreduce_sum_async / _rsag); consumer = "
+                                        "the update that opens the same stream's next step",
+                    "multi_gpu_measurement": "none in any round (no multi-GPU lease): the algorithm per bucket is a design "
+                                             "choice from the xGMI figures of SURVEY.md 8e, not a measured one",
                     "schedule": "pipelined (two steps in flight, all-reduce buckets on the communication stream)"
                     if type(fn).__name__ == "_PipeTrainFn" else
                     "one step at a time; all-reduce schedule autotuned among %s" %

@@ -595,6 +595,16 @@ int tn_allreduce_max(tn_ctx* ctx, float* buf, size_t n);
  * consumer -- the update that opens the stream's next step -- waits for it with tn_event_wait.  tn_sync also waits
  * for the communication stream.                                                                                  */
 int tn_allreduce_sum_async(tn_ctx* ctx, float* buf, size_t n, void* done_event);
+/* The same in-place sum as a DIRECT reduce-scatter + all-gather (ncclReduceScatter then ncclAllGather, in place: rank r
+ * owns elements [r q, (r+1) q), q = n / world; the n % world elements behind them travel in a small all-reduce).
+ * MI355X's xGMI is fully connected, so for the large buckets (wide6: 67 MB of dense-layer gradients)
+ * the two half-collectives move 2 (S / world) per link pair against a ring's 2 (world - 1) / world * S through every
+ * link in turn.  Every element is summed once, at its owner, and broadcast: all ranks hold the same bits.
+ * on_comm_stream != 0: ordered and signalled like tn_allreduce_sum_async (done_event may be NULL); 0: on the ctx
+ * stream like tn_allreduce_sum (done_event ignored).  theanet_amd/comm.py picks the form per bucket (TN_DP_ALGO,
+ * TN_DP_RSAG_MIN_BYTES); the reference has no counterpart (single process; the batch mean of outlayers.py:50-51 is what
+ * makes the sum of shard gradients the gradient).                                                                   */
+int tn_allreduce_sum_rsag(tn_ctx* ctx, float* buf, size_t n, int on_comm_stream, void* done_event);
 int tn_axpby(tn_ctx* ctx, float* y, const float* x, size_t n, float a, float b); /* y = a*x + b*y */
 
 #ifdef __cplusplus

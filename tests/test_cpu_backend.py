@@ -176,6 +176,58 @@ def test_bucketed_allreduce_equals_single_bucket(tmp_path, world):
             np.testing.assert_array_equal(a[k], b[k], err_msg=k)
 
 
+@pytest.mark.parametrize("world", [2, 4])
+def test_reduce_scatter_allgather_equals_allreduce(tmp_path, world):
+    """The direct reduce-scatter + all-gather form of a bucket's sum (tn_allreduce_sum_rsag; comm.collective_algo picks
+    it for buckets >= TN_DP_RSAG_MIN_BYTES; here forced for EVERY collective, bucket sizes not divisible by the rank
+    count included -- the remainder takes the small all-reduce) against one all-reduce per bucket: every element is
+    summed once, in rank order, at its owner -- costs, statistics and weights BIT-identical with 2 and with 4 ranks,
+    same number of collectives in the same order on every rank (TN_DP_CHECK_ORDER; the order hash carries the form)."""
+    worker = os.path.join(ROOT, "tests", "dp_gpu_worker.py")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    outs = {}
+    for n, algo in enumerate(("rsag", "allreduce")):
+        out = str(tmp_path / ("a%s.npz" % algo))
+        procs = []
+        for rank in range(world):
+            env = _env(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                       MASTER_PORT=str(port + n), TN_PIPELINE="1", TN_DP_BUCKETS="1", TN_DP_ALGO=algo,
+                       TN_DP_CHECK_ORDER="1", OMP_NUM_THREADS="2")
+            procs.append(subprocess.Popen([sys.executable, worker, out, "cifar_like.prms", "16", "3", "16", "7"],
+                                          env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+        for p in procs:
+            try:
+                o, _ = p.communicate(timeout=600)
+            except subprocess.TimeoutExpired:
+                for q in procs:
+                    q.kill()
+                raise
+            assert p.returncode == 0, o.decode()[-3000:]
+        outs[algo] = np.load(out)
+    a, b = outs["rsag"], outs["allreduce"]
+    assert str(a["schedule"]) == "pipelined" and int(a["bucket"]) > 0
+    assert int(a["n_collectives"]) == int(b["n_collectives"])
+    np.testing.assert_array_equal(a["costs"], b["costs"])
+    np.testing.assert_array_equal(a["stats"], b["stats"])
+    for k in a.files:
+        if k.startswith("w"):
+            np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+
+
+def test_collective_algo_rule():
+    from theanet_amd.comm import collective_algo
+    assert collective_algo(16788545, 8, {}) == "rsag"            # wide6's dense bucket, 67 MB
+    assert collective_algo(1145408, 8, {}) == "allreduce"        # its conv bucket, 4.6 MB
+    assert collective_algo(366593, 8, {}) == "allreduce"         # mnist.prms, 1.5 MB: latency-bound
+    assert collective_algo(16788545, 1, {}) == "allreduce"       # one rank: nothing to scatter
+    assert collective_algo(10, 1, {"TN_DP_ALGO": "rsag"}) == "rsag"
+    assert collective_algo(1 << 30, 8, {"TN_DP_ALGO": "allreduce"}) == "allreduce"
+    assert collective_algo(1 << 20, 8, {"TN_DP_RSAG_MIN_BYTES": "1024"}) == "rsag"
+
+
 @pytest.mark.parametrize("prms,extra,rows", [("mnist.prms", [], 512), ("wide6.prms", ["--img", "16"], 128)])
 def test_bench_dry_multi_plans_an_8_rank_run_without_a_communicator(prms, extra, rows):
     """bench.py --dry-multi 8: the scaling command line's plan (row shards of the first and last rank, the flat

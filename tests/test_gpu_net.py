@@ -615,13 +615,17 @@ def test_dp_delayed_allreduce_equals_plain(monkeypatch, name, img, ch, B):
 
 
 @pytest.mark.parametrize("name,img,ch,B,dtype", [("mnist.prms", 28, 1, 64, "float32"), ("cifar_like.prms", 32, 3, 16, "float32"),
-                                                  ("wide6.prms", 32, 3, 8, "float16_dp")])
+                                                  ("wide6.prms", 32, 3, 8, "float16_dp"),
+                                                  ("cifar_like.prms", 32, 3, 16, "float32_rsag"), ("wide6.prms", 32, 3, 8, "float16_rsag")])
 def test_dp_pipelined_equals_sequential(monkeypatch, name, img, ch, B, dtype):
     """Data-parallel step (1-rank RCCL communicator) with two steps in flight: the collectives of a step -- the dense
     group's bucket right after the dense layers' backward pass, the conv bucket (or everything, mnist.prms) at the end --
     travel on the context's communication stream (tn_allreduce_sum_async); the update that consumes them opens that
     stream's next step behind their event.  Same costs, outputs and weights as one step at a time with the plain
-    all-reduce schedule."""
+    all-reduce schedule.  ``_rsag``: every collective in its direct reduce-scatter + all-gather form
+    (tn_allreduce_sum_rsag: ncclReduceScatter + ncclAllGather in place on the communication stream; TN_DP_ALGO=rsag)."""
+    if dtype.endswith("_rsag"):
+        monkeypatch.setenv("TN_DP_ALGO", "rsag")
     from theanet_amd import NeuralNet
     from theanet_amd.neuralnet import _PipeTrainFn
     import copy
@@ -705,6 +709,57 @@ def test_two_gpu_product_path(tmp_path, name, img, ch, B, pipe):
     for k in one.files:
         if k.startswith("w"):
             assert_close(two[k], one[k], 1e-5, 1e-6, what="2-GPU vs 1-GPU " + k)
+
+
+@pytest.mark.parametrize("knob,arms", [("TN_DP_BUCKETS", ("1", "0")), ("TN_DP_ALGO", ("rsag", "allreduce"))])
+def test_two_gpu_bucketed_and_rsag_equal_one_allreduce(tmp_path, knob, arms):
+    """The cross-stream orderings of the default data-parallel schedule, on two real GPUs (round-4 advisor: they had only
+    run where streams are no-ops): the dense bucket on the communication stream while the conv backward continues, the
+    conv bucket at the end, the update waiting on _ar_done_ev -- against ONE all-reduce per step; and every collective
+    as reduce-scatter + all-gather against ncclAllReduce.  With two ranks a + b has one order: costs, statistics and
+    weights must be BIT-identical.  Needs two visible GPUs; skipped on a one-GPU box."""
+    import ctypes
+    import socket
+    import subprocess
+    import sys
+    from theanet_amd import _lib
+    n = ctypes.c_int(0)
+    _lib.get_lib().tn_device_count(ctypes.byref(n))
+    if n.value < 2:
+        pytest.skip("needs two GPUs (found %d)" % n.value)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    worker = os.path.join(root, "tests", "dp_gpu_worker.py")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    outs = []
+    for k, arm in enumerate(arms):
+        out = str(tmp_path / ("arm%d.npz" % k))
+        procs = []
+        for rank in range(2):
+            env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                       MASTER_PORT=str(port + k), TN_PIPELINE="1", TN_DP_CHECK_ORDER="1", HSA_ENABLE_IPC_MODE_LEGACY="0",
+                       PYTHONPATH=root)
+            env[knob] = arm
+            procs.append(subprocess.Popen([sys.executable, worker, out, "cifar_like.prms", "32", "3", "16", "7"],
+                                          env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+        for p in procs:
+            try:
+                o, _ = p.communicate(timeout=600)
+            except subprocess.TimeoutExpired:
+                for q in procs:
+                    q.kill()
+                raise
+            assert p.returncode == 0, o.decode()[-3000:]
+        outs.append(np.load(out))
+    a, b = outs
+    assert str(a["schedule"]) == "pipelined" and str(b["schedule"]) == "pipelined"
+    np.testing.assert_array_equal(a["costs"], b["costs"])
+    np.testing.assert_array_equal(a["stats"], b["stats"])
+    for k in a.files:
+        if k.startswith("w"):
+            np.testing.assert_array_equal(a[k], b[k], err_msg=k)
 
 
 def test_train_py_end_to_end(tmp_path):

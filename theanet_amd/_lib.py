@@ -180,6 +180,7 @@ SIGNATURES = {
     "tn_allreduce_sum": (c_int, [CTX, P, c_size_t]),
     "tn_allreduce_max": (c_int, [CTX, P, c_size_t]),
     "tn_allreduce_sum_async": (c_int, [CTX, P, c_size_t, P]),
+    "tn_allreduce_sum_rsag": (c_int, [CTX, P, c_size_t, c_int, P]),
     "tn_axpby": (c_int, [CTX, P, P, c_size_t, c_float, c_float]),
 }
 

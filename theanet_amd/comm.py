@@ -164,6 +164,40 @@ class Rendezvous:
             arr[...] = np.frombuffer(_recv_exact(self.sock, nbytes), dtype=arr.dtype).reshape(arr.shape)
         return arr
 
+    def rsag_host(self, arr):
+        """The CPU backend's restatement of tn_allreduce_sum_rsag on a HOST float32 vector, in place: rank r owns
+        elements [r q, (r + 1) q), q = n // world; every slice is summed in rank order at its owner (rank 0 stands in
+        for the owners here: the star of sockets has no rank-to-rank links) and gathered by everybody; the n % world
+        elements behind the slices go through the all-reduce.  Rank order at the owner = rank order of
+        ``allreduce_host``: the same bits."""
+        W = self.world.size
+        if W == 1:
+            return arr
+        flat = arr.reshape(-1)
+        n = flat.size
+        q = n // W
+        body = q * W
+        if q:
+            if self.world.rank == 0:
+                parts = [flat[:body].copy()] + [np.frombuffer(_recv_exact(c, 4 * body), dtype=np.float32) for c in self.conns]
+                out = np.empty(body, np.float32)
+                for owner in range(W):                      # reduce-scatter: the owner's slice, contributions in rank order
+                    sl = slice(owner * q, (owner + 1) * q)
+                    acc = parts[0][sl].copy()
+                    for p_ in parts[1:]:
+                        acc = acc + p_[sl]
+                    out[sl] = acc
+                flat[:body] = out                           # all-gather
+                blob = out.tobytes()
+                for c in self.conns:
+                    c.sendall(blob)
+            else:
+                self.sock.sendall(flat[:body].tobytes())
+                flat[:body] = np.frombuffer(_recv_exact(self.sock, 4 * body), dtype=np.float32)
+        if n > body:
+            self.allreduce_host(flat[body:], "sum")
+        return arr
+
     def close(self):
         for c in self.conns:
             c.close()
@@ -198,6 +232,23 @@ def agree(value, what="value", rdzv=None):
     if hi != lo:
         raise RuntimeError("data-parallel ranks disagree on %s (min %r, max %r): every rank must build "
                            "the net from the same SEED / weights" % (what, lo, hi))
+
+
+def collective_algo(nfloats, world_size, env=None):
+    """Which form a bucket's sum takes: 'rsag' = direct reduce-scatter + all-gather
+    (tn_allreduce_sum_rsag) for buckets of TN_DP_RSAG_MIN_BYTES (default 8 MB) or more -- on the fully connected xGMI a
+    ring moves 2 (W-1)/W S through every link in turn, the two half-collectives 2 S/W per link pair: wide6's 67 MB dense
+    bucket 820 us against 117 us of wire at 8 GPUs --, 'allreduce' (one RCCL call, the library's own choice of
+    algorithm) for the small, latency-bound ones.  TN_DP_ALGO=allreduce / rsag forces one form for every bucket
+    (rsag also with one rank: the GPU tests exercise the entry point that way).  The choice depends on the bucket
+    size and the environment only: the same on every rank."""
+    env = os.environ if env is None else env
+    force = env.get("TN_DP_ALGO", "auto")
+    if force in ("allreduce", "rsag"):
+        return force
+    if world_size < 2:
+        return "allreduce"
+    return "rsag" if 4 * int(nfloats) >= int(env.get("TN_DP_RSAG_MIN_BYTES", 8 << 20)) else "allreduce"
 
 
 class DeviceGroup:
@@ -297,21 +348,34 @@ class DeviceGroup:
 
     def allreduce_sum(self, darr, count=None):
         n = darr.size if count is None else count
-        self._note("sum", n)
+        algo = collective_algo(n, self.world.size)
+        self._note("sum:" + algo, n)
         if self.ctx.backend == "cpu" and self.world.size > 1:      # "device" memory is host memory there
             self.ctx.rec_tainted = True                            # (host-side work: not a step tn_net_step can replay)
-            self.rdzv.allreduce_host(self._host_view(darr, n), "sum")
+            if algo == "rsag":
+                self.rdzv.rsag_host(self._host_view(darr, n))
+            else:
+                self.rdzv.allreduce_host(self._host_view(darr, n), "sum")
+        elif algo == "rsag":
+            self.ctx.call("tn_allreduce_sum_rsag", darr.ptr, n, 0, None)
         else:
             self.ctx.call("tn_allreduce_sum", darr.ptr, n)
 
     def allreduce_sum_async(self, darr, count=None, done_ev=None):
-        """The sum on the context's communication stream (tn_allreduce_sum_async): behind what the compute stream
-        holds so far, beside what it does next; ``done_ev`` is recorded behind it for the consumer to wait on."""
+        """The sum on the context's communication stream (tn_allreduce_sum_async / tn_allreduce_sum_rsag): behind what
+        the compute stream holds so far, beside what it does next; ``done_ev`` is recorded behind it for the consumer
+        to wait on."""
         n = darr.size if count is None else count
-        self._note("sum", n)
+        algo = collective_algo(n, self.world.size)
+        self._note("sum:" + algo, n)
         if self.ctx.backend == "cpu" and self.world.size > 1:      # host code is synchronous: nothing to order
             self.ctx.rec_tainted = True
-            self.rdzv.allreduce_host(self._host_view(darr, n), "sum")
+            if algo == "rsag":
+                self.rdzv.rsag_host(self._host_view(darr, n))
+            else:
+                self.rdzv.allreduce_host(self._host_view(darr, n), "sum")
+        elif algo == "rsag":
+            self.ctx.call("tn_allreduce_sum_rsag", darr.ptr, n, 1, done_ev)
         else:
             self.ctx.call("tn_allreduce_sum_async", darr.ptr, n, done_ev)
 

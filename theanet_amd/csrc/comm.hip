@@ -17,6 +17,8 @@ struct RcclApi {
     int (*CommInitRank)(tn_ncclComm_t*, int, tn_ncclUniqueId, int);
     int (*CommDestroy)(tn_ncclComm_t);
     int (*AllReduce)(const void*, void*, size_t, int, int, tn_ncclComm_t, hipStream_t);
+    int (*ReduceScatter)(const void*, void*, size_t, int, int, tn_ncclComm_t, hipStream_t);
+    int (*AllGather)(const void*, void*, size_t, int, tn_ncclComm_t, hipStream_t);
     const char* (*GetErrorString)(int);
 };
 static RcclApi g_rccl;
@@ -37,6 +39,8 @@ static int load_rccl(tn_ctx* ctx) {
     SYM(CommInitRank, "ncclCommInitRank");
     SYM(CommDestroy, "ncclCommDestroy");
     SYM(AllReduce, "ncclAllReduce");
+    SYM(ReduceScatter, "ncclReduceScatter");
+    SYM(AllGather, "ncclAllGather");
     SYM(GetErrorString, "ncclGetErrorString");
 #undef SYM
     ctx->rccl_lib = lib;
@@ -107,5 +111,26 @@ int tn_allreduce_sum_async(tn_ctx* ctx, float* buf, size_t n, void* done_event) 
     return TN_OK;
 }
 int tn_allreduce_max(tn_ctx* ctx, float* buf, size_t n) { return allreduce(ctx, buf, n, TN_NCCL_MAX); }
+
+int tn_allreduce_sum_rsag(tn_ctx* ctx, float* buf, size_t n, int on_comm_stream, void* done_event) {
+    if (!ctx->comm) return tn_fail(ctx, TN_E_COMM, "all-reduce without tn_comm_init");
+    hipStream_t st = ctx->stream;
+    if (on_comm_stream) {
+        TN_HIP(hipEventRecord(ctx->comm_ev, ctx->stream));
+        TN_HIP(hipStreamWaitEvent(ctx->comm_stream, ctx->comm_ev, 0));
+        st = ctx->comm_stream;
+    }
+    const size_t W = (size_t)ctx->world, q = n / W, body = q * W;
+    tn_ncclComm_t comm = (tn_ncclComm_t)ctx->comm;
+    if (q) {
+        // in place: rank r's sums land in its own slice, the gather fills in everybody else's
+        float* mine = buf + (size_t)ctx->rank * q;
+        TN_NCCL(g_rccl.ReduceScatter(buf, mine, q, TN_NCCL_FLOAT32, TN_NCCL_SUM, comm, st));
+        TN_NCCL(g_rccl.AllGather(mine, buf, q, TN_NCCL_FLOAT32, comm, st));
+    }
+    if (n > body) TN_NCCL(g_rccl.AllReduce(buf + body, buf + body, n - body, TN_NCCL_FLOAT32, TN_NCCL_SUM, comm, st));
+    if (on_comm_stream && done_event) TN_HIP(hipEventRecord((hipEvent_t)done_event, ctx->comm_stream));
+    return TN_OK;
+}
 
 }  // extern "C"

@@ -1204,6 +1204,10 @@ int tn_allreduce_sum_async(tn_ctx* ctx, float*, size_t, void*) {     // (host co
     REQUIRE(ctx->world == 1, "tn_allreduce_sum_async: multi-rank reductions of the CPU backend run in theanet_amd.comm (host buffers)");
     return TN_OK;
 }
+int tn_allreduce_sum_rsag(tn_ctx* ctx, float*, size_t, int, void*) {     // one rank: the sum is the buffer itself
+    REQUIRE(ctx->world == 1, "tn_allreduce_sum_rsag: multi-rank reductions of the CPU backend run in theanet_amd.comm (host buffers)");
+    return TN_OK;
+}
 int tn_allreduce_max(tn_ctx* ctx, float*, size_t) {
     REQUIRE(ctx->world == 1, "tn_allreduce_max: multi-rank reductions of the CPU backend run in theanet_amd.comm (host buffers)");
     return TN_OK;
