@@ -313,7 +313,9 @@ __global__ __launch_bounds__(256, 2) void c8_conv_kernel(C8G g) {
     // one filter tile, one chunk (a first layer; any C <= 16, K <= 32 FT): every step of the block meets the SAME weights
     // and biases -- both LDS buffers are filled once, the bias registers loaded once (the loop is bound by the instructions
     // a wave issues, and such a layer runs one body per tile)
-    const bool wconst = g.KT == 1 && g.nchunk == 1;
+    // (only in the tap-packed instantiations, TK: as a run-time flag in every instantiation its branches around the weight
+    // loads cost the multi-chunk layers' loop its schedule -- wide6 conv5 input gradient 34.0 -> 38.0 us, round 5 bisection)
+    const bool wconst = TK && g.KT == 1 && g.nchunk == 1;
     auto gloadw = [&]() __attribute__((always_inline)) {
         if (wconst) return;
         const char* w_ = reinterpret_cast<const char*>(g.wt) + ((size_t)skt * g.nchunk + sch) * WB + 16 * t;
