@@ -24,6 +24,13 @@
 
 #include <type_traits>
 
+// ablation builds of c8_conv_kernel (wrong results, timing only; hipcc -DC8_FEXP=n into a side library, run through
+// TN_HIP_LIB): 1 no input staging, 2 no weight staging, 4 no epilogue (the products go with it: dead code), 8 one tap's
+// matrix work instead of nine.  Round 5, wide6 conv2 forward (us): 49.9 as is, 37.6 without input staging, 33.7 with one
+// tap of nine, 20.6 staging only, 7.1 the bare loop -- the phases of a block add up.
+#ifndef C8_FEXP
+#define C8_FEXP 0
+#endif
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 typedef int int4v __attribute__((ext_vector_type(4)));
@@ -502,8 +509,8 @@ __global__ __launch_bounds__(256, 2) void c8_conv_kernel(C8G g) {
     auto body = [&](int seq, auto Pc) __attribute__((always_inline)) {
         constexpr int P = decltype(Pc)::value;
         sadv();
-        gloadw();                    // step seq + 1
-        gloadx(Pc);                  // step seq + 2
+        if (!(C8_FEXP & 2)) gloadw();                    // step seq + 1
+        if (!(C8_FEXP & 1)) gloadx(Pc);                  // step seq + 2
         if (!DGRAD && !wconst && cch + 1 == g.nchunk) bias_load(decode(ci + 1).kt);
         const char* x0 = Xs + P * XB + boff[0];
         const char* x1 = Xs + P * XB + boff[1];
@@ -517,7 +524,7 @@ __global__ __launch_bounds__(256, 2) void c8_conv_kernel(C8G g) {
         b[0][1] = *reinterpret_cast<const half8*>(x1 + (TK ? toff[0] : 0));
         __builtin_amdgcn_sched_group_barrier(0x100, FT + 2, 0);
 #pragma unroll
-        for (int tap = 0; tap < NTS; ++tap) {
+        for (int tap = 0; tap < ((C8_FEXP & 8) ? 1 : NTS); ++tap) {
             const int cur = tap & 1, nx = cur ^ 1;
             if (tap + 1 < NTS) {
                 const int bo = TK ? toff[(tap + 1) % NTS] : ((tap + 1) / 3) * RS16 + ((tap + 1) % 3) * 16;
@@ -538,12 +545,12 @@ __global__ __launch_bounds__(256, 2) void c8_conv_kernel(C8G g) {
         // step seq + 1 (fetched a step ago into the other register set) goes into the other LDS buffer
         unsigned long long s0 = 0, s1 = 0, s2 = 0;
         if (g.dbg) s0 = __builtin_readcyclecounter();
-        if (seq + 1 < SEQ) lstore(P ^ 1, std::integral_constant<int, P ^ 1>{});
+        if (seq + 1 < SEQ && !(C8_FEXP & 1)) lstore(P ^ 1, std::integral_constant<int, P ^ 1>{});
         if (g.dbg) s1 = __builtin_readcyclecounter();
         if (++cch == g.nchunk) {
             const Tile tc = decode(ci);
             asm volatile("; c8 epilogue begin");
-            epilogue(tc);
+            if (!(C8_FEXP & 4)) epilogue(tc);
             asm volatile("; c8 epilogue end");
             acc_init();
             cch = 0; ++ci;
