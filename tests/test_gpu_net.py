@@ -434,6 +434,12 @@ def test_step_cost_hands_out_every_cost_in_order(pipeline, monkeypatch):
         want = loop(ref_fn, lo, hi, False)
         got = loop(fn, lo, hi, True)
         np.testing.assert_array_equal(got, want)
+        if lo == 45:
+            # plain enqueue() calls between two step_cost() loops (bench.py does this): the ring that drain_costs() left
+            # in place must neither overrun nor hand their costs to the next loop
+            for s in range(7):
+                ref_fn.enqueue(s % 12)
+                fn.enqueue(s % 12)
         if lo == 0:
             # the steps of the first loop were watched, recorded and then REPLAYED (ring slots baked into four phases)
             assert fn._plan.ready and fn._plan.period == 4, (fn._plan.why, fn._plan.period)

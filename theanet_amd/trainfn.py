@@ -59,6 +59,8 @@ class _CostRing:
             self.ev.append(e)
         self.next_take = 0          # first step number whose cost the caller has not been handed yet
         self.sent_upto = 0          # copies have been issued for the steps below
+        self.strict = False         # True while a step_cost() call is enqueueing
+        self.stale = False          # steps were enqueued outside step_cost() since the last one
 
     def send(self, step, d_cost, net=None):
         """The copy is ordered behind the launch that summed the cost, on the copy stream; nothing else holds the
@@ -66,7 +68,12 @@ class _CostRing:
         ``net._guard_cost()`` (NeuralNet) does, in front of every such launch -- a step or two later in the lazy
         schedules (the copy has long run), a few tens of microseconds later where the cost is summed mid-step
         (data-parallel pipelined steps, weight-cost nets)."""
-        assert step == self.sent_upto and step - self.next_take < self.R, "cost ring overrun"
+        assert step == self.sent_upto, "cost ring out of step"
+        if step - self.next_take >= self.R:
+            # nobody is collecting: plain enqueue() calls while the ring is kept for the next step_cost() loop (drain_costs
+            # leaves it in place) -- the oldest cost is dropped; inside a step_cost() loop this would be a bug
+            assert not self.strict, "cost ring overrun"
+            self.next_take = step - self.R + 1
         s = step % self.R
         self.ctx.call("tn_d2h_early_ev", self.buf.ptr + 4 * s, d_cost.ptr, 4, self.ev[s])
         if net is not None:
@@ -133,8 +140,12 @@ class _TrainFn:
             net._cost_pending = st[2]
         net._dp_cur, net._dp_pending = st[3], st[4]
         if self._ring is not None:                # (the replayed step has sent its cost like an interpreted one)
-            self._ring.sent_upto = self._n + 1
-            net._cost_guard_ev = self._ring.ev[self._n % self._ring.R]
+            r = self._ring
+            r.sent_upto = self._n + 1
+            if not r.strict:
+                r.stale = True
+                r.next_take = max(r.next_take, self._n + 2 - r.R)
+            net._cost_guard_ev = r.ev[self._n % r.R]
         self._n += 1
 
     def _plannable(self):
@@ -203,6 +214,8 @@ class _TrainFn:
         net._train_step(y, y_row0)
         if self._ring is not None:                # the step's cost exists behind its last launch: off it goes
             self._ring.send(self._n, net.d_cost, net)
+            if not self._ring.strict:
+                self._ring.stale = True
         self._n += 1
 
     # -- costs a few calls late (what train.py's loop needs of a step; see _CostRing) ----------------------------
@@ -222,9 +235,17 @@ class _TrainFn:
             if self._plan is not None:
                 self._plan.restart("cost ring on")
         r, out = self._ring, []
+        if r.stale:                               # plain enqueue() calls in between: their costs are nobody's
+            r.next_take = r.sent_upto = self._n
+            self._ring_base = self._n - self._sc_n
+            r.stale = False
         if self._n - r.next_take >= r.lag:
             out.append((r.next_take - self._ring_base, r.take(r.next_take)))
-        self.enqueue(i)
+        r.strict = True
+        try:
+            self.enqueue(i)
+        finally:
+            r.strict = False
         self._sc_n += 1
         return out
 
@@ -234,6 +255,9 @@ class _TrainFn:
         r, out = self._ring, []
         if r is None:
             return out
+        if r.stale:                               # only plain enqueue() calls since the last loop: nothing is owed
+            r.next_take = r.sent_upto
+            r.stale = False
         while r.next_take < r.sent_upto:
             out.append((r.next_take - self._ring_base, r.take(r.next_take)))
         if keep:
@@ -394,6 +418,9 @@ class _PipeTrainFn:
         r = self._ring
         if r is not None and self.t - 2 >= r.sent_upto:
             r.sent_upto = self.t - 1              # (the replayed step has sent the cost of step t - 2)
+            if not r.strict:
+                r.stale = True
+                r.next_take = max(r.next_take, self.t - r.R)
             self.nets[self.t & 1]._cost_guard_ev = r.ev[(self.t - 2) % r.R]
         self.t += 1
 
@@ -531,6 +558,8 @@ class _PipeTrainFn:
             # -- also when that update already ran because something read the weights in between (sync_weights)
             r.sent_upto = t - 2
             r.send(t - 2, X.d_cost, X)
+            if not r.strict:
+                r.stale = True
         self._updated = False
         self._lr_prev = self._lr_now()
         slot = X.x
@@ -565,9 +594,17 @@ class _PipeTrainFn:
             self._ring_base = self.t - self._sc_n
             self._plan.restart("cost ring on")
         r, out = self._ring, []
+        if r.stale:                               # plain enqueue() calls in between: their costs are nobody's
+            r.next_take = r.sent_upto = self.t
+            self._ring_base = self.t - self._sc_n
+            r.stale = False
         if self.t - r.next_take >= r.lag:
             out.append((r.next_take - self._ring_base, r.take(r.next_take)))
-        self.enqueue(i)
+        r.strict = True
+        try:
+            self.enqueue(i)
+        finally:
+            r.strict = False
         self._count()
         return pre + out
 
@@ -584,6 +621,9 @@ class _PipeTrainFn:
         if r is None:
             return out
         assert self._seq is None
+        if r.stale:                               # only plain enqueue() calls since the last loop: nothing is owed
+            r.next_take = r.sent_upto = self.t
+            r.stale = False
         if not keep:
             self._ring = None
         self._flush_parked()

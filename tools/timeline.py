@@ -1,6 +1,7 @@
 """Timeline of a rocprofv3 --kernel-trace CSV (tools/timeline.sh): overlap statistics of the two streams of the
 pipelined schedule and one step pair printed kernel by kernel."""
 import csv
+import os
 import re
 import sys
 from collections import defaultdict
@@ -17,7 +18,8 @@ for e in ev:
     names[e[2]] += 1
 top = max(names, key=names.get)
 marks = [e[0] for e in ev if e[2] == top]
-lo, hi = marks[int(len(marks) * 0.3)], marks[int(len(marks) * 0.9)]
+# (TL_LO / TL_HI: another slice of the launches -- bench.py's legs follow each other: set-up and timed enqueue-only steps first)
+lo, hi = marks[int(len(marks) * float(os.environ.get('TL_LO', 0.3)))], marks[int(len(marks) * float(os.environ.get('TL_HI', 0.9)))]
 win = [e for e in ev if e[0] >= lo and e[1] <= hi]
 nsteps = sum(1 for e in win if e[2] == top)
 print("window: %.1f us, %d launches of %s -> %.2f us per step" % ((hi - lo) / 1e3, nsteps, top, (hi - lo) / 1e3 / nsteps))
