@@ -559,7 +559,15 @@ int tn_c8_fc_wgrad(tn_ctx* ctx, const void* x, const float* dz, float* dW, float
     g.Kc = ((C + 7) / 8) * HW * 8;
     g.gs = ctx->grad_scale; g.oscale = 1.f / ctx->grad_scale;
     const int kb = cdiv(g.Kc, 128), nb = cdiv(n_out, 128);
-    int S = cdiv(2 * ctx->num_cus, kb * nb);
+    // sample slabs: ONE block per CU (round 5; two per CU until then).  The launch is bound by its traffic, not by its
+    // products (cifar_like: 4.3 GFLOP, 83 MB per launch), and every slab is written here and read back by the update:
+    // cifar_like float16 step 0.3261 (8 slabs) -> 0.3175 (4) -> 0.3198 (2) ms same-box.  TN_FC8_WSLABS: half blocks per CU.
+    static int half_cu = -1;
+    if (half_cu < 0) {
+        const char* e = getenv("TN_FC8_WSLABS");
+        half_cu = e ? atoi(e) : 2;
+    }
+    int S = cdiv(half_cu * ctx->num_cus / 2, kb * nb);
     if (S > cdiv(B, 64)) S = cdiv(B, 64);
     if (S < 1) S = 1;
     g.krange = cdiv(cdiv(B, S), 64) * 64;
