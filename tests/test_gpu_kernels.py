@@ -105,6 +105,10 @@ CONVPOOL_CASES = [
     (2, 2, 12, 5, 5, "valid", "tanh", False),
     (2, 1, 10, 3, 5, "same", "relu", False),
     (70, 2, 9, 6, 3, "same", "sigmoid", False),
+    # conv2 of mnist.prms at longer, odd batches; 20 / 28 / 12 filters, a transcendental kind; 11 -> 6: partial last windows
+    (65, 4, 13, 20, 3, "valid", "relu05", False),
+    (200, 4, 13, 28, 3, "valid", "relu10", False),
+    (131, 4, 13, 12, 3, "valid", "tanh", False),
 ]
 
 
