@@ -205,6 +205,11 @@ int tn_c8_conv_wgrad(tn_ctx* ctx, const void* x, const void* dz, float* dW, floa
 int tn_c8_fc_supported(int B, int C, int HW, int n_out);
 int tn_c8_fc_fwd(tn_ctx* ctx, const void* x, const float* W, const float* b, float* a, int B, int C, int HW, int n_out,
                  int act, float act_param, const uint8_t* mask);
+/* ... with the layer's dropout mask drawn in the same launch (dropout.py:10-13; the numbers of tn_dropout_mask with the
+ * same seed / step / elem0) and written to mask_out for the backward pass.                                          */
+int tn_c8_fc_fwd_dropout(tn_ctx* ctx, const void* x, const float* W, const float* b, float* a, int B, int C, int HW,
+                         int n_out, int act, float act_param, uint8_t* mask_out, float pdrop, uint64_t seed, uint32_t step,
+                         const uint32_t* d_step, uint64_t elem0);
 int tn_c8_fc_dgrad(tn_ctx* ctx, const float* dz, const float* W, void* dx, int B, int C, int HW, int n_out, const void* y,
                    int act, float act_param);
 int tn_c8_fc_wgrad(tn_ctx* ctx, const void* x, const float* dz, float* dW, float* db, int B, int C, int HW, int n_out);

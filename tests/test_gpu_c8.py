@@ -213,6 +213,13 @@ def test_c8_fc_ops(case, f16_mode):
     a = empty((B, N))
     call("tn_c8_fc_fwd", xd.ptr, Wd.ptr, bd.ptr, a.ptr, B, C, HW, N, LEAKY, SLOPE, dev(mask).ptr)
     assert _rel(a.get_value(), U.leaky(z, SLOPE) * mask) < 2e-5
+    # the same product with the mask drawn in the launch: the bits of tn_dropout_mask, the masked output of the call above
+    want, got_mask, a2 = empty((B * N,), np.uint8), empty((B * N,), np.uint8), empty((B, N))
+    call("tn_dropout_mask", want.ptr, B * N, .3, 99, 5, None, 1000)
+    call("tn_c8_fc_fwd_dropout", xd.ptr, Wd.ptr, bd.ptr, a2.ptr, B, C, HW, N, LEAKY, SLOPE, got_mask.ptr, .3, 99, 5, None, 1000)
+    assert np.array_equal(got_mask.get_value(), want.get_value())
+    call("tn_c8_fc_fwd", xd.ptr, Wd.ptr, bd.ptr, a.ptr, B, C, HW, N, LEAKY, SLOPE, want.ptr)
+    assert np.array_equal(a2.get_value(), a.get_value())
     dz = (rng.randn(B, N) * 1e-3).astype(np.float32)
     dz16 = U.r16(GS * dz)
     y = U.r16(rng.randn(B, Kc)); y[0, :3] = 0

@@ -92,6 +92,7 @@ SIGNATURES = {
     "tn_c8_conv_wgrad": (c_int, [CTX, P, P, P, P] + [c_int] * 5 + [c_int, P]),
     "tn_c8_fc_supported": (c_int, [c_int] * 4),
     "tn_c8_fc_fwd": (c_int, [CTX, P, P, P, P] + [c_int] * 5 + [c_float, P]),
+    "tn_c8_fc_fwd_dropout": (c_int, [CTX, P, P, P, P] + [c_int] * 5 + [c_float, P, c_float, c_uint64, c_uint32, P, c_uint64]),
     "tn_c8_fc_dgrad": (c_int, [CTX, P, P, P] + [c_int] * 4 + [P, c_int, c_float]),
     "tn_c8_fc_wgrad": (c_int, [CTX, P, P, P, P] + [c_int] * 4),
     "tn_c8_pack": (c_int, [CTX, P, c_int64, P, c_int, c_int, c_int, c_float]),

@@ -206,9 +206,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
 // out = act(sum of the K slabs + bias) (* mask), slabs added in order; thread = one output (short batches: 128 x 1024
 // outputs are only 512 blocks even so -- with four outputs per thread the kernel ran on 128 blocks at 1.5 TB/s)
+struct Fc8Drop {            // dropout drawn by the finishing kernel (tn_c8_fc_fwd_dropout): the numbers of tn_dropout_mask
+    uint8_t* mask_out;      // NULL: no inline dropout
+    float pdrop;
+    uint32_t k0, k1, step;
+    const uint32_t* d_step;
+    uint64_t elem0;
+};
 __global__ __launch_bounds__(256) void fc8_fwd_finish_kernel(const float* __restrict__ ws, int S, size_t MN, int N,
                                                             const float* __restrict__ bias, const uint8_t* __restrict__ mask,
-                                                            float* __restrict__ out, int act, float prm) {
+                                                            float* __restrict__ out, int act, float prm, Fc8Drop dr) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= MN) return;
     float v = 0.f;
@@ -216,7 +223,19 @@ __global__ __launch_bounds__(256) void fc8_fwd_finish_kernel(const float* __rest
     for (int z = 0; z < S; ++z) v += ws[(size_t)z * MN + i];
     v += bias[i % N];
     v = act == TN_ACT_LEAKY ? fmaxf(0.f, v) + fminf(0.f, v) * prm : tn_act_fwd(v, act, prm);
-    if (mask) v = mask[i] ? v : 0.f;
+    if (dr.mask_out) {
+        // element e = elem0 + i uses word (e & 3) of philox(e >> 2): one call per thread (a thread per output keeps the
+        // launch wide for short batches; the four-fold redundant calls are ~100 instructions beside S slab reads)
+        const uint64_t e = dr.elem0 + i, cq = e >> 2;
+        const u32x4 r = philox4x32((uint32_t)cq, (uint32_t)(cq >> 32), dr.step + (dr.d_step ? *dr.d_step : 0u),
+                                   TN_STREAM_DROPOUT, dr.k0, dr.k1);
+        const uint32_t w = ((e & 3) == 0) ? r.x : ((e & 3) == 1) ? r.y : ((e & 3) == 2) ? r.z : r.w;
+        const bool keep = tn_u01(w) >= dr.pdrop;
+        dr.mask_out[i] = keep ? 1 : 0;
+        v = keep ? v : 0.f;
+    } else if (mask) {
+        v = mask[i] ? v : 0.f;
+    }
     out[i] = v;
 }
 
@@ -493,8 +512,8 @@ int tn_c8_fc_supported(int B, int C, int HW, int n_out) {
 
 // a (B, n_out) fp32 = act(x16 . W + b) (* mask); x16 (B, C8*HW*8) halfs in c8 order, W (C*HW, n_out) fp32 in the reference's
 // NCHW-flattened row order (hidden.py:30, neuralnet.py:168-173)
-int tn_c8_fc_fwd(tn_ctx* ctx, const void* x, const float* W, const float* b, float* a, int B, int C, int HW, int n_out,
-                 int act, float act_param, const uint8_t* mask) {
+static int fc8_fwd_run(tn_ctx* ctx, const void* x, const float* W, const float* b, float* a, int B, int C, int HW, int n_out,
+                       int act, float act_param, const uint8_t* mask, const Fc8Drop& dr) {
     int rc = fc8_check(ctx, B, C, HW, n_out, "tn_c8_fc_fwd");
     if (rc) return rc;
     FC8 g{};
@@ -515,9 +534,23 @@ int tn_c8_fc_fwd(tn_ctx* ctx, const void* x, const float* W, const float* b, flo
     fc8_fwd_kernel<<<dim3(colg, S, rowg), 256, 0, ctx->stream>>>(g);
     TN_LAUNCH_CHECK();
     const size_t MN = (size_t)B * n_out;
-    fc8_fwd_finish_kernel<<<cdiv(MN, 256), 256, 0, ctx->stream>>>(g.ws, S, MN, n_out, b, mask, a, act, act_param);
+    fc8_fwd_finish_kernel<<<cdiv(MN, 256), 256, 0, ctx->stream>>>(g.ws, S, MN, n_out, b, mask, a, act, act_param, dr);
     TN_LAUNCH_CHECK();
     return TN_OK;
+}
+int tn_c8_fc_fwd(tn_ctx* ctx, const void* x, const float* W, const float* b, float* a, int B, int C, int HW, int n_out,
+                 int act, float act_param, const uint8_t* mask) {
+    return fc8_fwd_run(ctx, x, W, b, a, B, C, HW, n_out, act, act_param, mask, Fc8Drop{});
+}
+// the same with the dropout mask drawn by the finishing kernel (dropout.py:12: keep = u01 >= pdrop, no rescale) and
+// written to mask_out for the backward pass: the numbers of tn_dropout_mask(mask_out, B * n_out, pdrop, seed, step,
+// d_step, elem0), one launch and one pass over the mask less
+int tn_c8_fc_fwd_dropout(tn_ctx* ctx, const void* x, const float* W, const float* b, float* a, int B, int C, int HW,
+                         int n_out, int act, float act_param, uint8_t* mask_out, float pdrop, uint64_t seed, uint32_t step,
+                         const uint32_t* d_step, uint64_t elem0) {
+    TN_REQUIRE(mask_out != nullptr, "tn_c8_fc_fwd_dropout: NULL mask");
+    Fc8Drop dr{mask_out, pdrop, (uint32_t)seed, (uint32_t)(seed >> 32), step, d_step, elem0};
+    return fc8_fwd_run(ctx, x, W, b, a, B, C, HW, n_out, act, act_param, nullptr, dr);
 }
 
 // dx16 (B, C8*HW*8) halfs = fp16(gs * dz . W^T * act'(y16)): dz (B, n_out) fp32 = d cost / d z of this layer, y16 = output

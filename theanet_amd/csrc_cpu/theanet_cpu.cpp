@@ -191,6 +191,8 @@ int tn_c8_conv_wgrad(tn_ctx* ctx, const void*, const void*, float*, float*, int,
 int tn_c8_fc_supported(int, int, int, int) { return 0; }
 int tn_c8_fc_fwd(tn_ctx* ctx, const void*, const float*, const float*, float*, int, int, int, int, int, float,
                  const uint8_t*) { NOT_HERE("tn_c8_fc_fwd"); }
+int tn_c8_fc_fwd_dropout(tn_ctx* ctx, const void*, const float*, const float*, float*, int, int, int, int, int, float,
+                         uint8_t*, float, uint64_t, uint32_t, const uint32_t*, uint64_t) { NOT_HERE("tn_c8_fc_fwd_dropout"); }
 int tn_c8_fc_dgrad(tn_ctx* ctx, const float*, const float*, void*, int, int, int, int, const void*, int, float) {
     NOT_HERE("tn_c8_fc_dgrad");
 }

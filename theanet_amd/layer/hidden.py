@@ -84,11 +84,17 @@ class HiddenLayer(Layer):
     def forward(self, train=True):
         drop = self.drop
         if self.c8 is not None:
-            if drop is not None:
-                drop.generate()
             c, h, wd = self.c8
-            self.ctx.call("tn_c8_fc_fwd", self.inpt.ptr, self.w.ptr, self.b.ptr, self.output.ptr, self.batch_sz, c, h * wd,
-                          self.n_out, self.act.kind, self.act.prm, drop.mask.ptr if drop is not None else None)
+            if drop is not None and not drop.injected and not drop.ready:
+                # the mask is drawn by the product's finishing kernel (and kept for the backward pass)
+                self.ctx.call("tn_c8_fc_fwd_dropout", self.inpt.ptr, self.w.ptr, self.b.ptr, self.output.ptr, self.batch_sz,
+                              c, h * wd, self.n_out, self.act.kind, self.act.prm, drop.mask.ptr, drop.pdrop, drop.seed, 0,
+                              drop.d_step.ptr if drop.d_step is not None else None, drop.elem0)
+            else:
+                if drop is not None:
+                    drop.generate()
+                self.ctx.call("tn_c8_fc_fwd", self.inpt.ptr, self.w.ptr, self.b.ptr, self.output.ptr, self.batch_sz, c, h * wd,
+                              self.n_out, self.act.kind, self.act.prm, drop.mask.ptr if drop is not None else None)
         elif drop is not None and not drop.injected and not drop.ready:
             # the mask is drawn inside the layer's own launch (and kept for the backward pass)
             self.ctx.call("tn_fc_fwd_dropout", self.inpt.ptr, self.w.ptr, self.b.ptr, self.output.ptr,
