@@ -479,6 +479,15 @@ typedef struct tn_pipe_seg {
 int tn_sgd_update_net(tn_ctx* ctx, int mode, const void* d_segs, const void* h_segs, int nseg, size_t max_n,
                       const float* d_lr, float gscale, uint32_t* d_step, uint32_t step_inc, int flags,
                       const float* rowloss, int nrow, float cost_scale, float* d_cost);
+/* tn_sgd_update_net followed by tn_maxnorm_multi(h_mn, nmn) -- the whole update expression of layer.py:82-103 -- as one
+ * call: in the TN_UPD_LAZY / TN_UPD_PIPE forms the update launch walks a 2-D max-norm tensor in tn_maxnorm's tiles and
+ * leaves its column sums of squares (same partial sums, same order: same bits), so the matrix is not read a second
+ * time; only the rescaling pass (which touches nothing while every column is within the bound) follows.  Tensors the
+ * walk cannot take, and the other modes, run the two calls back to back.  nmn <= 32.                               */
+int tn_sgd_update_net_maxnorm(tn_ctx* ctx, int mode, const void* d_segs, const void* h_segs, int nseg, size_t max_n,
+                              const float* d_lr, float gscale, uint32_t* d_step, uint32_t step_inc, int flags,
+                              const float* rowloss, int nrow, float cost_scale, float* d_cost, const tn_mn_seg* h_mn,
+                              int nmn);
 
 /* ---- elastic input stage (replaces ElasticLayer's graph; inlayers.py:63-144) ----
  * draws layout (float32, device): [0:2] translation u(-1,1) ; [2:4] origin u(.25,.75) ;

@@ -697,6 +697,56 @@ def test_maxnorm_multi_equals_per_tensor_calls():
         assert not mx or not np.array_equal(x.get_value(), h)
 
 
+@pytest.mark.parametrize("mode", ["lazy", "pipe", "pipe_first_steps", "plain"])
+def test_update_with_column_norm_rider_equals_update_then_maxnorm(mode):
+    """tn_sgd_update_net_maxnorm (layer.py:82-103 as one call; the update launch leaves the dense matrices' column sums
+    of squares) against tn_sgd_update_net + tn_maxnorm_multi: the same bits in weights and velocities, for tensors the
+    tile walk takes (columns % 4 == 0) and tensors it does not, with columns on both sides of the bound."""
+    from theanet_amd import _lib
+    rng = np.random.RandomState(11)
+    shapes = [(300, 132), (132,), (12, 3, 3, 3), (64, 130), (1030, 512), (512,)]
+    mxs = [2.0, 0.5, 1.0, 1.5, 3.0, 0.0]
+    P = [rng.randn(*sh).astype(np.float32) * (.1 if len(sh) == 2 else 1) for sh in shapes]
+    for w in P:
+        if w.ndim == 2:
+            w[:, ::3] *= 40.0                            # every third column far outside the bound
+    V = [rng.randn(*sh).astype(np.float32) * .1 for sh in shapes]
+    G = [rng.randn(*sh).astype(np.float32) for sh in shapes]
+    lr = dev(np.array([.1], np.float32))
+    res = []
+    for fused in (False, True):
+        p, v, g = [dev(x) for x in P], [dev(x) for x in V], [dev(x) for x in G]
+        p2 = [empty(sh) for sh in shapes]                # TN_UPD_PIPE: the stepping stream's own copy
+        if mode.startswith("pipe"):
+            dt = np.dtype([('p', 'u8'), ('psrc', 'u8'), ('v', 'u8'), ('g', 'u8'), ('n', 'u8'), ('m', 'f4'), ('rate', 'f4')])
+            segs = np.array([(b.ptr, a.ptr, c.ptr, d.ptr, h.size, .9, .5) for a, b, c, d, h in zip(p, p2, v, g, P)], dtype=dt)
+            out, m, flags = p2, _lib.TN_UPD_PIPE, 0 if mode == "pipe_first_steps" else 1
+        else:
+            dt = np.dtype([('p', 'u8'), ('v', 'u8'), ('g', 'u8'), ('n', 'u8'), ('m', 'f4'), ('rate', 'f4'), ('L1', 'f4'),
+                           ('L2', 'f4')])
+            segs = np.array([(a.ptr, c.ptr, d.ptr, h.size, .9, .5, .001, .002) for a, c, d, h in zip(p, v, g, P)], dtype=dt)
+            out, m, flags = p, _lib.TN_UPD_LAZY if mode == "lazy" else _lib.TN_UPD_PLAIN, 0
+        assert dt.itemsize == 48
+        dsegs = dev(segs.view(np.uint8))
+        mdt = np.dtype([('p', 'u8'), ('ndim', 'i4'), ('d0', 'i4'), ('rest', 'i4'), ('mx', 'f4')])
+        tab = np.array([(d.ptr, len(sh), sh[0], 1 if len(sh) == 1 else int(np.prod(sh[1:])), mx)
+                        for d, sh, mx in zip(out, shapes, mxs)], dtype=mdt)
+        args = (m, dsegs.ptr, segs.ctypes.data, len(segs), max(h.size for h in P), lr.ptr, 1.0, None, 0, flags, None, 0, 0.0,
+                None)
+        if fused:
+            call("tn_sgd_update_net_maxnorm", *args, tab.ctypes.data, len(tab))
+        else:
+            call("tn_sgd_update_net", *args)
+            call("tn_maxnorm_multi", tab.ctypes.data, len(tab))
+        res.append(([x.get_value() for x in out], [x.get_value() for x in v]))
+    for a, b, w, mx in zip(res[0][0], res[1][0], P, mxs):
+        assert np.array_equal(a, b)
+        if w.ndim == 2:                                  # (and the projection happened)
+            assert np.sqrt((a.astype(np.float64) ** 2).sum(0)).max() < mx * (1 + 1e-5)
+    for a, b in zip(res[0][1], res[1][1]):
+        assert np.array_equal(a, b)
+
+
 def test_dropout_mask_statistics_and_sharding_invariance():
     n = 4096 * 500
     m = empty((n,), np.uint8)

@@ -844,13 +844,16 @@ def test_graph_capture_of_abi_ops():
 
 
 @pytest.mark.parametrize("name,img,ch,B,dtype", [("mnist.prms", 28, 1, 64, "float32"), ("cifar_like.prms", 32, 3, 16, "float32"),
-                                                  pytest.param("cifar_like.prms", 32, 3, 16, "float16", id="cifar_like-f16")])
+                                                  pytest.param("cifar_like.prms", 32, 3, 16, "float16", id="cifar_like-f16"),
+                                                  ("wide6.prms", 16, 3, 4, "float32"),
+                                                  pytest.param("wide6.prms", 32, 3, 8, "float16", id="wide6-f16")])
 def test_fused_step_equals_separate_launches(monkeypatch, name, img, ch, B, dtype):
     """The sequential step's fusions -- weight-gradient slab sums and the minibatch cost inside the update launch
     (tn_sgd_update_net, TN_UPD_LAZY), the next minibatch's elastic field riding in the
     paired GEMM launch (DTYPE float16: in the dense layer's weight-gradient launch, fc8_wgrad_kernel) or built beside
     the update (tn_step_tail) -- are pure re-scheduling: against the generic schedule (NeuralNet.fused_step = False: one
-    launch per piece of work) costs, log-probabilities, gradients and weights match bit for bit."""
+    launch per piece of work) costs, log-probabilities, gradients and weights match bit for bit.  wide6.prms: the dense
+    matrix's column sums of squares for the max-norm projection are left by the update launch (tn_sgd_update_net_maxnorm)."""
     from theanet_amd import NeuralNet
     import copy
     prms = load_prms(name, img, batch=B)

@@ -139,6 +139,8 @@ SIGNATURES = {
                              P, c_uint64, P, c_int, c_int, c_double, c_double, c_double, c_int, c_double,
                              c_int, P, P, P, P]),
     "tn_sgd_update_net": (c_int, [CTX, c_int, P, P, c_int, c_size_t, P, c_float, P, c_uint32, c_int, P, c_int, c_float, P]),
+    "tn_sgd_update_net_maxnorm": (c_int, [CTX, c_int, P, P, c_int, c_size_t, P, c_float, P, c_uint32, c_int, P, c_int, c_float, P,
+                                          P, c_int]),
     "tn_softmax_cost_ws_bytes": (c_size_t, [c_int]),
     "tn_softmax_nll_cost": (c_int, [CTX, P, P, c_int64, P, P, P, P, P, P, c_int, c_int, c_float,
                                     c_float, P, P]),

@@ -1229,6 +1229,14 @@ int tn_maxnorm_multi(tn_ctx* ctx, const tn_mn_seg* h_segs, int nseg) {
     }
     return TN_OK;
 }
+// the update followed by the projection (layer.py:82-103 as one op; this library keeps them two passes)
+int tn_sgd_update_net_maxnorm(tn_ctx* ctx, int mode, const void* d_segs, const void* h_segs, int nseg, size_t max_n,
+                              const float* d_lr, float gscale, uint32_t* d_step, uint32_t step_inc, int flags,
+                              const float* rowloss, int nrow, float cost_scale, float* d_cost, const tn_mn_seg* h_mn, int nmn) {
+    int rc = tn_sgd_update_net(ctx, mode, d_segs, h_segs, nseg, max_n, d_lr, gscale, d_step, step_inc, flags, rowloss, nrow,
+                               cost_scale, d_cost);
+    return rc ? rc : tn_maxnorm_multi(ctx, h_mn, nmn);
+}
 
 }  // extern "C"
 

@@ -725,6 +725,7 @@ class NeuralNet():
             lyr.get_wtcost(self.d_cost)
         if rider:
             self._guard_cost()
+        mn_done = False
         if delayed:
             pass
         elif tail:
@@ -734,10 +735,11 @@ class NeuralNet():
                      self.d_cost.ptr if rider else None, first.draws.ptr, first.seed, self.d_step.ptr,
                      *field_args)
         elif lazy:
-            ctx.call("tn_sgd_update_net", _lib.TN_UPD_LAZY, self._d_segs.ptr, self._h_segs.ctypes.data, self._n_segs,
-                     self._max_seg, self.cur_learn_rate.ptr, 1.0, self.d_step.ptr, 1, 0,
-                     out.rowloss.ptr if rider else None, self.local_bsz, 1.0 / self.batch_sz,
-                     self.d_cost.ptr if rider else None)
+            self._update_and_maxnorm(_lib.TN_UPD_LAZY, self._d_segs.ptr, self._h_segs.ctypes.data, self._n_segs,
+                                     self._max_seg, self.cur_learn_rate.ptr, 1.0, self.d_step.ptr, 1, 0,
+                                     out.rowloss.ptr if rider else None, self.local_bsz, 1.0 / self.batch_sz,
+                                     self.d_cost.ptr if rider else None)
+            mn_done = True
         elif self._n_segs or rider:               # also advances the RNG step counter
             ctx.call("tn_sgd_update_net", _lib.TN_UPD_PLAIN, self._d_segs.ptr if self._n_segs else None, None,
                      self._n_segs, self._max_seg, self.cur_learn_rate.ptr, 1.0, self.d_step.ptr, 1, 0,
@@ -747,9 +749,20 @@ class NeuralNet():
             ctx.call("tn_add_u32", self.d_step.ptr, 1)
         if ahead:
             first._cur, first._pre_valid = nxt, True
-        self._apply_maxnorm_all()
+        if not mn_done:
+            self._apply_maxnorm_all()
         if self.dtype == 'float16':
             self._c8_stale()
+
+    def _update_and_maxnorm(self, *args):
+        """Layer.get_updates of every tensor (layer.py:70-107) as ONE call: tn_sgd_update_net + the max-norm projection,
+        the column sums of the dense matrices left by the update launch itself (tn_sgd_update_net_maxnorm)."""
+        tab = self._maxnorm_table()
+        if 0 < len(tab) <= 32 and os.environ.get("TN_MN_FUSED", "1") != "0":
+            self.ctx.call("tn_sgd_update_net_maxnorm", *args, tab.ctypes.data, len(tab))
+        else:
+            self.ctx.call("tn_sgd_update_net", *args)
+            self._apply_maxnorm_all()
 
     def _guard_cost(self):
         """In front of a launch that writes ``d_cost``: a step_cost() loop may still owe the host the previous value (a
@@ -806,6 +819,12 @@ class NeuralNet():
     def _apply_maxnorm_all(self):
         """layer.py:88-103 for every parameter of the net in ONE call (tn_maxnorm_multi: the biases and conv kernels
         share a launch; Layer.apply_maxnorm is the per-layer form of the same projection)."""
+        tab = self._maxnorm_table()
+        for i in range(0, len(tab), 32):
+            chunk = tab[i:i + 32]
+            self.ctx.call("tn_maxnorm_multi", chunk.ctypes.data, len(chunk))
+
+    def _maxnorm_table(self):
         tab = getattr(self, "_mn_tab", None)
         if tab is None:
             rows = []
@@ -819,9 +838,7 @@ class NeuralNet():
             dt = np.dtype([('p', 'u8'), ('ndim', 'i4'), ('d0', 'i4'), ('rest', 'i4'), ('mx', 'f4')])
             assert dt.itemsize == 24          # tn_mn_seg
             tab = self._mn_tab = np.array(rows, dtype=dt) if rows else np.zeros((0,), dt)
-        for i in range(0, len(tab), 32):
-            chunk = tab[i:i + 32]
-            self.ctx.call("tn_maxnorm_multi", chunk.ctypes.data, len(chunk))
+        return tab
 
     # ------------------------------------------------------------------------------
     def _check_images(self, x_data, y_data=None):

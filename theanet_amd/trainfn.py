@@ -447,12 +447,11 @@ class _PipeTrainFn:
         rider = X._cost_pending
         if rider:
             X._guard_cost()
-        ctx.call("tn_sgd_update_net", _lib.TN_UPD_PIPE, self._segs[k].ptr, self._hsegs[k].ctypes.data, self._nseg,
-                 self._max_seg, self._lr[k].ptr, 1.0, X.d_step.ptr, 2 if t >= 2 else 0, 1 if t >= 2 else 0,
-                 out.rowloss.ptr if rider else None, X.local_bsz, 1.0 / X.batch_sz,
-                 X.d_cost.ptr if rider else None)
+        X._update_and_maxnorm(_lib.TN_UPD_PIPE, self._segs[k].ptr, self._hsegs[k].ctypes.data, self._nseg,
+                              self._max_seg, self._lr[k].ptr, 1.0, X.d_step.ptr, 2 if t >= 2 else 0, 1 if t >= 2 else 0,
+                              out.rowloss.ptr if rider else None, X.local_bsz, 1.0 / X.batch_sz,
+                              X.d_cost.ptr if rider else None)
         X._cost_pending = False
-        X._apply_maxnorm_all()
         ctx.call("tn_event_record", self._ev[k])
 
     def sync_weights(self):
