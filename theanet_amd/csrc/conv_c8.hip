@@ -1320,7 +1320,17 @@ static int c8w_geometry(C8WG& g, int num_cus, bool pool, int tm = 1) {
     g.KG = cdiv(g.K, 32 * NFT);
     g.CG = NCT ? cdiv(g.C, 32 * NCT) : 1;
     g.NTILES = cdiv(g.N, g.NI) * g.RT;
-    int S = num_cus / (g.KG * g.CG);
+    // Sample slabs for HALF the CUs.  A block owns its CU (512 threads, up to 160 KB of LDS) and is bound by latencies and
+    // its fixed costs (prologue, 147 KB of slab through LDS), not by the matrix pipe: with two steps in flight the other
+    // stream's launches fill the CUs left free, every block amortises its fixed costs over twice the pixels, and the slabs
+    // written here and read back by the update halve (wide6: 189 MB per step).  Same count under every schedule (the
+    // slab order is part of the result's bits); one step at a time pays ~10 % for it.  TN_C8_WSLAB_DIV=1: every CU (A/B).
+    static int div_ = -1;
+    if (div_ < 0) {
+        const char* e = getenv("TN_C8_WSLAB_DIV");
+        div_ = e && atoi(e) > 0 ? atoi(e) : 2;
+    }
+    int S = num_cus / div_ / (g.KG * g.CG);
     if (S > g.NTILES) S = g.NTILES;
     if (S < 1) S = 1;
     g.tpb = cdiv(g.NTILES, S);
