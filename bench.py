@@ -261,6 +261,9 @@ def conv_roofline(ctx, net, fn, n_batches, nsteps, prms_name, dtype):
                "flops_per_step": fl}
         if f16:
             rec["frac_of_fp32_peak"] = ach / roofline.MFMA_F32_PEAK_TFLOPS
+            if "backward" in label:
+                rec["note"] = ("weight-gradient launches take half the CUs by design (DESIGN.md 4.3): timed alone here the "
+                               "other half idles, in the step the other stream's launches run there")
         if per_layer:
             rec["per_layer"] = per_layer
         recs.append(rec)
