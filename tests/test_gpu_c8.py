@@ -194,7 +194,8 @@ def _rowmap(C, HW):
     return np.where(ch < C, ch * HW + p, -1)
 
 
-@pytest.mark.parametrize("case", [(5, 16, 4, 32), (37, 24, 16, 96), (128, 40, 8, 160), (200, 64, 1, 64), (300, 128, 16, 512)])
+@pytest.mark.parametrize("case", [(5, 16, 4, 32), (37, 24, 16, 96), (128, 40, 8, 160), (200, 64, 1, 64), (300, 128, 16, 512),
+                                  (2000, 128, 16, 1024)])      # (the last: one K slab, the forward finishes its own outputs)
 def test_c8_fc_ops(case, f16_mode):
     """Dense products on a c8 input: W (C*HW, n_out) keeps the reference's NCHW-flattened row order (neuralnet.py:168-173)
     and is walked through the row map."""
@@ -215,11 +216,13 @@ def test_c8_fc_ops(case, f16_mode):
     assert _rel(a.get_value(), U.leaky(z, SLOPE) * mask) < 2e-5
     # the same product with the mask drawn in the launch: the bits of tn_dropout_mask, the masked output of the call above
     want, got_mask, a2 = empty((B * N,), np.uint8), empty((B * N,), np.uint8), empty((B, N))
-    call("tn_dropout_mask", want.ptr, B * N, .3, 99, 5, None, 1000)
-    call("tn_c8_fc_fwd_dropout", xd.ptr, Wd.ptr, bd.ptr, a2.ptr, B, C, HW, N, LEAKY, SLOPE, got_mask.ptr, .3, 99, 5, None, 1000)
-    assert np.array_equal(got_mask.get_value(), want.get_value())
-    call("tn_c8_fc_fwd", xd.ptr, Wd.ptr, bd.ptr, a.ptr, B, C, HW, N, LEAKY, SLOPE, want.ptr)
-    assert np.array_equal(a2.get_value(), a.get_value())
+    for elem0 in (1000, 1003):               # (1003: an output quad straddles two Philox blocks)
+        call("tn_dropout_mask", want.ptr, B * N, .3, 99, 5, None, elem0)
+        call("tn_c8_fc_fwd_dropout", xd.ptr, Wd.ptr, bd.ptr, a2.ptr, B, C, HW, N, LEAKY, SLOPE, got_mask.ptr, .3, 99, 5, None,
+             elem0)
+        assert np.array_equal(got_mask.get_value(), want.get_value())
+        call("tn_c8_fc_fwd", xd.ptr, Wd.ptr, bd.ptr, a.ptr, B, C, HW, N, LEAKY, SLOPE, want.ptr)
+        assert np.array_equal(a2.get_value(), a.get_value())
     dz = (rng.randn(B, N) * 1e-3).astype(np.float32)
     dz16 = U.r16(GS * dz)
     y = U.r16(rng.randn(B, Kc)); y[0, :3] = 0

@@ -89,6 +89,49 @@ __device__ __forceinline__ half4v fc8_cvt4(const fc8_f4 v) {
 // once and is bound by that (short batches) -- and one LDS tile at a time feeds the matrix core: x as stored
 // ([row][k], 16-byte reads), W converted to halfs as stored ([k][n]) and read through the transposing LDS read.
 // ---------------------------------------------------------------------------------------------------------------
+struct Fc8Drop {            // dropout drawn by the finishing kernel (tn_c8_fc_fwd_dropout): the numbers of tn_dropout_mask
+    uint8_t* mask_out;      // NULL: no inline dropout
+    float pdrop;
+    uint32_t k0, k1, step;
+    const uint32_t* d_step;
+    uint64_t elem0;
+};
+// bias + activation + dropout of FOUR consecutive outputs i .. i+3 of row-major (M, N) (i % 4 == 0: one bias quad): the
+// arithmetic of fc8_fwd_finish_kernel for one slab, used by the forward kernel itself when the product has one K slab
+__device__ __forceinline__ float4 fc8_finish4(float4 v, size_t i, int n, const float* __restrict__ bias,
+                                              const uint8_t* __restrict__ mask, int act, float prm, const Fc8Drop& dr) {
+    const float4 b4 = *reinterpret_cast<const float4*>(bias + n);
+    float x[4] = {0.f + v.x + b4.x, 0.f + v.y + b4.y, 0.f + v.z + b4.z, 0.f + v.w + b4.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) x[j] = act == TN_ACT_LEAKY ? fmaxf(0.f, x[j]) + fminf(0.f, x[j]) * prm : tn_act_fwd(x[j], act, prm);
+    if (dr.mask_out) {
+        const uint64_t e = dr.elem0 + i, cq = e >> 2;
+        const uint32_t st = dr.step + (dr.d_step ? *dr.d_step : 0u);
+        const u32x4 r0 = philox4x32((uint32_t)cq, (uint32_t)(cq >> 32), st, TN_STREAM_DROPOUT, dr.k0, dr.k1);
+        uint32_t w[8] = {r0.x, r0.y, r0.z, r0.w, 0u, 0u, 0u, 0u};
+        const int sh = (int)(e & 3);
+        if (sh) {                               // (elem0 not a multiple of 4: the quad straddles two Philox blocks)
+            const uint64_t c1 = cq + 1;
+            const u32x4 r1 = philox4x32((uint32_t)c1, (uint32_t)(c1 >> 32), st, TN_STREAM_DROPOUT, dr.k0, dr.k1);
+            w[4] = r1.x; w[5] = r1.y; w[6] = r1.z; w[7] = r1.w;
+        }
+        uint32_t m4 = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t wj = sh == 0 ? w[j] : sh == 1 ? w[j + 1] : sh == 2 ? w[j + 2] : w[j + 3];
+            const bool keep = tn_u01(wj) >= dr.pdrop;
+            m4 |= (keep ? 1u : 0u) << (8 * j);
+            x[j] = keep ? x[j] : 0.f;
+        }
+        *reinterpret_cast<uint32_t*>(dr.mask_out + i) = m4;
+    } else if (mask) {
+        const uint32_t m4 = *reinterpret_cast<const uint32_t*>(mask + i);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) x[j] = ((m4 >> (8 * j)) & 0xffu) ? x[j] : 0.f;
+    }
+    return make_float4(x[0], x[1], x[2], x[3]);
+}
+
 static int fc8_xcd_on() {             // TN_FC8_XCD=0: plain block decode (A/B)
     static int on = -1;
     if (on < 0) {
@@ -100,7 +143,10 @@ static int fc8_xcd_on() {             // TN_FC8_XCD=0: plain block decode (A/B)
 #define FC8_NST 4
 #define FC8F_XS 144         // x tile row stride (64 halfs + 16 bytes: 9 x 16 B, every 16-byte read of 32 rows on its own banks)
 #define FC8F_WS 192         // W tile row stride (64 halfs + 64 bytes = 64 (mod 128): the 4 rows of a transposing read on disjoint banks)
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void fc8_fwd_kernel(FC8 g) {
+// FIN: the product has ONE K slab and whole 64-column tiles: bias, activation and dropout happen on the way out and the
+// outputs go straight to g.out (no slab, no finishing launch)
+template <bool FIN>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void fc8_fwd_kernel(FC8 g, Fc8Drop dr) {
     __shared__ __attribute__((aligned(16))) char xs[128 * FC8F_XS];
     __shared__ __attribute__((aligned(16))) char wsm[64 * FC8F_WS];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, hi = lane >> 5;
@@ -190,7 +236,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 const int idx = lane + 64 * q, row = idx >> 3, c4 = idx & 7;
                 const int m = m0 + wm * 64 + 32 * i + row;
                 const float4 v = *reinterpret_cast<const float4*>(T + row * 32 + 4 * c4);
-                if (m < g.M) *reinterpret_cast<float4*>(wz + (size_t)m * g.N + n0 + wn * 32 + 4 * c4) = v;
+                const int nn = n0 + wn * 32 + 4 * c4;
+                if (FIN) {
+                    if (m < g.M)
+                        *reinterpret_cast<float4*>(g.out + (size_t)m * g.N + nn) =
+                            fc8_finish4(v, (size_t)m * g.N + nn, nn, g.bias, g.mask, g.act, g.prm, dr);
+                } else if (m < g.M) {
+                    *reinterpret_cast<float4*>(wz + (size_t)m * g.N + nn) = v;
+                }
             }
         }
         return;
@@ -206,13 +259,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
 // out = act(sum of the K slabs + bias) (* mask), slabs added in order; thread = one output (short batches: 128 x 1024
 // outputs are only 512 blocks even so -- with four outputs per thread the kernel ran on 128 blocks at 1.5 TB/s)
-struct Fc8Drop {            // dropout drawn by the finishing kernel (tn_c8_fc_fwd_dropout): the numbers of tn_dropout_mask
-    uint8_t* mask_out;      // NULL: no inline dropout
-    float pdrop;
-    uint32_t k0, k1, step;
-    const uint32_t* d_step;
-    uint64_t elem0;
-};
 __global__ __launch_bounds__(256) void fc8_fwd_finish_kernel(const float* __restrict__ ws, int S, size_t MN, int N,
                                                             const float* __restrict__ bias, const uint8_t* __restrict__ mask,
                                                             float* __restrict__ out, int act, float prm, Fc8Drop dr) {
@@ -528,10 +574,21 @@ static int fc8_fwd_run(tn_ctx* ctx, const void* x, const float* W, const float* 
     g.krange = cdiv(cdiv(g.Kc, S), 64) * 64;
     S = cdiv(g.Kc, g.krange);
     g.S = S;
+    g.xcd = fc8_xcd_on() && (S * rowg) % 8 == 0;
+    static int fin_on = -1;                // TN_FC8_FIN=0: the finishing launch also for one slab (A/B)
+    if (fin_on < 0) {
+        const char* e = getenv("TN_FC8_FIN");
+        fin_on = e ? atoi(e) : 1;
+    }
+    if (S == 1 && n_out % 64 == 0 && fin_on && (((uintptr_t)a | (uintptr_t)b | (uintptr_t)mask | (uintptr_t)dr.mask_out) & 15) == 0) {
+        g.bias = b; g.mask = mask; g.out = a; g.act = act; g.prm = act_param;
+        fc8_fwd_kernel<true><<<dim3(colg, 1, rowg), 256, 0, ctx->stream>>>(g, dr);
+        TN_LAUNCH_CHECK();
+        return TN_OK;
+    }
     rc = tn_scratch_get(ctx, (size_t)S * B * n_out * sizeof(float), &g.ws);
     if (rc) return rc;
-    g.xcd = fc8_xcd_on() && (S * rowg) % 8 == 0;
-    fc8_fwd_kernel<<<dim3(colg, S, rowg), 256, 0, ctx->stream>>>(g);
+    fc8_fwd_kernel<false><<<dim3(colg, S, rowg), 256, 0, ctx->stream>>>(g, dr);
     TN_LAUNCH_CHECK();
     const size_t MN = (size_t)B * n_out;
     fc8_fwd_finish_kernel<<<cdiv(MN, 256), 256, 0, ctx->stream>>>(g.ws, S, MN, n_out, b, mask, a, act, act_param, dr);
