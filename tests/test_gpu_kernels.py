@@ -747,6 +747,55 @@ def test_update_with_column_norm_rider_equals_update_then_maxnorm(mode):
         assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("mode", ["lazy", "pipe"])
+def test_update_column_norm_rider_sums_pending_slabs(mode):
+    """The tile walk of tn_sgd_update_net_maxnorm on a tensor whose gradient is still a stack of deferred split-K slabs
+    (tn_defer_reductions window + tn_fc_wgrad, 8 slabs of the 720 x 500 product): slab sum, update, column sums and
+    projection in the update's launches against the unfused calls -- gradient, velocity and weights bit for bit, the
+    gradient also against the float64 product."""
+    from theanet_amd import _lib
+    B, n_in, n_out = 4096, 720, 500
+    rng = np.random.RandomState(13)
+    x = rng.rand(B, n_in).astype(np.float32)
+    dz = (rng.randn(B, n_out) / B).astype(np.float32)
+    P = [rng.randn(n_in, n_out).astype(np.float32) * .05, rng.randn(n_out).astype(np.float32)]
+    P[0][:, ::3] *= 40.0
+    V = [rng.randn(*w.shape).astype(np.float32) * .1 for w in P]
+    xd, dzd, lr = dev(x), dev(dz), dev(np.array([.1], np.float32))
+    ws = empty((ctx().lib.tn_fc_wgrad_ws_bytes(B, n_in, n_out) // 4 + 1,))
+    res = []
+    for fused in (False, True):
+        p, v, g = [dev(w) for w in P], [dev(w) for w in V], [empty(w.shape) for w in P]
+        p2 = [empty(w.shape) for w in P]
+        if mode == "pipe":
+            dt = np.dtype([('p', 'u8'), ('psrc', 'u8'), ('v', 'u8'), ('g', 'u8'), ('n', 'u8'), ('m', 'f4'), ('rate', 'f4')])
+            segs = np.array([(b.ptr, a.ptr, c.ptr, d.ptr, h.size, .9, .5) for a, b, c, d, h in zip(p, p2, v, g, P)], dtype=dt)
+            out, m, flags = p2, _lib.TN_UPD_PIPE, 1
+        else:
+            dt = np.dtype([('p', 'u8'), ('v', 'u8'), ('g', 'u8'), ('n', 'u8'), ('m', 'f4'), ('rate', 'f4'), ('L1', 'f4'),
+                           ('L2', 'f4')])
+            segs = np.array([(a.ptr, c.ptr, d.ptr, h.size, .9, .5, 0., .002) for a, c, d, h in zip(p, v, g, P)], dtype=dt)
+            out, m, flags = p, _lib.TN_UPD_LAZY, 0
+        dsegs = dev(segs.view(np.uint8))
+        mdt = np.dtype([('p', 'u8'), ('ndim', 'i4'), ('d0', 'i4'), ('rest', 'i4'), ('mx', 'f4')])
+        tab = np.array([(out[0].ptr, 2, n_in, n_out, 2.0), (out[1].ptr, 1, n_out, 1, .5)], dtype=mdt)
+        call("tn_defer_reductions", 1)
+        call("tn_fc_wgrad", xd.ptr, dzd.ptr, g[0].ptr, g[1].ptr, B, n_in, n_out, ws.ptr)
+        args = (m, dsegs.ptr, segs.ctypes.data, 2, P[0].size, lr.ptr, 1.0, None, 0, flags, None, 0, 0.0, None)
+        if fused:
+            call("tn_sgd_update_net_maxnorm", *args, tab.ctypes.data, 2)
+        else:
+            call("tn_sgd_update_net", *args)
+            call("tn_maxnorm_multi", tab.ctypes.data, 2)
+        call("tn_defer_reductions", 0)
+        res.append([a.get_value() for a in out] + [a.get_value() for a in v] + [a.get_value() for a in g])
+    for a, b in zip(res[0], res[1]):
+        assert np.array_equal(a, b)
+    assert_close(res[1][4], x.astype(np.float64).T @ dz.astype(np.float64), atol=1e-5, what="dW from the slab stack")
+    assert np.sqrt((res[1][0].astype(np.float64) ** 2).sum(0)).max() < 2.0 * (1 + 1e-5)
+    assert not np.array_equal(res[1][0], P[0])
+
+
 def test_dropout_mask_statistics_and_sharding_invariance():
     n = 4096 * 500
     m = empty((n,), np.uint8)
