@@ -1330,7 +1330,9 @@ static int c8w_geometry(C8WG& g, int num_cus, bool pool, int tm = 1) {
         const char* e = getenv("TN_C8_WSLAB_DIV");
         div_ = e && atoi(e) > 0 ? atoi(e) : 2;
     }
-    int S = num_cus / div_ / (g.KG * g.CG);
+    // (first layers -- one octet plane, taps packed, a slab of a few KB -- keep every CU: cifar_like float16 0.3130 ->
+    // 0.3031 ms same-box against half)
+    int S = num_cus / (NCT == 0 ? 1 : div_) / (g.KG * g.CG);
     if (S > g.NTILES) S = g.NTILES;
     if (S < 1) S = 1;
     g.tpb = cdiv(g.NTILES, S);
