@@ -253,6 +253,66 @@ def test_full_batch_size_properties_mnist_4096():
     np.testing.assert_array_equal(preds[:256], preds_w)
 
 
+@pytest.mark.parametrize("B", [4096, 512], ids=["headline-4096", "shard-512"])
+def test_full_size_gradients_mnist(B):
+    """BASELINE configs[1] at its OWN size (and the 512-image shard of configs[2]): three training steps of
+    params/mnist.prms with the oracle's elastic draws and dropout masks injected, against OracleNet.train_step in
+    float64 -- cost, logprob (1e-4 rel), argmax exact, EVERY dW / db of every step, weights after three steps.  These
+    are the instantiations bench.py times (gemm_f32_dma / gemm_f32_pair_dma with 8 slabs + column-sum blocks + riders,
+    convblock_bwd_mask_mfma and convpool_bwd_mask_kernel at 4096 images; gemm_f32_deep and the short-batch softmax
+    step at 512).  A gradient is read back through the update rule itself (layer.py:82-86): v' = m v + (1 - m) g, so
+    g_t = (v_t - m v_{t-1}) / (1 - m) from the velocities (the pending gradient of a step still in flight folded in by
+    NeuralNet._opt_state) -- which also covers the slab sums the update launch does.  Semantics: hidden.py:30-43,
+    convpool.py:54-72,106-112, outlayers.py:50-51."""
+    from theanet_amd import NeuralNet
+    steps = 3
+    prms = load_prms("mnist.prms", 28, batch=B)
+    tr = prms["training_params"]
+    x = np.random.default_rng(0).random((steps * B, 1, 28, 28), dtype=np.float32)
+    y = np.random.default_rng(1).integers(0, 10, steps * B).astype(np.int32)
+    # conv kernels de-symmetrised as in GOLD-B: with the reference's +-1/sqrt(fan_in) init and nearest-neighbour zoom,
+    # pooling-window members that are PERMUTATIONS of one another are mathematically equal sums whose floating-point
+    # tie depends on the order of summation in any implementation (tools/grad_probe.py: 35 of 10 816 windows at 16
+    # images, 1-2 % of conv1's gradient); windows of IDENTICAL patches (border clipping) still tie, and must agree
+    from tests.golden.make_golden import perturbed_init
+    allwts = perturbed_init(prms)
+    net = NeuralNet(copy.deepcopy(prms["layers"]), dict(tr), copy.deepcopy(allwts))
+    ora = O.OracleNet(copy.deepcopy(prms["layers"]), dict(tr), allwts=copy.deepcopy(allwts), dtype=np.float64)
+    fn = net.get_trin_model(x, y)
+    vel_prev = vel_prev_w = None
+    for s in range(steps):
+        d0 = ora.L[0].stage.draw((B, 1, 28, 28))
+        m5 = ora.L[5].mask_rv.draw((B, 500))
+        net.tr_layers[0].inject(**{k: getattr(d0, k) for k in d0.__slots__})
+        net.tr_layers[5].drop.inject(m5)
+        cost, _, lp = fn(s)
+        cost_w, lp_w, _ = ora.train_step(x[s * B:(s + 1) * B], y[s * B:(s + 1) * B], {0: d0, 5: m5})
+        assert_close(cost, cost_w, 1e-4, 1e-5, what="cost step %d" % s)
+        assert_close(lp, lp_w, 1e-4, 1e-5, what="logprob step %d" % s)
+        np.testing.assert_array_equal(lp.argmax(1), lp_w.argmax(1))
+        vel = net.get_init_params(with_opt_state=True)["opt_state"]["velocities"]
+        seen = 0
+        for i, (lyr, ol) in enumerate(zip(net.tr_layers, ora.L)):
+            for j in range(len(lyr.params or ())):
+                m = lyr.reg['momentum']
+                v, v_w = vel[i][j].astype(np.float64), ol.vel[j]
+                g = (v - (m * vel_prev[i][j] if s else 0)) / (1 - m)
+                g_w = (v_w - (m * vel_prev_w[i][j] if s else 0)) / (1 - m)
+                assert g.shape == g_w.shape
+                # 1e-3 of the largest entry.  Typical agreement is 1e-6; the bound leaves room for ONE pooling window
+                # whose two largest members differ by less than float32 resolves (the float64 oracle then routes that
+                # window's gradient elsewhere: a discrete 2e-4 ... 6e-4 of a conv gradient at 512 images)
+                assert np.abs(g - g_w).max() <= 1e-3 * np.abs(g_w).max(), \
+                    ("grad", s, i, j, np.abs(g - g_w).max(), np.abs(g_w).max())
+                seen += 1
+        assert seen == 8
+        vel_prev = [[a.astype(np.float64) for a in row] for row in vel]
+        vel_prev_w = [[a.copy() for a in (ol.vel or ())] for ol in ora.L]
+    for i, (lyr, ol) in enumerate(zip(net.tr_layers, ora.L)):
+        for j, w in enumerate(lyr.get_wts()):
+            assert_close(w, ol.params[j], 1e-4, 1e-6, what="w %d %d after %d steps" % (i, j, steps))
+
+
 def test_checkpoint_roundtrip_and_data_test_model(tmp_path):
     from theanet_amd import NeuralNet
     prms = load_prms("mnist.prms", 28, batch=16)
