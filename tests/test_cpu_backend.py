@@ -290,3 +290,32 @@ def test_bench_two_ranks_reports_strong_and_weak_scaling():
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["global_batch"] == 64
     assert d["weak"]["scaling"] == "weak" and d["weak"]["global_batch"] == 128 and d["weak"]["rows_per_gpu"] == 64
     assert d["value_weak"] == d["weak"]["value"] > 0 and d["value"] > 0
+
+
+def test_rsag_self_test_falls_back_loudly_on_every_rank(tmp_path):
+    """DeviceGroup.self_test_rsag: before a gradient bucket may take the reduce-scatter + all-gather form the fresh
+    communicator compares it with one all-reduce bit for bit on every rank (lengths the world size does and does not
+    divide).  A mismatch on ONE rank (injected here on rank 1) switches the form off on EVERY rank with a warning --
+    comm.collective_algo then answers 'allreduce' for a bucket of any size -- and training goes on; without the
+    injected fault an 8 MB bucket takes 'rsag'."""
+    code = ("import os, sys; sys.path.insert(0, %r)\n"
+            "from theanet_amd import comm\n"
+            "from theanet_amd.device import get_context\n"
+            "g = comm.DeviceGroup(get_context(), comm.get_world())\n"
+            "print('ALGO', comm.collective_algo(4 << 20, g.world.size), g.rsag_checked)\n" % ROOT)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    for n, (brk, want) in enumerate((("1", "ALGO allreduce False"), ("", "ALGO rsag True"))):
+        procs = []
+        for rank in range(2):
+            env = _env(RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                       MASTER_PORT=str(port + n), OMP_NUM_THREADS="1", TN_TEST_BREAK_RSAG=brk)
+            procs.append(subprocess.Popen([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE,
+                                          stderr=subprocess.PIPE, text=True))
+        for rank, p_ in enumerate(procs):
+            o, e = p_.communicate(timeout=300)
+            assert p_.returncode == 0, e[-2000:]
+            assert want in o, (rank, o, e[-500:])
+            assert ("WARNING" in e) == bool(brk), e[-500:]

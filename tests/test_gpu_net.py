@@ -512,6 +512,42 @@ def test_step_cost_hands_out_every_cost_in_order(pipeline, monkeypatch):
             np.testing.assert_array_equal(wa, wb)
 
 
+@pytest.mark.parametrize("pipeline", ["1", "0"])
+def test_step_cost_loop_keeps_its_costs_across_plain_enqueues(pipeline, monkeypatch):
+    """A plain enqueue() / fn(i) in the MIDDLE of a step_cost() loop (the docstring says "do not", a caller may): the
+    costs the loop is still owed at that point (up to `lag` of them; two steps in flight: four) are collected then and
+    handed out by the next step_cost() / drain_costs() -- not dropped, a NaN among them would slip past the guard of
+    train.py:225.  Every step_cost() step's cost arrives once, in order, equal to fn(i)'s."""
+    from theanet_amd import NeuralNet
+    monkeypatch.setenv("TN_PIPELINE", pipeline)
+    prms = load_prms("mnist.prms", 28, batch=16)
+    rng = np.random.RandomState(6)
+    x = rng.rand(16 * 6, 1, 28, 28).astype(np.float32)
+    y = rng.randint(0, 10, 16 * 6).astype(np.int32)
+    ref_net = NeuralNet(copy.deepcopy(prms["layers"]), dict(prms["training_params"]))
+    ref_fn = ref_net.get_trin_model(x, y)
+    net = NeuralNet(copy.deepcopy(prms["layers"]), dict(prms["training_params"]))
+    fn = net.get_trin_model(x, y)
+    plan = ["c"] * 9 + ["e"] * 3 + ["c"] * 7 + ["f"] + ["c"] * 6 + ["e"] * 9 + ["c"] * 5
+    want, got = [], {}
+    for s, kind in enumerate(plan):
+        c = ref_fn(s % 6)[0]
+        if kind == "c":
+            want.append(c)
+            for k, v in fn.step_cost(s % 6):
+                assert k not in got
+                got[k] = v
+        elif kind == "e":
+            fn.enqueue(s % 6)
+        else:
+            assert fn(s % 6)[0] == c
+    for k, v in fn.drain_costs():
+        assert k not in got
+        got[k] = v
+    assert sorted(got) == list(range(len(want))), sorted(got)
+    np.testing.assert_array_equal(np.array([got[k] for k in range(len(want))], np.float32), np.array(want, np.float32))
+
+
 def test_take_index_list_mode():
     from theanet_amd import NeuralNet
     prms = load_prms("mnist.prms", 28, batch=8)
@@ -940,6 +976,42 @@ def test_fused_step_equals_separate_launches(monkeypatch, name, img, ch, B, dtyp
     for la, lb in zip(nets[0][0].tr_layers, nets[1][0].tr_layers):
         for wa, wb in zip(la.get_wts(), lb.get_wts()):
             np.testing.assert_array_equal(wa, wb)
+
+
+@pytest.mark.parametrize("img", [40, 47, 52])
+def test_elastic_field_rider_fits_the_kernel_it_rides_in(monkeypatch, img):
+    """The next minibatch's elastic field rides in the paired dense backward launch and works in that kernel's STATIC
+    LDS.  gemm_f32_pair_dma declares 17 408 bytes, the register form 20 480: a 47 x 47 field at sigma 8 needs 18.9 KB --
+    it must not ride in the DMA kernel (round 5: it did, wrote past the block's LDS and produced a silently wrong
+    field).  Whatever carries it, the run equals the unfused schedule bit for bit; 40 x 40 rides, 52 x 52 never did.
+    inlayers.py:77-118 (one field per minibatch)."""
+    from theanet_amd import NeuralNet
+    B = 2048
+    layers = [("ElasticLayer", {"img_sz": img, "num_maps": 1, "translation": 2, "zoom": 1.1, "magnitude": 30, "sigma": 8,
+                                "pflip": .02, "angle": 5, "nearest": True}),
+              ("HiddenLayer", {"n_out": 512, "actvn": "relu10"}),
+              ("HiddenLayer", {"n_out": 512, "pdrop": .5, "actvn": "relu05"}),
+              ("SoftmaxLayer", {"n_out": 10})]
+    tr = {"SEED": 7, "BATCH_SZ": B, "INIT_LEARNING_RATE": .05, "EPOCHS_TO_HALF_RATE": 1}
+    rng = np.random.RandomState(img)
+    x = rng.rand(2 * B, 1, img, img).astype(np.float32)
+    y = rng.randint(0, 10, 2 * B).astype(np.int32)
+    monkeypatch.setenv("TN_PIPELINE", "0")
+    runs = []
+    for fused in (True, False):
+        monkeypatch.setattr(NeuralNet, "fused_step", fused)
+        net = NeuralNet(copy.deepcopy(layers), dict(tr))
+        fn = net.get_trin_model(x, y)
+        outs = [fn(s % 2) for s in range(4)]
+        runs.append((outs, net.tr_layers[0].output.get_value(), [l.get_wts() for l in net.tr_layers]))
+    for (c0, _, l0), (c1, _, l1) in zip(runs[0][0], runs[1][0]):
+        assert c0 == c1
+        np.testing.assert_array_equal(l0, l1)
+    np.testing.assert_array_equal(runs[0][1], runs[1][1])          # the distorted minibatch itself
+    assert np.abs(runs[0][1] - x[B:2 * B]).max() > .1                # ... and it IS distorted
+    for wa, wb in zip(runs[0][2], runs[1][2]):
+        for a, b in zip(wa, wb):
+            np.testing.assert_array_equal(a, b)
 
 
 @pytest.mark.parametrize("name,img,ch,B", [("mnist.prms", 28, 1, 64), ("cifar_like.prms", 32, 3, 16),

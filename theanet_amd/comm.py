@@ -13,6 +13,7 @@ math and the rendezvous with world_size 2, and the host-buffer reduction through
 ``torch.distributed``'s gloo backend (``HostGroup``).
 """
 import os
+import sys
 import socket
 import struct
 import time
@@ -234,6 +235,11 @@ def agree(value, what="value", rdzv=None):
                            "the net from the same SEED / weights" % (what, lo, hi))
 
 
+# set (on every rank alike) when a communicator's start-up self-test found the reduce-scatter + all-gather form
+# unequal to one all-reduce: every bucket then keeps the plain all-reduce (DeviceGroup.self_test_rsag)
+_rsag_disabled = False
+
+
 def collective_algo(nfloats, world_size, env=None):
     """Which form a bucket's sum takes: 'rsag' = direct reduce-scatter + all-gather
     (tn_allreduce_sum_rsag) for buckets of TN_DP_RSAG_MIN_BYTES (default 8 MB) or more -- on the fully connected xGMI a
@@ -246,7 +252,7 @@ def collective_algo(nfloats, world_size, env=None):
     force = env.get("TN_DP_ALGO", "auto")
     if force in ("allreduce", "rsag"):
         return force
-    if world_size < 2:
+    if world_size < 2 or _rsag_disabled:
         return "allreduce"
     return "rsag" if 4 * int(nfloats) >= int(env.get("TN_DP_RSAG_MIN_BYTES", 8 << 20)) else "allreduce"
 
@@ -327,6 +333,72 @@ class DeviceGroup:
             for e in evs:
                 ctx.lib.tn_event_destroy(ctx.h, e)
         self.verify_order()
+        self.self_test_rsag(timeout)
+
+    def self_test_rsag(self, timeout=60.0):
+        """The reduce-scatter + all-gather form (tn_allreduce_sum_rsag: in-place ncclReduceScatter into the rank's own
+        slice, ncclAllGather, a small all-reduce for the n % world floats behind the slices) against ONE all-reduce of
+        the same vectors, on every rank, before any gradient bucket may take it: integer-valued rank-stamped data (sums
+        exact in any order, so a differing BIT is a wrong offset or count, not a rounding), lengths that the world size
+        does and does not divide, on the compute stream and on the communication stream behind an event.  A mismatch
+        on ANY rank switches the form off on EVERY rank (comm.collective_algo then answers 'allreduce'
+        for every bucket) with a loud message -- it does not raise: the plain all-reduce just passed its own test.
+        TN_DP_ALGO=rsag still forces the form."""
+        import ctypes
+        global _rsag_disabled
+        ctx, R, r = self.ctx, self.world.size, self.world.rank
+        if R < 2 or os.environ.get("TN_DP_ALGO", "auto") == "allreduce":
+            return True
+        ok, why = 1.0, ""
+        cpu = ctx.backend == "cpu"
+        ev = ctypes.c_void_p()
+        if not cpu:
+            ctx.call("tn_event_create", ctypes.byref(ev))
+        try:
+            for n, on_comm in ((R * 1024, False), (R * 1024 + R - 1, False), (5 * R + 3, True), (3, False),
+                               (R * 4096 + 1, True)):
+                pat = ((np.arange(n) * 7 + 3) % 251).astype(np.float32)
+                src = (r + 1) * pat + r
+                a, b = ctx.array(src), ctx.array(src)
+                if cpu:
+                    self.rdzv.allreduce_host(self._host_view(a, n), "sum")
+                    self.rdzv.rsag_host(self._host_view(b, n))
+                else:
+                    ctx.call("tn_allreduce_sum", a.ptr, n)
+                    if on_comm:
+                        ctx.call("tn_allreduce_sum_rsag", b.ptr, n, 1, ev)
+                        done, t0 = ctypes.c_int(0), time.time()
+                        while not done.value:
+                            ctx.call("tn_event_query", ev, ctypes.byref(done))
+                            if time.time() - t0 > timeout:
+                                raise RuntimeError("theanet_amd: communicator self-test timed out after %.0f s on rank %d of "
+                                                   "%d: reduce-scatter + all-gather of %d floats on the communication "
+                                                   "stream did not finish (set TN_DP_ALGO=allreduce to skip the form)"
+                                                   % (timeout, r, R, n))
+                            time.sleep(0.002)
+                    else:
+                        ctx.call("tn_allreduce_sum_rsag", b.ptr, n, 0, None)
+                    ctx.sync()
+                want = (R * (R + 1) / 2.0) * pat + R * (R - 1) / 2.0
+                ga, gb = a.get_value(), b.get_value()
+                if os.environ.get("TN_TEST_BREAK_RSAG") == str(r) and n > 8:     # (tests: a wrong offset on one rank)
+                    gb = np.roll(gb, 1)
+                if not np.array_equal(ga, want.astype(np.float32)):
+                    raise RuntimeError("theanet_amd: all-reduce of %d floats is wrong on rank %d of %d" % (n, r, R))
+                if ok and not np.array_equal(gb, ga):       # (no early exit: the ranks stay in step through every case)
+                    bad = int(np.argmax(gb != ga))
+                    ok, why = 0.0, "%d floats: element %d is %r, one all-reduce gives %r" % (n, bad, float(gb[bad]), float(ga[bad]))
+        finally:
+            if not cpu:
+                ctx.lib.tn_event_destroy(ctx.h, ev)
+        all_ok = -self.rdzv.gather_max(-ok)          # the minimum over ranks
+        if all_ok < 1.0:
+            _rsag_disabled = True
+            print("theanet_amd: WARNING: the reduce-scatter + all-gather all-reduce failed its start-up check%s; every "
+                  "gradient bucket keeps one ncclAllReduce (TN_DP_ALGO=allreduce)" %
+                  ((" on this rank (rank %d: %s)" % (r, why)) if not ok else " on another rank"), file=sys.stderr, flush=True)
+        self.rsag_checked = all_ok >= 1.0
+        return self.rsag_checked
 
     def _note(self, kind, count):
         self.n_issued += 1

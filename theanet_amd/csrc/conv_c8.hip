@@ -1562,7 +1562,8 @@ static int c8_current_cus() {
     return n;
 }
 int tn_c8_conv_wgrad_supported(int N, int C, int H, int Wd, int K) {
-    static const int cus = c8_current_cus();
+    const int cus = c8_current_cus();       // (asked every time: the answer must follow the device that is current NOW;
+                                            //  what the check reads -- LDS bytes, DMA chunks per stage -- does not depend on it)
     C8WG g{};
     g.N = N; g.C = C; g.C8 = (C + 7) / 8; g.H = H; g.Wd = Wd; g.K = K; g.K8 = K / 8;
     if ((K & 7) || !c8w_geometry(g, cus, true) || c8w_ngx(g) > 5) return 0;

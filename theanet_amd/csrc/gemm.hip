@@ -1160,8 +1160,10 @@ static void launch_gemm(tn_ctx* ctx, GemmArgs& g, int S) {
         // two blocks per CU or fewer: the deep ring; else four stages
         const int ns = nsf ? nsf : (nb <= 2 * ctx->num_cus ? 8 : 4);
         if (dbg_on) {
-            if (!gemm_dbg_buf) (void)hipMalloc(&gemm_dbg_buf, 8 * sizeof(unsigned long long) * 65536);
-            (void)hipMemsetAsync(gemm_dbg_buf, 0, 8 * sizeof(unsigned long long) * 65536, ctx->stream);
+            // (cycle stamps: 8 words per wave, 4 waves per block, 65536 records)
+            TN_REQUIRE(grid * 4 <= 65536, "TN_GEMM_DBG: %d blocks do not fit the stamp buffer", grid);
+            if (!gemm_dbg_buf) TN_HIP(hipMalloc(&gemm_dbg_buf, 8 * sizeof(unsigned long long) * 65536));
+            TN_HIP(hipMemsetAsync(gemm_dbg_buf, 0, 8 * sizeof(unsigned long long) * 65536, ctx->stream));
             g.dbg = gemm_dbg_buf;
             if (ns == 8) gemm_f32_dma<AKC, BKC, 8, true><<<grid, 256, pad, ctx->stream>>>(g, nb);
             else if (ns == 2) gemm_f32_dma<AKC, BKC, 2, true><<<grid, 256, pad, ctx->stream>>>(g, nb);
@@ -1661,7 +1663,20 @@ int tn_fc_bwd(tn_ctx* ctx, const float* x, const float* dz, const float* W, floa
             int nrider = 0;
             size_t rlds = 0;
             ElField rider{};
-            if (ctx->rider_valid && ctx->rider_lds <= sizeof(float) * gemm_smem_floats<1, 1, 16>()) {
+            static int pns = -1;
+            if (pns < 0) {
+                const char* e = getenv("TN_PAIR_DMA");      // ring stages * 10 + waves per SIMD (experiments)
+                pns = e ? atoi(e) : 26;
+            }
+            const bool use_dma = gemm_dma_ok<false, false>(g1, Sx) && gemm_dma_ok<true, true>(g2, 1);
+            // the rider works in the STATIC LDS of the kernel that is launched: the DMA form declares its ring
+            // (gemm_dma_smem_floats<NS>: 17 408 bytes at two stages), the register form 20 480 bytes -- a field that needs
+            // more than the chosen kernel has runs standalone (tn_elastic_field) instead of riding
+            const size_t rider_cap = sizeof(float) * (!use_dma ? (size_t)gemm_smem_floats<1, 1, 16>()
+                                                      : pns / 10 >= 8 ? (size_t)gemm_dma_smem_floats<8>()
+                                                      : pns / 10 >= 4 ? (size_t)gemm_dma_smem_floats<4>()
+                                                                      : (size_t)gemm_dma_smem_floats<2>());
+            if (ctx->rider_valid && ctx->rider_lds <= rider_cap) {
                 rider = ctx->rider;
                 nrider = cdiv(rider.h * rider.w, 4);
                 rlds = 0;                                  // the rider works in the tile's static LDS
@@ -1688,13 +1703,8 @@ int tn_fc_bwd(tn_ctx* ctx, const float* x, const float* dz, const float* W, floa
                     if (n1 + n2 <= 8 * ctx->num_cus) rlds += 8192;
                 }
             }
-            if (gemm_dma_ok<false, false>(g1, Sx) && gemm_dma_ok<true, true>(g2, 1)) {
+            if (use_dma) {
                 const int ncs = Sx * g1.NT;
-                static int pns = -1;
-                if (pns < 0) {
-                    const char* e = getenv("TN_PAIR_DMA");      // ring stages * 10 + waves per SIMD (experiments)
-                    pns = e ? atoi(e) : 26;
-                }
                 const int grid = n1 + n2 + ncs + nrider;
 #define TN_PAIR_CASE(NS_, W_) case NS_ * 10 + W_: gemm_f32_pair_dma<false, false, true, true, NS_, W_><<<grid, 256, rlds, ctx->stream>>>(g1, g2, n1, n2, ncs, rider); break;
                 switch (pns) {

@@ -384,6 +384,16 @@ class NeuralNet():
                 # replicas must start from identical weights (same SEED or same checkpoint on every rank)
                 chk = float(sum(np.float64(w.astype(np.float64).sum()) for l in self.tr_layers for w in l.get_wts()))
                 comm.agree(chk, "the initial weights (checksum)")
+                # The ORDER in which partial sums are added is part of a gradient's bits, and replicas must stay
+                # bit-identical: the process-static knobs that set slab counts / kernel forms and the CU count the slab
+                # geometry is cut for must be the same on every rank (a rank with another TN_C8_WSLAB_DIV or another
+                # device would round differently, silently)
+                import zlib
+                knobs = ("TN_C8_WSLAB_DIV", "TN_C8_ROLL", "TN_FC8_WSLABS", "TN_FC_WSPLIT", "TN_FC_DGRAD_SPLIT", "TN_GEMM_DEEP",
+                         "TN_GEMM_DMA", "TN_GEMM_DMA_NS", "TN_PAIR_DMA", "TN_CONVPOOL_KS", "TN_SOFTMAX_TRAIN", "TN_FC_SKINNY",
+                         "TN_CB_W44", "TN_POOL_MASK", "TN_ELASTIC_CONV", "TN_MN_FUSED", "TN_FC8_FIN", "TN_FC8_XCD")
+                sig = "|".join("%s=%s" % (k, os.environ.get(k, "")) for k in knobs) + "|cus=%s" % self.ctx.info()[1]
+                comm.agree(float(zlib.crc32(sig.encode())), "the kernel tunables / CU count (%s)" % sig)
         # Optional overlap of the gradient all-reduce with the backward pass (TN_DP_OVERLAP=1): the
         # fully-connected layers sit on top of the net and hold almost all parameters; their gradients
         # (the tail of the flat buffer, cost included) are reduced on the second stream while the conv

@@ -123,7 +123,7 @@ class _TrainFn:
         # the step as one C call once its calls have been seen to repeat (plan.py); index-list batches upload per step
         self._plan = None if take_index_list else StepPlan(ctx, net.batch_sz, net.shard_lo)
         self._ring, self._n = None, 0          # step_cost(): costs read two calls late; steps enqueued so far
-        self._sc_n = 0
+        self._sc_n, self._owed = 0, []
 
     def _plan_state(self):
         net = self.net
@@ -144,7 +144,7 @@ class _TrainFn:
             r.sent_upto = self._n + 1
             if not r.strict:
                 r.stale = True
-                r.next_take = max(r.next_take, self._n + 2 - r.R)
+                r.next_take = max(r.next_take, self._n + 1 - r.R)      # (as send(): the last R steps stay)
             net._cost_guard_ev = r.ev[self._n % r.R]
         self._n += 1
 
@@ -161,6 +161,13 @@ class _TrainFn:
                                  % (self.net.batch_sz, self.x_data.shape[0]))
         else:
             _batch_in_range(i, self.x_data.shape[0], self.net.batch_sz)
+        r = self._ring
+        if r is not None and not r.strict and self._n == getattr(self, "_sc_hi", -1) and r.next_take < self._n:
+            # a plain enqueue() / fn(i) in the middle of a step_cost() loop: the costs that loop is still owed are
+            # collected NOW (the ring only keeps the last R steps) and handed out by the next step_cost() / drain_costs()
+            # -- dropped, a NaN among them would slip past train.py's guard (train.py:225)
+            self._owed += self._ring_rest(keep=True)
+            r.stale = True                        # (the next step_cost() call starts its numbering behind the plain steps)
         pl = self._plan
         if pl is not None and not pl.off:
             ok = self._plannable()
@@ -223,8 +230,9 @@ class _TrainFn:
         """Enqueue step i; return [(step number, cost), ...] of the steps whose cost has become due (step numbers count
         the step_cost calls since the last drain_costs()).  Do not mix with enqueue() / fn(i) before drain_costs()."""
         net = self.net
+        pre, self._owed = self._owed, []
         if net._dp_delayed or net._dp_tune is not None or self.take_index_list or net._injecting():
-            out = self._ring_rest()                   # (the cost travels on the second stream / per-step host work)
+            out = pre + self._ring_rest()             # (the cost travels on the second stream / per-step host work)
             out.append((self._sc_n, np.float32(self(i)[0])))
             self._sc_n += 1
             return out
@@ -234,9 +242,9 @@ class _TrainFn:
             self._ring_base = self._n - self._sc_n
             if self._plan is not None:
                 self._plan.restart("cost ring on")
-        r, out = self._ring, []
+        r, out = self._ring, pre
         if r.stale:                               # plain enqueue() calls in between: their costs are nobody's
-            r.next_take = r.sent_upto = self._n
+            r.next_take = r.sent_upto = self._n   # (what step_cost() calls before them were owed is in `pre`)
             self._ring_base = self._n - self._sc_n
             r.stale = False
         if self._n - r.next_take >= r.lag:
@@ -247,6 +255,7 @@ class _TrainFn:
         finally:
             r.strict = False
         self._sc_n += 1
+        self._sc_hi = self._n                     # (a plain enqueue() right behind this step finds the loop's costs owed)
         return out
 
     def _ring_rest(self, keep=False):
@@ -271,7 +280,8 @@ class _TrainFn:
         """The costs step_cost() has not handed out yet, in order; afterwards step numbers start from 0 again.  train.py
         calls this at the end of every epoch: ring and plan survive it (an epoch of mnist.prms at batch 4096 is 12
         steps -- fewer than it takes to watch and record a step)."""
-        out = self._ring_rest(keep=True)
+        out, self._owed = self._owed, []
+        out += self._ring_rest(keep=True)
         self._sc_n = 0
         if self._ring is not None:
             self._ring_base = self._n
@@ -420,7 +430,7 @@ class _PipeTrainFn:
             r.sent_upto = self.t - 1              # (the replayed step has sent the cost of step t - 2)
             if not r.strict:
                 r.stale = True
-                r.next_take = max(r.next_take, self.t - r.R)
+                r.next_take = max(r.next_take, self.t - 1 - r.R)       # (as send(): the last R sent steps stay)
             self.nets[self.t & 1]._cost_guard_ev = r.ev[(self.t - 2) % r.R]
         self.t += 1
 
@@ -510,6 +520,12 @@ class _PipeTrainFn:
     # -- the step ---------------------------------------------------------------------------------
     def enqueue(self, i):
         _batch_in_range(i, self.x_data.shape[0], self.net.batch_sz)
+        r = self._ring
+        if r is not None and self._seq is None and not r.strict and self.t == getattr(self, "_sc_hi", -1) and r.next_take < self.t:
+            # a plain enqueue() / fn(i) in the middle of a step_cost() loop: what that loop is still owed is collected now
+            # (as at the end of an epoch) instead of being dropped -- see _TrainFn.enqueue
+            self._owed = self._owed + self._leave_ring(keep=True)
+            r.stale = True                        # (the next step_cost() call starts its numbering behind the plain steps)
         pl = self._plan
         if pl is None or pl.off:
             return self._enqueue(i)
@@ -605,6 +621,7 @@ class _PipeTrainFn:
         finally:
             r.strict = False
         self._count()
+        self._sc_hi = self.t                      # (a plain enqueue() right behind this step finds the loop's costs owed)
         return pre + out
 
     def _count(self):
