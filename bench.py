@@ -135,7 +135,7 @@ def plan_batches(prms_name, batch, scaling, world_size):
     return base * world_size, base, "weak"
 
 
-def build(prms_name, global_batch, per_gpu, img, dtype, group=None):
+def build(prms_name, global_batch, per_gpu, img, dtype, group=None, n_batches=None):
     from theanet_amd import NeuralNet
     prms = load_prms(prms_name)
     prms["_name"] = prms_name
@@ -153,7 +153,8 @@ def build(prms_name, global_batch, per_gpu, img, dtype, group=None):
     net = NeuralNet(copy.deepcopy(prms["layers"]), dict(tr))
     if group is not None:
         net._dev_group = group              # a second net of the same launch: ONE communicator per process
-    n_batches = max(2, 65536 // global_batch) if per_gpu * img * img * C < (1 << 24) else 2
+    if n_batches is None:
+        n_batches = max(2, 65536 // global_batch) if per_gpu * img * img * C < (1 << 24) else 2
     x, y = synthetic(n_batches * global_batch, C, img)
     fn = net.get_trin_model(x, y)
     return prms, tr, net, fn, n_batches, img, C
@@ -318,6 +319,51 @@ def other_config_leg(ctx, prms_name, dtype, steps):
     return rec
 
 
+def shard_leg(ctx, steps, rows=512):
+    """What ONE rank of BASELINE configs[2] does per step (mnist.prms, batch 4096 sharded 8 ways = 512 rows), timed on
+    this GPU through the data-parallel code path: TN_DP_FORCE=1 builds the net with a 1-rank RCCL communicator, so the
+    step is the N > 1 step -- two steps in flight, the gradient bucket's ncclAllReduce on the communication stream, the
+    update waiting for its event -- with the collective's launch cost inside and its wire time absent.  The ratio
+    t(4096 rows) / t(512 rows) is the CEILING of the 8-GPU strong-scaling factor (a free interconnect); no scaling
+    curve is measured here."""
+    import gc
+    old = os.environ.get("TN_DP_FORCE")
+    os.environ["TN_DP_FORCE"] = "1"
+    try:
+        prms, tr, net, fn, n_batches, img, C = build("mnist.prms", rows, rows, 0, "f32")
+        n_setup = settle(ctx, fn, n_batches, None, 0.15)
+        ctx.sync()
+        t0 = time.perf_counter()
+        for i in range(16):
+            fn.enqueue(i % n_batches)
+        ctx.sync()
+        est = (time.perf_counter() - t0) / 16
+        n = int(max(steps, min(6000, 0.3 / max(est, 1e-6))))
+        ctx.sync()
+        t0 = time.perf_counter()
+        for i in range(n):
+            fn.enqueue(i % n_batches)
+        ctx.sync()
+        dt = time.perf_counter() - t0
+        cost = float(fn.fetch()[0])
+        assert np.isfinite(cost), "training diverged (shard leg)"
+        rec = {"cfg": "mnist.prms", "rows": rows, "dtype": "f32", "ms_per_step": round(1e3 * dt / n, 5), "steps": n,
+               "setup_steps": n_setup, "value": rows * n / dt,
+               "schedule": "two steps in flight" if type(fn).__name__ == "_PipeTrainFn" and fn._twin is not None
+               else "one step at a time",
+               "dp": "1-rank RCCL communicator (TN_DP_FORCE=1): %s schedule, %d collective(s) per step on the communication "
+                     "stream" % (getattr(net, "dp_schedule", "?"), 2 if getattr(net, "_dp_bucket", None) is not None else 1),
+               "what": "one rank's share of BASELINE configs[2] (batch 4096 sharded 8 ways), wire time absent"}
+        del fn, net
+        gc.collect()
+        return rec
+    finally:
+        if old is None:
+            os.environ.pop("TN_DP_FORCE", None)
+        else:
+            os.environ["TN_DP_FORCE"] = old
+
+
 DTYPE_LABEL = {"f32": "f32", "f16": "f16 (fp16 tensors and MFMA operands, fp32 accumulate, fp32 master weights)",
                "b3": "f32 tensors; dense products as six bf16 MFMA products of exactly split operands (MATMUL 'bf16x3', opt-in)"}
 
@@ -376,6 +422,92 @@ def dry_multi(args):
                                 "--master-port P bench.py --gpus %d --steps K --warmup W" % (N, N)}))
 
 
+SELFCHECK_PLAIN = {"TN_PIPELINE": "0", "TN_DP_PIPELINE": "0", "TN_DP_BUCKETS": "0", "TN_DP_ALGO": "allreduce", "TN_DP_OVERLAP": "0"}
+
+
+def dp_selfcheck_child():
+    """One rank of the start-up check of an N > 1 run (its own process and communicator, so that a hang here cannot hang
+    the benchmark): cifar_like.prms (two gradient buckets) at 8 rows per rank, 6 steps under the DEFAULT schedule -- two
+    steps in flight, the buckets on the communication stream, every bucket forced into its reduce-scatter + all-gather
+    form -- and 6 steps under the PLAIN one (one step at a time, one ncclAllReduce after the backward pass) from the same
+    SEED, device RNG on.  Replicas must agree bit for bit within a schedule (comm.agree raises otherwise); the two
+    schedules sum in different orders, so their weight checksums are compared to 1e-5.  Rank 0 prints the record (one
+    line starting with "{": the only kind this script lets through to its stdout)."""
+    from theanet_amd import comm
+    world = comm.get_world()
+    hang = os.environ.get("TN_TEST_SELFCHECK_HANG")
+    sums = {}
+    for label, env in (("default", {"TN_DP_RSAG_MIN_BYTES": "4096"}), ("plain", SELFCHECK_PLAIN)):
+        saved = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            gb = 8 * world.size
+            prms, tr, net, fn, n_batches, img, C = build("cifar_like.prms", gb, 8, 0, "f32", n_batches=6)
+            for i in range(6):
+                fn.enqueue(i % n_batches)
+                if hang is not None and int(hang) == world.rank and label == "default" and i == 3:
+                    time.sleep(3600)            # (tests: a rank that stops issuing collectives)
+            cost = float(fn.fetch()[0])
+            chk = float(sum(np.float64(w.astype(np.float64).sum()) for l in net.tr_layers for w in l.get_wts()))
+            comm.agree(chk, "the weights after 6 steps of the %s schedule (checksum)" % label, net._group().rdzv)
+            net._group().verify_order()
+            sums[label] = {"checksum": chk, "cost": cost, "schedule": str(getattr(net, "dp_schedule", "?")),
+                           "collectives": net._group().n_issued}
+            del fn, net
+        finally:
+            for k, v in saved.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+    a, b = sums["default"]["checksum"], sums["plain"]["checksum"]
+    ok = abs(a - b) <= 1e-5 * max(1.0, abs(b)) and np.isfinite(a)
+    if world.rank == 0:
+        print(json.dumps({"selfcheck": {"ok": bool(ok), "rel_diff": abs(a - b) / max(1.0, abs(b)), **sums}}), flush=True)
+    return 0 if ok else 3
+
+
+def dp_selfcheck(world):
+    """N > 1, before this process touches the GPU: every rank runs dp_selfcheck_child() in a CHILD process (rendezvous on
+    MASTER_PORT + 110) and waits for it at most TN_BENCH_SELFCHECK_TIMEOUT seconds (default 180).  A child that fails,
+    disagrees or does not come back (it is killed by its exact pid) on ANY rank makes EVERY rank fall back, loudly, to
+    the plain schedule for the measured run.  Returns the record for the JSON line (`dp_selfcheck`)."""
+    import subprocess
+    from theanet_amd import comm
+    if os.environ.get("TN_BENCH_SELFCHECK", "1") == "0":
+        return {"ok": None, "skipped": "TN_BENCH_SELFCHECK=0"}
+    limit = float(os.environ.get("TN_BENCH_SELFCHECK_TIMEOUT", 180))
+    env = dict(os.environ, MASTER_PORT=str(world.master_port + 110))
+    t0 = time.perf_counter()
+    child = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--dp-selfcheck-child"], env=env,
+                             stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    rec, why = None, ""
+    try:
+        out, err = child.communicate(timeout=limit)
+        for l in out.splitlines():
+            if l.startswith("{") and '"selfcheck"' in l:
+                rec = json.loads(l)["selfcheck"]
+        if child.returncode != 0:
+            why = "rank %d: the check exited with %d: %s" % (world.rank, child.returncode, (err or out)[-300:].replace("\n", " | "))
+    except subprocess.TimeoutExpired:
+        child.kill()
+        child.communicate()
+        why = "rank %d: the check did not finish within %.0f s (killed)" % (world.rank, limit)
+    bad = comm.get_rendezvous().gather_max(1.0 if why else 0.0)
+    out = {"ok": not bad, "seconds": round(time.perf_counter() - t0, 1), "what": "cifar_like.prms, 8 rows per rank, 6 steps: "
+           "pipelined + bucketed + reduce-scatter/all-gather on the communication stream against one step at a time with "
+           "one all-reduce, same SEED; replicas bit-identical within a schedule, checksums of the two schedules to 1e-5"}
+    if rec:
+        out.update({k: rec[k] for k in ("rel_diff", "default", "plain") if k in rec})
+    if bad:
+        out["error"] = why or "another rank's check failed or timed out"
+        out["fallback"] = "plain schedule for the measured run: " + " ".join("%s=%s" % kv for kv in SELFCHECK_PLAIN.items())
+        os.environ.update(SELFCHECK_PLAIN)
+        print("bench.py: WARNING: the data-parallel self-check FAILED (%s): the measured run uses the plain schedule "
+              "(one step at a time, one ncclAllReduce per step)" % out["error"], file=sys.stderr, flush=True)
+    return out
+
+
 REAL_STDOUT_FD = None        # the launcher's stdout (set under __main__: fd 1 itself is pointed at stderr for the run)
 
 
@@ -404,7 +536,10 @@ def main():
                     help="one step at a time (TN_PIPELINE=0) instead of two steps in flight")
     ap.add_argument("--time-op", default="", help="C-ABI function to bracket with HIP events, "
                     "e.g. tn_fc_wgrad:1 (nth call inside a step)")
+    ap.add_argument("--dp-selfcheck-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.dp_selfcheck_child:
+        sys.exit(dp_selfcheck_child())
 
     from theanet_amd import comm, roofline
     from theanet_amd.device import get_context
@@ -416,6 +551,31 @@ def main():
     world = comm.get_world()
     assert world.size == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
     global_batch, per_gpu, scaling = plan_batches(args.prms, args.batch, args.scaling, world.size)
+    selfcheck = dp_selfcheck(world) if world.size > 1 else None
+
+    # N > 1: a rank stuck in a collective is not an exception.  A watchdog thread (ctypes calls release the interpreter
+    # lock) prints whatever has been measured so far -- with "error": "rank stuck in <phase>" -- and leaves, so that the
+    # first multi-GPU run yields a line whatever happens.  TN_BENCH_TIMEOUT seconds (default 600) for everything up to
+    # and including the train-loop leg.
+    import threading
+    progress = {"phase": "building the net", "line": None}
+
+    def stuck():
+        ph = progress["phase"]
+        if world.rank == 0:
+            rec = progress["line"] or {"metric": "training images/sec (fwd+bwd+update) MNIST-CNN bs4096, 1/2/4/8 MI355X",
+                                       "value": None, "unit": "images/sec", "n_gpus": world.size, "steps": args.steps,
+                                       "warmup": args.warmup, "higher_is_better": True, "scaling": scaling}
+            rec = dict(rec, error="rank stuck in: %s (no progress within %s s; TN_BENCH_TIMEOUT)" % (ph, limit_main),
+                       dp_selfcheck=selfcheck)
+            os.write(REAL_STDOUT_FD if REAL_STDOUT_FD is not None else 1, (json.dumps(rec) + "\n").encode())
+        os._exit(0 if progress["line"] else 4)
+
+    limit_main = float(os.environ.get("TN_BENCH_TIMEOUT", 600))
+    dog_main = threading.Timer(limit_main, stuck) if world.size > 1 else None
+    if dog_main is not None:
+        dog_main.daemon = True
+        dog_main.start()
 
     ctx = get_context()
     prms, tr, net, fn, n_batches, img, C = build(args.prms, global_batch, per_gpu, args.img, args.dtype)
@@ -432,19 +592,34 @@ def main():
     while getattr(net, "_dp_tune", None) is not None and tune_steps < 1000:
         fn.enqueue(tune_steps % n_batches)
         tune_steps += 1
+    progress["phase"] = "set-up steps (schedule %s)" % getattr(net, "dp_schedule", "single GPU")
     setup_steps = tune_steps + settle(ctx, fn, n_batches, group)
+    progress["phase"] = "warm-up steps"
     for i in range(args.warmup):
         fn.enqueue(i % n_batches)
     barrier()
+    progress["phase"] = "the timed region (%d steps, schedule %s)" % (args.steps, getattr(net, "dp_schedule", "single GPU"))
+    hang = os.environ.get("TN_TEST_BENCH_HANG")
     t0 = time.perf_counter()
     for i in range(args.steps):
         fn.enqueue(i % n_batches)
+        if hang is not None and int(hang) == world.rank and i == args.steps // 2:
+            time.sleep(3600)                    # (tests: a rank that stops issuing its collectives)
     barrier()
     dt = time.perf_counter() - t0
     if group is not None:
         dt = group.rdzv.gather_max(dt)
     cost = fn.fetch()[0]
     assert np.isfinite(cost), "training diverged"
+    # (what the watchdog prints should a LATER leg hang: the headline is measured)
+    progress["line"] = {"metric": "training images/sec (fwd+bwd+update) MNIST-CNN bs4096, 1/2/4/8 MI355X",
+                        "value": tr["BATCH_SZ"] * args.steps / dt, "unit": "images/sec", "n_gpus": world.size,
+                        "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+                        "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": DTYPE_LABEL[args.dtype],
+                        "data": "synthetic", "config": {"workload": "params/%s, global batch %d = %d images/GPU/step x %d"
+                                                        % (args.prms, tr["BATCH_SZ"], per_gpu, world.size),
+                                                        "dp_schedule": getattr(net, "dp_schedule", None)}}
+    progress["phase"] = "the legs behind the timed region (sustained / sync API / train loop)"
 
     # The driver's --steps can make the timed region a few milliseconds: a second, longer loop of the
     # same enqueue-only steps (>= 0.5 s) is reported beside it as `sustained`.
@@ -492,6 +667,8 @@ def main():
         dt_loop = group.rdzv.gather_max(dt_loop)
     assert seen == n_loop and np.isfinite(tot), "the cost ring lost a step"
     value_train_loop = tr["BATCH_SZ"] * n_loop / dt_loop
+    if dog_main is not None:
+        dog_main.cancel()
 
     # ---- per-kernel roofline leg: HIP events (on the stream the kernel runs on) around the
     # heavy kernels of the SAME workload; the dominant one (largest share of the step) is
@@ -598,6 +775,8 @@ def main():
         "roofline_others": others,
         "final_cost": float(cost),
     }
+    if selfcheck is not None:
+        line["dp_selfcheck"] = selfcheck
     # N > 1: `value` is STRONG scaling, as BASELINE configs[2] states it (the global batch sharded N ways).  The same
     # launch then times the WEAK form (the stated batch per GPU, N times the global batch) and reports it beside it:
     # for mnist.prms the strong figure is bounded by the kernels' fixed costs at 4096/N rows,
@@ -654,6 +833,17 @@ def main():
             line["bf16x3"] = {k: b3[k] for k in ("ms_per_step", "steps", "dtype", "final_cost")}
         except Exception as e:
             line["bf16x3"] = {"error": "%s: %s" % (type(e).__name__, str(e)[-300:])}
+        # the 512-row shard of the 8-way strong-scaling run, through the data-parallel step
+        try:
+            line["shard_leg"] = shard_leg(ctx, args.steps)
+            t_full = (sustained or {}).get("ms_per_step") or line["ms_per_step"]
+            line["strong_scaling_ceiling_8"] = {
+                "value": t_full / line["shard_leg"]["ms_per_step"],
+                "what": "t(4096 rows) / t(512 rows) on ONE GPU = the most an 8-GPU strong-scaling run of configs[2] can gain "
+                        "with a free all-reduce; NOT a measured scaling curve (none exists: no multi-GPU lease)",
+                "t_4096_ms": round(t_full, 5), "t_512_ms": line["shard_leg"]["ms_per_step"]}
+        except Exception as e:
+            line["shard_leg"] = {"cfg": "mnist.prms", "rows": 512, "error": "%s: %s" % (type(e).__name__, str(e)[-300:])}
     if world.size == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(prms, img, C, tr["BATCH_SZ"])
     # The compact figures once more, LAST in the line: a reader that keeps only the tail of the output (the round
@@ -671,6 +861,12 @@ def main():
         legs.append({"cfg": wl, "dtype": str(rec.get("dtype", "?"))[:3], "ms_per_step": round(rec["ms_per_step"], 5)
                      if "ms_per_step" in rec else None, "conv_fwd_frac": frac(rec, "forward"), "conv_bwd_frac": frac(rec, "backward"),
                      "error": rec.get("error")})
+    if isinstance(line.get("shard_leg"), dict):
+        sl = line["shard_leg"]
+        legs.append({"cfg": "mnist.prms", "rows": 512, "dtype": "f32", "ms_per_step": sl.get("ms_per_step"),
+                     "dp": "1-rank RCCL, two steps in flight" if "error" not in sl else None, "error": sl.get("error"),
+                     "strong_scaling_ceiling_8": round(line["strong_scaling_ceiling_8"]["value"], 3)
+                     if "strong_scaling_ceiling_8" in line else None})
     line["legs"] = legs
     line["tail"] = {"ms_per_step": round(line["ms_per_step"], 5), "value": round(line["value"], 1),
                     "value_train_loop": round(value_train_loop, 1) if value_train_loop else None,

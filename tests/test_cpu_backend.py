@@ -290,6 +290,58 @@ def test_bench_two_ranks_reports_strong_and_weak_scaling():
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["global_batch"] == 64
     assert d["weak"]["scaling"] == "weak" and d["weak"]["global_batch"] == 128 and d["weak"]["rows_per_gpu"] == 64
     assert d["value_weak"] == d["weak"]["value"] > 0 and d["value"] > 0
+    # the start-up self-check of an N > 1 run (its own processes): default schedule == plain schedule
+    sc = d["dp_selfcheck"]
+    assert sc["ok"] is True and sc["default"]["schedule"] == "pipelined" and sc["plain"]["schedule"] == "plain"
+    assert sc["rel_diff"] <= 1e-5 and sc["default"]["collectives"] > sc["plain"]["collectives"]
+
+
+def _bench_ranks(world, extra_env, timeout=300):
+    import json
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for rank in range(world):
+        env = _env(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), OMP_NUM_THREADS="2", **extra_env)
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "3",
+                                       "--warmup", "1", "--batch", "64", "--no-cpu-baseline", "--no-roofline", "--no-weak-leg"],
+                                      cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        try:
+            o, e = p.communicate(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append((p.returncode, o, e))
+    lines = [l for l in outs[0][1].splitlines() if l.strip()]
+    assert len(lines) == 1, outs[0]
+    assert all(o.strip() == "" for _, o, _ in outs[1:])
+    return json.loads(lines[0]), outs
+
+
+def test_bench_self_check_hang_falls_back_to_the_plain_schedule():
+    """bench.py --gpus 4 with a rank whose self-check stops issuing collectives (injected): every rank's check child is
+    killed at the time limit, EVERY rank falls back to the plain schedule with a warning, and the run still measures."""
+    d, outs = _bench_ranks(4, {"TN_TEST_SELFCHECK_HANG": "2", "TN_BENCH_SELFCHECK_TIMEOUT": "12"})
+    assert all(rc == 0 for rc, _, _ in outs), [e[-300:] for _, _, e in outs]
+    sc = d["dp_selfcheck"]
+    assert sc["ok"] is False and "did not finish" in sc["error"] and "TN_PIPELINE=0" in sc["fallback"]
+    assert d["config"]["dp_schedule"] == "plain" and d["value"] > 0 and d["n_gpus"] == 4
+    assert all("self-check FAILED" in e for _, _, e in outs)
+
+
+def test_bench_watchdog_prints_a_line_when_a_rank_hangs_in_the_timed_region():
+    """A rank stuck in the primary timed loop (injected: rank 1 stops enqueueing, the others wait in their collectives /
+    barrier) is not an exception: the watchdog prints ONE line with "error": "rank stuck in: the timed region ..." and the
+    self-check record, and every rank leaves (non-zero: nothing was measured)."""
+    d, outs = _bench_ranks(2, {"TN_TEST_BENCH_HANG": "1", "TN_BENCH_TIMEOUT": "15"})
+    assert d["value"] is None and "rank stuck in: the timed region" in d["error"] and d["dp_selfcheck"]["ok"] is True
+    assert all(rc == 4 for rc, _, _ in outs)
 
 
 def test_rsag_self_test_falls_back_loudly_on_every_rank(tmp_path):
