@@ -569,6 +569,15 @@ static int fc8_fwd_run(tn_ctx* ctx, const void* x, const float* W, const float* 
     const int colg = cdiv(n_out, 64), rowg = cdiv(B, 128);
     // K slabs: one block per CU (two measured 15 % slower: twice the slab traffic), at least four chunks of 64 columns per block
     int S = cdiv(ctx->num_cus, colg * rowg);
+    // TN_FC8_FWD_HALF=1 (round 6 A/B): a product whose tiles fill at least half the CUs takes ONE K slab -- no slab written
+    // and read back, no finishing launch, and with two steps in flight the other stream's launches fill the idle half
+    // (what paid for the fp16 weight gradients, DESIGN.md lesson 18): cifar_like's 2048 x 2048 -> 512 dense layer, 128 tiles
+    static int half_ok = -1;
+    if (half_ok < 0) {
+        const char* e = getenv("TN_FC8_FWD_HALF");
+        half_ok = e ? atoi(e) : 0;
+    }
+    if (half_ok && 2 * colg * rowg >= ctx->num_cus) S = 1;
     if (S > g.Kc / 256) S = g.Kc / 256;
     if (S < 1) S = 1;
     g.krange = cdiv(cdiv(g.Kc, S), 64) * 64;
