@@ -1254,6 +1254,389 @@ __global__ __launch_bounds__(512) void c8_wgrad_kernel(C8WG g) {
     }
 }
 
+// =================================================================================================
+// Round 6: the same weight gradient with a block's work split BY ROLE over sixteen waves (c8_wgrad_tr_kernel), for the
+// 64-filter x 64-channel block tile (K, C >= 64: every layer of wide6 from conv2 on, conv3 of cifar_like).
+// Stamps of the eight-wave kernel above (wide6 conv2, profiles/r06_wgrad_stamps.txt): a wave's 16-pixel step is a chain
+// of nine LDS round trips (two transposing reads - s_waitcnt - product) and takes ~930 cycles for 320 cycles of matrix
+// work; two such waves per SIMD = 69 % of the pipe inside the steps; every wave also issues four LDS-DMAs per tile
+// (~100 cycles of its issue each), and 15 % of a block's life are barrier waits.  Here
+//   * TWELVE compute waves = (filter tile, channel tile) x TAP ROW: 48 accumulators instead of 144, <= 128 registers,
+//     three compute waves per SIMD -- three independent chains of round trips feed each matrix pipe instead of two;
+//     a wave takes all eight steps of a 128-pixel tile, so there are no step subsets to add up at the end;
+//   * FOUR loader waves (one per SIMD) own every LDS-DMA issue, the ring / tile bookkeeping, the counted vmcnt waits
+//     and the pooled-gradient expansion: a compute wave's loop holds ds_read_b64_tr_b16, v_mfma and one s_barrier per
+//     tile, nothing else;
+//   * same LDS images, same DMA chunk lists, same slab layout as the eight-wave kernel (c8w_geometry serves both).
+// The bias product of a step is taken by ONE of the six waves that share its dz operand, by step number.
+// =================================================================================================
+template <int NGX, bool POOL, bool ROLL>
+__global__ __launch_bounds__(1024) void c8_wgrad_tr_kernel(C8WG g) {
+    extern __shared__ __attribute__((aligned(16))) float ct_smem[];
+    constexpr int RGB = 2048, ZRO = 4 * RGB;
+    constexpr int KP = 8, CP = 8, KBF = 64, CBF = 64, NCW = 12, NLW = 4, NSTEP = 8;
+    constexpr int NGD = POOL ? 0 : 2 * KP / NLW, NG = NGX + NGD;
+    char* const smem = reinterpret_cast<char*>(ct_smem);
+    const int bid = blockIdx.x, per = g.KG * g.CG;
+    const int z = ((bid >> 3) / per) * 8 + (bid & 7), rem = (bid >> 3) % per;
+    if (z >= g.S) return;
+    const int kg = rem / g.CG, cg = rem - kg * g.CG;
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), l31 = lane & 31, hi = lane >> 5;
+    const bool loader = wave >= NCW;
+    const int tile_beg = z * g.tpb, tile_end = min(g.NTILES, tile_beg + g.tpb);
+    const int HW = g.H * g.Wd, Wp = g.Wd >> 1, THm = g.TH - 1, Wm = g.Wd - 1;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) void*)ct_smem;
+    unsigned long long d_bar = 0, d_mm = 0, d_t0 = 0, d_w0 = 0;
+    if (g.dbg) { d_t0 = __builtin_readcyclecounter(); d_w0 = wall_clock64(); }
+
+    if (ROLL) {          // the zero row of every plane (read as the halo of an image's first / last band)
+        for (int i = t; i < CP * g.Wd; i += 1024)
+            *reinterpret_cast<uint4*>(smem + (i >> g.lgW) * g.XPS + 16 + ZRO + (i & Wm) * 16) = make_uint4(0u, 0u, 0u, 0u);
+    }
+
+    f32x16 acc[3], accb;
+#pragma unroll
+    for (int a_ = 0; a_ < 3; ++a_)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a_][r] = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accb[r] = 0.f;
+    const int ft = wave & 1, ct = (wave >> 1) & 1, u = wave >> 2;      // compute roles (waves 0..11)
+
+    if (loader) {
+        // ================================ loader waves: every DMA of the block ================================
+        const int lw = wave - NCW, lt = t - 64 * NCW;
+        const char* const zero_src = reinterpret_cast<const char*>(&c8_zero_cell_g);
+        // POOL: one pooled cell (16 + 8 bytes) of the next tile per loader thread, expanded into four dz cells
+        int pg_rel = 0, pg_fl = 0, pg_dst = 0;
+        if (POOL) {
+            const int plane = lt >> 5, pc = lt & 31;
+            const int ni = pc >> (g.lgP - 2), prow = (pc >> (g.lgW - 1)) & ((g.TH >> 1) - 1), pcol = pc & (Wp - 1);
+            pg_rel = (ni * g.K8 + plane) * (HW >> 2) + prow * Wp + pcol;
+            pg_fl = 1 | (kg * KP + plane >= g.K8 ? 2 : 0) | (ni << 8);
+            pg_dst = g.offD + plane * g.DPS + ((ni << g.lgP) + ((2 * prow) << g.lgW) + 2 * pcol) * 16;
+        }
+        int4v pgv;
+        int2v pmv;
+        auto pool_load = [&](int tile) __attribute__((always_inline)) {
+            const int tc = min(max(tile, 0), g.NTILES - 1), gi_ = tc / g.RT, n0 = gi_ * g.NI, r0 = (tc - gi_ * g.RT) * g.TH;
+            const long long db = ((long long)(n0 * g.K8 + kg * KP) * (g.H >> 1) + (r0 >> 1)) * Wp;
+            const bool zero = (pg_fl & 3) != 1 || (pg_fl >> 8) >= g.N - n0;
+            const char* sg = zero ? zero_src : reinterpret_cast<const char*>(g.dz + db) + (long long)pg_rel * 16;
+            const char* sm = zero ? zero_src : reinterpret_cast<const char*>(g.mask + db) + (long long)pg_rel * 8;
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(pgv) : "v"(sg));
+            asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(pmv) : "v"(sm));
+        };
+        auto pool_expand = [&](int stage) __attribute__((always_inline)) {
+            char* const d0 = smem + (ROLL ? g.XA : 0) + stage * g.SB + pg_dst;
+            const uint4 gq = __builtin_bit_cast(uint4, pgv);
+            const uint2 mq = __builtin_bit_cast(uint2, pmv);
+            *reinterpret_cast<uint4*>(d0) = c8_pool_cell(gq, mq, 0);
+            *reinterpret_cast<uint4*>(d0 + 16) = c8_pool_cell(gq, mq, 1);
+            *reinterpret_cast<uint4*>(d0 + 16 * g.Wd) = c8_pool_cell(gq, mq, 2);
+            *reinterpret_cast<uint4*>(d0 + 16 * g.Wd + 16) = c8_pool_cell(gq, mq, 3);
+        };
+        // this wave's chunks of a stage (the eight-wave kernel's lists, dealt to four waves): NGX x chunks q = 4 j + lw,
+        // then (not POOL) NGD dz chunks; beyond a kind's count: a filler (zero cell -> the dump KB)
+        int gl_rel[NG], gl_fl[NG], gl_dst[NG];
+#pragma unroll
+        for (int j = 0; j < NG; ++j) {
+            int rel = 0, fl = 1 | 2, dst = g.offDump;
+            if (ROLL && j < NGX) {
+                const int q = NLW * j + lw;
+                if (q < g.nQx) {
+                    const int plane = q >> 1, sub = q & 1, pc = min(cg * CP + plane, g.C8 - 1) - cg * CP;
+                    rel = pc * HW + sub * 64 + lane;
+                    fl = 1;
+                    dst = plane * g.XPS + 16 + sub * 1024;
+                }
+            } else if (j < NGX) {
+                const int q = NLW * j + lw;
+                if (q < g.nQx) {
+                    const int plane = q / g.XCH, c = (q - plane * g.XCH) * 64 + lane;
+                    const int cc = min(c, g.XC - 1), colp = cc % g.RS, rr = cc / g.RS, rowh = rr % g.THi, ni = rr / g.THi;
+                    const bool zero = colp == 0 || colp == g.RS - 1 || cg * CP + plane >= g.C8;
+                    rel = (ni * g.C8 + plane) * HW + (rowh - 1) * g.Wd + (colp - 1);
+                    fl = (c < g.XC ? 1 : 0) | (zero ? 2 : 0) | (rowh == 0 ? 4 : 0) | (rowh == g.THi - 1 ? 8 : 0) | (ni << 8);
+                    dst = plane * g.XPS + (q - plane * g.XCH) * 1024;
+                }
+            } else if (!POOL) {
+                const int qq = NLW * (j - NGX) + lw;
+                if (qq < 2 * KP) {
+                    const int plane = qq >> 1, sub = qq & 1, pp = sub * 64 + lane;
+                    const int ni = pp >> g.lgP, row = (pp >> g.lgW) & THm, col = pp & Wm;
+                    const int pk = ROLL ? min(kg * KP + plane, g.K8 - 1) - kg * KP : plane;
+                    rel = (ni * g.K8 + pk) * HW + row * g.Wd + col;
+                    fl = ROLL ? 1 : (1 | (kg * KP + plane >= g.K8 ? 2 : 0) | (ni << 8));
+                    dst = g.offD + plane * g.DPS + sub * 1024;
+                }
+            }
+            gl_rel[j] = rel; gl_fl[j] = fl;
+            gl_dst[j] = __builtin_amdgcn_readfirstlane(dst);
+        }
+        const char* cur_xp = reinterpret_cast<const char*>(g.x);
+        const char* cur_dp = reinterpret_cast<const char*>(g.dz);
+        int cur_zmask = 0, cur_nlim = 0;
+        unsigned cur_sb = lds0, cur_xr = 0;
+        int rf_gi = tile_beg / g.RT, rf_rt = tile_beg - rf_gi * g.RT, rf_tile = tile_beg;
+        auto roll_setup = [&](int tile, int stage, int region) __attribute__((always_inline)) {
+            const int tc = min(max(tile, 0), g.NTILES - 1), n0 = tc / g.RT, r0 = (tc - n0 * g.RT) * g.TH;
+            cur_xp = reinterpret_cast<const char*>(g.x + ((long long)(n0 * g.C8 + cg * CP) * g.H + r0) * g.Wd);
+            cur_dp = reinterpret_cast<const char*>(g.dz + ((long long)(n0 * g.K8 + kg * KP) * g.H + r0) * g.Wd);
+            cur_sb = lds0 + g.XA + stage * g.SB;
+            cur_xr = lds0 + region * RGB;
+        };
+        auto tile_setup = [&](int stage) __attribute__((always_inline)) {
+            const int n0 = rf_gi * g.NI, r0 = rf_rt * g.TH;
+            cur_zmask = 2 | (r0 == 0 ? 4 : 0) | (r0 + g.TH >= g.H ? 8 : 0);
+            cur_nlim = g.N - n0;
+            cur_xp = reinterpret_cast<const char*>(g.x + ((long long)(n0 * g.C8 + cg * CP) * g.H + r0) * g.Wd);
+            cur_dp = reinterpret_cast<const char*>(g.dz + ((long long)(n0 * g.K8 + kg * KP) * g.H + r0) * g.Wd);
+            cur_sb = lds0 + stage * g.SB;
+            if (rf_tile + 1 < tile_end) {
+                ++rf_tile;
+                if (++rf_rt == g.RT) { rf_rt = 0; ++rf_gi; }
+            }
+        };
+        auto issue_range = [&](auto J0c, auto J1c) __attribute__((always_inline)) {
+            constexpr int J0 = decltype(J0c)::value, J1 = decltype(J1c)::value;
+#pragma unroll
+            for (int j = J0; j < J1; ++j) {
+                if (ROLL) {
+                    const char* src = (j < NGX ? cur_xp : cur_dp) + (long long)gl_rel[j] * 16;
+                    c8_glds16(src, __builtin_amdgcn_readfirstlane((j < NGX ? cur_xr : cur_sb) + gl_dst[j]));
+                    continue;
+                }
+                const int fl = gl_fl[j];
+                const bool zero = (fl & cur_zmask) || (fl >> 8) >= cur_nlim;
+                const char* src = (j < NGX ? cur_xp : cur_dp) + (long long)gl_rel[j] * 16;
+                src = zero ? zero_src : src;
+                if (fl & 1) c8_glds16(src, __builtin_amdgcn_readfirstlane(cur_sb + gl_dst[j]));
+            }
+        };
+        using J_0 = std::integral_constant<int, 0>;
+        using J_X = std::integral_constant<int, NGX>;
+        using J_N = std::integral_constant<int, NG>;
+        if (ROLL) {
+            roll_setup(tile_beg - 1, 0, 3);
+            issue_range(J_0{}, J_X{});
+            roll_setup(tile_beg, 0, 0);
+            issue_range(J_0{}, J_N{});
+            roll_setup(tile_beg + 1, 1, 1);
+            issue_range(J_0{}, J_N{});
+        } else {
+            tile_setup(0);
+            issue_range(J_0{}, J_N{});
+            if (g.nstage > 2) {
+                tile_setup(1);
+                issue_range(J_0{}, J_N{});
+            }
+        }
+        if (POOL) {
+            pool_load(tile_beg);
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(pgv), "+v"(pmv));
+            pool_expand(0);
+        }
+        unsigned long long l_wait = 0, l_bar = 0, l_iss = 0;
+        for (int tile = tile_beg, it = 0; tile < tile_end; ++tile, ++it) {
+            unsigned long long q0 = 0, q1 = 0, q2 = 0;
+            if (g.dbg) q0 = __builtin_readcyclecounter();
+            // the DMAs of this tile's stage have landed (ROLL: and the x rows of the next tile, its lower halo) ...
+            if (ROLL) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NG - NGX) : "memory");
+            else if (g.nstage > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NG) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (POOL) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // (the stores into the tile's dz image)
+            if (g.dbg) q1 = __builtin_readcyclecounter();
+            __builtin_amdgcn_s_barrier();       // ... everybody's; the compute waves are done with the stage refilled next
+            if (g.dbg) q2 = __builtin_readcyclecounter();
+            if (ROLL) roll_setup(tile + 2, (it + 2) % 3, (it + 2) & 3);
+            else tile_setup((it + g.nstage - 1) % g.nstage);
+            if (POOL) pool_load(tile + 1);
+            issue_range(J_0{}, J_N{});
+            if (POOL) {
+                asm volatile("s_waitcnt vmcnt(%2)" : "+v"(pgv), "+v"(pmv) : "n"(NGX));
+                pool_expand((it + 1) % g.nstage);
+            }
+            if (g.dbg) { l_wait += q1 - q0; l_bar += q2 - q1; l_iss += __builtin_readcyclecounter() - q2; }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the trailing refills land before LDS is reused
+        if (g.dbg && lt == 0) {      // (first loader wave: DMA wait, its own barrier wait, issue + set-up time)
+            unsigned long long* d = g.dbg + 8 * (size_t)bid;
+            d[3] = l_wait; d[1] = l_iss; (void)l_bar;
+        }
+    } else {
+        // ================================ compute waves: tap row u of a 32 x 32 tile ================================
+        const bool want_b = cg == 0;
+        const half8 ones = {(_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f,
+                            (_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f};
+        const int grp = lane >> 4, r4 = (lane >> 2) & 3, q8 = lane & 3;
+        const int a_off = g.offD + (ft * 4 + 2 * (grp & 1) + (q8 >> 1)) * g.DPS + (q8 & 1) * 8;
+        const int b_off = (ct * 4 + 2 * (grp & 1) + (q8 >> 1)) * g.XPS + (q8 & 1) * 8;
+        const int RS16 = g.RS * 16, W16 = g.Wd * 16;
+        int c_rt = tile_beg % g.RT;
+        // ROLL: the band row of step i's 16 pixels, tile after tile the same: (row - 1) * row bytes; first / last band row
+        int st_ro[NSTEP];
+        bool st_top[NSTEP], st_bot[NSTEP];
+        if (ROLL) {
+#pragma unroll
+            for (int i = 0; i < NSTEP; ++i) {
+                const int rl = ((16 * i) >> g.lgW) & THm;
+                st_ro[i] = (rl - 1) * W16;
+                st_top[i] = rl == 0;
+                st_bot[i] = rl == THm;
+            }
+        }
+        // The tile loop exists SIX times, once per (tap row, channel tile) of the wave: with the tap row a compile-time
+        // constant the row of a step's operands is one scalar select (as a run-time value it compiled to four scalar
+        // branches per step) and the bias product of step i -- taken by the wave whose (tap row, channel tile) is
+        // (i % 3, (i / 3) & 1) -- is there or not at compile time: no branch inside a tile's steps at all.
+        auto run = [&](auto Uc, auto CTc) __attribute__((always_inline)) {
+            constexpr int U = decltype(Uc)::value, CT = decltype(CTc)::value;
+            for (int tile = tile_beg, it = 0; tile < tile_end; ++tile, ++it) {
+                const int stage = it % g.nstage;
+                unsigned long long s1 = 0, s2 = 0;
+                if (g.dbg) s1 = __builtin_readcyclecounter();
+                __builtin_amdgcn_s_barrier();
+                if (g.dbg) { s2 = __builtin_readcyclecounter(); d_bar += s2 - s1; }
+                const char* const sb = smem + (ROLL ? g.XA : 0) + stage * g.SB;
+                int reg_off = 0, edge_off = 0;       // ROLL: this tile's band in the ring; the row above (U = 0) / below (U = 2) it
+                if (ROLL) {
+                    const int region = it & 3;
+                    reg_off = region * RGB;
+                    if (U == 0) edge_off = c_rt == 0 ? ZRO : ((region + 3) & 3) * RGB + THm * W16;
+                    if (U == 2) edge_off = c_rt == g.RT - 1 ? ZRO : ((region + 1) & 3) * RGB;
+                    if (++c_rt == g.RT) c_rt = 0;
+                }
+                const char* const ab = sb + a_off;
+                // one software pipeline over the tile's eight steps: the eight transposing reads of step i + 1 are issued in
+                // front of the products of step i (two operand sets; LDS returns in order, the compiler counts lgkmcnt)
+                half4v av[2][2], bv[2][3][2];
+                auto load = [&](auto Ic) __attribute__((always_inline)) {
+                    constexpr int i = decltype(Ic)::value, B_ = i & 1;
+                    const int p = 16 * i + 8 * (grp >> 1) + r4;
+                    const char* ap = ab + p * 16;
+                    av[B_][0] = c8_tr16(ap);
+                    av[B_][1] = c8_tr16(ap + 64);
+                    const char* xp;
+                    if (ROLL) {
+                        const int rbase = reg_off + st_ro[i];
+                        const int ro = U == 0 ? (st_top[i] ? edge_off : rbase) : U == 1 ? rbase + W16 : (st_bot[i] ? edge_off : rbase + 2 * W16);
+                        xp = smem + b_off + (p & Wm) * 16 + ro;
+                    } else {
+                        xp = sb + b_off + (((p >> g.lgP) * g.THi + ((p >> g.lgW) & THm)) * g.RS + (p & Wm)) * 16 + U * RS16;
+                    }
+#pragma unroll
+                    for (int v = 0; v < 3; ++v) {
+                        bv[B_][v][0] = c8_tr16(xp + v * 16);
+                        bv[B_][v][1] = c8_tr16(xp + v * 16 + 64);
+                    }
+                };
+                auto mult = [&](auto Ic) __attribute__((always_inline)) {
+                    constexpr int i = decltype(Ic)::value, B_ = i & 1;
+                    if (ROLL) {
+                        // the k element whose cell lies left of column 0 (tap column 0) / right of column W - 1 (tap column 2)
+                        const unsigned mL = (((16 * i) & Wm) == 0 && (grp >> 1) == 0) ? 0xffff0000u : 0xffffffffu;
+                        const unsigned mR = (((16 * i + 16) & Wm) == 0 && (grp >> 1) == 1) ? 0x0000ffffu : 0xffffffffu;
+                        uint2 e0 = __builtin_bit_cast(uint2, bv[B_][0][0]);
+                        e0.x &= mL;
+                        bv[B_][0][0] = __builtin_bit_cast(half4v, e0);
+                        uint2 e2 = __builtin_bit_cast(uint2, bv[B_][2][1]);
+                        e2.y &= mR;
+                        bv[B_][2][1] = __builtin_bit_cast(half4v, e2);
+                    }
+                    const half8 a = {av[B_][0][0], av[B_][0][1], av[B_][0][2], av[B_][0][3], av[B_][1][0], av[B_][1][1], av[B_][1][2], av[B_][1][3]};
+#pragma unroll
+                    for (int v = 0; v < 3; ++v) {
+                        const half8 b = {bv[B_][v][0][0], bv[B_][v][0][1], bv[B_][v][0][2], bv[B_][v][0][3],
+                                         bv[B_][v][1][0], bv[B_][v][1][1], bv[B_][v][1][2], bv[B_][v][1][3]};
+                        acc[v] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[v], 0, 0, 0);
+                    }
+                    if (i % 3 == U && ((i / 3) & 1) == CT && want_b) accb = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, ones, accb, 0, 0, 0);
+                };
+                load(std::integral_constant<int, 0>{});
+#define C8T_ST(I) load(std::integral_constant<int, I + 1>{}); mult(std::integral_constant<int, I>{});
+                C8T_ST(0) C8T_ST(1) C8T_ST(2) C8T_ST(3) C8T_ST(4) C8T_ST(5) C8T_ST(6)
+#undef C8T_ST
+                mult(std::integral_constant<int, 7>{});
+                if (g.dbg) d_mm += __builtin_readcyclecounter() - s2;
+            }
+        };
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, 1>;
+        using I2 = std::integral_constant<int, 2>;
+        if (u == 0) { if (ct == 0) run(I0{}, I0{}); else run(I0{}, I1{}); }
+        else if (u == 1) { if (ct == 0) run(I1{}, I0{}); else run(I1{}, I1{}); }
+        else { if (ct == 0) run(I2{}, I0{}); else run(I2{}, I1{}); }
+    }
+    if (g.dbg && t == 0) {
+        unsigned long long* d = g.dbg + 8 * (size_t)bid;
+        d[0] = d_t0; d[2] = __builtin_readcyclecounter(); d[6] = d_bar; d[7] = d_mm;       // (d[1], d[3]: the first loader wave)
+        d[4] = d_w0; d[5] = wall_clock64();
+    }
+    if (g.dbg && lane == 0 && !loader && bid < 256) {      // per compute wave: records 4096 + 16 bid + wave (tools/dbg_c8.py WAVES=1)
+        unsigned long long* d = g.dbg + 8 * (size_t)(4096 + 16 * bid + wave);
+        d[0] = d_t0; d[2] = __builtin_readcyclecounter(); d[6] = d_bar; d[7] = d_mm;
+    }
+    __syncthreads();                            // every stage is dead: LDS becomes the epilogue's
+
+    const float os = g.oscale;
+    // ---- bias gradient partial of the slab: the six waves that shared a filter tile's dz add up in (channel tile, tap
+    // row) order through LDS; column 0 of the product against ones
+    if (cg == 0) {
+        if (!loader) {
+            float* const bslot = ct_smem + (size_t)wave * 16 * 64 + lane;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) bslot[r * 64] = accb[r];
+        }
+        __syncthreads();
+        if (wave < 2 && l31 == 0) {                 // wave = ft, (ct, u) = (0, 0)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float sum = 0.f;
+#pragma unroll
+                for (int role = 0; role < 6; ++role)
+                    sum += ct_smem[(size_t)(wave + 2 * (role / 3) + 4 * (role % 3)) * 16 * 64 + r * 64 + lane];
+                const int k = kg * KBF + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                if (k < g.K) g.dbws[(size_t)z * g.K + k] = sum * os;
+            }
+        }
+        __syncthreads();
+    }
+    // ---- slab z: dW layout, tap (u, v) of the correlation is element (2 - u, 2 - v) = 8 - (3 u + v)
+    if (g.K % KBF == 0 && g.C % CBF == 0) {
+        constexpr int ROWF = CBF * 9;               // through LDS [k][c * 9 + tap]: every thread stores 16 bytes beside its neighbour's
+        if (!loader) {
+            float* const T = ct_smem + (size_t)(ft * 32 + 4 * hi) * ROWF + (ct * 32 + l31) * 9;
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+#pragma unroll
+                for (int v = 0; v < 3; ++v) T[((r & 3) + 8 * (r >> 2)) * ROWF + 8 - (3 * u + v)] = acc[v][r] * os;
+        }
+        __syncthreads();
+        float* const wz = g.ws + (size_t)z * g.K * g.C * 9 + ((size_t)kg * KBF * g.C + (size_t)cg * CBF) * 9;
+        constexpr int Q = ROWF / 4;
+        for (int idx = t; idx < KBF * Q; idx += 1024) {
+            const int row = idx / Q, q = idx - row * Q;
+            *reinterpret_cast<float4*>(wz + (size_t)row * g.C * 9 + 4 * q) =
+                *reinterpret_cast<const float4*>(ct_smem + (size_t)row * ROWF + 4 * q);
+        }
+        return;
+    }
+    if (loader) return;
+    const int c = cg * CBF + ct * 32 + l31;
+    if (c < g.C) {
+        float* wz = g.ws + (size_t)z * g.K * g.C * 9;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int k = kg * KBF + ft * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            if (k < g.K) {
+#pragma unroll
+                for (int v = 0; v < 3; ++v) wz[((size_t)k * g.C + c) * 9 + 8 - (3 * u + v)] = acc[v][r] * os;
+            }
+        }
+    }
+}
+
 static int c8w_log2(int v) { int l = 0; while ((1 << l) < v) ++l; return (1 << l) == v ? l : -1; }
 
 static void c8w_tiles(int K, int C, int& NFT, int& NCT) {
@@ -1261,6 +1644,14 @@ static void c8w_tiles(int K, int C, int& NFT, int& NCT) {
     NCT = C > 32 ? 2 : (C > 8 ? 1 : 0);          // 0: one octet, taps packed into the columns (c8_wgrad_kernel)
 }
 
+static int c8w_tr_on() {             // TN_C8_WTR=0: the eight-wave kernel everywhere (A/B)
+    static int on = -1;
+    if (on < 0) {
+        const char* e = getenv("TN_C8_WTR");
+        on = e ? atoi(e) : 1;
+    }
+    return on;
+}
 static int c8w_roll_on() {           // TN_C8_ROLL=0: the halo-tile form everywhere (A/B)
     static int on = -1;
     if (on < 0) {
@@ -1304,7 +1695,10 @@ static int c8w_geometry(C8WG& g, int num_cus, bool pool, int tm = 1) {
     g.NQ = g.nQx + g.nQd;
     g.nstage = 3 * g.SB <= 160 * 1024 ? 3 : 2;
     g.roll = 0; g.XA = 0;
-    if (NCT && tm == 1 && g.NI == 1 && g.RT >= 2 && lgW >= (c8w_roll_on() == 2 ? 4 : 5) && c8w_roll_on()) {
+    // (16-pixel rows: the ring only under the sixteen-wave kernel -- its four loader waves are bound by the NUMBER of LDS-DMAs
+    // they issue, 8 per tile with the ring against 10 with halo tiles; under the eight-wave kernel the ring lost there, round 4)
+    const bool tr_shape = NFT == 2 && NCT == 2 && tm == 1 && c8w_tr_on();
+    if (NCT && tm == 1 && g.NI == 1 && g.RT >= 2 && lgW >= ((c8w_roll_on() == 2 || tr_shape) ? 4 : 5) && c8w_roll_on()) {
         // ROLL (c8_wgrad_kernel): x ring of four TH-row regions + a zero row per plane, no halo columns; three dz stages
         const int xps = (16 + 4 * 2048 + g.Wd * 16 + 16 + 255) / 256 * 256 + 64;
         const int offG = KP * g.DPS, offM = offG;
@@ -1377,6 +1771,43 @@ static int c8w_launch(tn_ctx* ctx, C8WG& g) {
     return TN_OK;
 }
 
+// the sixteen-wave form (c8_wgrad_tr_kernel): x chunks per LOADER wave and stage
+template <int NGX, bool POOL, bool ROLL>
+static int c8w_tr_launch(tn_ctx* ctx, C8WG& g) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        TN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&c8_wgrad_tr_kernel<NGX, POOL, ROLL>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    const int grid = 8 * cdiv(g.S, 8) * g.KG * g.CG;
+    static int dbg_on = -1;
+    if (dbg_on < 0) {
+        const char* e = getenv("TN_C8_DBG");
+        dbg_on = e ? atoi(e) : 0;
+    }
+    if (dbg_on) {
+        if (!c8_dbg_buf) TN_HIP(hipMalloc(&c8_dbg_buf, 8 * sizeof(unsigned long long) * 65536));
+        TN_HIP(hipMemsetAsync(c8_dbg_buf, 0, 8 * sizeof(unsigned long long) * 65536, ctx->stream));
+        g.dbg = grid <= 65536 ? c8_dbg_buf : nullptr;
+    }
+    c8_wgrad_tr_kernel<NGX, POOL, ROLL><<<grid, 1024, c8w_lds_bytes(g), ctx->stream>>>(g);
+    TN_LAUNCH_CHECK();
+    return TN_OK;
+}
+template <bool POOL>
+static int c8w_tr_go(tn_ctx* ctx, C8WG& g) {
+    const int ngx = cdiv(g.nQx, 4);
+    if (g.roll) return c8w_tr_launch<4, POOL, true>(ctx, g);          // 16 x chunks: two per plane
+    switch (ngx) {                                                     // 8 planes x XCH chunks over four loader waves
+        case 4: return c8w_tr_launch<4, POOL, false>(ctx, g);
+        case 6: return c8w_tr_launch<6, POOL, false>(ctx, g);
+        case 8: return c8w_tr_launch<8, POOL, false>(ctx, g);
+        case 10: return c8w_tr_launch<10, POOL, false>(ctx, g);
+    }
+    return tn_fail(ctx, TN_E_ARG, "c8 conv wgrad: %d LDS-DMA chunks per x stage", g.nQx);
+}
+
 // x chunks per wave and stage: a compile-time count (the waits are counted); shapes land in one of four buckets
 static int c8w_ngx(const C8WG& g) { return cdiv(g.nQx, 8); }
 template <int NFT, int NCT, bool POOL>
@@ -1419,7 +1850,9 @@ static int c8w_run(tn_ctx* ctx, C8WG& g, float* dW, float* db, bool pool) {
     g.dbws = g.ws + (size_t)g.S * n;
     g.oscale = 1.f / ctx->grad_scale;
 #define C8W_GO(A, B) rc = pool ? c8w_launch_ng<A, B, true>(ctx, g, tm) : c8w_launch_ng<A, B, false>(ctx, g, tm)
-    if (NCT == 0 && NFT == 2) C8W_GO(2, 0);
+    if (NFT == 2 && NCT == 2 && tm == 1 && c8w_tr_on() && (g.roll || (g.nQx % 8 == 0 && g.nQx / 8 >= 2 && g.nQx / 8 <= 5)))
+        rc = pool ? c8w_tr_go<true>(ctx, g) : c8w_tr_go<false>(ctx, g);
+    else if (NCT == 0 && NFT == 2) C8W_GO(2, 0);
     else if (NCT == 0) C8W_GO(1, 0);
     else if (NFT == 2 && NCT == 2) C8W_GO(2, 2);
     else if (NFT == 2) C8W_GO(2, 1);

@@ -3,6 +3,7 @@
 # s_memrealtime) inside the product's own matrix-core kernels and inside a bare MFMA loop, same box, back to back.
 #   bash tools/clock_evidence.sh > profiles/r06_probe_clock.txt
 cd "$(dirname "$0")/.."
+export ITERS=${ITERS:-1500}     # the stamped launch is the last of a sustained run of them
 echo "== bare MFMA loops (tools/probe/clock_probe.hip): no memory traffic, every CU busy"
 [ -x tools/probe/clock_probe ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -w tools/probe/clock_probe.hip -o tools/probe/clock_probe
 tools/probe/clock_probe

@@ -19,7 +19,7 @@ dx = ctx.empty((N, C8, H, H, 8), np.uint16)
 LK = _lib.TN_ACT_LEAKY
 dW, db = ctx.empty((K, C, 3, 3)), ctx.empty((K,))
 ctx.call("tn_set_matmul_dtype", 1, 4096.0)
-for it in range(3):
+for it in range(int(os.environ.get("ITERS", 3))):      # (ITERS=2000: stamps of a launch in a sustained run)
     if op == "fwd":
         ctx.call("tn_c8_conv_fwd", x.ptr, W.ptr, b.ptr, y.ptr, None, N, C, H, H, K, LK, .1, 0, None)
     elif op == "fwdpool":
@@ -39,12 +39,20 @@ nb = int(os.environ.get("NB", 8192))
 buf = np.zeros((nb, 8), np.uint64)
 rc = ctx.lib.tn_c8_dbg_read(ctx.h, ctypes.c_void_p(buf.ctypes.data), ctypes.c_int(nb))
 assert rc == 0, rc
+if os.environ.get("WAVES"):           # sixteen-wave weight gradient: per compute wave (records 4096 + 16 block + wave)
+    wv = buf[4096:4096 + 16 * 256].reshape(256, 16, 8).astype(np.int64)
+    live = wv[:, 0, 0] > 0
+    for w in range(12):
+        print("wave %2d (ft %d ct %d u %d): matrix steps median %7d   barrier wait %7d" % (
+            w, w & 1, (w >> 1) & 1, w >> 2, np.median(wv[live, w, 7]), np.median(wv[live, w, 6])))
+    buf = buf[:4096]
 buf = buf[buf[:, 0] > 0]
 tot = (buf[:, 2] - buf[:, 0]).astype(np.int64)
 print("%s N%d C%d K%d H%d: blocks stamped: %d" % (op, N, C, K, H, len(buf)))
 wg = op.startswith("wgrad")
 dW, db = ctx.empty((K, C, 3, 3)), ctx.empty((K,))
-for nm, v in (("block life", tot), ("prologue", (buf[:, 1] - buf[:, 0]).astype(np.int64)),
+tr = wg and os.environ.get("TN_C8_WTR", "1") != "0" and C > 32 and K > 32      # sixteen-wave form: d[1] = loader issue time
+for nm, v in (("block life", tot), ("loader: DMA issue + set-up" if tr else "prologue", (buf[:, 1] if tr else buf[:, 1] - buf[:, 0]).astype(np.int64)),
               ("DMA wait" if wg else "LDS stores (+ wait for loads)", buf[:, 3].astype(np.int64)),
               ("barriers" if wg else "epilogues", buf[:, 6].astype(np.int64)), ("matrix steps" if wg else "barriers", buf[:, 7].astype(np.int64))):
     print("%-30s cycles: median %8d  p10 %8d  p90 %8d   (%.0f %% of life)" % (nm, np.median(v), np.percentile(v, 10), np.percentile(v, 90),

@@ -13,7 +13,7 @@ x = ctx.array(rng.standard_normal((B, n_in)).astype(np.float32)); W = ctx.array(
 b = ctx.zeros((n_out,)); a = ctx.empty((B, n_out)); dz = ctx.array(rng.standard_normal((B, n_out)).astype(np.float32))
 dW = ctx.empty((n_in, n_out)); db = ctx.empty((n_out,)); dx = ctx.empty((B, n_in))
 ws = ctx.empty(((lib.tn_fc_wgrad_ws_bytes(B, n_in, n_out) + 3) // 4,))
-for it in range(3):
+for it in range(int(os.environ.get("ITERS", 3))):      # (ITERS=2000: stamps of a launch in a sustained run)
     if op == "fwd": ctx.call("tn_fc_fwd", x.ptr, W.ptr, b.ptr, a.ptr, B, n_in, n_out, 1, 0.1, None)
     elif op == "dgrad": ctx.call("tn_fc_dgrad", dz.ptr, W.ptr, dx.ptr, B, n_in, n_out, None, 0, 0.0, None)
     else: ctx.call("tn_fc_wgrad", x.ptr, dz.ptr, dW.ptr, db.ptr, B, n_in, n_out, ws.ptr)
