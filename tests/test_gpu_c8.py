@@ -69,6 +69,7 @@ C8_CASES = [  # N, C, H, K
     (3, 16, 16, 32), (2, 64, 64, 64), (5, 24, 8, 40), (2, 128, 32, 128), (2, 8, 64, 64), (3, 64, 32, 128),
     (3, 3, 64, 64), (37, 3, 32, 32), (9, 256, 16, 256), (33, 40, 8, 72),
     (520, 3, 32, 32), (131, 5, 64, 40), (2100, 8, 16, 32),      # first layers with enough pixels for 512-pixel weight-gradient tiles
+    (40, 32, 16, 64), (21, 32, 8, 64), (6, 24, 32, 96),           # 32-channel layers (conv2 of cifar_like): the sixteen-wave weight gradient with two step subsets
 ]
 
 

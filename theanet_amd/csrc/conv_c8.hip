@@ -1270,11 +1270,14 @@ __global__ __launch_bounds__(512) void c8_wgrad_kernel(C8WG g) {
 //   * same LDS images, same DMA chunk lists, same slab layout as the eight-wave kernel (c8w_geometry serves both).
 // The bias product of a step is taken by ONE of the six waves that share its dz operand, by step number.
 // =================================================================================================
-template <int NGX, bool POOL, bool ROLL>
+template <int NCT, int NGX, bool POOL, bool ROLL>
 __global__ __launch_bounds__(1024) void c8_wgrad_tr_kernel(C8WG g) {
     extern __shared__ __attribute__((aligned(16))) float ct_smem[];
     constexpr int RGB = 2048, ZRO = 4 * RGB;
-    constexpr int KP = 8, CP = 8, KBF = 64, CBF = 64, NCW = 12, NLW = 4, NSTEP = 8;
+    // NCT = 2: 64 channels, wave = (filter tile, channel tile, tap row), all eight steps of a tile.  NCT = 1: 32 channels
+    // (conv2 of cifar_like), wave = (filter tile, tap row, step subset): PS = 2 interleaved subsets of four steps, added up
+    // through LDS at the end
+    constexpr int KP = 8, CP = 4 * NCT, KBF = 64, CBF = 32 * NCT, NCW = 12, NLW = 4, PS = 2 / NCT, NSTEP = 8 / PS;
     constexpr int NGD = POOL ? 0 : 2 * KP / NLW, NG = NGX + NGD;
     char* const smem = reinterpret_cast<char*>(ct_smem);
     const int bid = blockIdx.x, per = g.KG * g.CG;
@@ -1301,7 +1304,9 @@ __global__ __launch_bounds__(1024) void c8_wgrad_tr_kernel(C8WG g) {
         for (int r = 0; r < 16; ++r) acc[a_][r] = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) accb[r] = 0.f;
-    const int ft = wave & 1, ct = (wave >> 1) & 1, u = wave >> 2;      // compute roles (waves 0..11)
+    // compute roles (waves 0..11); xr = the wave's second coordinate: channel tile (NCT = 2) / step subset (NCT = 1)
+    const int ft = wave & 1, xr = NCT == 2 ? (wave >> 1) & 1 : wave / 6, u = NCT == 2 ? wave >> 2 : (wave >> 1) % 3;
+    const int ct = NCT == 2 ? xr : 0;
 
     if (loader) {
         // ================================ loader waves: every DMA of the block ================================
@@ -1424,39 +1429,43 @@ __global__ __launch_bounds__(1024) void c8_wgrad_tr_kernel(C8WG g) {
             issue_range(J_0{}, J_N{});
             roll_setup(tile_beg + 1, 1, 1);
             issue_range(J_0{}, J_N{});
-        } else {
+        } else {            // (three stages: the host only picks this kernel then)
             tile_setup(0);
             issue_range(J_0{}, J_N{});
-            if (g.nstage > 2) {
-                tile_setup(1);
-                issue_range(J_0{}, J_N{});
-            }
+            tile_setup(1);
+            issue_range(J_0{}, J_N{});
         }
-        if (POOL) {
+        if (POOL) {         // the dz images of the slab's first two tiles; the third tile's pooled cells stay in flight
             pool_load(tile_beg);
             asm volatile("s_waitcnt vmcnt(0)" : "+v"(pgv), "+v"(pmv));
             pool_expand(0);
+            pool_load(tile_beg + 1);
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(pgv), "+v"(pmv));
+            pool_expand(1);
+            pool_load(tile_beg + 2);
         }
         unsigned long long l_wait = 0, l_bar = 0, l_iss = 0;
         for (int tile = tile_beg, it = 0; tile < tile_end; ++tile, ++it) {
             unsigned long long q0 = 0, q1 = 0, q2 = 0;
             if (g.dbg) q0 = __builtin_readcyclecounter();
             // the DMAs of this tile's stage have landed (ROLL: and the x rows of the next tile, its lower halo) ...
-            if (ROLL) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NG - NGX) : "memory");
-            else if (g.nstage > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NG) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (POOL) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // (the stores into the tile's dz image)
+            // (POOL: the two loads of pooled cells issued behind the last DMAs may stay in flight)
+            if (ROLL) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NG - NGX + (POOL ? 2 : 0)) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NG + (POOL ? 2 : 0)) : "memory");
+            if (POOL) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // (the stores into the dz images)
             if (g.dbg) q1 = __builtin_readcyclecounter();
             __builtin_amdgcn_s_barrier();       // ... everybody's; the compute waves are done with the stage refilled next
             if (g.dbg) q2 = __builtin_readcyclecounter();
             if (ROLL) roll_setup(tile + 2, (it + 2) % 3, (it + 2) & 3);
-            else tile_setup((it + g.nstage - 1) % g.nstage);
-            if (POOL) pool_load(tile + 1);
-            issue_range(J_0{}, J_N{});
+            else tile_setup((it + 2) % 3);
             if (POOL) {
-                asm volatile("s_waitcnt vmcnt(%2)" : "+v"(pgv), "+v"(pmv) : "n"(NGX));
-                pool_expand((it + 1) % g.nstage);
+                // the pooled cells of tile + 2 have been travelling for a whole tile: expanded into the stage two tiles
+                // ahead (as far ahead as a DMA'd dz image), then the cells of tile + 3 set out
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(pgv), "+v"(pmv));
+                pool_expand((it + 2) % 3);
             }
+            issue_range(J_0{}, J_N{});
+            if (POOL) pool_load(tile + 3);
             if (g.dbg) { l_wait += q1 - q0; l_bar += q2 - q1; l_iss += __builtin_readcyclecounter() - q2; }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the trailing refills land before LDS is reused
@@ -1480,7 +1489,7 @@ __global__ __launch_bounds__(1024) void c8_wgrad_tr_kernel(C8WG g) {
         if (ROLL) {
 #pragma unroll
             for (int i = 0; i < NSTEP; ++i) {
-                const int rl = ((16 * i) >> g.lgW) & THm;
+                const int rl = ((16 * (NCT == 2 ? i : xr + PS * i)) >> g.lgW) & THm;
                 st_ro[i] = (rl - 1) * W16;
                 st_top[i] = rl == 0;
                 st_bot[i] = rl == THm;
@@ -1490,10 +1499,10 @@ __global__ __launch_bounds__(1024) void c8_wgrad_tr_kernel(C8WG g) {
         // constant the row of a step's operands is one scalar select (as a run-time value it compiled to four scalar
         // branches per step) and the bias product of step i -- taken by the wave whose (tap row, channel tile) is
         // (i % 3, (i / 3) & 1) -- is there or not at compile time: no branch inside a tile's steps at all.
-        auto run = [&](auto Uc, auto CTc) __attribute__((always_inline)) {
-            constexpr int U = decltype(Uc)::value, CT = decltype(CTc)::value;
+        auto run = [&](auto Uc, auto Xc) __attribute__((always_inline)) {
+            constexpr int U = decltype(Uc)::value, X = decltype(Xc)::value;        // X: channel tile (NCT = 2) / step subset (NCT = 1)
             for (int tile = tile_beg, it = 0; tile < tile_end; ++tile, ++it) {
-                const int stage = it % g.nstage;
+                const int stage = it % 3;
                 unsigned long long s1 = 0, s2 = 0;
                 if (g.dbg) s1 = __builtin_readcyclecounter();
                 __builtin_amdgcn_s_barrier();
@@ -1512,8 +1521,8 @@ __global__ __launch_bounds__(1024) void c8_wgrad_tr_kernel(C8WG g) {
                 // front of the products of step i (two operand sets; LDS returns in order, the compiler counts lgkmcnt)
                 half4v av[2][2], bv[2][3][2];
                 auto load = [&](auto Ic) __attribute__((always_inline)) {
-                    constexpr int i = decltype(Ic)::value, B_ = i & 1;
-                    const int p = 16 * i + 8 * (grp >> 1) + r4;
+                    constexpr int i = decltype(Ic)::value, B_ = i & 1, gi = NCT == 2 ? i : X + PS * i;     // gi: step of the tile
+                    const int p = 16 * gi + 8 * (grp >> 1) + r4;
                     const char* ap = ab + p * 16;
                     av[B_][0] = c8_tr16(ap);
                     av[B_][1] = c8_tr16(ap + 64);
@@ -1532,11 +1541,11 @@ __global__ __launch_bounds__(1024) void c8_wgrad_tr_kernel(C8WG g) {
                     }
                 };
                 auto mult = [&](auto Ic) __attribute__((always_inline)) {
-                    constexpr int i = decltype(Ic)::value, B_ = i & 1;
+                    constexpr int i = decltype(Ic)::value, B_ = i & 1, gi = NCT == 2 ? i : X + PS * i;
                     if (ROLL) {
                         // the k element whose cell lies left of column 0 (tap column 0) / right of column W - 1 (tap column 2)
-                        const unsigned mL = (((16 * i) & Wm) == 0 && (grp >> 1) == 0) ? 0xffff0000u : 0xffffffffu;
-                        const unsigned mR = (((16 * i + 16) & Wm) == 0 && (grp >> 1) == 1) ? 0x0000ffffu : 0xffffffffu;
+                        const unsigned mL = (((16 * gi) & Wm) == 0 && (grp >> 1) == 0) ? 0xffff0000u : 0xffffffffu;
+                        const unsigned mR = (((16 * gi + 16) & Wm) == 0 && (grp >> 1) == 1) ? 0x0000ffffu : 0xffffffffu;
                         uint2 e0 = __builtin_bit_cast(uint2, bv[B_][0][0]);
                         e0.x &= mL;
                         bv[B_][0][0] = __builtin_bit_cast(half4v, e0);
@@ -1551,22 +1560,27 @@ __global__ __launch_bounds__(1024) void c8_wgrad_tr_kernel(C8WG g) {
                                          bv[B_][v][1][0], bv[B_][v][1][1], bv[B_][v][1][2], bv[B_][v][1][3]};
                         acc[v] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[v], 0, 0, 0);
                     }
-                    if (i % 3 == U && ((i / 3) & 1) == CT && want_b) accb = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, ones, accb, 0, 0, 0);
+                    // the bias product of a step: ONE of the waves that share its dz operand, known at compile time
+                    if ((NCT == 2 ? (i % 3 == U && ((i / 3) & 1) == X) : (i % 3 == U)) && want_b)
+                        accb = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, ones, accb, 0, 0, 0);
                 };
                 load(std::integral_constant<int, 0>{});
-#define C8T_ST(I) load(std::integral_constant<int, I + 1>{}); mult(std::integral_constant<int, I>{});
+                // (forcing the next step's reads between this step's products with sched_group_barrier -- product, three
+                // reads, product, three reads, product, two reads -- made every wave slower: conv5 of wide6 65.8 k -> 71.7 k
+                // cycles per block; hipcc's own order stays)
+#define C8T_ST(I) if (NSTEP > I + 1) { load(std::integral_constant<int, (I + 1) % NSTEP>{}); mult(std::integral_constant<int, I % NSTEP>{}); }
                 C8T_ST(0) C8T_ST(1) C8T_ST(2) C8T_ST(3) C8T_ST(4) C8T_ST(5) C8T_ST(6)
 #undef C8T_ST
-                mult(std::integral_constant<int, 7>{});
+                mult(std::integral_constant<int, NSTEP - 1>{});
                 if (g.dbg) d_mm += __builtin_readcyclecounter() - s2;
             }
         };
         using I0 = std::integral_constant<int, 0>;
         using I1 = std::integral_constant<int, 1>;
         using I2 = std::integral_constant<int, 2>;
-        if (u == 0) { if (ct == 0) run(I0{}, I0{}); else run(I0{}, I1{}); }
-        else if (u == 1) { if (ct == 0) run(I1{}, I0{}); else run(I1{}, I1{}); }
-        else { if (ct == 0) run(I2{}, I0{}); else run(I2{}, I1{}); }
+        if (u == 0) { if (xr == 0) run(I0{}, I0{}); else run(I0{}, I1{}); }
+        else if (u == 1) { if (xr == 0) run(I1{}, I0{}); else run(I1{}, I1{}); }
+        else { if (xr == 0) run(I2{}, I0{}); else run(I2{}, I1{}); }
     }
     if (g.dbg && t == 0) {
         unsigned long long* d = g.dbg + 8 * (size_t)bid;
@@ -1580,8 +1594,25 @@ __global__ __launch_bounds__(1024) void c8_wgrad_tr_kernel(C8WG g) {
     __syncthreads();                            // every stage is dead: LDS becomes the epilogue's
 
     const float os = g.oscale;
-    // ---- bias gradient partial of the slab: the six waves that shared a filter tile's dz add up in (channel tile, tap
-    // row) order through LDS; column 0 of the product against ones
+    if (NCT == 1) {             // the two step subsets of a (filter tile, tap row) pair: subset 1 onto subset 0 through LDS
+        float* const slot = ct_smem + (size_t)(wave % 6) * (3 * 16 * 64) + lane;
+        if (!loader && xr == 1) {
+#pragma unroll
+            for (int a_ = 0; a_ < 3; ++a_)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) slot[(a_ * 16 + r) * 64] = acc[a_][r];
+        }
+        __syncthreads();
+        if (!loader && xr == 0) {
+#pragma unroll
+            for (int a_ = 0; a_ < 3; ++a_)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a_][r] += slot[(a_ * 16 + r) * 64];
+        }
+        __syncthreads();
+    }
+    // ---- bias gradient partial of the slab: the six waves that shared a filter tile's dz (waves ft, ft + 2, ... ft + 10)
+    // add up in wave order through LDS; column 0 of the product against ones
     if (cg == 0) {
         if (!loader) {
             float* const bslot = ct_smem + (size_t)wave * 16 * 64 + lane;
@@ -1595,7 +1626,7 @@ __global__ __launch_bounds__(1024) void c8_wgrad_tr_kernel(C8WG g) {
                 float sum = 0.f;
 #pragma unroll
                 for (int role = 0; role < 6; ++role)
-                    sum += ct_smem[(size_t)(wave + 2 * (role / 3) + 4 * (role % 3)) * 16 * 64 + r * 64 + lane];
+                    sum += ct_smem[(size_t)(wave + 2 * role) * 16 * 64 + r * 64 + lane];
                 const int k = kg * KBF + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
                 if (k < g.K) g.dbws[(size_t)z * g.K + k] = sum * os;
             }
@@ -1605,7 +1636,7 @@ __global__ __launch_bounds__(1024) void c8_wgrad_tr_kernel(C8WG g) {
     // ---- slab z: dW layout, tap (u, v) of the correlation is element (2 - u, 2 - v) = 8 - (3 u + v)
     if (g.K % KBF == 0 && g.C % CBF == 0) {
         constexpr int ROWF = CBF * 9;               // through LDS [k][c * 9 + tap]: every thread stores 16 bytes beside its neighbour's
-        if (!loader) {
+        if (!loader && (NCT == 2 || xr == 0)) {
             float* const T = ct_smem + (size_t)(ft * 32 + 4 * hi) * ROWF + (ct * 32 + l31) * 9;
 #pragma unroll
             for (int r = 0; r < 16; ++r)
@@ -1622,7 +1653,7 @@ __global__ __launch_bounds__(1024) void c8_wgrad_tr_kernel(C8WG g) {
         }
         return;
     }
-    if (loader) return;
+    if (loader || (NCT == 1 && xr != 0)) return;
     const int c = cg * CBF + ct * 32 + l31;
     if (c < g.C) {
         float* wz = g.ws + (size_t)z * g.K * g.C * 9;
@@ -1697,7 +1728,7 @@ static int c8w_geometry(C8WG& g, int num_cus, bool pool, int tm = 1) {
     g.roll = 0; g.XA = 0;
     // (16-pixel rows: the ring only under the sixteen-wave kernel -- its four loader waves are bound by the NUMBER of LDS-DMAs
     // they issue, 8 per tile with the ring against 10 with halo tiles; under the eight-wave kernel the ring lost there, round 4)
-    const bool tr_shape = NFT == 2 && NCT == 2 && tm == 1 && c8w_tr_on();
+    const bool tr_shape = NFT == 2 && NCT >= 1 && tm == 1 && c8w_tr_on();
     if (NCT && tm == 1 && g.NI == 1 && g.RT >= 2 && lgW >= ((c8w_roll_on() == 2 || tr_shape) ? 4 : 5) && c8w_roll_on()) {
         // ROLL (c8_wgrad_kernel): x ring of four TH-row regions + a zero row per plane, no halo columns; three dz stages
         const int xps = (16 + 4 * 2048 + g.Wd * 16 + 16 + 255) / 256 * 256 + 64;
@@ -1772,11 +1803,11 @@ static int c8w_launch(tn_ctx* ctx, C8WG& g) {
 }
 
 // the sixteen-wave form (c8_wgrad_tr_kernel): x chunks per LOADER wave and stage
-template <int NGX, bool POOL, bool ROLL>
+template <int NCT, int NGX, bool POOL, bool ROLL>
 static int c8w_tr_launch(tn_ctx* ctx, C8WG& g) {
     static bool attr_set = false;
     if (!attr_set) {
-        TN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&c8_wgrad_tr_kernel<NGX, POOL, ROLL>),
+        TN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&c8_wgrad_tr_kernel<NCT, NGX, POOL, ROLL>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
@@ -1791,19 +1822,25 @@ static int c8w_tr_launch(tn_ctx* ctx, C8WG& g) {
         TN_HIP(hipMemsetAsync(c8_dbg_buf, 0, 8 * sizeof(unsigned long long) * 65536, ctx->stream));
         g.dbg = grid <= 65536 ? c8_dbg_buf : nullptr;
     }
-    c8_wgrad_tr_kernel<NGX, POOL, ROLL><<<grid, 1024, c8w_lds_bytes(g), ctx->stream>>>(g);
+    c8_wgrad_tr_kernel<NCT, NGX, POOL, ROLL><<<grid, 1024, c8w_lds_bytes(g), ctx->stream>>>(g);
     TN_LAUNCH_CHECK();
     return TN_OK;
 }
-template <bool POOL>
+// (NCT planes x 4) x XCH chunks of a halo-tile stage over four loader waves: NCT * XCH each; the ring: 2 chunks per plane
+static bool c8w_tr_shape_ok(const C8WG& g, int NCT) {
+    if (g.nstage != 3) return false;
+    if (g.roll) return true;
+    const int xch = g.nQx / (4 * NCT);
+    return g.nQx == 4 * NCT * xch && xch >= 2 && xch <= 5;
+}
+template <int NCT, bool POOL>
 static int c8w_tr_go(tn_ctx* ctx, C8WG& g) {
-    const int ngx = cdiv(g.nQx, 4);
-    if (g.roll) return c8w_tr_launch<4, POOL, true>(ctx, g);          // 16 x chunks: two per plane
-    switch (ngx) {                                                     // 8 planes x XCH chunks over four loader waves
-        case 4: return c8w_tr_launch<4, POOL, false>(ctx, g);
-        case 6: return c8w_tr_launch<6, POOL, false>(ctx, g);
-        case 8: return c8w_tr_launch<8, POOL, false>(ctx, g);
-        case 10: return c8w_tr_launch<10, POOL, false>(ctx, g);
+    if (g.roll) return c8w_tr_launch<NCT, 2 * NCT, POOL, true>(ctx, g);
+    switch (g.nQx / (4 * NCT)) {
+        case 2: return c8w_tr_launch<NCT, 2 * NCT, POOL, false>(ctx, g);
+        case 3: return c8w_tr_launch<NCT, 3 * NCT, POOL, false>(ctx, g);
+        case 4: return c8w_tr_launch<NCT, 4 * NCT, POOL, false>(ctx, g);
+        case 5: return c8w_tr_launch<NCT, 5 * NCT, POOL, false>(ctx, g);
     }
     return tn_fail(ctx, TN_E_ARG, "c8 conv wgrad: %d LDS-DMA chunks per x stage", g.nQx);
 }
@@ -1850,9 +1887,10 @@ static int c8w_run(tn_ctx* ctx, C8WG& g, float* dW, float* db, bool pool) {
     g.dbws = g.ws + (size_t)g.S * n;
     g.oscale = 1.f / ctx->grad_scale;
 #define C8W_GO(A, B) rc = pool ? c8w_launch_ng<A, B, true>(ctx, g, tm) : c8w_launch_ng<A, B, false>(ctx, g, tm)
-    if (NFT == 2 && NCT == 2 && tm == 1 && c8w_tr_on() && (g.roll || (g.nQx % 8 == 0 && g.nQx / 8 >= 2 && g.nQx / 8 <= 5)))
-        rc = pool ? c8w_tr_go<true>(ctx, g) : c8w_tr_go<false>(ctx, g);
-    else if (NCT == 0 && NFT == 2) C8W_GO(2, 0);
+    if (NFT == 2 && NCT >= 1 && tm == 1 && c8w_tr_on() && c8w_tr_shape_ok(g, NCT)) {
+        if (NCT == 2) rc = pool ? c8w_tr_go<2, true>(ctx, g) : c8w_tr_go<2, false>(ctx, g);
+        else rc = pool ? c8w_tr_go<1, true>(ctx, g) : c8w_tr_go<1, false>(ctx, g);
+    } else if (NCT == 0 && NFT == 2) C8W_GO(2, 0);
     else if (NCT == 0) C8W_GO(1, 0);
     else if (NFT == 2 && NCT == 2) C8W_GO(2, 2);
     else if (NFT == 2) C8W_GO(2, 1);
