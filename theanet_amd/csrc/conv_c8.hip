@@ -1482,6 +1482,9 @@ __global__ __launch_bounds__(1024) void c8_wgrad_tr_kernel(C8WG g) {
         const int a_off = g.offD + (ft * 4 + 2 * (grp & 1) + (q8 >> 1)) * g.DPS + (q8 & 1) * 8;
         const int b_off = (ct * 4 + 2 * (grp & 1) + (q8 >> 1)) * g.XPS + (q8 & 1) * 8;
         const int RS16 = g.RS * 16, W16 = g.Wd * 16;
+        const int l16 = 8 * (grp >> 1) + r4;                    // this lane's pixel inside a step's sixteen
+        const char* const x_lane = smem + b_off + l16 * 16;     // ROLL: + (column of the step, row in the ring) = the cell of tap column 0
+        const unsigned lmL = (grp >> 1) == 0 ? 0xffff0000u : 0xffffffffu, lmR = (grp >> 1) == 1 ? 0x0000ffffu : 0xffffffffu;
         int c_rt = tile_beg % g.RT;
         // ROLL: the band row of step i's 16 pixels, tile after tile the same: (row - 1) * row bytes; first / last band row
         int st_ro[NSTEP];
@@ -1517,20 +1520,24 @@ __global__ __launch_bounds__(1024) void c8_wgrad_tr_kernel(C8WG g) {
                     if (++c_rt == g.RT) c_rt = 0;
                 }
                 const char* const ab = sb + a_off;
+                // a step's 16 pixels start at a multiple of 16 and this lane's pixel is 8 (grp >> 1) + r4 < 16 further: its operand
+                // addresses are ONE lane register per operand + a compile-time constant (dz: 256 bytes per step, an immediate of
+                // the read) / a scalar (x, ring form: the step's column and row in the ring).  Left to itself hipcc kept sixteen
+                // per-step lane addresses and sixteen per-step edge masks in registers across the tile loop and spilled
+                const char* const a_lane = ab + l16 * 16;
                 // one software pipeline over the tile's eight steps: the eight transposing reads of step i + 1 are issued in
                 // front of the products of step i (two operand sets; LDS returns in order, the compiler counts lgkmcnt)
                 half4v av[2][2], bv[2][3][2];
                 auto load = [&](auto Ic) __attribute__((always_inline)) {
                     constexpr int i = decltype(Ic)::value, B_ = i & 1, gi = NCT == 2 ? i : X + PS * i;     // gi: step of the tile
-                    const int p = 16 * gi + 8 * (grp >> 1) + r4;
-                    const char* ap = ab + p * 16;
-                    av[B_][0] = c8_tr16(ap);
-                    av[B_][1] = c8_tr16(ap + 64);
+                    const int p = 16 * gi + l16;
+                    av[B_][0] = c8_tr16(a_lane + 256 * gi);
+                    av[B_][1] = c8_tr16(a_lane + 256 * gi + 64);
                     const char* xp;
                     if (ROLL) {
                         const int rbase = reg_off + st_ro[i];
                         const int ro = U == 0 ? (st_top[i] ? edge_off : rbase) : U == 1 ? rbase + W16 : (st_bot[i] ? edge_off : rbase + 2 * W16);
-                        xp = smem + b_off + (p & Wm) * 16 + ro;
+                        xp = x_lane + __builtin_amdgcn_readfirstlane(((16 * gi) & Wm) * 16 + ro);
                     } else {
                         xp = sb + b_off + (((p >> g.lgP) * g.THi + ((p >> g.lgW) & THm)) * g.RS + (p & Wm)) * 16 + U * RS16;
                     }
@@ -1543,9 +1550,10 @@ __global__ __launch_bounds__(1024) void c8_wgrad_tr_kernel(C8WG g) {
                 auto mult = [&](auto Ic) __attribute__((always_inline)) {
                     constexpr int i = decltype(Ic)::value, B_ = i & 1, gi = NCT == 2 ? i : X + PS * i;
                     if (ROLL) {
-                        // the k element whose cell lies left of column 0 (tap column 0) / right of column W - 1 (tap column 2)
-                        const unsigned mL = (((16 * gi) & Wm) == 0 && (grp >> 1) == 0) ? 0xffff0000u : 0xffffffffu;
-                        const unsigned mR = (((16 * gi + 16) & Wm) == 0 && (grp >> 1) == 1) ? 0x0000ffffu : 0xffffffffu;
+                        // the k element whose cell lies left of column 0 (tap column 0) / right of column W - 1 (tap column 2):
+                        // the lane's mask (lmL / lmR) where the step touches the edge (a scalar), all ones elsewhere
+                        const unsigned mL = lmL | (unsigned)__builtin_amdgcn_readfirstlane(((16 * gi) & Wm) == 0 ? 0 : -1);
+                        const unsigned mR = lmR | (unsigned)__builtin_amdgcn_readfirstlane(((16 * gi + 16) & Wm) == 0 ? 0 : -1);
                         uint2 e0 = __builtin_bit_cast(uint2, bv[B_][0][0]);
                         e0.x &= mL;
                         bv[B_][0][0] = __builtin_bit_cast(half4v, e0);
@@ -1568,7 +1576,11 @@ __global__ __launch_bounds__(1024) void c8_wgrad_tr_kernel(C8WG g) {
                 // (forcing the next step's reads between this step's products with sched_group_barrier -- product, three
                 // reads, product, three reads, product, two reads -- made every wave slower: conv5 of wide6 65.8 k -> 71.7 k
                 // cycles per block; hipcc's own order stays)
-#define C8T_ST(I) if (NSTEP > I + 1) { load(std::integral_constant<int, (I + 1) % NSTEP>{}); mult(std::integral_constant<int, I % NSTEP>{}); }
+                // sched_barrier: hipcc otherwise sinks the reads of step i + 1 below the products of step i, right in front of their
+                // own products (ISA of round 6's first version: six reads - s_waitcnt - three products, the round trip exposed
+                // in every step)
+#define C8T_ST(I) if (NSTEP > I + 1) { load(std::integral_constant<int, (I + 1) % NSTEP>{}); __builtin_amdgcn_sched_barrier(0); \
+                                       mult(std::integral_constant<int, I % NSTEP>{}); __builtin_amdgcn_sched_barrier(0); }
                 C8T_ST(0) C8T_ST(1) C8T_ST(2) C8T_ST(3) C8T_ST(4) C8T_ST(5) C8T_ST(6)
 #undef C8T_ST
                 mult(std::integral_constant<int, NSTEP - 1>{});
