@@ -1576,11 +1576,16 @@ __global__ __launch_bounds__(1024) void c8_wgrad_tr_kernel(C8WG g) {
                 // (forcing the next step's reads between this step's products with sched_group_barrier -- product, three
                 // reads, product, three reads, product, two reads -- made every wave slower: conv5 of wide6 65.8 k -> 71.7 k
                 // cycles per block; hipcc's own order stays)
-                // sched_barrier: hipcc otherwise sinks the reads of step i + 1 below the products of step i, right in front of their
-                // own products (ISA of round 6's first version: six reads - s_waitcnt - three products, the round trip exposed
-                // in every step)
-#define C8T_ST(I) if (NSTEP > I + 1) { load(std::integral_constant<int, (I + 1) % NSTEP>{}); __builtin_amdgcn_sched_barrier(0); \
-                                       mult(std::integral_constant<int, I % NSTEP>{}); __builtin_amdgcn_sched_barrier(0); }
+                // What round 6 tried on this loop and dropped, each a same-box A/B of the wide6 / cifar_like float16 STEP
+                // (tools/ab.py, A/A resolution 0.2-0.4 %; docs/EXPERIMENTS.md):
+                //  * sched_barrier(0) around load / mult (a true one-step-ahead pipeline; hipcc sinks most reads of step i + 1
+                //    next to their own products): +0.9 % -- the waves do not wait for the round trip;
+                //  * the three taps cut out of FOUR aligned reads with five v_alignbit (6 reads per step instead of 8): +0.4 ...
+                //    +0.8 % -- nor for the LDS' read rate;
+                //  * two LDS counters instead of the per-tile s_barrier (a wave starts tile t when the loaders have signalled
+                //    it, a loader refills a stage when the twelve compute waves have left it), static or rotating s_setprio:
+                //    +0 ... +0.6 % -- nor for each other: the sum of the three waves' step time per SIMD did not move.
+#define C8T_ST(I) if (NSTEP > I + 1) { load(std::integral_constant<int, (I + 1) % NSTEP>{}); mult(std::integral_constant<int, I % NSTEP>{}); }
                 C8T_ST(0) C8T_ST(1) C8T_ST(2) C8T_ST(3) C8T_ST(4) C8T_ST(5) C8T_ST(6)
 #undef C8T_ST
                 mult(std::integral_constant<int, NSTEP - 1>{});
