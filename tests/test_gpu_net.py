@@ -289,7 +289,13 @@ def test_full_size_gradients_mnist(B):
         cost_w, lp_w, _ = ora.train_step(x[s * B:(s + 1) * B], y[s * B:(s + 1) * B], {0: d0, 5: m5})
         assert_close(cost, cost_w, 1e-4, 1e-5, what="cost step %d" % s)
         assert_close(lp, lp_w, 1e-4, 1e-5, what="logprob step %d" % s)
-        np.testing.assert_array_equal(lp.argmax(1), lp_w.argmax(1))
+        # argmax: exact, except on rows whose two best classes the float64 oracle itself separates by less than float32
+        # resolves (an untrained net: every log-probability is near -2.3; among 3 x 4096 rows one such row turns up in
+        # roughly every third run -- this assertion flaked once in four full-suite runs before the exemption)
+        pa, pw = lp.argmax(1), lp_w.argmax(1)
+        for r in np.nonzero(pa != pw)[0]:
+            top2 = np.sort(lp_w[r])[-2:]
+            assert top2[1] - top2[0] < 1e-5, ("argmax differs away from a tie", s, r, lp[r], lp_w[r])
         vel = net.get_init_params(with_opt_state=True)["opt_state"]["velocities"]
         seen = 0
         for i, (lyr, ol) in enumerate(zip(net.tr_layers, ora.L)):
@@ -299,10 +305,12 @@ def test_full_size_gradients_mnist(B):
                 g = (v - (m * vel_prev[i][j] if s else 0)) / (1 - m)
                 g_w = (v_w - (m * vel_prev_w[i][j] if s else 0)) / (1 - m)
                 assert g.shape == g_w.shape
-                # 1e-3 of the largest entry.  Typical agreement is 1e-6; the bound leaves room for ONE pooling window
-                # whose two largest members differ by less than float32 resolves (the float64 oracle then routes that
-                # window's gradient elsewhere: a discrete 2e-4 ... 6e-4 of a conv gradient at 512 images)
-                assert np.abs(g - g_w).max() <= 1e-3 * np.abs(g_w).max(), \
+                # Typical agreement is 1e-6 of the largest entry.  Dense tensors: 1e-4.  Conv tensors: 2e-3 -- the bound leaves
+                # room for TWO pooling windows whose two largest members differ by less than float32 resolves (the float64
+                # oracle then routes that window's gradient elsewhere: a discrete 2e-4 ... 6e-4 of a conv gradient at 512
+                # images, seen in about one run of four on the CPU backend)
+                tol = 2e-3 if i in (1, 3) else 1e-4
+                assert np.abs(g - g_w).max() <= tol * np.abs(g_w).max(), \
                     ("grad", s, i, j, np.abs(g - g_w).max(), np.abs(g_w).max())
                 seen += 1
         assert seen == 8
