@@ -101,7 +101,7 @@ def cpu_baseline(prms, hw, c, batch, budget_s=18.0):
                       % (prms.get("_name", "net"), batch, sweep, best, results[best][1], results[best][2])}
 
 
-PMC_FILE = "r05_traffic.json"
+PMC_FILE = "r06_traffic.json"
 
 
 def _pmc_table(config):

@@ -5,7 +5,7 @@
 #   FETCH_SIZE / WRITE_SIZE are collected in their own passes (TCC has 4 slots: 3 + 2 do not fit
 #   together) and PMC passes never carry a trace domain other than --kernel-trace, exactly as
 #   /opt/skills/guides/MI355X_MICROARCH.md prescribes.
-TAG=${1:-r05}
+TAG=${1:-r06}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp

@@ -39,7 +39,7 @@ nb = int(os.environ.get("NB", 8192))
 buf = np.zeros((nb, 8), np.uint64)
 rc = ctx.lib.tn_c8_dbg_read(ctx.h, ctypes.c_void_p(buf.ctypes.data), ctypes.c_int(nb))
 assert rc == 0, rc
-if os.environ.get("WAVES"):           # sixteen-wave weight gradient: per compute wave (records 4096 + 16 block + wave)
+if os.environ.get("WAVES", "0") == "1":           # sixteen-wave weight gradient: per compute wave (records 4096 + 16 block + wave)
     wv = buf[4096:4096 + 16 * 256].reshape(256, 16, 8).astype(np.int64)
     live = wv[:, 0, 0] > 0
     for w in range(12):
