@@ -1270,6 +1270,12 @@ __global__ __launch_bounds__(512) void c8_wgrad_kernel(C8WG g) {
 //   * same LDS images, same DMA chunk lists, same slab layout as the eight-wave kernel (c8w_geometry serves both).
 // The bias product of a step is taken by ONE of the six waves that share its dz operand, by step number.
 // =================================================================================================
+// ablation builds of c8_wgrad_tr_kernel (wrong results, timing only; hipcc -DC8W_ABL=n into a side library, run through
+// TN_HIP_LIB; tools/abl_wgrad.sh): 1 no products, 2 no operand reads (the products run on stale registers), 4 no LDS-DMA
+// (the loaders only keep the barriers), 8 no edge masks
+#ifndef C8W_ABL
+#define C8W_ABL 0
+#endif
 template <int NCT, int NGX, bool POOL, bool ROLL>
 __global__ __launch_bounds__(1024) void c8_wgrad_tr_kernel(C8WG g) {
     extern __shared__ __attribute__((aligned(16))) float ct_smem[];
@@ -1407,6 +1413,7 @@ __global__ __launch_bounds__(1024) void c8_wgrad_tr_kernel(C8WG g) {
             constexpr int J0 = decltype(J0c)::value, J1 = decltype(J1c)::value;
 #pragma unroll
             for (int j = J0; j < J1; ++j) {
+                if (C8W_ABL & 4) continue;
                 if (ROLL) {
                     const char* src = (j < NGX ? cur_xp : cur_dp) + (long long)gl_rel[j] * 16;
                     c8_glds16(src, __builtin_amdgcn_readfirstlane((j < NGX ? cur_xr : cur_sb) + gl_dst[j]));
@@ -1528,9 +1535,18 @@ __global__ __launch_bounds__(1024) void c8_wgrad_tr_kernel(C8WG g) {
                 // one software pipeline over the tile's eight steps: the eight transposing reads of step i + 1 are issued in
                 // front of the products of step i (two operand sets; LDS returns in order, the compiler counts lgkmcnt)
                 half4v av[2][2], bv[2][3][2];
+                if (C8W_ABL & 2) {
+#pragma unroll
+                    for (int b_ = 0; b_ < 2; ++b_) {
+                        av[b_][0] = av[b_][1] = half4v{(_Float16)lane, (_Float16)1.f, (_Float16)2.f, (_Float16)3.f};
+#pragma unroll
+                        for (int v = 0; v < 3; ++v) bv[b_][v][0] = bv[b_][v][1] = av[b_][0];
+                    }
+                }
                 auto load = [&](auto Ic) __attribute__((always_inline)) {
                     constexpr int i = decltype(Ic)::value, B_ = i & 1, gi = NCT == 2 ? i : X + PS * i;     // gi: step of the tile
                     const int p = 16 * gi + l16;
+                    if (C8W_ABL & 2) return;
                     av[B_][0] = c8_tr16(a_lane + 256 * gi);
                     av[B_][1] = c8_tr16(a_lane + 256 * gi + 64);
                     const char* xp;
@@ -1549,7 +1565,7 @@ __global__ __launch_bounds__(1024) void c8_wgrad_tr_kernel(C8WG g) {
                 };
                 auto mult = [&](auto Ic) __attribute__((always_inline)) {
                     constexpr int i = decltype(Ic)::value, B_ = i & 1, gi = NCT == 2 ? i : X + PS * i;
-                    if (ROLL) {
+                    if (ROLL && !(C8W_ABL & 8)) {
                         // the k element whose cell lies left of column 0 (tap column 0) / right of column W - 1 (tap column 2):
                         // the lane's mask (lmL / lmR) where the step touches the edge (a scalar), all ones elsewhere
                         const unsigned mL = lmL | (unsigned)__builtin_amdgcn_readfirstlane(((16 * gi) & Wm) == 0 ? 0 : -1);
@@ -1566,10 +1582,11 @@ __global__ __launch_bounds__(1024) void c8_wgrad_tr_kernel(C8WG g) {
                     for (int v = 0; v < 3; ++v) {
                         const half8 b = {bv[B_][v][0][0], bv[B_][v][0][1], bv[B_][v][0][2], bv[B_][v][0][3],
                                          bv[B_][v][1][0], bv[B_][v][1][1], bv[B_][v][1][2], bv[B_][v][1][3]};
+                        if (C8W_ABL & 1) { asm volatile("" :: "v"(a), "v"(b)); continue; }      // (the reads stay: their values are "used")
                         acc[v] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[v], 0, 0, 0);
                     }
                     // the bias product of a step: ONE of the waves that share its dz operand, known at compile time
-                    if ((NCT == 2 ? (i % 3 == U && ((i / 3) & 1) == X) : (i % 3 == U)) && want_b)
+                    if ((NCT == 2 ? (i % 3 == U && ((i / 3) & 1) == X) : (i % 3 == U)) && want_b && !(C8W_ABL & 1))
                         accb = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, ones, accb, 0, 0, 0);
                 };
                 load(std::integral_constant<int, 0>{});
