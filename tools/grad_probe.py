@@ -1,3 +1,10 @@
+"""One training step of params/mnist.prms against the float64 oracle, gradient by gradient:
+    python tools/grad_probe.py BATCH ELASTIC(0|1) [p]      (p: conv kernels de-symmetrised as in GOLD-B, perturbed_init)
+Prints cost, max |dlogprob| and, per parametrised tensor, max |g - g_oracle| / max |g_oracle| (then the same for the
+velocities after the update).  With ELASTIC=1 and the reference's own init (+-1/sqrt(fan_in)) conv1's gradient differs by
+0.5-7 % from ANY other implementation's: nearest-mode zoom duplicates pixels, pooling-window members whose patches are
+permutations of one another are mathematically equal sums, and the tie is broken by the order of summation (DESIGN.md
+section 2).  With `p` the agreement is 1e-6.  Works on the GPU and with THEANET_BACKEND=cpu."""
 import copy, sys, numpy as np
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import theanet_oracle as O
