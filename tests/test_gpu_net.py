@@ -305,11 +305,15 @@ def test_full_size_gradients_mnist(B):
                 g = (v - (m * vel_prev[i][j] if s else 0)) / (1 - m)
                 g_w = (v_w - (m * vel_prev_w[i][j] if s else 0)) / (1 - m)
                 assert g.shape == g_w.shape
-                # Typical agreement is 1e-6 of the largest entry.  Dense tensors: 1e-4.  Conv tensors: 2e-3 -- the bound leaves
-                # room for TWO pooling windows whose two largest members differ by less than float32 resolves (the float64
-                # oracle then routes that window's gradient elsewhere: a discrete 2e-4 ... 6e-4 of a conv gradient at 512
-                # images, seen in about one run of four on the CPU backend)
-                tol = 2e-3 if i in (1, 3) else 1e-4
+                # Typical agreement is 1e-6 of the largest entry; the bound is 2e-3 because float32 against float64 has DISCRETE
+                # disagreements at these sizes, each seen in the wild (4 full-suite runs on the GPU, 4 on the CPU backend):
+                #  * a pooling window whose two largest members differ by less than float32 resolves -- the oracle routes that
+                #    window's gradient elsewhere: 2e-4 ... 6e-4 of a conv gradient at 512 images;
+                #  * a hidden unit whose pre-activation is within rounding of zero on one row -- its leaky-ReLU derivative is
+                #    1 on one side and 0.01 on the other: a whole column of fc1's dW off by 9e-4 of the largest entry (two
+                #    runs of four at 3 x 4096 rows x 500 units).
+                # Two such events in one tensor and one step fit the bound; anything systematic is orders of magnitude above it.
+                tol = 2e-3
                 assert np.abs(g - g_w).max() <= tol * np.abs(g_w).max(), \
                     ("grad", s, i, j, np.abs(g - g_w).max(), np.abs(g_w).max())
                 seen += 1
